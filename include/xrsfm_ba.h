@@ -1,0 +1,160 @@
+/*
+ * xrsfm_ba.h — C-ABI of the MI355X-native bundle-adjustment engine.
+ *
+ * Drop-in boundary for the global/local BA step of openxrlab/xrsfm.  The
+ * reference has no FFI for this path: it is the C++ class xrsfm::BASolver
+ * (/root/reference/src/optimization/ba_solver.h:14-30) whose GBA/KGBA/LBA
+ * methods build a ceres::Problem out of raw pointers into Map storage
+ * (/root/reference/src/optimization/ba_solver.cc:345-347) and call
+ * ceres::Solve (ba_solver.cc:591,636,672).  The entry points below are what a
+ * binding for that path has to call instead of Ceres: the same parameter
+ * blocks, handed over as flat FP64/int32 arrays (caller-owned, results written
+ * in place like Ceres does), the same solver options the reference sets
+ * (ba_solver.cc:70-77, 586-589, 626-634, 667-670), and a summary carrying the
+ * quantities PrintSolverSummary prints (ba_solver.cc:14-68).
+ * The source-compatible adapter on top is xrsfm_amd/csrc/compat/.
+ *
+ * Plain C, no torch / HIP types in any signature.  All functions return 0 on
+ * success or a negative XRSFM_BA_E* code; nothing throws across the boundary.
+ */
+#ifndef XRSFM_BA_H
+#define XRSFM_BA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XRSFM_BA_VERSION 1
+
+/* error codes */
+#define XRSFM_BA_OK 0
+#define XRSFM_BA_EINVAL (-1)   /* bad argument / inconsistent indices            */
+#define XRSFM_BA_ENODEV (-2)   /* no HIP device, or the HIP runtime reported an error */
+#define XRSFM_BA_ENOMEM (-3)
+#define XRSFM_BA_ECOMM (-4)    /* RCCL unavailable or a collective failed         */
+#define XRSFM_BA_ESTATE (-5)   /* call order violated                            */
+
+/* camera models: ids of /root/reference/src/base/camera_model.hpp:93-209 */
+#define XRSFM_BA_SIMPLE_PINHOLE 0 /* {f,cx,cy}             uv = 2f*xn + c (reference quirk, :102-105) */
+#define XRSFM_BA_PINHOLE 1        /* {fx,fy,cx,cy}         same quirk (:121-124)                       */
+#define XRSFM_BA_SIMPLE_RADIAL 2  /* {f,cx,cy,k}                                                      */
+#define XRSFM_BA_RADIAL 3         /* {fx,fy,cx,cy,k}       single k (:155-177)                         */
+#define XRSFM_BA_OPENCV 4         /* {fx,fy,cx,cy,k1,k2,p1,p2}                                         */
+
+/* cam_const bits: which parameter blocks of a frame are held constant
+ * (problem.SetParameterBlockConstant, ba_solver.cc:611-621) */
+#define XRSFM_BA_CONST_Q 1u
+#define XRSFM_BA_CONST_T 2u
+
+/* One BA call = one ceres::Problem of the reference (ba_solver.cc:596,645,536).
+ * Observation order is free (the reference's is frame-major, ba_solver.cc:598-601). */
+typedef struct xrsfm_ba_problem {
+    int32_t n_cams;   /* frames added by SetUp/SetUpLBA (ba_solver.cc:330-391)          */
+    int32_t n_points; /* tracks referenced by those frames                             */
+    int32_t n_obs;    /* residual blocks = ReProjectionCost instances                  */
+    int32_t n_intr;   /* distinct camera_id's (intrinsics always constant, :602-606)   */
+    double *cam_q;              /* [n_cams][4]  Tcw.q.coeffs() = x,y,z,w   in/out        */
+    double *cam_t;              /* [n_cams][3]  Tcw.t                      in/out        */
+    const uint8_t *cam_const;   /* [n_cams]     XRSFM_BA_CONST_* bits, NULL = all free   */
+    const int32_t *cam_intr;    /* [n_cams]     index into intr_*                        */
+    const int32_t *intr_model;  /* [n_intr]     XRSFM_BA_<MODEL>                         */
+    const double *intr_params;  /* [n_intr][8]  camera.params_ (zero padded)             */
+    double *points;             /* [n_points][3] track.point3d_            in/out        */
+    const uint8_t *point_const; /* [n_points]   non-zero = constant (SetUpLBA :380-382), NULL = all free */
+    const int32_t *obs_cam;     /* [n_obs] */
+    const int32_t *obs_pt;      /* [n_obs] */
+    const double *obs_uv;       /* [n_obs][2]   frame.points[i]                          */
+} xrsfm_ba_problem;
+
+#define XRSFM_BA_SOLVER_PCG 0   /* implicit-Schur PCG on the reduced camera system   */
+
+typedef struct xrsfm_ba_options {
+    int32_t max_iterations;      /* GBA accurate 50 / fast 20 / KGBA 20 / LBA 5        */
+    double function_tolerance;   /* 1e-5 / 1e-4                                       */
+    double parameter_tolerance;  /* 1e-6 / 1e-5                                       */
+    double gradient_tolerance;   /* Ceres default 1e-10                               */
+    double initial_radius;       /* Ceres default 1e4, KGBA 1e6 (ba_solver.cc:667)    */
+    double huber_a;              /* 5.99 (ba_solver.cc:343,374)                       */
+    int32_t linear_solver;       /* XRSFM_BA_SOLVER_*                                 */
+    double pcg_tolerance;        /* |r|_2 <= tol*|b|_2; 1e-12 follows the exact solve */
+    int32_t pcg_max_iterations;
+    int32_t profile;             /* !=0: HIP-event timing of the dominant kernel      */
+    int32_t verbose;             /* !=0: Ceres-style progress table on stdout         */
+} xrsfm_ba_options;
+
+/* termination codes (ceres::TerminationType as printed by ba_solver.cc:41-66) */
+#define XRSFM_BA_CONVERGENCE 0
+#define XRSFM_BA_NO_CONVERGENCE 1
+#define XRSFM_BA_FAILURE 2
+
+typedef struct xrsfm_ba_summary {
+    double initial_cost;   /* 1/2 sum rho(|r|^2) at entry                              */
+    double final_cost;     /* ... at the last accepted state                           */
+    int32_t num_residuals;          /* num_residuals_reduced = 2*n_obs                 */
+    int32_t num_effective_params;   /* num_effective_parameters_reduced                */
+    int32_t n_successful;           /* LM steps accepted (iteration 0 not counted)     */
+    int32_t n_unsuccessful;         /* LM steps rejected or invalid                    */
+    int32_t termination;            /* XRSFM_BA_CONVERGENCE / ...                      */
+    int32_t termination_reason;     /* 1 gradient, 2 parameter, 3 function tolerance, 4 min radius, 5 max iterations, 6 invalid steps */
+    int32_t pcg_iterations;         /* total over all LM steps                         */
+    int32_t lm_steps_attempted;     /* incl. the step that triggered a tolerance exit  */
+    double total_time_s;            /* wall time of the solve, device-resident inputs  */
+    double dom_kernel_ms;           /* profile!=0: sum of HIP-event durations of the Schur-product kernel */
+    int32_t dom_kernel_launches;    /* profile!=0: launches counted in dom_kernel_ms   */
+    int32_t reserved;
+} xrsfm_ba_summary;
+
+typedef struct xrsfm_ba_context xrsfm_ba_context; /* opaque: device buffers, stream, communicator */
+
+/* Fill `opt` with the reference's GBA(accurate=true) settings + Ceres defaults. */
+void xrsfm_ba_default_options(xrsfm_ba_options *opt);
+
+/* Library / device probe: returns XRSFM_BA_VERSION, *n_devices = visible HIP devices (0 if none). */
+int xrsfm_ba_version(int *n_devices);
+
+/* Build a device-resident problem on HIP device `device`: validates indices,
+ * orders tracks, uploads everything.  The host arrays are only read. */
+int xrsfm_ba_create(const xrsfm_ba_problem *problem, int device, xrsfm_ba_context **out);
+
+/* Multi-GPU (points sharded by rank, cameras replicated): attach an RCCL
+ * communicator.  `unique_id` is the 128-byte ncclUniqueId obtained from
+ * xrsfm_ba_comm_unique_id on rank 0 and distributed by the caller. */
+int xrsfm_ba_comm_unique_id(unsigned char id[128]);
+int xrsfm_ba_comm_init(xrsfm_ba_context *ctx, int n_ranks, int rank, const unsigned char id[128]);
+
+/* Run Levenberg-Marquardt on the device-resident state (blocking). */
+int xrsfm_ba_run(xrsfm_ba_context *ctx, const xrsfm_ba_options *opt, xrsfm_ba_summary *summary);
+
+/* Restore the device-resident state to the values uploaded by xrsfm_ba_create. */
+int xrsfm_ba_reset(xrsfm_ba_context *ctx);
+
+/* Copy the current state back into caller arrays laid out like the problem
+ * (cam_q [n_cams][4], cam_t [n_cams][3], points [n_points][3]); NULL skips one. */
+int xrsfm_ba_download(xrsfm_ba_context *ctx, double *cam_q, double *cam_t, double *points);
+
+void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
+
+/* One-shot convenience = create + run + download into problem->{cam_q,cam_t,points} + destroy:
+ * the call that replaces ceres::Solve(options, &problem, &summary). */
+int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm_ba_summary *summary);
+
+/* ---- test/diagnostic entry points (kernel-level parity against the oracle) ---- */
+
+/* Linearise at the current state with Jacobi scaling `use_scaling` (0: scale = 1).
+ * Outputs are in the caller's observation / point / camera order; any may be NULL.
+ *   r [n_obs][2], Jc [n_obs][2][6], Jp [n_obs][2][3]   robustified, scaled
+ *   Hpp [n_points][6] (upper: 00 01 02 11 12 22), gp [n_points][3]
+ *   Hcc_diag [n_cams][6], gc [n_cams][6], *cost */
+int xrsfm_ba_debug_linearize(xrsfm_ba_context *ctx, double huber_a, int use_scaling, double *r, double *Jc,
+                             double *Jp, double *Hpp, double *gp, double *Hcc_diag, double *gc, double *cost);
+
+/* After debug_linearize: y = S(radius) * x for a caller vector x [n_cams][6]; also returns rhs b [n_cams][6]. */
+int xrsfm_ba_debug_schur_product(xrsfm_ba_context *ctx, double radius, const double *x, double *y, double *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRSFM_BA_H */

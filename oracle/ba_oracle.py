@@ -1,0 +1,516 @@
+"""CPU oracle (numpy/scipy, FP64) for XRSfM's bundle-adjustment hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``xrsfm_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do.  The product path is the HIP library behind
+``include/xrsfm_ba.h``.
+
+PARITY UNPINNED: the arithmetic of the reference path lives in Ceres-Solver
+(``ceres::Solve`` called at /root/reference/src/optimization/ba_solver.cc:591,
+636,672), which is neither vendored under /root/reference nor installed in
+this image, and the reference ships no tests or golden vectors for this path
+(SURVEY.md section 4 and 8c).  The trust-region semantics below restate the
+published Ceres 2.0/2.1 algorithm (TrustRegionMinimizer,
+LevenbergMarquardtStrategy, SchurComplementSolver, HuberLoss, Corrector,
+EigenQuaternionParameterization) — SURVEY.md Appendix A.  What *is* pinned to
+reference source is the residual model:
+
+* residual                /root/reference/src/optimization/cost_factor_ceres.h:19-40
+* camera models           /root/reference/src/base/camera_model.hpp:57-68, 93-209
+* problem construction    /root/reference/src/optimization/ba_solver.cc:330-391,594-678
+* solver options          /root/reference/src/optimization/ba_solver.cc:70-77,586-589,626-634,667-670
+
+The Jacobians here are cross-checked against torch.autograd (FP64) in
+tests/test_oracle_jacobian.py, i.e. against what Ceres' autodiff of the
+reference functor produces.
+"""
+from __future__ import annotations
+
+import dataclasses
+import math
+from typing import Optional
+
+import numpy as np
+
+HUBER_A = 5.99          # ba_solver.cc:343,374
+MIN_DEPTH = 1e-2        # cost_factor_ceres.h:29
+CLAMP_RES = 12.0        # cost_factor_ceres.h:31
+
+# camera_model.hpp: model id -> (num params, ifx, ify, icx, icy, idistort)
+MODEL_INFO = {
+    0: (3, 0, 0, 1, 2, -1),   # SIMPLE_PINHOLE :93-110
+    1: (4, 0, 1, 2, 3, -1),   # PINHOLE        :112-129
+    2: (4, 0, 0, 1, 2, 3),    # SIMPLE_RADIAL  :131-153
+    3: (5, 0, 1, 2, 3, 4),    # RADIAL         :155-177 (single k)
+    4: (8, 0, 1, 2, 3, 4),    # OPENCV         :179-209
+}
+
+
+@dataclasses.dataclass
+class Problem:
+    """Flat SoA view of one BA call (the same arrays the C-ABI takes)."""
+    cam_q: np.ndarray        # [Nc,4] x,y,z,w (Eigen coeffs order, ba_solver.cc:346)
+    cam_t: np.ndarray        # [Nc,3]
+    cam_const: np.ndarray    # [Nc] uint8  bit0: q constant, bit1: t constant
+    cam_intr: np.ndarray     # [Nc] int32
+    intr_model: np.ndarray   # [Ni] int32
+    intr_params: np.ndarray  # [Ni,8]
+    points: np.ndarray       # [Np,3]
+    point_const: np.ndarray  # [Np] uint8
+    obs_cam: np.ndarray      # [No] int32
+    obs_pt: np.ndarray       # [No] int32
+    obs_uv: np.ndarray       # [No,2]
+
+    def copy(self) -> "Problem":
+        return Problem(**{f.name: np.array(getattr(self, f.name), copy=True)
+                          for f in dataclasses.fields(self)})
+
+
+@dataclasses.dataclass
+class Options:
+    """Ceres options as set by the reference (ba_solver.cc) + library defaults."""
+    max_iterations: int = 50             # GBA accurate  :627
+    function_tolerance: float = 1e-5     # :628
+    parameter_tolerance: float = 1e-6    # :629
+    gradient_tolerance: float = 1e-10    # Ceres default
+    initial_radius: float = 1e4          # Ceres default (KGBA 1e6, :667)
+    max_radius: float = 1e16
+    min_radius: float = 1e-32
+    min_relative_decrease: float = 1e-3
+    min_lm_diagonal: float = 1e-6
+    max_lm_diagonal: float = 1e32
+    max_consecutive_invalid_steps: int = 5
+    huber_a: float = HUBER_A
+    linear_solver: str = "exact"         # "exact" (Schur + Cholesky) | "pcg"
+    pcg_tol: float = 1e-12
+    pcg_max_iter: int = 500
+
+
+@dataclasses.dataclass
+class Summary:
+    initial_cost: float = 0.0
+    final_cost: float = 0.0
+    num_residuals: int = 0
+    num_effective_params: int = 0
+    n_successful: int = 0
+    n_unsuccessful: int = 0
+    termination: str = ""
+    trace: list = dataclasses.field(default_factory=list)
+    pcg_iterations: int = 0
+
+
+# ----------------------------------------------------------------------------
+# residual + Jacobian (Appendix A.1 / A.2)
+# ----------------------------------------------------------------------------
+def rotation_from_quat(q: np.ndarray) -> np.ndarray:
+    """M(q) = I + 2w[u]x + 2[u]x^2 for q = (x,y,z,w); equals R(q) for unit q.
+
+    This is Eigen's QuaternionBase::_transformVector written as a matrix (the
+    reference applies ``qcw * pw`` without normalising, cost_factor_ceres.h:28).
+    """
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    M = np.empty(q.shape[:-1] + (3, 3))
+    M[..., 0, 0] = 1 - 2 * (y * y + z * z)
+    M[..., 0, 1] = 2 * (x * y - w * z)
+    M[..., 0, 2] = 2 * (x * z + w * y)
+    M[..., 1, 0] = 2 * (x * y + w * z)
+    M[..., 1, 1] = 1 - 2 * (x * x + z * z)
+    M[..., 1, 2] = 2 * (y * z - w * x)
+    M[..., 2, 0] = 2 * (x * z - w * y)
+    M[..., 2, 1] = 2 * (y * z + w * x)
+    M[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return M
+
+
+def _intrinsics_per_obs(model: np.ndarray, prm: np.ndarray):
+    """Return fx, fy, cx, cy and the per-model distortion parameters."""
+    n = model.shape[0]
+    fx = np.empty(n); fy = np.empty(n); cx = np.empty(n); cy = np.empty(n)
+    for mid, (_, ifx, ify, icx, icy, _) in MODEL_INFO.items():
+        m = model == mid
+        if m.any():
+            fx[m] = prm[m, ifx]; fy[m] = prm[m, ify]
+            cx[m] = prm[m, icx]; cy[m] = prm[m, icy]
+    return fx, fy, cx, cy
+
+
+def project(problem: Problem, q=None, t=None, P=None, want_jac=True):
+    """Per-observation residual and (unrobustified) Jacobian blocks.
+
+    Returns r [No,2], valid [No] and, if want_jac, J_rot [No,2,3] (w.r.t. the
+    3-dim local rotation increment of EigenQuaternionParameterization),
+    J_t [No,2,3], J_P [No,2,3].  Clamp case z < 1e-2: r = (12,12), J = 0
+    (cost_factor_ceres.h:29-31).
+    """
+    q = problem.cam_q if q is None else q
+    t = problem.cam_t if t is None else t
+    P = problem.points if P is None else P
+    ci, pi = problem.obs_cam, problem.obs_pt
+    M = rotation_from_quat(q)[ci]                       # [No,3,3]
+    Pw = P[pi]
+    RP = np.einsum("nij,nj->ni", M, Pw)
+    Pc = RP + t[ci]
+    z = Pc[:, 2]
+    valid = ~(z < MIN_DEPTH)
+    zs = np.where(valid, z, 1.0)
+    iz = 1.0 / zs
+    xn = Pc[:, 0] * iz
+    yn = Pc[:, 1] * iz
+
+    intr = problem.cam_intr[ci]
+    model = problem.intr_model[intr]
+    prm = problem.intr_params[intr]
+    fx, fy, cx, cy = _intrinsics_per_obs(model, prm)
+
+    n = ci.shape[0]
+    du = np.zeros(n); dv = np.zeros(n)
+    # D = I + d(du,dv)/d(xn,yn)
+    D00 = np.ones(n); D01 = np.zeros(n); D10 = np.zeros(n); D11 = np.ones(n)
+    r2 = xn * xn + yn * yn
+
+    m01 = (model == 0) | (model == 1)           # reference quirk: duv = xy (camera_model.hpp:102-105,121-124)
+    du[m01] = xn[m01]; dv[m01] = yn[m01]
+    D00[m01] = 2.0; D11[m01] = 2.0
+
+    for mid, ik in ((2, 3), (3, 4)):            # SIMPLE_RADIAL / RADIAL: k*r2*(xn,yn)
+        m = model == mid
+        if m.any():
+            k = prm[m, ik]
+            du[m] = xn[m] * (k * r2[m]); dv[m] = yn[m] * (k * r2[m])
+            D00[m] = 1 + k * r2[m] + 2 * k * xn[m] ** 2
+            D11[m] = 1 + k * r2[m] + 2 * k * yn[m] ** 2
+            D01[m] = 2 * k * xn[m] * yn[m]
+            D10[m] = D01[m]
+
+    m = model == 4                              # OPENCV :188-204
+    if m.any():
+        k1, k2, p1, p2 = prm[m, 4], prm[m, 5], prm[m, 6], prm[m, 7]
+        x, y, rr = xn[m], yn[m], r2[m]
+        rad = k1 * rr + k2 * rr * rr
+        du[m] = x * rad + 2 * p1 * x * y + p2 * (rr + 2 * x * x)
+        dv[m] = y * rad + 2 * p2 * x * y + p1 * (rr + 2 * y * y)
+        rad_x = 2 * k1 * x + 4 * k2 * rr * x
+        rad_y = 2 * k1 * y + 4 * k2 * rr * y
+        D00[m] = 1 + rad + x * rad_x + 2 * p1 * y + 6 * p2 * x
+        D01[m] = x * rad_y + 2 * p1 * x + 2 * p2 * y
+        D10[m] = y * rad_x + 2 * p2 * y + 2 * p1 * x
+        D11[m] = 1 + rad + y * rad_y + 2 * p2 * x + 6 * p1 * y
+
+    r = np.empty((n, 2))
+    r[:, 0] = fx * (xn + du) + cx - problem.obs_uv[:, 0]
+    r[:, 1] = fy * (yn + dv) + cy - problem.obs_uv[:, 1]
+    r[~valid] = CLAMP_RES
+    if not want_jac:
+        return r, valid
+
+    A00 = fx * D00; A01 = fx * D01; A10 = fy * D10; A11 = fy * D11
+    Jproj = np.zeros((n, 2, 3))
+    Jproj[:, 0, 0] = A00 * iz; Jproj[:, 0, 1] = A01 * iz
+    Jproj[:, 0, 2] = -(A00 * xn + A01 * yn) * iz
+    Jproj[:, 1, 0] = A10 * iz; Jproj[:, 1, 1] = A11 * iz
+    Jproj[:, 1, 2] = -(A10 * xn + A11 * yn) * iz
+    Jproj[~valid] = 0.0
+    J_t = Jproj
+    J_P = np.einsum("nij,njk->nik", Jproj, M)
+    # row^T * (-2 [RP]x) = -2 * (row x RP)
+    J_rot = -2.0 * np.cross(Jproj, RP[:, None, :])
+    return r, valid, J_rot, J_t, J_P
+
+
+def huber(s: np.ndarray, a: float = HUBER_A):
+    """ceres::HuberLoss(a): rho, rho' on s = |r|^2 (Appendix A.3)."""
+    b = a * a
+    out = s > b
+    sq = np.sqrt(np.where(out, s, 1.0))
+    rho = np.where(out, 2 * a * sq - b, s)
+    rho1 = np.where(out, np.maximum(np.finfo(float).tiny, a / sq), 1.0)
+    return rho, rho1
+
+
+def quat_plus(q: np.ndarray, d: np.ndarray) -> np.ndarray:
+    """EigenQuaternionParameterization::Plus: dq(full angle) (x) q, q = xyzw."""
+    n = np.linalg.norm(d, axis=-1)
+    safe = np.where(n > 0, n, 1.0)
+    s = np.where(n > 0, np.sin(safe) / safe, 0.0)
+    av = d * s[..., None]
+    aw = np.where(n > 0, np.cos(n), 1.0)
+    bv = q[..., :3]; bw = q[..., 3]
+    out = np.empty_like(q)
+    out[..., 3] = aw * bw - np.sum(av * bv, axis=-1)
+    out[..., :3] = aw[..., None] * bv + bw[..., None] * av + np.cross(av, bv)
+    ident = ~(n > 0)
+    out[ident] = q[ident]
+    return out
+
+
+# ----------------------------------------------------------------------------
+# evaluation: cost, robustified residuals and tangent Jacobian blocks
+# ----------------------------------------------------------------------------
+def evaluate(problem: Problem, q, t, P, a=HUBER_A, want_jac=True):
+    if want_jac:
+        r, valid, Jr, Jt, JP = project(problem, q, t, P, True)
+    else:
+        r, valid = project(problem, q, t, P, False)
+    s = np.sum(r * r, axis=1)
+    rho, rho1 = huber(s, a)
+    cost = 0.5 * float(np.sum(rho))
+    if not want_jac:
+        return cost
+    sw = np.sqrt(rho1)
+    rt = r * sw[:, None]
+    Fc = np.concatenate([Jr, Jt], axis=2) * sw[:, None, None]   # [No,2,6] (rot, t)
+    Ep = JP * sw[:, None, None]                                 # [No,2,3]
+    # constant blocks are removed from the program (A.4): zero their columns
+    qc = (problem.cam_const[problem.obs_cam] & 1) != 0
+    tc = (problem.cam_const[problem.obs_cam] & 2) != 0
+    Fc[qc, :, 0:3] = 0.0
+    Fc[tc, :, 3:6] = 0.0
+    pc = problem.point_const[problem.obs_pt] != 0
+    Ep[pc] = 0.0
+    return cost, rt, Fc, Ep
+
+
+def rmse_pair(problem: Problem, q=None, t=None, P=None, a=HUBER_A):
+    """(reference-style sqrt(cost/num_residuals), plain sqrt(sum|r|^2/N_obs))."""
+    r, _ = project(problem, q, t, P, False)
+    s = np.sum(r * r, axis=1)
+    rho, _ = huber(s, a)
+    n = r.shape[0]
+    return math.sqrt(0.5 * rho.sum() / (2 * n)), math.sqrt(s.sum() / n)
+
+
+class _Linearization:
+    """Normal-equation blocks at one point, in Jacobi-scaled coordinates."""
+
+    def __init__(self, problem: Problem, rt, Fs, Es):
+        self.rt, self.Fs, self.Es = rt, Fs, Es
+        Nc, Np = problem.cam_q.shape[0], problem.points.shape[0]
+        ci, pi = problem.obs_cam, problem.obs_pt
+        self.Hcc = np.zeros((Nc, 6, 6)); np.add.at(self.Hcc, ci, np.einsum("nki,nkj->nij", Fs, Fs))
+        self.Hpp = np.zeros((Np, 3, 3)); np.add.at(self.Hpp, pi, np.einsum("nki,nkj->nij", Es, Es))
+        self.gc = np.zeros((Nc, 6)); np.add.at(self.gc, ci, np.einsum("nki,nk->ni", Fs, rt))
+        self.gp = np.zeros((Np, 3)); np.add.at(self.gp, pi, np.einsum("nki,nk->ni", Es, rt))
+        self.W = np.einsum("nki,nkj->nij", Fs, Es)          # [No,6,3] = F^T E
+
+
+def _active_points(problem: Problem) -> np.ndarray:
+    m = np.zeros(problem.points.shape[0], bool)
+    m[problem.obs_pt] = True
+    return m
+
+
+def _solve_exact(problem: Problem, lin: _Linearization, Dc2, Dp2):
+    """(Js^T Js + D^2) y = Js^T r via exact Schur complement (Appendix A.7)."""
+    import scipy.linalg as sla
+    Nc = problem.cam_q.shape[0]
+    ci, pi = problem.obs_cam, problem.obs_pt
+    Hpp_d = lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3))
+    Hinv = np.linalg.inv(Hpp_d)
+    # dense reduced camera matrix
+    S = np.zeros((Nc * 6, Nc * 6))
+    for c in range(Nc):
+        S[6 * c:6 * c + 6, 6 * c:6 * c + 6] = lin.Hcc[c] + np.diag(Dc2[c])
+    WH = np.einsum("nij,njk->nik", lin.W, Hinv[pi])        # [No,6,3]
+    b = lin.gc - _scatter_add(Nc, ci, np.einsum("nij,nj->ni", WH, lin.gp[pi]))
+    order = np.argsort(pi, kind="stable")
+    ptr = np.searchsorted(pi[order], np.arange(problem.points.shape[0] + 1))
+    # group tracks by length to vectorise the pair loop; duplicates are summed by coo->dense
+    import scipy.sparse as sp
+    lens = np.diff(ptr)
+    rows_l, cols_l, vals_l = [], [], []
+    i6 = np.arange(6)
+    for L in np.unique(lens):
+        if L == 0:
+            continue
+        pts = np.nonzero(lens == L)[0]
+        idx = order[ptr[pts][:, None] + np.arange(L)[None, :]]     # [n,L] obs ids
+        for a_ in range(L):
+            for b_ in range(L):
+                blk = np.einsum("nij,nkj->nik", WH[idx[:, a_]], lin.W[idx[:, b_]])  # [n,6,6]
+                ca, cb = ci[idx[:, a_]], ci[idx[:, b_]]
+                rows = np.broadcast_to(6 * ca[:, None, None] + i6[None, :, None], blk.shape)
+                cols = np.broadcast_to(6 * cb[:, None, None] + i6[None, None, :], blk.shape)
+                rows_l.append(rows.reshape(-1)); cols_l.append(cols.reshape(-1)); vals_l.append(blk.reshape(-1))
+    if vals_l:
+        S -= sp.coo_matrix((np.concatenate(vals_l), (np.concatenate(rows_l), np.concatenate(cols_l))),
+                           shape=S.shape).toarray()
+    cf = sla.cho_factor(S, lower=True, check_finite=False)
+    yc = sla.cho_solve(cf, b.reshape(-1), check_finite=False).reshape(Nc, 6)
+    yp = _back_substitute(problem, lin, Hinv, yc)
+    return yc, yp, 0
+
+
+def _scatter_add(n, idx, vals):
+    out = np.zeros((n,) + vals.shape[1:])
+    np.add.at(out, idx, vals)
+    return out
+
+
+def _back_substitute(problem, lin, Hinv, yc):
+    pi, ci = problem.obs_pt, problem.obs_cam
+    Np = problem.points.shape[0]
+    Wty = _scatter_add(Np, pi, np.einsum("nij,ni->nj", lin.W, yc[ci]))
+    return np.einsum("nij,nj->ni", Hinv, lin.gp - Wty)
+
+
+def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter):
+    """Implicit-Schur PCG with block-Jacobi (6x6) preconditioner.
+
+    Same iteration the HIP path runs: x0 = 0, stop when
+    |r|_2 <= tol * |b|_2.
+    """
+    Nc, Np = problem.cam_q.shape[0], problem.points.shape[0]
+    ci, pi = problem.obs_cam, problem.obs_pt
+    Hinv = np.linalg.inv(lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3)))
+    WH = np.einsum("nij,njk->nik", lin.W, Hinv[pi])
+    b = lin.gc - _scatter_add(Nc, ci, np.einsum("nij,nj->ni", WH, lin.gp[pi]))
+    Scc = lin.Hcc + np.einsum("ni,ij->nij", Dc2, np.eye(6)) \
+        - _scatter_add(Nc, ci, np.einsum("nij,nkj->nik", WH, lin.W))
+    Minv = np.linalg.inv(Scc)
+
+    def matvec(p):
+        v = np.einsum("nki,ni->nk", lin.Fs, p[ci])
+        tj = _scatter_add(Np, pi, np.einsum("nki,nk->ni", lin.Es, v))
+        u = np.einsum("nij,nj->ni", Hinv, tj)
+        zz = v - np.einsum("nki,ni->nk", lin.Es, u[pi])
+        return Dc2 * p + _scatter_add(Nc, ci, np.einsum("nki,nk->ni", lin.Fs, zz))
+
+    x = np.zeros((Nc, 6)); r = b.copy()
+    z = np.einsum("nij,nj->ni", Minv, r); p = z.copy()
+    rz = float(np.sum(r * z)); bnorm = float(np.linalg.norm(b)); it = 0
+    if bnorm == 0.0:
+        return x, _back_substitute(problem, lin, Hinv, x), 0
+    while it < max_iter:
+        if float(np.linalg.norm(r)) <= tol * bnorm:
+            break
+        qv = matvec(p)
+        alpha = rz / float(np.sum(p * qv))
+        x += alpha * p; r -= alpha * qv
+        z = np.einsum("nij,nj->ni", Minv, r)
+        rz_new = float(np.sum(r * z))
+        p = z + (rz_new / rz) * p; rz = rz_new; it += 1
+    return x, _back_substitute(problem, lin, Hinv, x), it
+
+
+# ----------------------------------------------------------------------------
+# trust-region loop (Appendix A.5 / A.6)
+# ----------------------------------------------------------------------------
+def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
+    """Levenberg-Marquardt on `problem`, results written in place (like Ceres)."""
+    opt = opt or Options()
+    summ = Summary()
+    q = problem.cam_q.copy(); t = problem.cam_t.copy(); P = problem.points.copy()
+    qvar = (problem.cam_const & 1) == 0
+    tvar = (problem.cam_const & 2) == 0
+    act = _active_points(problem)
+    pvar = (problem.point_const == 0) & act
+    # cameras without observations are not part of the program (ba_solver.cc:350-352)
+    cam_act = np.zeros(q.shape[0], bool); cam_act[problem.obs_cam] = True
+    qvar &= cam_act; tvar &= cam_act
+    summ.num_residuals = 2 * problem.obs_cam.shape[0]
+    summ.num_effective_params = int(3 * qvar.sum() + 3 * tvar.sum() + 3 * pvar.sum())
+
+    def x_norm(q_, t_, P_):
+        return math.sqrt(float((q_[qvar] ** 2).sum() + (t_[tvar] ** 2).sum() + (P_[pvar] ** 2).sum()))
+
+    a = opt.huber_a
+    cost, rt, Fc, Ep = evaluate(problem, q, t, P, a)
+    summ.initial_cost = cost
+    # Jacobi scaling, computed once at iteration 0: 1/(1+||col||)
+    ci, pi = problem.obs_cam, problem.obs_pt
+    cn_c = np.sqrt(_scatter_add(q.shape[0], ci, np.sum(Fc * Fc, axis=1)))
+    cn_p = np.sqrt(_scatter_add(P.shape[0], pi, np.sum(Ep * Ep, axis=1)))
+    sc_c = 1.0 / (1.0 + cn_c); sc_p = 1.0 / (1.0 + cn_p)
+
+    def linearize(rt_, Fc_, Ep_):
+        return _Linearization(problem, rt_, Fc_ * sc_c[ci][:, None, :], Ep_ * sc_p[pi][:, None, :])
+
+    def grad_max(lin_, q_, t_, P_):
+        # Ceres: |x - Plus(x, -g)|_inf with the unscaled gradient
+        gc = lin_.gc / sc_c; gp = lin_.gp / sc_p
+        m = 0.0
+        if qvar.any():
+            m = max(m, float(np.abs(q_[qvar] - quat_plus(q_[qvar], -gc[qvar, 0:3])).max()))
+        if tvar.any():
+            m = max(m, float(np.abs(gc[tvar, 3:6]).max()))
+        if pvar.any():
+            m = max(m, float(np.abs(gp[pvar]).max()))
+        return m
+
+    lin = linearize(rt, Fc, Ep)
+    summ.trace.append(dict(it=0, cost=cost, radius=opt.initial_radius, ok=True))
+
+    def finish(term, cost_):
+        summ.termination = term
+        summ.final_cost = cost_
+        problem.cam_q[:] = q; problem.cam_t[:] = t; problem.points[:] = P
+        return summ
+
+    if grad_max(lin, q, t, P) <= opt.gradient_tolerance:
+        return finish("CONVERGENCE: gradient tolerance", cost)
+
+    radius = opt.initial_radius
+    decrease = 2.0
+    xn = x_norm(q, t, P)
+    it = 0
+    invalid = 0
+    while True:
+        if it >= opt.max_iterations:
+            return finish("NO_CONVERGENCE: max iterations", cost)
+        it += 1
+        diag_c = np.clip(np.einsum("nii->ni", lin.Hcc), opt.min_lm_diagonal, opt.max_lm_diagonal)
+        diag_p = np.clip(np.einsum("nii->ni", lin.Hpp), opt.min_lm_diagonal, opt.max_lm_diagonal)
+        Dc2 = diag_c / radius; Dp2 = diag_p / radius
+        if opt.linear_solver == "exact":
+            yc, yp, k = _solve_exact(problem, lin, Dc2, Dp2)
+        else:
+            yc, yp, k = _solve_pcg(problem, lin, Dc2, Dp2, opt.pcg_tol, opt.pcg_max_iter)
+        summ.pcg_iterations += k
+        ok = np.isfinite(yc).all() and np.isfinite(yp).all()
+        # step = -y; model residual m = Js*step
+        mres = -(np.einsum("nki,ni->nk", lin.Fs, yc[ci]) + np.einsum("nki,ni->nk", lin.Es, yp[pi]))
+        model_change = -float(np.sum(mres * (lin.rt + 0.5 * mres)))
+        if (not ok) or not (model_change > 0.0):
+            invalid += 1
+            summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=False, invalid=True))
+            if invalid >= opt.max_consecutive_invalid_steps:
+                return finish("FAILURE: too many invalid steps", cost)
+            radius /= decrease; decrease *= 2.0
+            summ.n_unsuccessful += 1
+            continue
+        invalid = 0
+        dc = -yc * sc_c; dp = -yp * sc_p
+        dc[~qvar, 0:3] = 0.0; dc[~tvar, 3:6] = 0.0; dp[~pvar] = 0.0
+        q2 = q.copy(); q2[qvar] = quat_plus(q[qvar], dc[qvar, 0:3])
+        t2 = t + dc[:, 3:6]
+        P2 = P + dp
+        cost2 = evaluate(problem, q2, t2, P2, a, want_jac=False)
+        step_norm = math.sqrt(float(((q2 - q)[qvar] ** 2).sum() + ((t2 - t)[tvar] ** 2).sum()
+                                    + ((P2 - P)[pvar] ** 2).sum()))
+        if step_norm <= opt.parameter_tolerance * (xn + opt.parameter_tolerance):
+            summ.trace.append(dict(it=it, cost=cost2, radius=radius, ok=None, step_norm=step_norm))
+            return finish("CONVERGENCE: parameter tolerance", cost)
+        cost_change = cost - cost2
+        if abs(cost_change) <= opt.function_tolerance * cost:
+            summ.trace.append(dict(it=it, cost=cost2, radius=radius, ok=None, step_norm=step_norm))
+            return finish("CONVERGENCE: function tolerance", cost)
+        rel = cost_change / model_change
+        if rel > opt.min_relative_decrease:
+            q, t, P = q2, t2, P2
+            xn = x_norm(q, t, P)
+            cost, rt, Fc, Ep = evaluate(problem, q, t, P, a)
+            lin = linearize(rt, Fc, Ep)
+            radius = min(opt.max_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) ** 3))
+            decrease = 2.0
+            summ.n_successful += 1
+            summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=True, step_norm=step_norm,
+                                   rel=rel, model_change=model_change))
+            if grad_max(lin, q, t, P) <= opt.gradient_tolerance:
+                return finish("CONVERGENCE: gradient tolerance", cost)
+        else:
+            radius /= decrease; decrease *= 2.0
+            summ.n_unsuccessful += 1
+            summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=False, step_norm=step_norm,
+                                   rel=rel, model_change=model_change))
+            if radius < opt.min_radius:
+                return finish("CONVERGENCE: min trust region radius", cost)

@@ -1,0 +1,164 @@
+"""GPU parity tests (call through the C-ABI; oracle = oracle/ba_oracle.py, parity unpinned vs real Ceres).
+
+Tolerances: kernel-level blocks 1e-11 relative (FP64, different summation order);
+full solves: reference-style RMSE within 1e-6 px, camera parameters within 1e-5
+(BASELINE.json north_star).
+"""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import ba_oracle as bo
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _lin_oracle(pr, use_scaling):
+    cost, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    ci, pi = pr.obs_cam, pr.obs_pt
+    if use_scaling:
+        sc_c = 1 / (1 + np.sqrt(bo._scatter_add(pr.cam_q.shape[0], ci, np.sum(Fc * Fc, axis=1))))
+        sc_p = 1 / (1 + np.sqrt(bo._scatter_add(pr.points.shape[0], pi, np.sum(Ep * Ep, axis=1))))
+        Fc = Fc * sc_c[ci][:, None, :]; Ep = Ep * sc_p[pi][:, None, :]
+    return cost, rt, Fc, Ep, bo._Linearization(pr, rt, Fc, Ep)
+
+
+@pytest.mark.parametrize("use_scaling", [False, True])
+@pytest.mark.parametrize("variant", ["kitti", "models", "behind", "consts"])
+def test_linearize_blocks(lib, variant, use_scaling):
+    from xrsfm_amd import capi
+    arr = H.make(8, 300, 4, seed=101)
+    if variant == "models":
+        arr = H.with_models(arr, seed=3)
+    if variant == "behind":      # some points behind / too close to their cameras -> clamp branch (12,12), J = 0
+        arr["points"][::7] += np.array([0.0, 0.0, -60.0])
+    if variant == "consts":
+        arr["cam_const"][:] = 0; arr["cam_const"][2] = 3; arr["cam_const"][5] = 1
+        arr["point_const"][::3] = 1
+    pr = H.to_oracle(arr)
+    ctx = capi.Context(H.to_product(arr))
+    out = ctx.debug_linearize(5.99, use_scaling)
+    cost, rt, Fc, Ep, lin = _lin_oracle(pr, use_scaling)
+    assert abs(out["cost"] - cost) <= 1e-12 * cost
+    assert H.rel_err(out["r"], rt) < 1e-12
+    assert H.rel_err(out["Jc"], Fc) < 1e-11
+    assert H.rel_err(out["Jp"], Ep) < 1e-11
+    Hpp = lin.Hpp
+    got = out["Hpp"]
+    ref = np.stack([Hpp[:, 0, 0], Hpp[:, 0, 1], Hpp[:, 0, 2], Hpp[:, 1, 1], Hpp[:, 1, 2], Hpp[:, 2, 2]], axis=1)
+    assert H.rel_err(got, ref) < 1e-11
+    assert H.rel_err(out["gp"], lin.gp) < 1e-11
+    assert H.rel_err(out["Hcc_diag"], np.einsum("nii->ni", lin.Hcc)) < 1e-11
+    assert H.rel_err(out["gc"], lin.gc) < 1e-11
+    if variant == "behind":
+        assert (np.abs(out["r"] - 12.0 * math.sqrt(5.99 / math.sqrt(288.0))).max(axis=1) < 1e-12).sum() > 10
+    ctx.close()
+
+
+@pytest.mark.parametrize("k_obs,n_pts", [(4, 300), (3, 257), (70, 12)])
+def test_schur_product(lib, k_obs, n_pts):
+    """y = S x and rhs b against the dense Schur complement of the oracle (long tracks: k_obs=70 > 64 lanes)."""
+    from xrsfm_amd import capi
+    n_cams = 8 if k_obs < 10 else 80
+    arr = H.make(n_cams, n_pts, k_obs, seed=102, min_tri_angle_deg=0.5)
+    pr = H.to_oracle(arr)
+    ctx = capi.Context(H.to_product(arr))
+    ctx.debug_linearize(5.99, True)
+    _, _, _, _, lin = _lin_oracle(pr, True)
+    radius = 1e4
+    Dc2 = np.clip(np.einsum("nii->ni", lin.Hcc), 1e-6, 1e32) / radius
+    Dp2 = np.clip(np.einsum("nii->ni", lin.Hpp), 1e-6, 1e32) / radius
+    Hinv = np.linalg.inv(lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3)))
+    ci, pi = pr.obs_cam, pr.obs_pt
+    rng = np.random.default_rng(5)
+    x = rng.normal(size=(n_cams, 6))
+    v = np.einsum("nki,ni->nk", lin.Fs, x[ci])
+    tj = bo._scatter_add(n_pts, pi, np.einsum("nki,nk->ni", lin.Es, v))
+    u = np.einsum("nij,nj->ni", Hinv, tj)
+    zz = v - np.einsum("nki,ni->nk", lin.Es, u[pi])
+    y_ref = Dc2 * x + bo._scatter_add(n_cams, ci, np.einsum("nki,nk->ni", lin.Fs, zz))
+    WH = np.einsum("nij,njk->nik", lin.W, Hinv[pi])
+    b_ref = lin.gc - bo._scatter_add(n_cams, ci, np.einsum("nij,nj->ni", WH, lin.gp[pi]))
+    y, b = ctx.debug_schur_product(radius, x)
+    assert H.rel_err(y, y_ref) < 1e-10
+    assert H.rel_err(b, b_ref) < 1e-10
+    ctx.close()
+
+
+def _solve_both(arr, opt_kw=None, oracle_solver="exact"):
+    from xrsfm_amd import capi
+    opt_kw = opt_kw or {}
+    pr = H.to_oracle(arr)
+    o = bo.Options(linear_solver=oracle_solver, **{k: v for k, v in opt_kw.items() if hasattr(bo.Options, k)})
+    s_ref = bo.solve(pr, o)
+    prod = H.to_product(arr)
+    copt = capi.default_options(**{k: v for k, v in opt_kw.items()})
+    s = capi.solve(prod, copt)
+    return pr, s_ref, prod, s
+
+
+@pytest.mark.parametrize("variant", ["kitti", "models", "structure_only", "lba", "kgba"])
+def test_full_solve_parity(lib, variant):
+    arr = H.make(10, 400, 4, seed=103)
+    kw = {}
+    if variant == "models":
+        arr = H.with_models(arr, seed=4)
+    if variant == "structure_only":          # GBA(map, true, true): every pose constant (ba_solver.cc:616-621)
+        arr["cam_const"][:] = 3
+    if variant == "lba":                     # LBA options + points not seen by the new frame constant (:380-382,:587-589)
+        kw = dict(max_iterations=5, function_tolerance=1e-4, parameter_tolerance=1e-5)
+        seen = np.zeros(arr["points"].shape[0], bool); seen[arr["obs_pt"][arr["obs_cam"] == 9]] = True
+        arr["point_const"][:] = (~seen).astype(np.uint8)
+    if variant == "kgba":                    # KGBA options (:667-670)
+        kw = dict(max_iterations=20, function_tolerance=1e-4, parameter_tolerance=1e-5, initial_radius=1e6)
+    pr, s_ref, prod, s = _solve_both(arr, kw)
+    n_res = 2 * arr["obs_cam"].shape[0]
+    rmse_ref = math.sqrt(s_ref.final_cost / n_res); rmse = math.sqrt(s.final_cost / n_res)
+    assert s.n_successful == s_ref.n_successful and s.n_unsuccessful == s_ref.n_unsuccessful
+    assert abs(math.sqrt(s.initial_cost / n_res) - math.sqrt(s_ref.initial_cost / n_res)) < 1e-9
+    assert abs(rmse - rmse_ref) < 1e-6
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5
+    assert np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
+    assert s.num_residuals == s_ref.num_residuals and s.num_effective_params == s_ref.num_effective_params
+    # the plain RMSE of the returned state, evaluated by the oracle
+    r_plain_prod = bo.rmse_pair(H.to_oracle(prod.as_dict()))[1]
+    r_plain_ref = bo.rmse_pair(pr)[1]
+    assert abs(r_plain_prod - r_plain_ref) < 1e-6
+
+
+def test_context_reset_and_rerun(lib):
+    from xrsfm_amd import capi
+    arr = H.make(8, 200, 4, seed=104)
+    ctx = capi.Context(H.to_product(arr))
+    s1 = ctx.run()
+    q1, t1, P1 = ctx.download()
+    ctx.reset()
+    s2 = ctx.run()
+    q2, t2, P2 = ctx.download()
+    assert s1.final_cost == s2.final_cost and s1.n_successful == s2.n_successful
+    assert np.array_equal(q1, q2) and np.array_equal(t1, t2) and np.array_equal(P1, P2)   # bit-reproducible
+    ctx.close()
+
+
+def test_edge_cases(lib):
+    from xrsfm_amd import capi
+    arr = H.make(6, 50, 3, seed=105)
+    # a point without observations and a camera without observations must be left untouched
+    arr["points"] = np.concatenate([arr["points"], [[1.0, 2.0, 3.0]]]); arr["point_const"] = np.append(arr["point_const"], 0).astype(np.uint8)
+    arr["cam_q"] = np.concatenate([arr["cam_q"], [[0, 0, 0, 1.0]]]); arr["cam_t"] = np.concatenate([arr["cam_t"], [[4.0, 5.0, 6.0]]])
+    arr["cam_const"] = np.append(arr["cam_const"], 0).astype(np.uint8); arr["cam_intr"] = np.append(arr["cam_intr"], 0).astype(np.int32)
+    pr, s_ref, prod, s = _solve_both(arr)
+    assert np.array_equal(prod.points[-1], [1.0, 2.0, 3.0]) and np.array_equal(prod.cam_t[-1], [4.0, 5.0, 6.0])
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost
+    # empty problem
+    empty = capi.ProblemArrays(cam_q=np.zeros((0, 4)), cam_t=np.zeros((0, 3)), cam_intr=np.zeros(0, np.int32),
+                               intr_model=np.zeros(0, np.int32), intr_params=np.zeros((0, 8)), points=np.zeros((0, 3)),
+                               obs_cam=np.zeros(0, np.int32), obs_pt=np.zeros(0, np.int32), obs_uv=np.zeros((0, 2)))
+    s0 = capi.solve(empty)
+    assert s0.final_cost == 0.0 and s0.termination == 0
+    # bad index -> EINVAL, not a crash
+    bad = H.to_product(arr); bad.obs_cam[0] = 99
+    with pytest.raises(RuntimeError):
+        capi.solve(bad)

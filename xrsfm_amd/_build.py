@@ -1,0 +1,41 @@
+"""Build helpers: compile the HIP library (gfx950) and the C test oracle in-tree."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "xrsfm_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "xrsfm_amd", "lib")
+LIB = os.path.join(LIBDIR, "libxrsfm_ba.so")
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def lib_sources():
+    srcs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(ROOT, "include", "xrsfm_ba.h"))
+    return srcs
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> xrsfm_amd/lib/libxrsfm_ba.so (cross-compiles without a GPU)."""
+    srcs = lib_sources()
+    if not force and _newer(LIB, srcs):
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libxrsfm_ba.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+           "-o", LIB, os.path.join(CSRC, "xrsfm_ba.hip"), "-ldl"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=ROOT)
+    return LIB

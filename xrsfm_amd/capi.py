@@ -1,0 +1,234 @@
+"""ctypes binding of the C-ABI in include/xrsfm_ba.h (the product path: HIP only).
+
+There is deliberately no CPU fallback here: if the shared library is missing or
+no HIP device is visible the calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import _build
+
+_c_double_p = C.POINTER(C.c_double)
+_c_int32_p = C.POINTER(C.c_int32)
+_c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class CProblem(C.Structure):
+    _fields_ = [
+        ("n_cams", C.c_int32), ("n_points", C.c_int32), ("n_obs", C.c_int32), ("n_intr", C.c_int32),
+        ("cam_q", _c_double_p), ("cam_t", _c_double_p), ("cam_const", _c_uint8_p), ("cam_intr", _c_int32_p),
+        ("intr_model", _c_int32_p), ("intr_params", _c_double_p),
+        ("points", _c_double_p), ("point_const", _c_uint8_p),
+        ("obs_cam", _c_int32_p), ("obs_pt", _c_int32_p), ("obs_uv", _c_double_p),
+    ]
+
+
+class COptions(C.Structure):
+    _fields_ = [
+        ("max_iterations", C.c_int32), ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+        ("gradient_tolerance", C.c_double), ("initial_radius", C.c_double), ("huber_a", C.c_double),
+        ("linear_solver", C.c_int32), ("pcg_tolerance", C.c_double), ("pcg_max_iterations", C.c_int32),
+        ("profile", C.c_int32), ("verbose", C.c_int32),
+    ]
+
+
+class CSummary(C.Structure):
+    _fields_ = [
+        ("initial_cost", C.c_double), ("final_cost", C.c_double),
+        ("num_residuals", C.c_int32), ("num_effective_params", C.c_int32),
+        ("n_successful", C.c_int32), ("n_unsuccessful", C.c_int32),
+        ("termination", C.c_int32), ("termination_reason", C.c_int32),
+        ("pcg_iterations", C.c_int32), ("lm_steps_attempted", C.c_int32),
+        ("total_time_s", C.c_double), ("dom_kernel_ms", C.c_double),
+        ("dom_kernel_launches", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+    def as_dict(self):
+        return {f: getattr(self, f) for f, _ in self._fields_}
+
+
+# every symbol include/xrsfm_ba.h declares
+EXPORTS = [
+    "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
+    "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
+    "xrsfm_ba_solve", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
+]
+
+ERRORS = {-1: "EINVAL", -2: "ENODEV (no HIP device / HIP error; there is no CPU fallback)", -3: "ENOMEM",
+          -4: "ECOMM", -5: "ESTATE"}
+
+_lib = None
+
+
+def load(path: str | None = None):
+    """dlopen libxrsfm_ba.so.  torch (if used in this process) must be imported
+    first so both share one HIP runtime (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or _build.LIB
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                           "the BA path has no fallback implementation")
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    vp = C.c_void_p
+    lib.xrsfm_ba_default_options.argtypes = [C.POINTER(COptions)]; lib.xrsfm_ba_default_options.restype = None
+    lib.xrsfm_ba_version.argtypes = [C.POINTER(C.c_int)]; lib.xrsfm_ba_version.restype = C.c_int
+    lib.xrsfm_ba_create.argtypes = [C.POINTER(CProblem), C.c_int, C.POINTER(vp)]; lib.xrsfm_ba_create.restype = C.c_int
+    lib.xrsfm_ba_comm_unique_id.argtypes = [C.c_char_p]; lib.xrsfm_ba_comm_unique_id.restype = C.c_int
+    lib.xrsfm_ba_comm_init.argtypes = [vp, C.c_int, C.c_int, C.c_char_p]; lib.xrsfm_ba_comm_init.restype = C.c_int
+    lib.xrsfm_ba_run.argtypes = [vp, C.POINTER(COptions), C.POINTER(CSummary)]; lib.xrsfm_ba_run.restype = C.c_int
+    lib.xrsfm_ba_reset.argtypes = [vp]; lib.xrsfm_ba_reset.restype = C.c_int
+    lib.xrsfm_ba_download.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p]; lib.xrsfm_ba_download.restype = C.c_int
+    lib.xrsfm_ba_destroy.argtypes = [vp]; lib.xrsfm_ba_destroy.restype = None
+    lib.xrsfm_ba_solve.argtypes = [C.POINTER(COptions), C.POINTER(CProblem), C.POINTER(CSummary)]; lib.xrsfm_ba_solve.restype = C.c_int
+    lib.xrsfm_ba_debug_linearize.argtypes = [vp, C.c_double, C.c_int] + [_c_double_p] * 8
+    lib.xrsfm_ba_debug_linearize.restype = C.c_int
+    lib.xrsfm_ba_debug_schur_product.argtypes = [vp, C.c_double, _c_double_p, _c_double_p, _c_double_p]
+    lib.xrsfm_ba_debug_schur_product.restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what} failed: {code} {ERRORS.get(code, '')}")
+
+
+def _dp(a):
+    return a.ctypes.data_as(_c_double_p) if a is not None else None
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    load().xrsfm_ba_version(C.byref(n))
+    return n.value
+
+
+def default_options(**kw) -> COptions:
+    o = COptions()
+    load().xrsfm_ba_default_options(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise AttributeError(k)
+        setattr(o, k, v)
+    return o
+
+
+class ProblemArrays:
+    """Owns contiguous numpy arrays of one BA call and the matching C struct."""
+    FIELDS = ("cam_q", "cam_t", "cam_const", "cam_intr", "intr_model", "intr_params",
+              "points", "point_const", "obs_cam", "obs_pt", "obs_uv")
+
+    def __init__(self, **arr):
+        f64 = lambda a, s: np.ascontiguousarray(np.asarray(a, np.float64).reshape(s))
+        self.cam_q = f64(arr["cam_q"], (-1, 4)); self.cam_t = f64(arr["cam_t"], (-1, 3))
+        n_c = self.cam_q.shape[0]
+        cc = arr.get("cam_const")
+        self.cam_const = np.ascontiguousarray(np.zeros(n_c, np.uint8) if cc is None else np.asarray(cc, np.uint8))
+        self.cam_intr = np.ascontiguousarray(np.asarray(arr["cam_intr"], np.int32))
+        self.intr_model = np.ascontiguousarray(np.asarray(arr["intr_model"], np.int32))
+        self.intr_params = f64(arr["intr_params"], (-1, 8))
+        self.points = f64(arr["points"], (-1, 3))
+        pc = arr.get("point_const")
+        self.point_const = np.ascontiguousarray(np.zeros(self.points.shape[0], np.uint8) if pc is None else np.asarray(pc, np.uint8))
+        self.obs_cam = np.ascontiguousarray(np.asarray(arr["obs_cam"], np.int32))
+        self.obs_pt = np.ascontiguousarray(np.asarray(arr["obs_pt"], np.int32))
+        self.obs_uv = f64(arr["obs_uv"], (-1, 2))
+        assert self.cam_t.shape[0] == n_c and self.cam_intr.shape[0] == n_c and self.cam_const.shape[0] == n_c
+        assert self.obs_pt.shape[0] == self.obs_cam.shape[0] == self.obs_uv.shape[0]
+
+    @property
+    def n_cams(self): return self.cam_q.shape[0]
+    @property
+    def n_points(self): return self.points.shape[0]
+    @property
+    def n_obs(self): return self.obs_cam.shape[0]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k in self.FIELDS}
+
+    def c_struct(self) -> CProblem:
+        i32 = lambda a: a.ctypes.data_as(_c_int32_p)
+        u8 = lambda a: a.ctypes.data_as(_c_uint8_p)
+        return CProblem(self.n_cams, self.n_points, self.n_obs, self.intr_model.shape[0],
+                        _dp(self.cam_q), _dp(self.cam_t), u8(self.cam_const), i32(self.cam_intr),
+                        i32(self.intr_model), _dp(self.intr_params), _dp(self.points), u8(self.point_const),
+                        i32(self.obs_cam), i32(self.obs_pt), _dp(self.obs_uv))
+
+
+class Context:
+    """Device-resident BA problem (xrsfm_ba_create ... xrsfm_ba_destroy)."""
+
+    def __init__(self, problem: ProblemArrays, device: int = 0):
+        self.lib = load()
+        self.problem = problem
+        self._h = C.c_void_p()
+        cs = problem.c_struct()
+        check(self.lib.xrsfm_ba_create(C.byref(cs), device, C.byref(self._h)), "xrsfm_ba_create")
+
+    def close(self):
+        if self._h:
+            self.lib.xrsfm_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def comm_init(self, n_ranks: int, rank: int, unique_id: bytes):
+        check(self.lib.xrsfm_ba_comm_init(self._h, n_ranks, rank, unique_id), "xrsfm_ba_comm_init")
+
+    def run(self, options: COptions | None = None) -> CSummary:
+        options = options or default_options()
+        s = CSummary()
+        check(self.lib.xrsfm_ba_run(self._h, C.byref(options), C.byref(s)), "xrsfm_ba_run")
+        return s
+
+    def reset(self):
+        check(self.lib.xrsfm_ba_reset(self._h), "xrsfm_ba_reset")
+
+    def download(self):
+        p = self.problem
+        q = np.empty_like(p.cam_q); t = np.empty_like(p.cam_t); P = p.points.copy()
+        check(self.lib.xrsfm_ba_download(self._h, _dp(q), _dp(t), _dp(P)), "xrsfm_ba_download")
+        return q, t, P
+
+    def debug_linearize(self, huber_a: float = 5.99, use_scaling: bool = False):
+        p = self.problem
+        out = dict(r=np.zeros((p.n_obs, 2)), Jc=np.zeros((p.n_obs, 2, 6)), Jp=np.zeros((p.n_obs, 2, 3)),
+                   Hpp=np.zeros((p.n_points, 6)), gp=np.zeros((p.n_points, 3)),
+                   Hcc_diag=np.zeros((p.n_cams, 6)), gc=np.zeros((p.n_cams, 6)))
+        cost = C.c_double(0)
+        check(self.lib.xrsfm_ba_debug_linearize(self._h, huber_a, int(use_scaling), _dp(out["r"]), _dp(out["Jc"]),
+                                                _dp(out["Jp"]), _dp(out["Hpp"]), _dp(out["gp"]), _dp(out["Hcc_diag"]),
+                                                _dp(out["gc"]), C.cast(C.byref(cost), _c_double_p)), "debug_linearize")
+        out["cost"] = cost.value
+        return out
+
+    def debug_schur_product(self, radius: float, x: np.ndarray):
+        x = np.ascontiguousarray(x, np.float64)
+        y = np.zeros_like(x); b = np.zeros_like(x)
+        check(self.lib.xrsfm_ba_debug_schur_product(self._h, radius, _dp(x), _dp(y), _dp(b)), "debug_schur_product")
+        return y, b
+
+
+def comm_unique_id() -> bytes:
+    buf = C.create_string_buffer(128)
+    check(load().xrsfm_ba_comm_unique_id(buf), "xrsfm_ba_comm_unique_id")
+    return buf.raw
+
+
+def solve(problem: ProblemArrays, options: COptions | None = None) -> CSummary:
+    """One-shot xrsfm_ba_solve: results are written into problem.cam_q / cam_t / points."""
+    options = options or default_options()
+    s = CSummary()
+    cs = problem.c_struct()
+    check(load().xrsfm_ba_solve(C.byref(options), C.byref(cs), C.byref(s)), "xrsfm_ba_solve")
+    return s

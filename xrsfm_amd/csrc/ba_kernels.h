@@ -1,0 +1,784 @@
+// HIP kernels (gfx950 / CDNA4, wave64) of the Schur-complement LM iteration.
+//
+// Data layout: observations are sorted by track and packed
+// into 64-slot *tiles*, one wavefront per tile, whole tracks per tile, so that
+// every per-track sum (3x3 point blocks, E^T v) is a segmented wave reduction
+// with shuffles and every per-observation array is a lane-contiguous SoA stream
+// (512 B per wave-load).  Tracks longer than 64 observations own a run of whole
+// tiles handled by one wave ("long item").  Camera-side sums go through a
+// camera-major scatter buffer + a fixed-order segmented sum, so results are
+// bit-reproducible for a given tiling (no floating-point atomics anywhere).
+#pragma once
+#include "ba_math.h"
+
+namespace xba {
+
+constexpr int kWave = 64;
+constexpr int kBlock = 256;          // 4 waves per workgroup, waves are independent
+constexpr int kWavesPerBlock = kBlock / kWave;
+
+struct Item { int first_tile; int n_tiles; };
+
+// status words of the PCG loop, device resident
+struct PcgStatus {
+    double rz;      // r^T M^-1 r
+    double rr;      // |r|^2
+    double bb;      // |b|^2
+    double pq;
+    int it;
+    int done;
+};
+
+// scalar slots (device buffer `scal`)
+enum Scal {
+    S_COST = 0, S_XNORM2_PTS, S_COST_CAND, S_MODEL, S_STEP2_PTS, S_STEP2_CAMS, S_XNORM2_CAMS,
+    S_GRADMAX_PTS, S_GRADMAX_CAMS, S_COUNT = 16
+};
+
+struct Dev {
+    int n_cams, n_pts, n_tiles, n_slots, n_items;
+    // per slot
+    const int* slot_cam; const int* slot_pt; const int* slot_campos;
+    const double* slot_u; const double* slot_v;
+    const Item* items;
+    // cameras
+    CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
+    // points (AoS xyz)
+    double* P; double* P_cand; const unsigned char* pt_const;
+    // Jacobi scaling
+    double* scale_c; double* scale_p;
+    // linearisation (SoA over slots: component-major)
+    double* rt; double* Fs; double* Es;
+    double* Hpp; double* gp; double* Hinv;
+    double* camlin;     // [Nc][12]: diag(Hcc) (6), gc (6)
+    double* Dc2;        // [Nc][6]
+    double* camS;       // [Nc][28]: Scc upper (21), rb (6), pad
+    double* Minv;       // [Nc][21]
+    double* b;          // [Nc][6]
+    // PCG vectors [Nc][6]
+    double* px; double* pr; double* pz; double* pp; double* pq;
+    double* yp;         // [Np][3] point step (scaled coords)
+    double* scat;       // camera-major scatter buffer, [n_obs][28]
+    double* part;       // per-item partial sums, 4 * n_items
+    double* campart;    // per-camera partials, 2 * n_cams
+    double* scal;       // S_COUNT scalars
+    PcgStatus* st;
+};
+
+// ---------------------------------------------------------------- wave helpers
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;  // valid in lane 0
+}
+
+// Segmented suffix-sum over contiguous segments (key = track id); the head lane
+// of each segment ends up with the segment total.  Fixed tree order.
+template <int N>
+__device__ __forceinline__ void seg_reduce(double (&v)[N], int key, int lane) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+        const int okey = __shfl_down(key, off, kWave);
+        const bool take = (lane + off < kWave) && (okey == key);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double o = __shfl_down(v[k], off, kWave);
+            if (take) v[k] += o;
+        }
+    }
+}
+
+__device__ __forceinline__ int seg_head_lane(bool head, int lane) {
+    const unsigned long long m = __ballot(head);
+    const unsigned long long below = m & ((2ull << lane) - 1ull);
+    return 63 - __clzll((long long)below);
+}
+
+struct SlotCtx {
+    int slot, cam, pt, lane;
+    bool valid, head;
+};
+
+__device__ __forceinline__ SlotCtx load_slot(const Dev& d, int tile, int lane) {
+    SlotCtx s;
+    s.lane = lane;
+    s.slot = tile * kWave + lane;
+    s.cam = d.slot_cam[s.slot];
+    s.pt = d.slot_pt[s.slot];
+    s.valid = s.cam >= 0;
+    const int prev = __shfl_up(s.pt, 1, kWave);
+    s.head = s.valid && (lane == 0 || prev != s.pt);
+    return s;
+}
+
+// ---------------------------------------------------------------- linearise
+// Residuals, robustified + Jacobi-scaled Jacobian blocks, per-track H_pp / g_p
+// (segmented wave reduction), per-observation camera-side terms into the
+// camera-major scatter buffer, cost and |x_points|^2 partials.
+__global__ __launch_bounds__(kBlock) void k_linearize(Dev d, double huber_a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    const bool is_long = it.n_tiles > 1;
+    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double cost = 0.0, xn2 = 0.0;
+    int long_pt = -1;
+    for (int tl = 0; tl < it.n_tiles; ++tl) {
+        const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
+        double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (s.valid) {
+            const CamRec& c = d.cam[s.cam];
+            double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
+            double t[3] = {c.t[0], c.t[1], c.t[2]};
+            const double* P = d.P + 3 * (size_t)s.pt;
+            const double Pw[3] = {P[0], P[1], P[2]};
+            double M[9];
+            quat_to_mat(q, M);
+            Proj pr;
+            project<true>(M, t, c.intr, d.cam_model[s.cam], Pw, d.slot_u[s.slot], d.slot_v[s.slot], pr);
+            double rho1;
+            const double rho = huber(pr.r0 * pr.r0 + pr.r1 * pr.r1, huber_a, rho1);
+            cost = cost + rho;
+            const double sw = sqrt(rho1);
+            const double r0 = pr.r0 * sw, r1 = pr.r1 * sw;
+            const unsigned cc = d.cam_const[s.cam];
+            const double mq = (cc & 1u) ? 0.0 : sw, mt = (cc & 2u) ? 0.0 : sw;
+            const double mp = d.pt_const[s.pt] ? 0.0 : sw;
+            const double* sc = d.scale_c + 6 * (size_t)s.cam;
+            const double* sp = d.scale_p + 3 * (size_t)s.pt;
+            double F[12], E[6];
+#pragma unroll
+            for (int row = 0; row < 2; ++row) {
+                const double* j = pr.jp + 3 * row;
+                // row^T (-2 [RP]x) = -2 (row x RP)
+                F[6 * row + 0] = -2.0 * (j[1] * pr.rp[2] - j[2] * pr.rp[1]) * mq * sc[0];
+                F[6 * row + 1] = -2.0 * (j[2] * pr.rp[0] - j[0] * pr.rp[2]) * mq * sc[1];
+                F[6 * row + 2] = -2.0 * (j[0] * pr.rp[1] - j[1] * pr.rp[0]) * mq * sc[2];
+                F[6 * row + 3] = j[0] * mt * sc[3];
+                F[6 * row + 4] = j[1] * mt * sc[4];
+                F[6 * row + 5] = j[2] * mt * sc[5];
+                E[3 * row + 0] = (j[0] * M[0] + j[1] * M[3] + j[2] * M[6]) * mp * sp[0];
+                E[3 * row + 1] = (j[0] * M[1] + j[1] * M[4] + j[2] * M[7]) * mp * sp[1];
+                E[3 * row + 2] = (j[0] * M[2] + j[1] * M[5] + j[2] * M[8]) * mp * sp[2];
+            }
+            const size_t ns = (size_t)d.n_slots;
+            d.rt[s.slot] = r0; d.rt[ns + s.slot] = r1;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) d.Fs[k * ns + s.slot] = F[k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d.Es[k * ns + s.slot] = E[k];
+            v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[0] * E[1] + E[3] * E[4]; v[2] = E[0] * E[2] + E[3] * E[5];
+            v[3] = E[1] * E[1] + E[4] * E[4]; v[4] = E[1] * E[2] + E[4] * E[5]; v[5] = E[2] * E[2] + E[5] * E[5];
+            v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
+            double2* out = reinterpret_cast<double2*>(d.scat + 12 * (size_t)d.slot_campos[s.slot]);
+            double cs[12];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                cs[k] = F[k] * F[k] + F[6 + k] * F[6 + k];
+                cs[6 + k] = F[k] * r0 + F[6 + k] * r1;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
+            if (s.head && (!is_long || tl == 0) && !d.pt_const[s.pt])
+                xn2 += Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
+            if (is_long && lane == 0 && tl == 0) long_pt = s.pt;
+        }
+        seg_reduce<9>(v, s.pt, lane);
+        if (!is_long) {
+            if (s.head) {
+                double* H = d.Hpp + 6 * (size_t)s.pt;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) H[k] = v[k];
+                double* g = d.gp + 3 * (size_t)s.pt;
+                g[0] = v[6]; g[1] = v[7]; g[2] = v[8];
+            }
+        } else if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += v[k];
+        }
+    }
+    if (is_long && lane == 0 && long_pt >= 0) {
+        double* H = d.Hpp + 6 * (size_t)long_pt;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) H[k] = acc[k];
+        double* g = d.gp + 3 * (size_t)long_pt;
+        g[0] = acc[6]; g[1] = acc[7]; g[2] = acc[8];
+    }
+    cost = wave_sum(cost);
+    xn2 = wave_sum(xn2);
+    if (lane == 0) { d.part[item] = cost; d.part[d.n_items + item] = xn2; }
+}
+
+// Cost only (1/2 sum rho is formed on the host side of the reduction), candidate state.
+__global__ __launch_bounds__(kBlock) void k_cost(Dev d, double huber_a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    double cost = 0.0;
+    for (int tl = 0; tl < it.n_tiles; ++tl) {
+        const int slot = (it.first_tile + tl) * kWave + lane;
+        const int cam = d.slot_cam[slot];
+        if (cam >= 0) {
+            const CamRec& c = d.cam_cand[cam];
+            double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
+            double t[3] = {c.t[0], c.t[1], c.t[2]};
+            const double* P = d.P_cand + 3 * (size_t)d.slot_pt[slot];
+            const double Pw[3] = {P[0], P[1], P[2]};
+            double M[9];
+            quat_to_mat(q, M);
+            Proj pr;
+            project<false>(M, t, c.intr, d.cam_model[cam], Pw, d.slot_u[slot], d.slot_v[slot], pr);
+            double rho1;
+            cost += huber(pr.r0 * pr.r0 + pr.r1 * pr.r1, huber_a, rho1);
+        }
+    }
+    cost = wave_sum(cost);
+    if (lane == 0) d.part[item] = cost;
+}
+
+// ---------------------------------------------------------------- camera-major segmented sum
+// One workgroup per camera; scat holds K doubles per observation in camera-major
+// order.  Thread (g,k) accumulates component k over observations g, g+G, ...;
+// the G partials are then added in fixed order.
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_cam_segsum(const double* __restrict__ scat, const int* __restrict__ cam_ptr,
+                                                       double* __restrict__ out, const PcgStatus* st) {
+    if (st && st->done) return;
+    constexpr int G = kBlock / K;
+    __shared__ double lds[G * K];
+    const int c = blockIdx.x;
+    const int t = threadIdx.x;
+    const int beg = cam_ptr[c], end = cam_ptr[c + 1];
+    if (t < G * K) {
+        const int g = t / K;
+        double acc = 0.0;
+        const double* base = scat + (size_t)beg * K + t;
+        const int n = end - beg;
+        for (int o = g; o < n; o += G) { acc += *base; base += (size_t)G * K; }
+        lds[t] = acc;
+    }
+    __syncthreads();
+    if (t < K) {
+        double s = 0.0;
+#pragma unroll 4
+        for (int g = 0; g < G; ++g) s += lds[g * K + t];
+        out[(size_t)c * K + t] = s;
+    }
+}
+
+// Jacobi scaling from the column norms of the unscaled Jacobian: 1/(1+|col|).
+__global__ void k_scale_from_norms(Dev d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < d.n_cams * 6) {
+        const int c = i / 6, k = i % 6;
+        d.scale_c[i] = 1.0 / (1.0 + sqrt(d.camlin[12 * (size_t)c + k]));
+    }
+    if (i < d.n_pts * 3) {
+        const int p = i / 3, k = i % 3;
+        const int di = (k == 0) ? 0 : (k == 1 ? 3 : 5);
+        d.scale_p[i] = 1.0 / (1.0 + sqrt(d.Hpp[6 * (size_t)p + di]));
+    }
+}
+
+__global__ void k_fill(double* p, double v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------- LM damping + point block inverse
+__global__ void k_point_prep(Dev d, double radius, double dmin, double dmax) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= d.n_pts) return;
+    const double* H = d.Hpp + 6 * (size_t)p;
+    double h[6] = {H[0], H[1], H[2], H[3], H[4], H[5]};
+    h[0] += clampd(h[0], dmin, dmax) / radius;
+    h[3] += clampd(h[3], dmin, dmax) / radius;
+    h[5] += clampd(h[5], dmin, dmax) / radius;
+    double inv[6];
+    sym3_inverse(h, inv);
+    double* o = d.Hinv + 6 * (size_t)p;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) o[k] = inv[k];
+}
+
+__global__ void k_cam_prep(Dev d, double radius, double dmin, double dmax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n_cams * 6) return;
+    const int c = i / 6, k = i % 6;
+    d.Dc2[i] = clampd(d.camlin[12 * (size_t)c + k], dmin, dmax) / radius;
+}
+
+// Per observation: block-Jacobi diagonal block and reduced right-hand side terms
+//   S_cc += F^T F - (F^T E) Hinv (E^T F),   rb -= (F^T E) Hinv g_p
+__global__ __launch_bounds__(kBlock) void k_schur_prep(Dev d) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= d.n_slots) return;
+    const int cam = d.slot_cam[slot];
+    if (cam < 0) return;
+    const int pt = d.slot_pt[slot];
+    const size_t ns = (size_t)d.n_slots;
+    double F[12], E[6];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + slot];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + slot];
+    const double* Hi = d.Hinv + 6 * (size_t)pt;
+    const double h[6] = {Hi[0], Hi[1], Hi[2], Hi[3], Hi[4], Hi[5]};
+    const double* g = d.gp + 3 * (size_t)pt;
+    const double g0 = g[0], g1 = g[1], g2 = g[2];
+    double W[18], WH[18];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[6 + a] * E[3 + b];
+        WH[3 * a + 0] = W[3 * a] * h[0] + W[3 * a + 1] * h[1] + W[3 * a + 2] * h[2];
+        WH[3 * a + 1] = W[3 * a] * h[1] + W[3 * a + 1] * h[3] + W[3 * a + 2] * h[4];
+        WH[3 * a + 2] = W[3 * a] * h[2] + W[3 * a + 1] * h[4] + W[3 * a + 2] * h[5];
+    }
+    double o[28];
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c = a; c < 6; ++c)
+            o[idx++] = F[a] * F[c] + F[6 + a] * F[6 + c]
+                       - (WH[3 * a] * W[3 * c] + WH[3 * a + 1] * W[3 * c + 1] + WH[3 * a + 2] * W[3 * c + 2]);
+#pragma unroll
+    for (int a = 0; a < 6; ++a) o[21 + a] = -(WH[3 * a] * g0 + WH[3 * a + 1] * g1 + WH[3 * a + 2] * g2);
+    o[27] = 0.0;
+    double2* out = reinterpret_cast<double2*>(d.scat + 28 * (size_t)d.slot_campos[slot]);
+#pragma unroll
+    for (int k = 0; k < 14; ++k) out[k] = make_double2(o[2 * k], o[2 * k + 1]);
+}
+
+// Per camera: M = S_cc + D_c^2, store M^-1 (symmetric, 21) via Cholesky; b = g_c + rb.
+__global__ void k_cam_factor(Dev d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n_cams) return;
+    const double* S = d.camS + 28 * (size_t)c;
+    double A[6][6];
+    int idx = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b2 = a; b2 < 6; ++b2) { A[a][b2] = S[idx]; A[b2][a] = S[idx]; ++idx; }
+    for (int a = 0; a < 6; ++a) A[a][a] += d.Dc2[6 * (size_t)c + a];
+    // Cholesky A = L L^T (lower, in place)
+    double L[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) L[i][j] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        double s = A[j][j];
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        const double ljj = sqrt(s);
+        L[j][j] = ljj;
+        const double inv = 1.0 / ljj;
+        for (int i = j + 1; i < 6; ++i) {
+            double v = A[i][j];
+            for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+            L[i][j] = v * inv;
+        }
+    }
+    // Linv (lower)
+    double Li[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) Li[i][j] = 0.0;
+    for (int j = 0; j < 6; ++j) {
+        Li[j][j] = 1.0 / L[j][j];
+        for (int i = j + 1; i < 6; ++i) {
+            double v = 0.0;
+            for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
+            Li[i][j] = v / L[i][i];
+        }
+    }
+    // Minv = Li^T Li
+    double* Mo = d.Minv + 21 * (size_t)c;
+    idx = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b2 = a; b2 < 6; ++b2) {
+            double v = 0.0;
+            for (int k = b2; k < 6; ++k) v += Li[k][a] * Li[k][b2];
+            Mo[idx++] = v;
+        }
+    for (int a = 0; a < 6; ++a) d.b[6 * (size_t)c + a] = d.camlin[12 * (size_t)c + 6 + a] + S[21 + a];
+}
+
+// ---------------------------------------------------------------- PCG
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();
+    if (lane == 0) lds[w] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int i = 0; i < NT / kWave; ++i) s += lds[i];
+    return s;  // same value in every thread
+}
+
+__device__ __forceinline__ void sym6_mul(const double* m, const double* x, double* y) {
+    // m: upper triangle row-major (21)
+    double A[6][6];
+    int idx = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) { A[a][b] = m[idx]; A[b][a] = m[idx]; ++idx; }
+    for (int a = 0; a < 6; ++a) {
+        double s = 0.0;
+        for (int b = 0; b < 6; ++b) s += A[a][b] * x[b];
+        y[a] = s;
+    }
+}
+
+constexpr int kPcgThreads = 1024;
+
+// x = 0, r = b, z = M^-1 r, p = z
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_init(Dev d) {
+    __shared__ double lds[kPcgThreads / kWave];
+    double rz = 0.0, bb = 0.0;
+    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
+        double r[6], z[6];
+        for (int k = 0; k < 6; ++k) r[k] = d.b[6 * (size_t)c + k];
+        sym6_mul(d.Minv + 21 * (size_t)c, r, z);
+        for (int k = 0; k < 6; ++k) {
+            d.px[6 * (size_t)c + k] = 0.0; d.pr[6 * (size_t)c + k] = r[k];
+            d.pz[6 * (size_t)c + k] = z[k]; d.pp[6 * (size_t)c + k] = z[k];
+            rz += r[k] * z[k]; bb += r[k] * r[k];
+        }
+    }
+    rz = block_sum<kPcgThreads>(rz, lds);
+    bb = block_sum<kPcgThreads>(bb, lds);
+    if (threadIdx.x == 0) {
+        d.st->rz = rz; d.st->rr = bb; d.st->bb = bb; d.st->pq = 0.0; d.st->it = 0;
+        d.st->done = (bb == 0.0) ? 1 : 0;
+    }
+}
+
+// Implicit Schur product, track side:  per observation v = F p_c, w = E^T v,
+// per track u = Hinv sum w (segmented wave reduction), z = v - E u, and the
+// camera-side term F^T z goes to the camera-major scatter buffer.
+__global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __restrict__ pvec) {
+    if (d.st->done) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    const size_t ns = (size_t)d.n_slots;
+    if (it.n_tiles == 1) {
+        const SlotCtx s = load_slot(d, it.first_tile, lane);
+        double F[12], E[6], v0 = 0.0, v1 = 0.0;
+        double w[3] = {0, 0, 0};
+        if (s.valid) {
+#pragma unroll
+            for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + s.slot];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + s.slot];
+            const double* p = pvec + 6 * (size_t)s.cam;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { const double pk = p[k]; v0 += F[k] * pk; v1 += F[6 + k] * pk; }
+            w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
+        }
+        seg_reduce<3>(w, s.pt, lane);
+        double u[3] = {0, 0, 0};
+        if (s.head) {
+            const double* h = d.Hinv + 6 * (size_t)s.pt;
+            u[0] = h[0] * w[0] + h[1] * w[1] + h[2] * w[2];
+            u[1] = h[1] * w[0] + h[3] * w[1] + h[4] * w[2];
+            u[2] = h[2] * w[0] + h[4] * w[1] + h[5] * w[2];
+        }
+        const int hl = seg_head_lane(s.head || !s.valid, lane);
+        u[0] = __shfl(u[0], hl, kWave); u[1] = __shfl(u[1], hl, kWave); u[2] = __shfl(u[2], hl, kWave);
+        if (s.valid) {
+            const double z0 = v0 - (E[0] * u[0] + E[1] * u[1] + E[2] * u[2]);
+            const double z1 = v1 - (E[3] * u[0] + E[4] * u[1] + E[5] * u[2]);
+            double2* out = reinterpret_cast<double2*>(d.scat + 6 * (size_t)d.slot_campos[s.slot]);
+            out[0] = make_double2(F[0] * z0 + F[6] * z1, F[1] * z0 + F[7] * z1);
+            out[1] = make_double2(F[2] * z0 + F[8] * z1, F[3] * z0 + F[9] * z1);
+            out[2] = make_double2(F[4] * z0 + F[10] * z1, F[5] * z0 + F[11] * z1);
+        }
+        return;
+    }
+    // long track: all lanes of all tiles belong to one track
+    double wsum[3] = {0, 0, 0};
+    int pt0 = -1;
+    for (int tl = 0; tl < it.n_tiles; ++tl) {
+        const int slot = (it.first_tile + tl) * kWave + lane;
+        const int cam = d.slot_cam[slot];
+        if (cam >= 0) {
+            pt0 = d.slot_pt[slot];
+            const double* p = pvec + 6 * (size_t)cam;
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + slot] * p[k]; v1 += d.Fs[(6 + k) * ns + slot] * p[k]; }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) wsum[k] += d.Es[k * ns + slot] * v0 + d.Es[(3 + k) * ns + slot] * v1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { wsum[k] = wave_sum(wsum[k]); wsum[k] = __shfl(wsum[k], 0, kWave); }
+    pt0 = __shfl(pt0, 0, kWave);
+    const double* h = d.Hinv + 6 * (size_t)pt0;
+    const double u0 = h[0] * wsum[0] + h[1] * wsum[1] + h[2] * wsum[2];
+    const double u1 = h[1] * wsum[0] + h[3] * wsum[1] + h[4] * wsum[2];
+    const double u2 = h[2] * wsum[0] + h[4] * wsum[1] + h[5] * wsum[2];
+    for (int tl = 0; tl < it.n_tiles; ++tl) {
+        const int slot = (it.first_tile + tl) * kWave + lane;
+        const int cam = d.slot_cam[slot];
+        if (cam >= 0) {
+            double F[12], E[6];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + slot];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + slot];
+            const double* p = pvec + 6 * (size_t)cam;
+            double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { v0 += F[k] * p[k]; v1 += F[6 + k] * p[k]; }
+            const double z0 = v0 - (E[0] * u0 + E[1] * u1 + E[2] * u2);
+            const double z1 = v1 - (E[3] * u0 + E[4] * u1 + E[5] * u2);
+            double* out = d.scat + 6 * (size_t)d.slot_campos[slot];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) out[k] = F[k] * z0 + F[6 + k] * z1;
+        }
+    }
+}
+
+// One PCG iteration's vector work on the (small) camera vectors; single workgroup.
+// On entry pq holds sum_i F^T z (all-reduced over ranks); D_c^2 p is added here.
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_update(Dev d, double tol, int max_it) {
+    if (d.st->done) return;
+    __shared__ double lds[kPcgThreads / kWave];
+    const double rz = d.st->rz, bb = d.st->bb;
+    const int it0 = d.st->it;
+    double pq = 0.0;
+    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads)
+        for (int k = 0; k < 6; ++k) {
+            const size_t i = 6 * (size_t)c + k;
+            const double qv = d.pq[i] + d.Dc2[i] * d.pp[i];
+            d.pq[i] = qv;
+            pq += d.pp[i] * qv;
+        }
+    pq = block_sum<kPcgThreads>(pq, lds);
+    const double alpha = rz / pq;
+    double rz_new = 0.0, rr = 0.0;
+    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
+        double r[6], z[6];
+        for (int k = 0; k < 6; ++k) {
+            const size_t i = 6 * (size_t)c + k;
+            d.px[i] += alpha * d.pp[i];
+            r[k] = d.pr[i] - alpha * d.pq[i];
+            d.pr[i] = r[k];
+        }
+        sym6_mul(d.Minv + 21 * (size_t)c, r, z);
+        for (int k = 0; k < 6; ++k) { d.pz[6 * (size_t)c + k] = z[k]; rz_new += r[k] * z[k]; rr += r[k] * r[k]; }
+    }
+    rz_new = block_sum<kPcgThreads>(rz_new, lds);
+    rr = block_sum<kPcgThreads>(rr, lds);
+    const double beta = rz_new / rz;
+    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads)
+        for (int k = 0; k < 6; ++k) {
+            const size_t i = 6 * (size_t)c + k;
+            d.pp[i] = d.pz[i] + beta * d.pp[i];
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        d.st->rz = rz_new; d.st->rr = rr; d.st->pq = pq; d.st->it = it0 + 1;
+        d.st->done = (rr <= tol * tol * bb || it0 + 1 >= max_it || !(pq > 0.0)) ? 1 : 0;
+    }
+}
+
+// ---------------------------------------------------------------- back-substitution + update
+// y_p = Hinv (g_p - sum E^T F y_c); model cost change; candidate points.
+__global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    const size_t ns = (size_t)d.n_slots;
+    double model = 0.0, step2 = 0.0;
+    if (it.n_tiles == 1) {
+        const SlotCtx s = load_slot(d, it.first_tile, lane);
+        double E[6], v0 = 0.0, v1 = 0.0, r0 = 0.0, r1 = 0.0;
+        double w[3] = {0, 0, 0};
+        if (s.valid) {
+            const double* y = d.px + 6 * (size_t)s.cam;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + s.slot] * y[k]; v1 += d.Fs[(6 + k) * ns + s.slot] * y[k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + s.slot];
+            r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
+            w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
+        }
+        seg_reduce<3>(w, s.pt, lane);
+        double u[3] = {0, 0, 0};
+        if (s.head) {
+            const double* h = d.Hinv + 6 * (size_t)s.pt;
+            const double* g = d.gp + 3 * (size_t)s.pt;
+            const double a0 = g[0] - w[0], a1 = g[1] - w[1], a2 = g[2] - w[2];
+            u[0] = h[0] * a0 + h[1] * a1 + h[2] * a2;
+            u[1] = h[1] * a0 + h[3] * a1 + h[4] * a2;
+            u[2] = h[2] * a0 + h[4] * a1 + h[5] * a2;
+            const double* sp = d.scale_p + 3 * (size_t)s.pt;
+            const double* P = d.P + 3 * (size_t)s.pt;
+            double* Pc = d.P_cand + 3 * (size_t)s.pt;
+            double* yo = d.yp + 3 * (size_t)s.pt;
+            const bool var = !d.pt_const[s.pt];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double dl = var ? -u[k] * sp[k] : 0.0;
+                const double pn = P[k] + dl;
+                Pc[k] = pn; yo[k] = u[k];
+                const double df = pn - P[k];
+                step2 += df * df;
+            }
+        }
+        const int hl = seg_head_lane(s.head || !s.valid, lane);
+        u[0] = __shfl(u[0], hl, kWave); u[1] = __shfl(u[1], hl, kWave); u[2] = __shfl(u[2], hl, kWave);
+        if (s.valid) {
+            const double m0 = v0 + E[0] * u[0] + E[1] * u[1] + E[2] * u[2];
+            const double m1 = v1 + E[3] * u[0] + E[4] * u[1] + E[5] * u[2];
+            model = m0 * (r0 - 0.5 * m0) + m1 * (r1 - 0.5 * m1);
+        }
+    } else {
+        double wsum[3] = {0, 0, 0};
+        int pt0 = -1;
+        for (int tl = 0; tl < it.n_tiles; ++tl) {
+            const int slot = (it.first_tile + tl) * kWave + lane;
+            const int cam = d.slot_cam[slot];
+            if (cam >= 0) {
+                pt0 = d.slot_pt[slot];
+                const double* y = d.px + 6 * (size_t)cam;
+                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + slot] * y[k]; v1 += d.Fs[(6 + k) * ns + slot] * y[k]; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) wsum[k] += d.Es[k * ns + slot] * v0 + d.Es[(3 + k) * ns + slot] * v1;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { wsum[k] = wave_sum(wsum[k]); wsum[k] = __shfl(wsum[k], 0, kWave); }
+        pt0 = __shfl(pt0, 0, kWave);
+        const double* h = d.Hinv + 6 * (size_t)pt0;
+        const double* g = d.gp + 3 * (size_t)pt0;
+        const double a0 = g[0] - wsum[0], a1 = g[1] - wsum[1], a2 = g[2] - wsum[2];
+        double u[3];
+        u[0] = h[0] * a0 + h[1] * a1 + h[2] * a2;
+        u[1] = h[1] * a0 + h[3] * a1 + h[4] * a2;
+        u[2] = h[2] * a0 + h[4] * a1 + h[5] * a2;
+        if (lane == 0) {
+            const double* sp = d.scale_p + 3 * (size_t)pt0;
+            const double* P = d.P + 3 * (size_t)pt0;
+            double* Pc = d.P_cand + 3 * (size_t)pt0;
+            double* yo = d.yp + 3 * (size_t)pt0;
+            const bool var = !d.pt_const[pt0];
+            for (int k = 0; k < 3; ++k) {
+                const double dl = var ? -u[k] * sp[k] : 0.0;
+                const double pn = P[k] + dl;
+                Pc[k] = pn; yo[k] = u[k];
+                const double df = pn - P[k];
+                step2 += df * df;
+            }
+        }
+        for (int tl = 0; tl < it.n_tiles; ++tl) {
+            const int slot = (it.first_tile + tl) * kWave + lane;
+            const int cam = d.slot_cam[slot];
+            if (cam >= 0) {
+                const double* y = d.px + 6 * (size_t)cam;
+                double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + slot] * y[k]; v1 += d.Fs[(6 + k) * ns + slot] * y[k]; }
+                const double m0 = v0 + d.Es[slot] * u[0] + d.Es[ns + slot] * u[1] + d.Es[2 * ns + slot] * u[2];
+                const double m1 = v1 + d.Es[3 * ns + slot] * u[0] + d.Es[4 * ns + slot] * u[1] + d.Es[5 * ns + slot] * u[2];
+                model += m0 * (d.rt[slot] - 0.5 * m0) + m1 * (d.rt[ns + slot] - 0.5 * m1);
+            }
+        }
+    }
+    model = wave_sum(model);
+    step2 = wave_sum(step2);
+    if (lane == 0) { d.part[2 * d.n_items + item] = model; d.part[3 * d.n_items + item] = step2; }
+}
+
+// Candidate cameras: Plus(x, -y*scale); |dx|^2 and |x|^2 per camera (ambient, variable blocks only).
+__global__ void k_cam_update(Dev d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n_cams) return;
+    const CamRec cur = d.cam[c];
+    CamRec nxt = cur;
+    const unsigned cc = d.cam_const[c];
+    const bool active = d.cam_ptr[c + 1] > d.cam_ptr[c];
+    const double* y = d.px + 6 * (size_t)c;
+    const double* sc = d.scale_c + 6 * (size_t)c;
+    double step2 = 0.0, xn2 = 0.0;
+    if (active && !(cc & 1u)) {
+        const double dl[3] = {-y[0] * sc[0], -y[1] * sc[1], -y[2] * sc[2]};
+        quat_plus(cur.q, dl, nxt.q);
+        for (int k = 0; k < 4; ++k) { const double df = nxt.q[k] - cur.q[k]; step2 += df * df; xn2 += cur.q[k] * cur.q[k]; }
+    }
+    if (active && !(cc & 2u)) {
+        for (int k = 0; k < 3; ++k) {
+            nxt.t[k] = cur.t[k] + (-y[3 + k] * sc[3 + k]);
+            const double df = nxt.t[k] - cur.t[k]; step2 += df * df; xn2 += cur.t[k] * cur.t[k];
+        }
+    }
+    d.cam_cand[c] = nxt;
+    d.campart[c] = step2;
+    d.campart[d.n_cams + c] = xn2;
+}
+
+// Ceres' gradient max-norm |x - Plus(x, -g)|_inf with the unscaled gradient.
+__global__ void k_gradmax_cams(Dev d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n_cams) return;
+    const unsigned cc = d.cam_const[c];
+    const bool active = d.cam_ptr[c + 1] > d.cam_ptr[c];
+    const double* g = d.camlin + 12 * (size_t)c + 6;
+    const double* sc = d.scale_c + 6 * (size_t)c;
+    double m = 0.0;
+    if (active && !(cc & 1u)) {
+        const CamRec& cur = d.cam[c];
+        const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
+        const double dl[3] = {-g[0] / sc[0], -g[1] / sc[1], -g[2] / sc[2]};
+        double qn[4];
+        quat_plus(q, dl, qn);
+        for (int k = 0; k < 4; ++k) m = fmax(m, fabs(q[k] - qn[k]));
+    }
+    if (active && !(cc & 2u))
+        for (int k = 0; k < 3; ++k) m = fmax(m, fabs(g[3 + k] / sc[3 + k]));
+    d.campart[c] = m;
+}
+
+__global__ void k_gradmax_pts(Dev d, double* out) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    double m = 0.0;
+    if (p < d.n_pts && !d.pt_const[p])
+        for (int k = 0; k < 3; ++k) m = fmax(m, fabs(d.gp[3 * (size_t)p + k] / d.scale_p[3 * (size_t)p + k]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
+    // non-negative doubles order like their bit patterns -> integer atomicMax is exact and order-free
+    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(m));
+}
+
+// Deterministic single-workgroup reductions of partial arrays.
+__global__ __launch_bounds__(kPcgThreads) void k_reduce_sum(const double* __restrict__ in, int n, double* out) {
+    __shared__ double lds[kPcgThreads / kWave];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += kPcgThreads) s += in[i];
+    s = block_sum<kPcgThreads>(s, lds);
+    if (threadIdx.x == 0) *out = s;
+}
+
+__global__ __launch_bounds__(kPcgThreads) void k_reduce_max(const double* __restrict__ in, int n, double* out) {
+    __shared__ double lds[kPcgThreads / kWave];
+    double m = 0.0;
+    for (int i = threadIdx.x; i < n; i += kPcgThreads) m = fmax(m, in[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int i = 0; i < kPcgThreads / kWave; ++i) r = fmax(r, lds[i]);
+        *out = r;
+    }
+}
+
+}  // namespace xba

@@ -1,0 +1,119 @@
+// Host-side packing: caller SoA (include/xrsfm_ba.h) -> track-major 64-slot tiles
+// + camera-major positions.  Replaces the reference's per-observation
+// problem.AddResidualBlock loop (/root/reference/src/optimization/ba_solver.cc:336-349).
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+#include <vector>
+
+#include "../../include/xrsfm_ba.h"
+
+namespace xba {
+
+struct Packed {
+    int n_cams = 0, n_pts = 0, n_obs = 0, n_tiles = 0, n_slots = 0;
+    std::vector<int> pt_orig;        // packed point -> caller point index
+    std::vector<int> slot_cam, slot_pt, slot_campos, slot_obs;  // slot_obs: caller obs index (-1 pad)
+    std::vector<double> slot_u, slot_v;
+    std::vector<int> items;          // pairs {first_tile, n_tiles}
+    std::vector<int> cam_ptr;        // [n_cams+1]
+    std::vector<unsigned char> pt_const;
+    int n_var_q = 0, n_var_t = 0, n_var_p = 0;
+};
+
+inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
+    if (p.n_cams < 0 || p.n_points < 0 || p.n_obs < 0 || p.n_intr < 0) return XRSFM_BA_EINVAL;
+    if (p.n_obs > 0 && (!p.obs_cam || !p.obs_pt || !p.obs_uv)) return XRSFM_BA_EINVAL;
+    if (p.n_cams > 0 && (!p.cam_q || !p.cam_t || !p.cam_intr)) return XRSFM_BA_EINVAL;
+    if (p.n_points > 0 && !p.points) return XRSFM_BA_EINVAL;
+    if (p.n_intr > 0 && (!p.intr_model || !p.intr_params)) return XRSFM_BA_EINVAL;
+    for (int c = 0; c < p.n_cams; ++c) {
+        const int ii = p.cam_intr[c];
+        if (ii < 0 || ii >= p.n_intr) return XRSFM_BA_EINVAL;
+        const int m = p.intr_model[ii];
+        if (m < 0 || m > 4) return XRSFM_BA_EINVAL;
+    }
+    const int No = p.n_obs, Np = p.n_points, Nc = p.n_cams;
+    std::vector<int> cnt(Np + 1, 0), mincam(Np, INT32_MAX);
+    for (int i = 0; i < No; ++i) {
+        const int c = p.obs_cam[i], j = p.obs_pt[i];
+        if (c < 0 || c >= Nc || j < 0 || j >= Np) return XRSFM_BA_EINVAL;
+        cnt[j + 1]++;
+        mincam[j] = std::min(mincam[j], c);
+    }
+    // CSR by caller point
+    std::vector<int> ptr(Np + 1, 0);
+    for (int j = 0; j < Np; ++j) ptr[j + 1] = ptr[j] + cnt[j + 1];
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1), csr(No);
+    for (int i = 0; i < No; ++i) csr[fill[p.obs_pt[i]]++] = i;
+    // active points: short tracks sorted by their lowest camera (locality of the
+    // camera gathers / scatters), long tracks (> 64 obs) at the end
+    std::vector<int> order;
+    order.reserve(Np);
+    for (int j = 0; j < Np; ++j)
+        if (cnt[j + 1] > 0) order.push_back(j);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        const bool la = cnt[a + 1] > 64, lb = cnt[b + 1] > 64;
+        if (la != lb) return lb;
+        return mincam[a] < mincam[b];
+    });
+    o.n_cams = Nc; o.n_pts = (int)order.size(); o.n_obs = No;
+    o.pt_orig = order;
+    o.pt_const.assign(o.n_pts, 0);
+    o.items.clear(); o.slot_cam.clear(); o.slot_pt.clear(); o.slot_obs.clear();
+    auto pad_tile = [&]() {
+        while (o.slot_cam.size() % 64) { o.slot_cam.push_back(-1); o.slot_pt.push_back(-1); o.slot_obs.push_back(-1); }
+    };
+    int cur_tile_start = -1;  // tile index of the open short tile, -1 if none
+    for (int pj = 0; pj < o.n_pts; ++pj) {
+        const int j = order[pj];
+        const int len = cnt[j + 1];
+        o.pt_const[pj] = (p.point_const && p.point_const[j]) ? 1 : 0;
+        // observations of one track ordered by camera (deterministic)
+        std::vector<int> obs(csr.begin() + ptr[j], csr.begin() + ptr[j + 1]);
+        std::stable_sort(obs.begin(), obs.end(), [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+        if (len <= 64) {
+            const int used = (int)(o.slot_cam.size() % 64);
+            if (cur_tile_start < 0 || used + len > 64 || used == 0) {
+                pad_tile();
+                cur_tile_start = (int)(o.slot_cam.size() / 64);
+                o.items.push_back(cur_tile_start); o.items.push_back(1);
+            }
+        } else {
+            pad_tile();
+            cur_tile_start = -1;
+            o.items.push_back((int)(o.slot_cam.size() / 64)); o.items.push_back((len + 63) / 64);
+        }
+        for (int i : obs) { o.slot_cam.push_back(p.obs_cam[i]); o.slot_pt.push_back(pj); o.slot_obs.push_back(i); }
+        if (len > 64) pad_tile();
+    }
+    pad_tile();
+    o.n_slots = (int)o.slot_cam.size();
+    o.n_tiles = o.n_slots / 64;
+    o.slot_u.assign(o.n_slots, 0.0); o.slot_v.assign(o.n_slots, 0.0);
+    for (int s = 0; s < o.n_slots; ++s)
+        if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
+    // camera-major positions (within a camera: slot order)
+    o.cam_ptr.assign(Nc + 1, 0);
+    for (int s = 0; s < o.n_slots; ++s)
+        if (o.slot_cam[s] >= 0) o.cam_ptr[o.slot_cam[s] + 1]++;
+    for (int c = 0; c < Nc; ++c) o.cam_ptr[c + 1] += o.cam_ptr[c];
+    std::vector<int> cf(o.cam_ptr.begin(), o.cam_ptr.end() - 1);
+    o.slot_campos.assign(o.n_slots, -1);
+    for (int s = 0; s < o.n_slots; ++s)
+        if (o.slot_cam[s] >= 0) o.slot_campos[s] = cf[o.slot_cam[s]]++;
+    // effective parameter count (num_effective_parameters_reduced)
+    o.n_var_q = o.n_var_t = o.n_var_p = 0;
+    for (int c = 0; c < Nc; ++c) {
+        if (o.cam_ptr[c + 1] == o.cam_ptr[c]) continue;
+        const unsigned cc = p.cam_const ? p.cam_const[c] : 0u;
+        if (!(cc & XRSFM_BA_CONST_Q)) o.n_var_q++;
+        if (!(cc & XRSFM_BA_CONST_T)) o.n_var_t++;
+    }
+    for (int pj = 0; pj < o.n_pts; ++pj)
+        if (!o.pt_const[pj]) o.n_var_p++;
+    return XRSFM_BA_OK;
+}
+
+}  // namespace xba

@@ -1,0 +1,189 @@
+"""Deterministic synthetic "BAL-style" BA problems.
+
+Shapes follow BASELINE.json configs 2 and 4: one shared SIMPLE_RADIAL camera
+with the KITTI-00 intrinsics the reference hard-codes
+(/root/reference/src/rec_kitti.cc:25), `k_obs` observations per point, 0.5 px
+Gaussian noise, 2 % gross outliers, perturbed initial state; frames 0 and 1
+play the role of ``map.init_id1/init_id2`` (their translation is held constant,
+/root/reference/src/optimization/ba_solver.cc:611-614).
+
+The arrays returned are exactly the flat SoA the C-ABI takes
+(include/xrsfm_ba.h); observation order is frame-major like the reference's
+problem construction (ba_solver.cc:598-601, 336-349).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+KITTI_INTR = (718.856, 607.1928, 185.27157, 0.0)   # rec_kitti.cc:25 -> {f, cx, cy, k}
+IMG_W, IMG_H = 1241.0, 376.0
+
+
+def _rot_from_quat(q):
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    M = np.empty(q.shape[:-1] + (3, 3))
+    M[..., 0, 0] = 1 - 2 * (y * y + z * z); M[..., 0, 1] = 2 * (x * y - w * z); M[..., 0, 2] = 2 * (x * z + w * y)
+    M[..., 1, 0] = 2 * (x * y + w * z); M[..., 1, 1] = 1 - 2 * (x * x + z * z); M[..., 1, 2] = 2 * (y * z - w * x)
+    M[..., 2, 0] = 2 * (x * z - w * y); M[..., 2, 1] = 2 * (y * z + w * x); M[..., 2, 2] = 1 - 2 * (x * x + y * y)
+    return M
+
+
+def _quat_from_rot(R):
+    """Rotation matrices [n,3,3] -> unit quaternions xyzw (w >= 0)."""
+    n = R.shape[0]
+    q = np.empty((n, 4))
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    for i in range(n):
+        m = R[i]
+        if tr[i] > 0:
+            s = np.sqrt(tr[i] + 1.0) * 2
+            q[i] = ((m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s, 0.25 * s)
+        elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+            s = np.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+            q[i] = (0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s, (m[2, 1] - m[1, 2]) / s)
+        elif m[1, 1] > m[2, 2]:
+            s = np.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+            q[i] = ((m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s, (m[0, 2] - m[2, 0]) / s)
+        else:
+            s = np.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+            q[i] = ((m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s, (m[1, 0] - m[0, 1]) / s)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[q[:, 3] < 0] *= -1
+    return q
+
+
+def _quat_plus(q, d):
+    n = np.linalg.norm(d, axis=-1)
+    safe = np.where(n > 0, n, 1.0)
+    s = np.where(n > 0, np.sin(safe) / safe, 0.0)
+    av = d * s[..., None]; aw = np.where(n > 0, np.cos(n), 1.0)
+    bv = q[..., :3]; bw = q[..., 3]
+    out = np.empty_like(q)
+    out[..., 3] = aw * bw - np.sum(av * bv, axis=-1)
+    out[..., :3] = aw[..., None] * bv + bw[..., None] * av + np.cross(av, bv)
+    return out
+
+
+def _project_simple_radial(q, t, P, intr):
+    f, cx, cy, k = intr
+    Pc = np.einsum("nij,nj->ni", _rot_from_quat(q), P) + t
+    z = Pc[:, 2]
+    zs = np.where(np.abs(z) > 1e-12, z, 1e-12)
+    xn = Pc[:, 0] / zs; yn = Pc[:, 1] / zs
+    r2 = xn * xn + yn * yn
+    u = f * (xn + xn * k * r2) + cx
+    v = f * (yn + yn * k * r2) + cy
+    return np.stack([u, v], axis=1), z
+
+
+def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
+                 mode: str = "sequential", k_dist: float = 0.0, noise: float = 0.5,
+                 outlier_frac: float = 0.02, perturb=(0.01, 0.05, 0.10),
+                 min_tri_angle_deg: float = 2.0) -> dict:
+    """Return a dict of flat arrays (keys = fields of ``xrsfm_ba_problem``) + ground truth."""
+    assert n_cams >= k_obs >= 1
+    rng = np.random.Generator(np.random.PCG64(seed))
+    intr = (KITTI_INTR[0], KITTI_INTR[1], KITTI_INTR[2], k_dist)
+    radius = 40.0
+    # closed loop for >= 100 cameras; an open arc with the 100-camera spacing below that
+    ang = 2 * np.pi * np.arange(n_cams) / max(n_cams, 100)
+    centre = np.stack([radius * np.cos(ang), rng.normal(0, 0.1, n_cams), radius * np.sin(ang)], axis=1)
+    if mode == "sequential":
+        fwd = np.stack([-np.sin(ang), np.zeros(n_cams), np.cos(ang)], axis=1)      # tangent
+    elif mode == "unordered":
+        fwd = -centre / np.linalg.norm(centre, axis=1, keepdims=True)              # look at origin
+    else:
+        raise ValueError(mode)
+    yaw = np.deg2rad(rng.uniform(-2, 2, n_cams)); pitch = np.deg2rad(rng.uniform(-2, 2, n_cams))
+    up = np.array([0.0, -1.0, 0.0])      # image y points down
+    Rcw = np.empty((n_cams, 3, 3))
+    for i in range(n_cams):
+        zc = fwd[i] / np.linalg.norm(fwd[i])
+        xc = np.cross(-up, zc); xc /= np.linalg.norm(xc)
+        yc = np.cross(zc, xc)
+        R0 = np.stack([xc, yc, zc], axis=0)          # rows = camera axes in world
+        cy_, sy_ = np.cos(yaw[i]), np.sin(yaw[i]); cp_, sp_ = np.cos(pitch[i]), np.sin(pitch[i])
+        Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+        Rx = np.array([[1, 0, 0], [0, cp_, -sp_], [0, sp_, cp_]])
+        Rcw[i] = Rx @ Ry @ R0
+    q_gt = _quat_from_rot(Rcw)
+    Rq = _rot_from_quat(q_gt)
+    t_gt = -np.einsum("nij,nj->ni", Rq, centre)
+
+    # points: base camera c0, placed in the frustum of camera c0 + k_obs/2, seen by k_obs cameras
+    P_gt = np.empty((n_points, 3))
+    cams_of = np.empty((n_points, k_obs), dtype=np.int64)
+    todo = np.arange(n_points)
+    f, cx, cy, _ = intr
+    rounds = 0
+    while todo.size:
+        rounds += 1
+        if rounds > 200:
+            raise RuntimeError("synthetic generator failed to place all points")
+        m = todo.size
+        if mode == "sequential":
+            c0 = rng.integers(0, n_cams, m)
+            cams = (c0[:, None] + np.arange(k_obs)[None, :]) % n_cams
+        else:
+            cams = rng.integers(0, n_cams, (m, k_obs))
+            srt = np.sort(cams, axis=1)
+            bad_dup = (np.diff(srt, axis=1) == 0).any(axis=1) if k_obs > 1 else np.zeros(m, bool)
+        cmid = cams[:, k_obs // 2]
+        depth = rng.uniform(5.0, 40.0, m)
+        u = rng.uniform(0.05 * IMG_W, 0.95 * IMG_W, m); v = rng.uniform(0.05 * IMG_H, 0.95 * IMG_H, m)
+        pc = np.stack([(u - cx) / f * depth, (v - cy) / f * depth, depth], axis=1)
+        if mode == "unordered":
+            # scene around the origin so that many ring cameras see it
+            pw = rng.uniform(-8.0, 8.0, (m, 3))
+        else:
+            pw = np.einsum("nji,nj->ni", Rq[cmid], pc - t_gt[cmid])       # R^T (pc - t)
+        ok = np.ones(m, bool)
+        if mode == "unordered":
+            ok &= ~bad_dup
+        for j in range(k_obs):
+            uv, z = _project_simple_radial(q_gt[cams[:, j]], t_gt[cams[:, j]], pw, intr)
+            ok &= (z > 1.0) & (uv[:, 0] >= 0) & (uv[:, 0] < IMG_W) & (uv[:, 1] >= 0) & (uv[:, 1] < IMG_H)
+        # keep only points the mapper would keep: max pairwise triangulation angle above the
+        # GBA filter threshold (FilterPoints3d, /root/reference/src/geometry/track_processor.cc:321-332)
+        if min_tri_angle_deg > 0 and k_obs > 1:
+            rays = pw[:, None, :] - centre[cams]                       # [m,k,3]
+            rays /= np.linalg.norm(rays, axis=2, keepdims=True)
+            cosang = np.einsum("mik,mjk->mij", rays, rays).min(axis=(1, 2))
+            ok &= cosang < np.cos(np.deg2rad(min_tri_angle_deg))
+        P_gt[todo[ok]] = pw[ok]; cams_of[todo[ok]] = cams[ok]
+        todo = todo[~ok]
+
+    # observations, frame-major order
+    obs_pt = np.repeat(np.arange(n_points), k_obs)
+    obs_cam = cams_of.reshape(-1)
+    order = np.lexsort((obs_pt, obs_cam))
+    obs_pt = obs_pt[order].astype(np.int32); obs_cam = obs_cam[order].astype(np.int32)
+    uv, _ = _project_simple_radial(q_gt[obs_cam], t_gt[obs_cam], P_gt[obs_pt], intr)
+    uv = uv + rng.normal(0, noise, uv.shape)
+    n_obs = uv.shape[0]
+    out = rng.random(n_obs) < outlier_frac
+    uv[out] += rng.uniform(-30, 30, (int(out.sum()), 2))
+
+    # perturbed initial state; frames 0/1 keep their translation (gauge)
+    s_rot, s_t, s_p = perturb
+    q0 = _quat_plus(q_gt, rng.normal(0, s_rot, (n_cams, 3)))
+    dt = rng.normal(0, s_t, (n_cams, 3)); dt[0:2] = 0.0
+    t0 = t_gt + dt
+    P0 = P_gt + rng.normal(0, s_p, (n_points, 3))
+    cam_const = np.zeros(n_cams, np.uint8); cam_const[0:2] = 2        # bit1: t constant
+    return dict(
+        cam_q=np.ascontiguousarray(q0), cam_t=np.ascontiguousarray(t0), cam_const=cam_const,
+        cam_intr=np.zeros(n_cams, np.int32),
+        intr_model=np.array([2], np.int32),
+        intr_params=np.array([[intr[0], intr[1], intr[2], intr[3], 0, 0, 0, 0]], np.float64),
+        points=np.ascontiguousarray(P0), point_const=np.zeros(n_points, np.uint8),
+        obs_cam=obs_cam, obs_pt=obs_pt, obs_uv=np.ascontiguousarray(uv),
+        gt_q=q_gt, gt_t=t_gt, gt_points=P_gt,
+    )
+
+
+CONFIGS = {
+    # BASELINE.json configs 2 and 4
+    "S": dict(n_cams=100, n_points=50_000, k_obs=4, seed=2),
+    "L": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4),
+}
