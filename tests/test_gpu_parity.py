@@ -62,7 +62,7 @@ def test_schur_product(lib, k_obs, n_pts):
     """y = S x and rhs b against the dense Schur complement of the oracle (long tracks: k_obs=70 > 64 lanes)."""
     from xrsfm_amd import capi
     n_cams = 8 if k_obs < 10 else 80
-    arr = H.make(n_cams, n_pts, k_obs, seed=102, min_tri_angle_deg=0.5)
+    arr = H.make(n_cams, n_pts, k_obs, seed=102, min_tri_angle_deg=0.5, mode="unordered" if k_obs > 10 else "sequential")
     pr = H.to_oracle(arr)
     ctx = capi.Context(H.to_product(arr))
     ctx.debug_linearize(5.99, True)

@@ -333,7 +333,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.px, nc * 6)); TRY(dev_alloc(c, &d.pr, nc * 6)); TRY(dev_alloc(c, &d.pz, nc * 6));
     TRY(dev_alloc(c, &d.pp, nc * 6)); TRY(dev_alloc(c, &d.pq, nc * 6));
     TRY(dev_alloc(c, &d.yp, np * 3));
-    TRY(dev_alloc(c, &d.scat, (size_t)k.n_obs * 28));
+    TRY(dev_alloc(c, &d.scat, (size_t)(k.n_obs > 0 ? k.n_obs : 1) * 28));
     TRY(dev_alloc(c, &d.part, (size_t)d.n_items * 4));
     TRY(dev_alloc(c, &d.campart, nc * 2));
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));

@@ -125,9 +125,13 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
             c0 = rng.integers(0, n_cams, m)
             cams = (c0[:, None] + np.arange(k_obs)[None, :]) % n_cams
         else:
-            cams = rng.integers(0, n_cams, (m, k_obs))
-            srt = np.sort(cams, axis=1)
-            bad_dup = (np.diff(srt, axis=1) == 0).any(axis=1) if k_obs > 1 else np.zeros(m, bool)
+            if 4 * k_obs > n_cams:        # dense visibility: sample without replacement
+                cams = np.argsort(rng.random((m, n_cams)), axis=1)[:, :k_obs]
+                bad_dup = np.zeros(m, bool)
+            else:
+                cams = rng.integers(0, n_cams, (m, k_obs))
+                srt = np.sort(cams, axis=1)
+                bad_dup = (np.diff(srt, axis=1) == 0).any(axis=1) if k_obs > 1 else np.zeros(m, bool)
         cmid = cams[:, k_obs // 2]
         depth = rng.uniform(5.0, 40.0, m)
         u = rng.uniform(0.05 * IMG_W, 0.95 * IMG_W, m); v = rng.uniform(0.05 * IMG_H, 0.95 * IMG_H, m)
