@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — BA iterations/sec x (cams+points) on synthetic BAL-style problems (BASELINE.json).
+
+A "step" is one complete GBA-shaped solve (reference settings of
+/root/reference/src/optimization/ba_solver.cc:626-629: <=50 LM iterations,
+ftol 1e-5, ptol 1e-6, Huber 5.99) from the same perturbed initial state, with
+the problem already resident in HBM (xrsfm_ba_create is outside the timed
+region; xrsfm_ba_reset restores the state between steps).  value = LM
+iterations (successful + unsuccessful, as the reference counts them,
+ba_solver.cc:22-25) x (cams + points) / second, whole job.
+
+N > 1: one process per GPU (torch.distributed.run), the tracks of the SAME
+problem are sharded by point over the ranks ("strong" scaling, BASELINE.json
+config 4), cameras replicated, per-camera sums all-reduced with RCCL inside the
+library (xrsfm_ba_comm_init).
+
+The JSON line carries `roofline` (dominant HBM-streaming kernel, algorithmic
+bytes of SURVEY.md section 8d / DESIGN.md section 5, duration from HIP events
+recorded by the library on its own stream) and `cpu_baseline` (oracle/ C
+restatement timed on the host cores, rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def shard_problem(arr: dict, rank: int, world: int) -> dict:
+    """Points (tracks) j with j % world == rank and their observations; all cameras replicated."""
+    if world == 1:
+        return arr
+    keep_pt = (np.arange(arr["points"].shape[0]) % world) == rank
+    new_idx = np.cumsum(keep_pt) - 1
+    keep_obs = keep_pt[arr["obs_pt"]]
+    out = dict(arr)
+    out["points"] = np.ascontiguousarray(arr["points"][keep_pt])
+    out["point_const"] = np.ascontiguousarray(arr["point_const"][keep_pt])
+    out["obs_cam"] = np.ascontiguousarray(arr["obs_cam"][keep_obs])
+    out["obs_pt"] = np.ascontiguousarray(new_idx[arr["obs_pt"][keep_obs]].astype(np.int32))
+    out["obs_uv"] = np.ascontiguousarray(arr["obs_uv"][keep_obs])
+    return out
+
+
+def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, n_pairs: int = 0):
+    """ALGORITHMIC HBM bytes of one launch, J-stored accounting of SURVEY.md section 8(d) / DESIGN.md section 5
+    (FP64 values, int32 indices).  None for kernels that are latency- or MFMA-bound."""
+    table = {
+        # read uv + 2 idx, write r[2] + Jc[2x6] + Jp[2x3]; read points and cameras            (B_lin)
+        "k_linearize": n_obs * (24 + 160) + n_pts * 24 + n_cams * 56,
+        # one implicit Schur product: read Jc, Jp, Hpp^-1; x in, y out                        (B_pcg(1))
+        "k_schur_matvec": n_obs * 144 + n_pts * 48 + n_cams * 96,
+        # read r, J; read Hpp^-1 (6) + g_p (3); write diagonal blocks of S (21) + rhs (6)      (B_prep)
+        "k_schur_prep": n_obs * 160 + n_pts * 72 + n_cams * 216,
+        # explicit-S accounting: read J once, one 6x6 block written per off-diagonal pair
+        "k_schur_pairs": n_obs * 144 + n_pts * 48 + n_pairs * 288,
+        # back-substitute: read J, r; Hpp^-1, g_p, points in, points out                       (B_back)
+        "k_backsub": n_obs * (144 + 16) + n_pts * 144 + n_cams * 48,
+        "k_cost": n_obs * 24 + n_pts * 24 + n_cams * 56,
+    }
+    return table.get(kernel)
+
+
+def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
+    """oracle/ C restatement (kind "port") timed on the host cores; None if it is not built."""
+    try:
+        from oracle import ba_cpu
+    except Exception:
+        return None
+    if not ba_cpu.available():
+        return None
+    threads = min(8, os.cpu_count() or 1)       # the reference asks Ceres for 8 threads (ba_solver.cc:72)
+    prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+    t0 = time.perf_counter()
+    summ = ba_cpu.solve(prob, max_iterations=max_iterations, threads=threads)
+    dt = time.perf_counter() - t0
+    iters = summ["n_successful"] + summ["n_unsuccessful"]
+    return {
+        "value": iters * (n_cams + n_points) / dt, "unit": "cam-pts*iter/s", "cores": threads, "kind": "port",
+        "sample": f"same problem, full solve ({iters} LM iterations, {dt:.2f} s), analytic Jacobians, exact Schur + "
+                  f"envelope Cholesky, OpenMP; host has {os.cpu_count()} cores",
+        "final_rmse_px": math.sqrt(summ["final_cost"] / (2 * arr["obs_cam"].shape[0])),
+        "iterations": iters, "seconds": dt,
+    }, prob
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="L", choices=["S", "L"])
+    ap.add_argument("--pcg-tol", type=float, default=None)
+    ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from xrsfm_amd import capi, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available() or capi.device_count() < 1:
+        raise SystemExit("bench.py needs a HIP device; the BA path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = synth.CONFIGS[args.config]
+    full = synth.make_problem(**cfg)
+    arr = {k: full[k] for k in capi.ProblemArrays.FIELDS}
+    n_cams, n_points, n_obs = arr["cam_q"].shape[0], arr["points"].shape[0], arr["obs_cam"].shape[0]
+    local = shard_problem(arr, rank, world)
+    prob = capi.ProblemArrays(**{k: np.array(v, copy=True) for k, v in local.items()})
+    ctx = capi.Context(prob, device=local_rank)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        ctx.comm_init(world, rank, bytes(uid.cpu().tolist()))
+
+    opt = capi.default_options(verbose=1 if (args.verbose and rank == 0) else 0)
+    if args.pcg_tol is not None:
+        opt.pcg_tolerance = args.pcg_tol
+    opt.linear_solver = {"auto": capi.SOLVER_AUTO, "pcg": capi.SOLVER_PCG, "cholesky": capi.SOLVER_CHOLESKY}[args.solver]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        ctx.reset()
+        ctx.run(opt)
+    barrier()
+    t0 = time.perf_counter()
+    iters = 0
+    pcg = 0
+    last = None
+    for _ in range(args.steps):
+        ctx.reset()
+        last = ctx.run(opt)
+        iters += last.n_successful + last.n_unsuccessful
+        pcg += last.pcg_iterations
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    # one extra, untimed, profiled solve: HIP-event durations per kernel class on the library's stream
+    popt = capi.default_options(profile=1)
+    popt.pcg_tolerance = opt.pcg_tolerance
+    popt.linear_solver = opt.linear_solver
+    ctx.reset()
+    ctx.run(popt)
+    q, t, P = ctx.download()
+    kernels = ctx.profile()
+    kernel_table = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in kernels.items() if v[1] > 0}
+    roofline = None
+    # dominant kernel = largest HIP-event total among the HBM-streaming kernels
+    cands = [(v[0], k) for k, v in kernels.items() if v[1] > 0 and algorithmic_bytes(k, 1, 1, 1) is not None]
+    if cands:
+        _, dom = max(cands)
+        ms, launches = kernels[dom]
+        avg_s = ms * 1e-3 / launches
+        track_len = np.bincount(local["obs_pt"], minlength=prob.n_points)
+        n_pairs = int((track_len * (track_len - 1) // 2).sum())
+        alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, n_pairs)
+        ach = alg / avg_s / 1e9
+        roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": None, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
+                    "algorithmic_bytes_per_launch": alg}
+
+    if rank == 0:
+        n_res = 2 * n_obs
+        out = {
+            "metric": "BA iterations/sec x (cams+points)", "value": iters * (n_cams + n_points) / dt,
+            "unit": "cam-pts*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic BAL-style {args.config}: {n_cams} cams / {n_points} points / {n_obs} obs, "
+                                   f"GBA accurate (ba_solver.cc:626-629), seed {cfg['seed']}",
+                       "parallelism": f"points sharded x{world}, cameras replicated" if world > 1 else "single GPU",
+                       "linear_solver": "cholesky (explicit reduced camera matrix, exact)" if last.linear_solver_used == 1
+                       else f"implicit-Schur PCG tol {opt.pcg_tolerance:g}"},
+            "lm_iterations_per_step": iters / args.steps, "pcg_iterations_per_step": pcg / args.steps,
+            "final_rmse_px": math.sqrt(last.final_cost / n_res),
+            "initial_rmse_px": math.sqrt(last.initial_cost / n_res),
+            "termination_reason": last.termination_reason,
+            "roofline": roofline, "cpu_baseline": None, "kernels": kernel_table,
+        }
+        if world == 1 and not args.no_cpu:
+            res = cpu_baseline(arr, n_cams, n_points, opt.max_iterations)
+            if res is not None:
+                base, cpu_prob = res
+                base["gpu_vs_cpu"] = out["value"] / base["value"]
+                base["rmse_diff_px"] = abs(base["final_rmse_px"] - out["final_rmse_px"])
+                base["max_cam_param_diff"] = float(max(np.abs(cpu_prob["cam_q"] - q).max(), np.abs(cpu_prob["cam_t"] - t).max()))
+                out["cpu_baseline"] = base
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -69,7 +69,10 @@ typedef struct xrsfm_ba_problem {
     const double *obs_uv;       /* [n_obs][2]   frame.points[i]                          */
 } xrsfm_ba_problem;
 
-#define XRSFM_BA_SOLVER_PCG 0   /* implicit-Schur PCG on the reduced camera system   */
+#define XRSFM_BA_SOLVER_PCG 0      /* implicit-Schur PCG on the reduced camera system (any size)            */
+#define XRSFM_BA_SOLVER_CHOLESKY 1 /* explicit reduced camera matrix + tile-sparse dense Cholesky (exact,
+                                      what Ceres SPARSE_SCHUR computes); needs 6*n_cams <= 12288            */
+#define XRSFM_BA_SOLVER_AUTO 2     /* CHOLESKY when it fits, else PCG                                       */
 
 typedef struct xrsfm_ba_options {
     int32_t max_iterations;      /* GBA accurate 50 / fast 20 / KGBA 20 / LBA 5        */
@@ -102,8 +105,10 @@ typedef struct xrsfm_ba_summary {
     int32_t pcg_iterations;         /* total over all LM steps                         */
     int32_t lm_steps_attempted;     /* incl. the step that triggered a tolerance exit  */
     double total_time_s;            /* wall time of the solve, device-resident inputs  */
-    double dom_kernel_ms;           /* profile!=0: sum of HIP-event durations of the Schur-product kernel */
+    double dom_kernel_ms;           /* profile!=0: sum of HIP-event durations of the costliest kernel */
     int32_t dom_kernel_launches;    /* profile!=0: launches counted in dom_kernel_ms   */
+    int32_t dom_kernel_id;          /* profile!=0: index for xrsfm_ba_profile_entry    */
+    int32_t linear_solver_used;     /* XRSFM_BA_SOLVER_PCG or _CHOLESKY                */
     int32_t reserved;
 } xrsfm_ba_summary;
 
@@ -141,6 +146,11 @@ void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
  * the call that replaces ceres::Solve(options, &problem, &summary). */
 int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm_ba_summary *summary);
 
+/* profile != 0 in the last xrsfm_ba_run: per-kernel totals measured with HIP events on the
+ * library's stream.  Returns 0 and fills the outputs for index < number of kernel classes,
+ * XRSFM_BA_EINVAL past the end. */
+int xrsfm_ba_profile_entry(xrsfm_ba_context *ctx, int index, const char **name, double *total_ms, int *launches);
+
 /* ---- test/diagnostic entry points (kernel-level parity against the oracle) ---- */
 
 /* Linearise at the current state with Jacobi scaling `use_scaling` (0: scale = 1).
@@ -153,6 +163,10 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context *ctx, double huber_a, int use_scal
 
 /* After debug_linearize: y = S(radius) * x for a caller vector x [n_cams][6]; also returns rhs b [n_cams][6]. */
 int xrsfm_ba_debug_schur_product(xrsfm_ba_context *ctx, double radius, const double *x, double *y, double *b);
+
+/* After debug_linearize: solve S(radius) y = b with the Cholesky path; y [n_cams][6].  If S_dense != NULL it
+ * receives the assembled reduced camera matrix before factorisation, [6 n_cams][6 n_cams] row-major, symmetric. */
+int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context *ctx, double radius, double *y, double *S_dense);
 
 #ifdef __cplusplus
 }

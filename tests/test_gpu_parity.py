@@ -91,7 +91,7 @@ def _solve_both(arr, opt_kw=None, oracle_solver="exact"):
     from xrsfm_amd import capi
     opt_kw = opt_kw or {}
     pr = H.to_oracle(arr)
-    o = bo.Options(linear_solver=oracle_solver, **{k: v for k, v in opt_kw.items() if hasattr(bo.Options, k)})
+    o = bo.Options(linear_solver=oracle_solver, **{k: v for k, v in opt_kw.items() if hasattr(bo.Options, k) and k != "linear_solver"})
     s_ref = bo.solve(pr, o)
     prod = H.to_product(arr)
     copt = capi.default_options(**{k: v for k, v in opt_kw.items()})
@@ -162,3 +162,64 @@ def test_edge_cases(lib):
     bad = H.to_product(arr); bad.obs_cam[0] = 99
     with pytest.raises(RuntimeError):
         capi.solve(bad)
+
+
+@pytest.mark.parametrize("n_cams,n_pts,k_obs,mode", [(8, 300, 4, "sequential"), (30, 500, 5, "sequential"),
+                                                     (80, 12, 70, "unordered"), (40, 800, 6, "unordered")])
+def test_cholesky_reduced_system(lib, n_cams, n_pts, k_obs, mode):
+    """Explicit reduced camera matrix S and the tile Cholesky solve against the oracle's dense Schur complement."""
+    import scipy.linalg as sla
+    from xrsfm_amd import capi
+    arr = H.make(n_cams, n_pts, k_obs, seed=106, min_tri_angle_deg=0.5, mode=mode)
+    pr = H.to_oracle(arr)
+    ctx = capi.Context(H.to_product(arr))
+    ctx.debug_linearize(5.99, True)
+    _, _, _, _, lin = _lin_oracle(pr, True)
+    radius = 3e3
+    Dc2 = np.clip(np.einsum("nii->ni", lin.Hcc), 1e-6, 1e32) / radius
+    Dp2 = np.clip(np.einsum("nii->ni", lin.Hpp), 1e-6, 1e32) / radius
+    # dense S via the implicit product applied to the identity (oracle arithmetic)
+    Hinv = np.linalg.inv(lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3)))
+    ci, pi = pr.obs_cam, pr.obs_pt
+    n = 6 * n_cams
+    S_ref = np.zeros((n, n))
+    WH = np.einsum("nij,njk->nik", lin.W, Hinv[pi])
+    for c in range(n_cams):
+        S_ref[6 * c:6 * c + 6, 6 * c:6 * c + 6] = lin.Hcc[c] + np.diag(Dc2[c])
+    order = np.argsort(pi, kind="stable")
+    ptr = np.searchsorted(pi[order], np.arange(n_pts + 1))
+    for j in range(n_pts):
+        ids = order[ptr[j]:ptr[j + 1]]
+        for a in ids:
+            for b2 in ids:
+                S_ref[6 * ci[a]:6 * ci[a] + 6, 6 * ci[b2]:6 * ci[b2] + 6] -= WH[a] @ lin.W[b2].T
+    b_ref = lin.gc - bo._scatter_add(n_cams, ci, np.einsum("nij,nj->ni", WH, lin.gp[pi]))
+    y_ref = sla.cho_solve(sla.cho_factor(S_ref, lower=True), b_ref.reshape(-1)).reshape(n_cams, 6)
+    y, S = ctx.debug_cholesky_solve(radius, want_S=True)
+    assert H.rel_err(S, S_ref) < 1e-11
+    assert H.rel_err(y, y_ref) < 1e-8       # conditioned by S; the full-solve tests bound the end effect
+    ctx.close()
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_solver_variants_agree(lib, solver):
+    """PCG (tol 1e-12) and Cholesky follow the same LM trajectory as the oracle's exact solve."""
+    from xrsfm_amd import capi
+    arr = H.make(20, 1500, 4, seed=107)
+    pr, s_ref, prod, s = _solve_both(arr, dict(linear_solver=solver))
+    assert s.linear_solver_used == solver
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert s.n_successful == s_ref.n_successful and s.n_unsuccessful == s_ref.n_unsuccessful
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert max(np.abs(prod.cam_q - pr.cam_q).max(), np.abs(prod.cam_t - pr.cam_t).max()) < 1e-5
+
+
+def test_profile_entries(lib):
+    from xrsfm_amd import capi
+    arr = H.make(12, 600, 4, seed=108)
+    ctx = capi.Context(H.to_product(arr))
+    s = ctx.run(capi.default_options(profile=1))
+    prof = ctx.profile()
+    assert prof["k_linearize"][1] == s.n_successful + 2      # two linearisations at iteration 0, one per accepted step
+    assert prof["k_potrf"][1] > 0 and s.dom_kernel_ms > 0
+    ctx.close()

@@ -44,7 +44,8 @@ class CSummary(C.Structure):
         ("termination", C.c_int32), ("termination_reason", C.c_int32),
         ("pcg_iterations", C.c_int32), ("lm_steps_attempted", C.c_int32),
         ("total_time_s", C.c_double), ("dom_kernel_ms", C.c_double),
-        ("dom_kernel_launches", C.c_int32), ("reserved", C.c_int32),
+        ("dom_kernel_launches", C.c_int32), ("dom_kernel_id", C.c_int32),
+        ("linear_solver_used", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):
@@ -55,8 +56,11 @@ class CSummary(C.Structure):
 EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
-    "xrsfm_ba_solve", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
+    "xrsfm_ba_solve", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
+    "xrsfm_ba_debug_cholesky_solve",
 ]
+
+SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
 
 ERRORS = {-1: "EINVAL", -2: "ENODEV (no HIP device / HIP error; there is no CPU fallback)", -3: "ENOMEM",
           -4: "ECOMM", -5: "ESTATE"}
@@ -90,6 +94,10 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_linearize.restype = C.c_int
     lib.xrsfm_ba_debug_schur_product.argtypes = [vp, C.c_double, _c_double_p, _c_double_p, _c_double_p]
     lib.xrsfm_ba_debug_schur_product.restype = C.c_int
+    lib.xrsfm_ba_debug_cholesky_solve.argtypes = [vp, C.c_double, _c_double_p, _c_double_p]
+    lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
+    lib.xrsfm_ba_profile_entry.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _c_double_p, C.POINTER(C.c_int)]
+    lib.xrsfm_ba_profile_entry.restype = C.c_int
     _lib = lib
     return lib
 
@@ -217,6 +225,26 @@ class Context:
         y = np.zeros_like(x); b = np.zeros_like(x)
         check(self.lib.xrsfm_ba_debug_schur_product(self._h, radius, _dp(x), _dp(y), _dp(b)), "debug_schur_product")
         return y, b
+
+
+    def debug_cholesky_solve(self, radius: float, want_S: bool = False):
+        n = 6 * self.problem.n_cams
+        y = np.zeros((self.problem.n_cams, 6))
+        S = np.zeros((n, n)) if want_S else None
+        check(self.lib.xrsfm_ba_debug_cholesky_solve(self._h, radius, _dp(y), _dp(S)), "debug_cholesky_solve")
+        return y, S
+
+    def profile(self) -> dict:
+        """Per-kernel HIP-event totals of the last run with options.profile != 0: name -> (ms, launches)."""
+        out = {}
+        i = 0
+        while True:
+            name = C.c_char_p(); ms = C.c_double(0); n = C.c_int(0)
+            if self.lib.xrsfm_ba_profile_entry(self._h, i, C.byref(name), C.cast(C.byref(ms), _c_double_p), C.byref(n)) != 0:
+                break
+            out[name.value.decode()] = (ms.value, n.value)
+            i += 1
+        return out
 
 
 def comm_unique_id() -> bytes:

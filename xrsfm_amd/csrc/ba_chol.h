@@ -1,0 +1,347 @@
+// Explicit reduced camera matrix S and its Cholesky solve (the exact solve Ceres'
+// SPARSE_SCHUR performs, /root/reference/src/optimization/ba_solver.cc:74).
+//
+//  * Off-diagonal 6x6 blocks  S(b,a) = - sum_tracks W_b Hinv W_a^T  are produced per
+//    track pair by wave shuffles, written to a block-major scatter buffer and summed
+//    in fixed order (bit-reproducible, no FP atomics).
+//  * S is expanded into dense row-major storage in 64x64 tiles; only tiles that are
+//    structurally non-zero after symbolic factorisation are touched, so a banded
+//    (sequential) problem costs O(N_c) and an unordered one degrades to dense.
+//  * Tile kernels: potrf (one workgroup, LDS), trsm and the rank-64 trailing update
+//    as 64x64x64 tile products on the FP64 matrix cores (v_mfma_f64_16x16x4_f64),
+//    forward / backward substitution one panel per launch.
+#pragma once
+#include "ba_kernels.h"
+
+namespace xba {
+
+constexpr int kNB = 64;          // tile size
+constexpr int kLdT = 66;         // LDS row stride (doubles): conflict-free ds_read_b64 for MFMA operands
+
+struct CholDev {
+    int n, n_pad, T;
+    double* S;        // [n_pad][n_pad] row-major, lower triangle valid
+    double* Linv;     // [T][64][64] inverse of the diagonal tiles of L
+    double* y;        // [n_pad] forward-substituted rhs
+    double* rhs;      // [n_pad] working copy of b
+    double* x;        // [n_pad]
+};
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------ S assembly
+// Off-diagonal blocks of one tile of tracks.  Lane = observation a; partner b = a + d
+// in the same track (b's camera id is larger).  block(b,a) = W_b * (W_a Hinv)^T.
+__global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr,
+                                                       const int* __restrict__ pair_dst, double* __restrict__ scat2) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    const size_t ns = (size_t)d.n_slots;
+    if (it.n_tiles == 1) {
+        const SlotCtx s = load_slot(d, it.first_tile, lane);
+        double W[18], WH[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) { W[k] = 0.0; WH[k] = 0.0; }
+        int npair = 0, pbase = 0;
+        if (s.valid) {
+            double F[12], E[6];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + s.slot];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + s.slot];
+            const double* h = d.Hinv + 6 * (size_t)s.pt;
+            const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+#pragma unroll
+                for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[6 + a] * E[3 + b];
+                WH[3 * a + 0] = W[3 * a] * h0 + W[3 * a + 1] * h1 + W[3 * a + 2] * h2;
+                WH[3 * a + 1] = W[3 * a] * h1 + W[3 * a + 1] * h3 + W[3 * a + 2] * h4;
+                WH[3 * a + 2] = W[3 * a] * h2 + W[3 * a + 1] * h4 + W[3 * a + 2] * h5;
+            }
+            pbase = slot_pair_ptr[s.slot];
+            npair = slot_pair_ptr[s.slot + 1] - pbase;
+        }
+        int maxp = npair;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, __shfl_xor(maxp, off, kWave));
+        for (int dd = 1; dd <= maxp; ++dd) {
+            double Wb[18];
+#pragma unroll
+            for (int k = 0; k < 18; ++k) Wb[k] = __shfl_down(W[k], dd, kWave);
+            if (dd <= npair) {
+                double2* out = reinterpret_cast<double2*>(scat2 + 36 * (size_t)pair_dst[pbase + dd - 1]);
+#pragma unroll
+                for (int rb = 0; rb < 6; ++rb) {
+                    double o[6];
+#pragma unroll
+                    for (int ca = 0; ca < 6; ++ca)
+                        o[ca] = Wb[3 * rb] * WH[3 * ca] + Wb[3 * rb + 1] * WH[3 * ca + 1] + Wb[3 * rb + 2] * WH[3 * ca + 2];
+                    out[3 * rb + 0] = make_double2(o[0], o[1]);
+                    out[3 * rb + 1] = make_double2(o[2], o[3]);
+                    out[3 * rb + 2] = make_double2(o[4], o[5]);
+                }
+            }
+        }
+        return;
+    }
+    // long track: lane handles observation a, loops over all later observations b of the track
+    const int s_begin = it.first_tile * kWave, s_end = s_begin + it.n_tiles * kWave;
+    for (int sa = s_begin + lane; sa < s_end; sa += kWave) {
+        if (d.slot_cam[sa] < 0) continue;
+        const int pt = d.slot_pt[sa];
+        const double* h = d.Hinv + 6 * (size_t)pt;
+        double WH[18];
+        for (int a = 0; a < 6; ++a) {
+            double w[3];
+            for (int b = 0; b < 3; ++b) w[b] = d.Fs[a * ns + sa] * d.Es[b * ns + sa] + d.Fs[(6 + a) * ns + sa] * d.Es[(3 + b) * ns + sa];
+            WH[3 * a + 0] = w[0] * h[0] + w[1] * h[1] + w[2] * h[2];
+            WH[3 * a + 1] = w[0] * h[1] + w[1] * h[3] + w[2] * h[4];
+            WH[3 * a + 2] = w[0] * h[2] + w[1] * h[4] + w[2] * h[5];
+        }
+        const int pbase = slot_pair_ptr[sa];
+        const int npair = slot_pair_ptr[sa + 1] - pbase;
+        for (int dd = 1; dd <= npair; ++dd) {
+            const int sb = sa + dd;
+            double* out = scat2 + 36 * (size_t)pair_dst[pbase + dd - 1];
+            for (int rb = 0; rb < 6; ++rb) {
+                double wb[3];
+                for (int m = 0; m < 3; ++m) wb[m] = d.Fs[rb * ns + sb] * d.Es[m * ns + sb] + d.Fs[(6 + rb) * ns + sb] * d.Es[(3 + m) * ns + sb];
+                for (int ca = 0; ca < 6; ++ca) out[6 * rb + ca] = wb[0] * WH[3 * ca] + wb[1] * WH[3 * ca + 1] + wb[2] * WH[3 * ca + 2];
+            }
+        }
+    }
+}
+
+// Sum the contributions of one block (fixed order): out[block][36]
+__global__ __launch_bounds__(kBlock) void k_block_segsum(const double* __restrict__ scat2, const int* __restrict__ blk_ptr,
+                                                         double* __restrict__ out) {
+    constexpr int K = 36, G = kBlock / K;
+    __shared__ double lds[G * K];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const int beg = blk_ptr[b], n = blk_ptr[b + 1] - beg;
+    if (t < G * K) {
+        const int g = t / K;
+        double acc = 0.0;
+        const double* base = scat2 + (size_t)beg * K + t;
+        for (int o = g; o < n; o += G) { acc += *base; base += (size_t)G * K; }
+        lds[t] = acc;
+    }
+    __syncthreads();
+    if (t < K) {
+        double s = 0.0;
+        for (int g = 0; g < G; ++g) s += lds[g * K + t];
+        out[(size_t)b * K + t] = s;
+    }
+}
+
+__global__ void k_zero_tiles(CholDev c, const int* __restrict__ tiles, int n_tiles) {
+    // tiles: pairs (ti, tj); one workgroup per tile
+    const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+    for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
+        const int r = e / kNB, col = e % kNB;
+        c.S[(size_t)(ti * kNB + r) * c.n_pad + tj * kNB + col] = 0.0;
+    }
+}
+
+// Dense fill: off-diagonal blocks (lower: row block b > col block a) = -sum; diagonal = Scc + Dc2; padding diag = 1
+__global__ void k_dense_fill_off(CholDev c, const double* __restrict__ Sblk, const int* __restrict__ blk_rc, int n_blocks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_blocks * 36) return;
+    const int b = i / 36, e = i % 36;
+    const int rb = blk_rc[2 * b], ca = blk_rc[2 * b + 1];
+    c.S[(size_t)(6 * rb + e / 6) * c.n_pad + 6 * ca + e % 6] = -Sblk[i];
+}
+
+__global__ void k_dense_fill_diag(CholDev c, Dev d) {
+    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
+    if (cam < d.n_cams) {
+        const double* S = d.camS + 28 * (size_t)cam;
+        int idx = 0;
+        for (int a = 0; a < 6; ++a)
+            for (int b = a; b < 6; ++b) {
+                double v = S[idx++];
+                if (a == b) v += d.Dc2[6 * (size_t)cam + a];
+                c.S[(size_t)(6 * cam + b) * c.n_pad + 6 * cam + a] = v;   // lower
+                c.S[(size_t)(6 * cam + a) * c.n_pad + 6 * cam + b] = v;   // (upper inside the diagonal tile is ignored)
+            }
+    }
+    const int r = c.n + cam;
+    if (cam >= 0 && r < c.n_pad && cam < c.n_pad - c.n) c.S[(size_t)r * c.n_pad + r] = 1.0;
+}
+
+// ------------------------------------------------------------ tile Cholesky
+// Diagonal tile: L = chol(A) in LDS, also Linv (lower) for the trsm / substitution steps.
+__global__ __launch_bounds__(256) void k_potrf(CholDev c, int k) {
+    __shared__ double A[kNB][kNB + 1];
+    __shared__ double Li[kNB][kNB + 1];
+    const int t = threadIdx.x;
+    double* base = c.S + (size_t)(k * kNB) * c.n_pad + k * kNB;
+    for (int e = t; e < kNB * kNB; e += 256) { const int r = e / kNB, col = e % kNB; A[r][col] = (col <= r) ? base[(size_t)r * c.n_pad + col] : 0.0; }
+    __syncthreads();
+    for (int j = 0; j < kNB; ++j) {
+        const double djj = sqrt(A[j][j]);
+        __syncthreads();
+        if (t >= j && t < kNB) A[t][j] = (t == j) ? djj : A[t][j] / djj;
+        __syncthreads();
+        // trailing update of the lower triangle: A[i][c2] -= A[i][j] * A[c2][j], j < c2 <= i
+        for (int e = t; e < kNB * kNB; e += 256) {
+            const int i = e / kNB, c2 = e % kNB;
+            if (c2 > j && c2 <= i) A[i][c2] -= A[i][j] * A[c2][j];
+        }
+        __syncthreads();
+    }
+    // Linv: column cc by forward substitution, one thread per column (threads 0..63)
+    if (t < kNB) {
+        const int cc = t;
+        for (int r = 0; r < kNB; ++r) {
+            double s = (r == cc) ? 1.0 : 0.0;
+            if (r < cc) { Li[r][cc] = 0.0; continue; }
+            for (int m = cc; m < r; ++m) s -= A[r][m] * Li[m][cc];
+            Li[r][cc] = s / A[r][r];
+        }
+    }
+    __syncthreads();
+    double* lo = c.Linv + (size_t)k * kNB * kNB;
+    for (int e = t; e < kNB * kNB; e += 256) {
+        const int r = e / kNB, col = e % kNB;
+        if (col <= r) base[(size_t)r * c.n_pad + col] = A[r][col];
+        lo[e] = Li[r][col];
+    }
+}
+
+// C(64x64) (op)= alpha * A(64x64) * B(64x64)^T on the FP64 matrix cores.  A, B row-major tiles in LDS
+// (stride kLdT).  4 waves, each a 32x32 quadrant = 2x2 MFMA 16x16 tiles, 16 k-steps of 4.
+__device__ __forceinline__ void tile_abt_mfma(const double* __restrict__ As, const double* __restrict__ Bs, v4d (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll 4
+    for (int k0 = 0; k0 < kNB; k0 += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a[m] = As[(r0 + 16 * m + li) * kLdT + k0 + lk];
+            b[m] = Bs[(c0 + 16 * m + li) * kLdT + k0 + lk];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n2], acc[m][n2], 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void load_tile_lds(double* dst, const double* __restrict__ src, size_t ld) {
+    for (int e = threadIdx.x; e < kNB * kNB; e += 256) { const int r = e / kNB, col = e % kNB; dst[r * kLdT + col] = src[(size_t)r * ld + col]; }
+}
+
+// A_ik <- A_ik * Linv_k^T for the tiles i listed in rows[]
+__global__ __launch_bounds__(256) void k_trsm(CholDev c, int k, const int* __restrict__ rows) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem; double* Bs = smem + kNB * kLdT;
+    const int i = rows[blockIdx.x];
+    double* Ag = c.S + (size_t)(i * kNB) * c.n_pad + k * kNB;
+    load_tile_lds(As, Ag, c.n_pad);
+    load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
+    __syncthreads();
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    tile_abt_mfma(As, Bs, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
+                Ag[(size_t)r * c.n_pad + col] = acc[m][n2][g];
+            }
+}
+
+// A_ij -= A_ik * A_jk^T for the tile pairs (i,j) listed in pairs[]
+__global__ __launch_bounds__(256) void k_update(CholDev c, int k, const int* __restrict__ pairs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem; double* Bs = smem + kNB * kLdT;
+    const int i = pairs[2 * blockIdx.x], j = pairs[2 * blockIdx.x + 1];
+    load_tile_lds(As, c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad);
+    load_tile_lds(Bs, c.S + (size_t)(j * kNB) * c.n_pad + k * kNB, c.n_pad);
+    __syncthreads();
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    tile_abt_mfma(As, Bs, acc);
+    double* Cg = c.S + (size_t)(i * kNB) * c.n_pad + j * kNB;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
+                Cg[(size_t)r * c.n_pad + col] -= acc[m][n2][g];
+            }
+}
+
+// 64x64 matrix-vector helpers (one workgroup of 256 threads): out = M v or M^T v, M row-major ld
+__device__ __forceinline__ void tile_gemv(const double* __restrict__ M, size_t ld, const double* v, double* out, bool transpose, double* red) {
+    // 4 threads per output element
+    const int t = threadIdx.x, o = t >> 2, part = t & 3;
+    double s = 0.0;
+    for (int m = part * 16; m < part * 16 + 16; ++m) s += (transpose ? M[(size_t)m * ld + o] : M[(size_t)o * ld + m]) * v[m];
+    s += __shfl_xor(s, 1, kWave);
+    s += __shfl_xor(s, 2, kWave);
+    if (part == 0) out[o] = s;
+    (void)red;
+}
+
+// forward substitution, panel k: y_k = Linv_k rhs_k;  rhs_i -= L_ik y_k for i in rows[]
+__global__ __launch_bounds__(256) void k_fwd(CholDev c, int k, const int* __restrict__ rows) {
+    __shared__ double v[kNB], yk[kNB], tmp[kNB];
+    if (threadIdx.x < kNB) v[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
+    __syncthreads();
+    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, v, yk, false, nullptr);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kNB) c.y[k * kNB + threadIdx.x] = yk[threadIdx.x];
+        return;
+    }
+    const int i = rows[blockIdx.x - 1];
+    tile_gemv(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, yk, tmp, false, nullptr);
+    __syncthreads();
+    if (threadIdx.x < kNB) c.rhs[i * kNB + threadIdx.x] -= tmp[threadIdx.x];
+}
+
+// backward substitution, panel k: x_k = Linv_k^T y_k;  y_j -= L_kj^T x_k for j in cols[]
+__global__ __launch_bounds__(256) void k_bwd(CholDev c, int k, const int* __restrict__ cols) {
+    __shared__ double v[kNB], xk[kNB], tmp[kNB];
+    if (threadIdx.x < kNB) v[threadIdx.x] = c.y[k * kNB + threadIdx.x];
+    __syncthreads();
+    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, v, xk, true, nullptr);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < kNB) c.x[k * kNB + threadIdx.x] = xk[threadIdx.x];
+        return;
+    }
+    const int j = cols[blockIdx.x - 1];
+    tile_gemv(c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad, xk, tmp, true, nullptr);
+    __syncthreads();
+    if (threadIdx.x < kNB) c.y[j * kNB + threadIdx.x] -= tmp[threadIdx.x];
+}
+
+__global__ void k_copy_pad(double* dst, const double* src, int n, int n_pad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0;
+}
+
+}  // namespace xba

@@ -43,6 +43,7 @@ struct Dev {
     const Item* items;
     // cameras
     CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
+    double* cam_act;    // [Nc] 1.0 if any rank observes the camera (cameras without observations are not in the program)
     // points (AoS xyz)
     double* P; double* P_cand; const unsigned char* pt_const;
     // Jacobi scaling
@@ -704,7 +705,7 @@ __global__ void k_cam_update(Dev d) {
     const CamRec cur = d.cam[c];
     CamRec nxt = cur;
     const unsigned cc = d.cam_const[c];
-    const bool active = d.cam_ptr[c + 1] > d.cam_ptr[c];
+    const bool active = d.cam_act[c] > 0.0;
     const double* y = d.px + 6 * (size_t)c;
     const double* sc = d.scale_c + 6 * (size_t)c;
     double step2 = 0.0, xn2 = 0.0;
@@ -729,7 +730,7 @@ __global__ void k_gradmax_cams(Dev d) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.n_cams) return;
     const unsigned cc = d.cam_const[c];
-    const bool active = d.cam_ptr[c + 1] > d.cam_ptr[c];
+    const bool active = d.cam_act[c] > 0.0;
     const double* g = d.camlin + 12 * (size_t)c + 6;
     const double* sc = d.scale_c + 6 * (size_t)c;
     double m = 0.0;

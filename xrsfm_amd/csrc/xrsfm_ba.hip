@@ -5,10 +5,12 @@
 // 636,672) with SPARSE_SCHUR + LEVENBERG_MARQUARDT (ba_solver.cc:74-75); the
 // accept/reject/termination rules restate Ceres' TrustRegionMinimizer
 // (SURVEY.md Appendix A.5/A.6).  All arithmetic on the state runs in the HIP
-// kernels of ba_kernels.h; the host only sees a handful of scalars per step.
+// kernels of ba_kernels.h / ba_chol.h; the host only sees a handful of scalars
+// per step.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -16,6 +18,7 @@
 #include <vector>
 
 #include "../../include/xrsfm_ba.h"
+#include "ba_chol.h"
 #include "ba_kernels.h"
 #include "ba_pack.h"
 
@@ -33,17 +36,14 @@ using namespace xba;
 
 // ---------------------------------------------------------------- RCCL (loaded lazily, only for n_ranks > 1)
 namespace {
+struct UniqueId { char internal[128]; };
 struct Rccl {
     void* lib = nullptr;
-    int (*GetUniqueId)(void*) = nullptr;
-    int (*CommInitRank)(void**, int, const void*, int) = nullptr;   // ncclUniqueId passed by value (128 B struct)
+    int (*GetUniqueId)(UniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;   // ncclUniqueId is passed by value (128 B struct)
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
 };
-struct UniqueId { char internal[128]; };
-typedef int (*fn_init_rank)(void**, int, UniqueId, int);
-typedef int (*fn_unique_id)(UniqueId*);
-
 Rccl g_rccl;
 bool load_rccl() {
     if (g_rccl.lib) return true;
@@ -53,34 +53,58 @@ bool load_rccl() {
         if (g_rccl.lib) break;
     }
     if (!g_rccl.lib) return false;
-    g_rccl.GetUniqueId = (int (*)(void*))dlsym(g_rccl.lib, "ncclGetUniqueId");
-    g_rccl.CommInitRank = (int (*)(void**, int, const void*, int))dlsym(g_rccl.lib, "ncclCommInitRank");
+    g_rccl.GetUniqueId = (int (*)(UniqueId*))dlsym(g_rccl.lib, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (int (*)(void**, int, UniqueId, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
     return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
 }
 constexpr int kNcclFloat64 = 8;   // ncclDouble
 constexpr int kNcclSum = 0, kNcclMax = 2;
+
+// kernel classes for the HIP-event profile
+enum Kid {
+    K_LINEARIZE = 0, K_COST, K_CAM_SEGSUM, K_SCHUR_PREP, K_SCHUR_MATVEC, K_PCG_VEC, K_BACKSUB, K_SCHUR_PAIRS, K_BLOCK_SEGSUM,
+    K_DENSE_FILL, K_POTRF, K_TRSM, K_UPDATE, K_TRISOLVE, K_SMALL, K_COUNT
+};
+const char* kKidName[K_COUNT] = {
+    "k_linearize", "k_cost", "k_cam_segsum", "k_schur_prep", "k_schur_matvec", "k_pcg_update", "k_backsub", "k_schur_pairs",
+    "k_block_segsum", "k_dense_fill", "k_potrf", "k_trsm", "k_update", "k_fwd_bwd", "small_kernels"};
+
+constexpr int kCholMaxN = 12288;
 }  // namespace
 
 // ---------------------------------------------------------------- context
+struct CholHost {
+    bool ready = false;
+    CholDev dev{};
+    int n_blocks = 0, n_pairs = 0, n_tiles_nz = 0, T = 0;
+    int *slot_pair_ptr = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr;
+    double *scat2 = nullptr, *Sblk = nullptr;
+    int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
+    int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
+    std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
+};
+
 struct xrsfm_ba_context {
     int device = 0;
     hipStream_t stream = nullptr;
     Packed pk;
     Dev d{};
     std::vector<void*> allocs;
-    // pristine copies for reset
-    CamRec* cam0 = nullptr; double* P0 = nullptr;
+    CamRec* cam0 = nullptr; double* P0 = nullptr;   // pristine copies for reset
     int n_points_caller = 0;
     double* h_scal = nullptr;       // pinned
     PcgStatus* h_st = nullptr;      // pinned
-    // comm
     void* comm = nullptr; int n_ranks = 1, rank = 0;
     // profiling
-    std::vector<hipEvent_t> ev;
-    bool linearized = false; bool scaled = false;
-    double dbg_radius = 0;
+    bool profiling = false;
+    std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
+    struct Rec { int kid; size_t e0; int tag; };
+    std::vector<Rec> recs;
+    double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
+    bool linearized = false;
+    CholHost chol;
 };
 
 namespace {
@@ -110,35 +134,62 @@ int allreduce(xrsfm_ba_context* c, double* buf, size_t n, int op) {
     return e == 0 ? 0 : XRSFM_BA_ECOMM;
 }
 
-// Linearise at the current state (scale arrays as they are).  Leaves S_COST,
-// S_XNORM2_PTS in d.scal and camlin / Hpp / gp filled.
-int linearize(xrsfm_ba_context* c, double huber_a) {
-    Dev& d = c->d;
-    const int nb = cdiv(d.n_items, kWavesPerBlock);
-    if (d.n_items > 0) hipLaunchKernelGGL(k_linearize, dim3(nb), dim3(kBlock), 0, c->stream, d, huber_a);
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, c->stream, d.scat, d.cam_ptr,
-                       d.camlin, (const PcgStatus*)nullptr);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.part, d.n_items, d.scal + S_COST);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.part + d.n_items, d.n_items,
-                       d.scal + S_XNORM2_PTS);
-    int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12, kNcclSum);
-    if (e) return e;
-    e = allreduce(c, d.scal + S_COST, 2, kNcclSum);   // S_COST, S_XNORM2_PTS adjacent
-    return e;
+// Launch wrapper: in profile mode every launch is bracketed by HIP events on the library's stream.
+struct Timed {
+    xrsfm_ba_context* c; int kid; int tag; size_t e0 = 0; bool on;
+    Timed(xrsfm_ba_context* c_, int kid_, int tag_ = -1) : c(c_), kid(kid_), tag(tag_), on(c_->profiling) {
+        if (!on) return;
+        while (c->ev_pool.size() < c->ev_used + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->ev_pool.push_back(e); }
+        e0 = c->ev_used; c->ev_used += 2;
+        (void)hipEventRecord(c->ev_pool[e0], c->stream);
+    }
+    ~Timed() {
+        if (!on) return;
+        (void)hipEventRecord(c->ev_pool[e0 + 1], c->stream);
+        c->recs.push_back({kid, e0, tag});
+    }
+};
+#define LAUNCH(ctx, kid, kern, grid, block, shmem, ...)                                  \
+    do { Timed t_((ctx), (kid)); hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__); } while (0)
+
+// resolve recorded event pairs (stream must be idle); records tagged with a PCG iteration index are only
+// counted if the iteration really ran (launches after `done` are no-ops)
+void profile_collect(xrsfm_ba_context* c, int tag_limit = 1 << 30) {
+    for (const auto& r : c->recs) {
+        if (r.tag >= tag_limit) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev_pool[r.e0], c->ev_pool[r.e0 + 1]) == hipSuccess) { c->prof_ms[r.kid] += ms; c->prof_n[r.kid]++; }
+    }
+    c->recs.clear();
+    c->ev_used = 0;
 }
 
 int fetch_scalars(xrsfm_ba_context* c) {
     HIPCHK(hipMemcpyAsync(c->h_scal, c->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->profiling) profile_collect(c);
     return 0;
+}
+
+// Linearise at the current state (scale arrays as they are).  Leaves S_COST, S_XNORM2_PTS in d.scal
+// and camlin / Hpp / gp filled.
+int linearize(xrsfm_ba_context* c, double huber_a) {
+    Dev& d = c->d;
+    if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
+    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camlin, (const PcgStatus*)nullptr);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part, d.n_items, d.scal + S_COST);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part + d.n_items, d.n_items, d.scal + S_XNORM2_PTS);
+    int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12, kNcclSum);
+    if (e) return e;
+    return allreduce(c, d.scal + S_COST, 2, kNcclSum);   // S_COST, S_XNORM2_PTS adjacent
 }
 
 int gradient_max(xrsfm_ba_context* c, double* out) {
     Dev& d = c->d;
     HIPCHK(hipMemsetAsync(d.scal + S_GRADMAX_PTS, 0, sizeof(double), c->stream));
-    if (d.n_pts > 0) hipLaunchKernelGGL(k_gradmax_pts, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, c->stream, d, d.scal + S_GRADMAX_PTS);
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_gradmax_cams, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, c->stream, d);
-    hipLaunchKernelGGL(k_reduce_max, dim3(1), dim3(kPcgThreads), 0, c->stream, d.campart, d.n_cams, d.scal + S_GRADMAX_CAMS);
+    if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_gradmax_pts, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, d, d.scal + S_GRADMAX_PTS);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
+    LAUNCH(c, K_SMALL, k_reduce_max, dim3(1), dim3(kPcgThreads), 0, d.campart, d.n_cams, d.scal + S_GRADMAX_CAMS);
     int e = allreduce(c, d.scal + S_GRADMAX_PTS, 1, kNcclMax);
     if (e) return e;
     e = fetch_scalars(c);
@@ -147,58 +198,42 @@ int gradient_max(xrsfm_ba_context* c, double* out) {
     return 0;
 }
 
-// Build everything that depends on the radius: D^2, Hpp^-1, block-Jacobi
-// preconditioner and the reduced right-hand side.
+// Everything that depends on the radius: D^2, Hpp^-1, diagonal blocks of S and the reduced right-hand side.
 int prepare_step(xrsfm_ba_context* c, double radius) {
     Dev& d = c->d;
     const double dmin = 1e-6, dmax = 1e32;
-    if (d.n_pts > 0) hipLaunchKernelGGL(k_point_prep, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, c->stream, d, radius, dmin, dmax);
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_cam_prep, dim3(cdiv((long long)d.n_cams * 6, kBlock)), dim3(kBlock), 0, c->stream, d, radius, dmin, dmax);
-    if (d.n_slots > 0) hipLaunchKernelGGL(k_schur_prep, dim3(cdiv(d.n_slots, kBlock)), dim3(kBlock), 0, c->stream, d);
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, c->stream, d.scat, d.cam_ptr, d.camS,
-                       (const PcgStatus*)nullptr);
+    if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_point_prep, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_prep, dim3(cdiv((long long)d.n_cams * 6, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
+    if (d.n_slots > 0) LAUNCH(c, K_SCHUR_PREP, k_schur_prep, dim3(cdiv(d.n_slots, kBlock)), dim3(kBlock), 0, d);
+    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, (const PcgStatus*)nullptr);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28, kNcclSum);
     if (e) return e;
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_cam_factor, dim3(cdiv(d.n_cams, 64)), dim3(64), 0, c->stream, d);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_factor, dim3(cdiv(d.n_cams, 64)), dim3(64), 0, d);
     return 0;
 }
 
 // y = sum_obs F^T (F p - E Hinv E^T F p)  (+ D_c^2 p is added by the consumer)
-int schur_product(xrsfm_ba_context* c, const double* p_dev, double* out_dev, bool timed, hipEvent_t e0, hipEvent_t e1) {
+int schur_product(xrsfm_ba_context* c, const double* p_dev, double* out_dev, int tag) {
     Dev& d = c->d;
-    if (timed) hipEventRecord(e0, c->stream);
-    if (d.n_items > 0) hipLaunchKernelGGL(k_schur_matvec, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, c->stream, d, p_dev);
-    if (timed) hipEventRecord(e1, c->stream);
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_cam_segsum<6>, dim3(d.n_cams), dim3(kBlock), 0, c->stream, d.scat, d.cam_ptr, out_dev,
-                       (const PcgStatus*)d.st);
+    if (d.n_items > 0) { Timed t_(c, K_SCHUR_MATVEC, tag); hipLaunchKernelGGL(k_schur_matvec, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, c->stream, d, p_dev); }
+    if (d.n_cams > 0) { Timed t_(c, K_CAM_SEGSUM, tag); hipLaunchKernelGGL(k_cam_segsum<6>, dim3(d.n_cams), dim3(kBlock), 0, c->stream, d.scat, d.cam_ptr, out_dev, (const PcgStatus*)d.st); }
     return allreduce(c, out_dev, (size_t)d.n_cams * 6, kNcclSum);
 }
 
 int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary* sum) {
     Dev& d = c->d;
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(kPcgThreads), 0, c->stream, d);
+    LAUNCH(c, K_PCG_VEC, k_pcg_init, dim3(1), dim3(kPcgThreads), 0, d);
     const int chunk = 8;
-    int launched = 0, it_prev = 0;
+    int launched = 0;
     while (true) {
         HIPCHK(hipMemcpyAsync(c->h_st, d.st, sizeof(PcgStatus), hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
-        if (opt.profile && launched > 0) {
-            // launches after `done` are no-ops and are not counted
-            const int eff = c->h_st->it - it_prev;
-            for (int i = 0; i < eff && i < chunk; ++i) {
-                float ms = 0.f;
-                if (hipEventElapsedTime(&ms, c->ev[2 * i], c->ev[2 * i + 1]) == hipSuccess) { sum->dom_kernel_ms += ms; sum->dom_kernel_launches++; }
-            }
-        }
-        it_prev = c->h_st->it;
+        if (c->profiling) profile_collect(c, c->h_st->it);
         if (c->h_st->done || launched >= opt.pcg_max_iterations) break;
-        const bool timed = opt.profile != 0;
-        if (timed)
-            while ((int)c->ev.size() < 2 * chunk) { hipEvent_t ev; if (hipEventCreate(&ev) != hipSuccess) return XRSFM_BA_ENODEV; c->ev.push_back(ev); }
         for (int i = 0; i < chunk; ++i) {
-            int e = schur_product(c, d.pp, d.pq, timed, timed ? c->ev[2 * i] : nullptr, timed ? c->ev[2 * i + 1] : nullptr);
+            int e = schur_product(c, d.pp, d.pq, launched);
             if (e) return e;
-            hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(kPcgThreads), 0, c->stream, d, opt.pcg_tolerance, opt.pcg_max_iterations);
+            { Timed t_(c, K_PCG_VEC, launched); hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(kPcgThreads), 0, c->stream, d, opt.pcg_tolerance, opt.pcg_max_iterations); }
             ++launched;
         }
     }
@@ -206,17 +241,148 @@ int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary
     return 0;
 }
 
+// ---------------------------------------------------------------- Cholesky path: structures
+int chol_setup(xrsfm_ba_context* c) {
+    CholHost& h = c->chol;
+    if (h.ready) return 0;
+    const Packed& k = c->pk;
+    const int Nc = k.n_cams, ns = k.n_slots;
+    const int n = 6 * Nc;
+    if (n > kCholMaxN) return XRSFM_BA_EINVAL;
+    // pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a
+    std::vector<int> spp(ns + 1, 0);
+    {
+        // length of the run of equal slot_pt starting at s, computed right-to-left
+        int run = 0;
+        std::vector<int> rest(ns, 0);
+        for (int s = ns - 1; s >= 0; --s) {
+            if (k.slot_cam[s] < 0) { run = 0; rest[s] = 0; continue; }
+            run = (s + 1 < ns && k.slot_cam[s + 1] >= 0 && k.slot_pt[s + 1] == k.slot_pt[s]) ? run + 1 : 0;
+            rest[s] = run;
+        }
+        for (int s = 0; s < ns; ++s) spp[s + 1] = spp[s] + rest[s];
+    }
+    const int n_pairs = spp[ns];
+    std::vector<std::pair<unsigned long long, int>> keyed(n_pairs);
+    for (int s = 0; s < ns; ++s) {
+        const int np = spp[s + 1] - spp[s];
+        for (int dd = 1; dd <= np; ++dd) {
+            const unsigned long long cb = (unsigned)k.slot_cam[s + dd], ca = (unsigned)k.slot_cam[s];
+            if (cb <= ca) return XRSFM_BA_EINVAL;   // two observations of one track in the same frame
+            keyed[spp[s] + dd - 1] = {(cb << 32) | ca, spp[s] + dd - 1};
+        }
+    }
+    std::sort(keyed.begin(), keyed.end());
+    std::vector<int> pair_dst(n_pairs), blk_ptr, blk_rc;
+    for (int i = 0; i < n_pairs; ++i) {
+        if (i == 0 || keyed[i].first != keyed[i - 1].first) {
+            blk_ptr.push_back(i);
+            blk_rc.push_back((int)(keyed[i].first >> 32)); blk_rc.push_back((int)(keyed[i].first & 0xffffffffu));
+        }
+        pair_dst[keyed[i].second] = i;
+    }
+    blk_ptr.push_back(n_pairs);
+    const int n_blocks = (int)blk_ptr.size() - 1;
+    // tile pattern + symbolic factorisation
+    const int T = (n + kNB - 1) / kNB > 0 ? (n + kNB - 1) / kNB : 1, n_pad = T * kNB;
+    std::vector<char> nz((size_t)T * T, 0);
+    auto mark = [&](int r0, int r1, int c0, int c1) {   // scalar index ranges, inclusive
+        for (int ti = r0 / kNB; ti <= r1 / kNB; ++ti)
+            for (int tj = c0 / kNB; tj <= c1 / kNB; ++tj)
+                if (ti >= tj) nz[(size_t)ti * T + tj] = 1;
+    };
+    for (int t = 0; t < T; ++t) nz[(size_t)t * T + t] = 1;
+    for (int cam = 0; cam < Nc; ++cam) mark(6 * cam, 6 * cam + 5, 6 * cam, 6 * cam + 5);
+    for (int b = 0; b < n_blocks; ++b) mark(6 * blk_rc[2 * b], 6 * blk_rc[2 * b] + 5, 6 * blk_rc[2 * b + 1], 6 * blk_rc[2 * b + 1] + 5);
+    std::vector<int> rows_flat, pairs_flat;
+    h.rows_off.assign(T + 1, 0); h.pairs_off.assign(T + 1, 0); h.cols_off.assign(T + 1, 0);
+    for (int kk = 0; kk < T; ++kk) {
+        std::vector<int> R;
+        for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) R.push_back(i);
+        for (int i : R) rows_flat.push_back(i);
+        for (size_t a = 0; a < R.size(); ++a)
+            for (size_t b2 = 0; b2 <= a; ++b2) { nz[(size_t)R[a] * T + R[b2]] = 1; pairs_flat.push_back(R[a]); pairs_flat.push_back(R[b2]); }
+        h.rows_off[kk + 1] = (int)rows_flat.size();
+        h.pairs_off[kk + 1] = (int)pairs_flat.size() / 2;
+    }
+    std::vector<int> cols_flat, tiles_nz;
+    for (int kk = 0; kk < T; ++kk) {
+        for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) cols_flat.push_back(j);
+        h.cols_off[kk + 1] = (int)cols_flat.size();
+        for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { tiles_nz.push_back(kk); tiles_nz.push_back(j); }
+    }
+    h.n_blocks = n_blocks; h.n_pairs = n_pairs; h.T = T; h.n_tiles_nz = (int)tiles_nz.size() / 2;
+    int e;
+#define TRYC(x) do { e = (x); if (e) return e; } while (0)
+    TRYC(dev_upload(c, &h.slot_pair_ptr, spp)); TRYC(dev_upload(c, &h.pair_dst, pair_dst));
+    TRYC(dev_upload(c, &h.blk_ptr, blk_ptr)); TRYC(dev_upload(c, &h.blk_rc, blk_rc));
+    TRYC(dev_upload(c, &h.tiles_nz, tiles_nz)); TRYC(dev_upload(c, &h.rows_flat, rows_flat));
+    TRYC(dev_upload(c, &h.pairs_flat, pairs_flat)); TRYC(dev_upload(c, &h.cols_flat, cols_flat));
+    TRYC(dev_alloc(c, &h.scat2, (size_t)(n_pairs > 0 ? n_pairs : 1) * 36));
+    TRYC(dev_alloc(c, &h.Sblk, (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
+    h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T;
+    TRYC(dev_alloc(c, &h.dev.S, (size_t)n_pad * n_pad));
+    TRYC(dev_alloc(c, &h.dev.Linv, (size_t)T * kNB * kNB));
+    TRYC(dev_alloc(c, &h.dev.y, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)n_pad));
+#undef TRYC
+    HIPCHK(hipMemset(h.dev.S, 0, sizeof(double) * (size_t)n_pad * n_pad));
+    (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kNB * kLdT * (int)sizeof(double));
+    (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kNB * kLdT * (int)sizeof(double));
+    h.ready = true;
+    return 0;
+}
+
+// Assemble the reduced camera matrix in dense tile storage (after prepare_step)
+int chol_assemble(xrsfm_ba_context* c) {
+    Dev& d = c->d;
+    CholHost& h = c->chol;
+    if (d.n_items > 0 && h.n_pairs > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
+    if (h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_block_segsum, dim3(h.n_blocks), dim3(kBlock), 0, h.scat2, h.blk_ptr, h.Sblk);
+    int e = allreduce(c, h.Sblk, (size_t)h.n_blocks * 36, kNcclSum);
+    if (e) return e;
+    if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_zero_tiles, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, h.tiles_nz, h.n_tiles_nz);
+    if (h.n_blocks > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_off, dim3(cdiv((long long)h.n_blocks * 36, 256)), dim3(256), 0, h.dev, h.Sblk, h.blk_rc, h.n_blocks);
+    LAUNCH(c, K_DENSE_FILL, k_dense_fill_diag, dim3(cdiv(std::max(d.n_cams, kNB), 256)), dim3(256), 0, h.dev, d);
+    return 0;
+}
+
+// Factor S = L L^T and solve S x = b; the solution lands in d.px
+int chol_factor_solve(xrsfm_ba_context* c) {
+    Dev& d = c->d;
+    CholHost& h = c->chol;
+    const int T = h.T;
+    const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
+    LAUNCH(c, K_SMALL, k_copy_pad, dim3(cdiv(h.dev.n_pad, 256)), dim3(256), 0, h.dev.rhs, d.b, h.dev.n, h.dev.n_pad);
+    for (int k = 0; k < T; ++k) {
+        LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, k);
+        const int nr = h.rows_off[k + 1] - h.rows_off[k];
+        if (nr > 0) LAUNCH(c, K_TRSM, k_trsm, dim3(nr), dim3(256), shm, h.dev, k, h.rows_flat + h.rows_off[k]);
+        const int np = h.pairs_off[k + 1] - h.pairs_off[k];
+        if (np > 0) LAUNCH(c, K_UPDATE, k_update, dim3(np), dim3(256), shm, h.dev, k, h.pairs_flat + 2 * (size_t)h.pairs_off[k]);
+    }
+    for (int k = 0; k < T; ++k) {
+        const int nr = h.rows_off[k + 1] - h.rows_off[k];
+        LAUNCH(c, K_TRISOLVE, k_fwd, dim3(1 + nr), dim3(256), 0, h.dev, k, h.rows_flat + h.rows_off[k]);
+    }
+    for (int k = T - 1; k >= 0; --k) {
+        const int ncol = h.cols_off[k + 1] - h.cols_off[k];
+        LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
+    }
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_copy_pad, dim3(cdiv(h.dev.n, 256)), dim3(256), 0, d.px, h.dev.x, h.dev.n, h.dev.n);
+    return 0;
+}
+
 // back-substitute, build the candidate state, evaluate its cost; scalars end up in h_scal
 int finish_step(xrsfm_ba_context* c, double huber_a) {
     Dev& d = c->d;
-    if (d.n_items > 0) hipLaunchKernelGGL(k_backsub, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, c->stream, d);
-    if (d.n_cams > 0) hipLaunchKernelGGL(k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, c->stream, d);
-    if (d.n_items > 0) hipLaunchKernelGGL(k_cost, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, c->stream, d, huber_a);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.part, d.n_items, d.scal + S_COST_CAND);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.part + 2 * (size_t)d.n_items, d.n_items, d.scal + S_MODEL);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.part + 3 * (size_t)d.n_items, d.n_items, d.scal + S_STEP2_PTS);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.campart, d.n_cams, d.scal + S_STEP2_CAMS);
-    hipLaunchKernelGGL(k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, c->stream, d.campart + d.n_cams, d.n_cams, d.scal + S_XNORM2_CAMS);
+    if (d.n_items > 0) LAUNCH(c, K_BACKSUB, k_backsub, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
+    if (d.n_items > 0) LAUNCH(c, K_COST, k_cost, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part, d.n_items, d.scal + S_COST_CAND);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part + 2 * (size_t)d.n_items, d.n_items, d.scal + S_MODEL);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part + 3 * (size_t)d.n_items, d.n_items, d.scal + S_STEP2_PTS);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.campart, d.n_cams, d.scal + S_STEP2_CAMS);
+    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.campart + d.n_cams, d.n_cams, d.scal + S_XNORM2_CAMS);
     int e = allreduce(c, d.scal + S_COST_CAND, 3, kNcclSum);   // COST_CAND, MODEL, STEP2_PTS adjacent
     if (e) return e;
     return fetch_scalars(c);
@@ -226,6 +392,22 @@ void print_progress(const xrsfm_ba_options& o, int it, double cost, double chang
     if (!o.verbose) return;
     if (it == 0) printf("iter      cost      cost_change  |gradient|   |step|    tr_ratio  tr_radius\n");
     printf("%4d  %.6e  %9.2e  %9.2e  %9.2e  %9.2e  %9.2e\n", it, cost, change, gmax, step, rho, radius);
+}
+
+int init_scaling_and_linearize(xrsfm_ba_context* c, double huber_a, bool use_scaling) {
+    Dev& d = c->d;
+    int e;
+    LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_cams * 6, kBlock) + 1), dim3(kBlock), 0, d.scale_c, 1.0, (size_t)d.n_cams * 6);
+    LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, d.scale_p, 1.0, (size_t)d.n_pts * 3);
+    if ((e = linearize(c, huber_a))) return e;
+    if (use_scaling) {
+        // point norms are local to the rank that owns the track; camera norms were all-reduced in linearize()
+        const long long n = std::max((long long)d.n_cams * 6, (long long)d.n_pts * 3);
+        LAUNCH(c, K_SMALL, k_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, d);
+        if ((e = linearize(c, huber_a))) return e;
+    }
+    c->linearized = true;
+    return 0;
 }
 
 }  // namespace
@@ -241,9 +423,9 @@ void xrsfm_ba_default_options(xrsfm_ba_options* o) {
     o->gradient_tolerance = 1e-10;     // Ceres default
     o->initial_radius = 1e4;           // Ceres default
     o->huber_a = 5.99;                 // :343
-    o->linear_solver = XRSFM_BA_SOLVER_PCG;
+    o->linear_solver = XRSFM_BA_SOLVER_AUTO;
     o->pcg_tolerance = 1e-12;
-    o->pcg_max_iterations = 1000;
+    o->pcg_max_iterations = 2000;
     o->profile = 0;
     o->verbose = 0;
 }
@@ -259,13 +441,13 @@ int xrsfm_ba_version(int* n_devices) {
 
 void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     if (!c) return;
-    hipSetDevice(c->device);
+    (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (hipEvent_t e : c->ev) hipEventDestroy(e);
-    for (void* p : c->allocs) hipFree(p);
-    if (c->h_scal) hipHostFree(c->h_scal);
-    if (c->h_st) hipHostFree(c->h_st);
-    if (c->stream) hipStreamDestroy(c->stream);
+    for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+    for (void* p : c->allocs) (void)hipFree(p);
+    if (c->h_scal) (void)hipHostFree(c->h_scal);
+    if (c->h_st) (void)hipHostFree(c->h_st);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -287,7 +469,6 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     Dev& d = c->d;
     c->n_points_caller = p->n_points;
     d.n_cams = k.n_cams; d.n_pts = k.n_pts; d.n_tiles = k.n_tiles; d.n_slots = k.n_slots; d.n_items = (int)k.items.size() / 2;
-    // cameras
     std::vector<CamRec> cams(k.n_cams);
     std::vector<int> model(k.n_cams);
     std::vector<unsigned char> cconst(k.n_cams);
@@ -304,6 +485,8 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     std::vector<double> P(3 * (size_t)k.n_pts);
     for (int j = 0; j < k.n_pts; ++j)
         for (int a = 0; a < 3; ++a) P[3 * (size_t)j + a] = p->points[3 * (size_t)k.pt_orig[j] + a];
+    std::vector<double> cam_act(k.n_cams);
+    for (int i = 0; i < k.n_cams; ++i) cam_act[i] = (k.cam_ptr[i + 1] > k.cam_ptr[i]) ? 1.0 : 0.0;
 #define TRY(x) do { e = (x); if (e) { xrsfm_ba_destroy(c); return e; } } while (0)
     int* tmp_i; double* tmp_d; unsigned char* tmp_u; Item* tmp_it; CamRec* tmp_c;
     TRY(dev_upload(c, &tmp_i, k.slot_cam)); d.slot_cam = tmp_i;
@@ -320,6 +503,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_upload(c, &tmp_i, model)); d.cam_model = tmp_i;
     TRY(dev_upload(c, &tmp_u, cconst)); d.cam_const = tmp_u;
     TRY(dev_upload(c, &tmp_i, k.cam_ptr)); d.cam_ptr = tmp_i;
+    TRY(dev_upload(c, &tmp_d, cam_act)); d.cam_act = tmp_d;
     TRY(dev_upload(c, &tmp_d, P)); d.P = tmp_d;
     TRY(dev_upload(c, &tmp_d, P)); d.P_cand = tmp_d;
     TRY(dev_upload(c, &tmp_d, P)); c->P0 = tmp_d;
@@ -330,7 +514,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.Hpp, np * 6)); TRY(dev_alloc(c, &d.gp, np * 3)); TRY(dev_alloc(c, &d.Hinv, np * 6));
     TRY(dev_alloc(c, &d.camlin, nc * 12)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
     TRY(dev_alloc(c, &d.Minv, nc * 21)); TRY(dev_alloc(c, &d.b, nc * 6));
-    TRY(dev_alloc(c, &d.px, nc * 6)); TRY(dev_alloc(c, &d.pr, nc * 6)); TRY(dev_alloc(c, &d.pz, nc * 6));
+    TRY(dev_alloc(c, &d.px, nc * 6 + kNB)); TRY(dev_alloc(c, &d.pr, nc * 6)); TRY(dev_alloc(c, &d.pz, nc * 6));
     TRY(dev_alloc(c, &d.pp, nc * 6)); TRY(dev_alloc(c, &d.pq, nc * 6));
     TRY(dev_alloc(c, &d.yp, np * 3));
     TRY(dev_alloc(c, &d.scat, (size_t)(k.n_obs > 0 ? k.n_obs : 1) * 28));
@@ -352,7 +536,7 @@ int xrsfm_ba_comm_unique_id(unsigned char id[128]) {
     if (!id) return XRSFM_BA_EINVAL;
     if (!load_rccl()) return XRSFM_BA_ECOMM;
     UniqueId u;
-    if (((fn_unique_id)g_rccl.GetUniqueId)(&u) != 0) return XRSFM_BA_ECOMM;
+    if (g_rccl.GetUniqueId(&u) != 0) return XRSFM_BA_ECOMM;
     memcpy(id, u.internal, 128);
     return 0;
 }
@@ -365,8 +549,12 @@ int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigne
     UniqueId u;
     memcpy(u.internal, id, 128);
     void* comm = nullptr;
-    if (((fn_init_rank)g_rccl.CommInitRank)(&comm, n_ranks, u, rank) != 0) return XRSFM_BA_ECOMM;
+    if (g_rccl.CommInitRank(&comm, n_ranks, u, rank) != 0) return XRSFM_BA_ECOMM;
     c->comm = comm; c->n_ranks = n_ranks; c->rank = rank;
+    // a camera is part of the program if ANY rank holds an observation of it
+    int e = allreduce(c, c->d.cam_act, (size_t)c->d.n_cams, kNcclMax);
+    if (e) return e;
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -404,32 +592,38 @@ int xrsfm_ba_download(xrsfm_ba_context* c, double* cam_q, double* cam_t, double*
 int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_summary* sum) {
     if (!c || !optp || !sum) return XRSFM_BA_EINVAL;
     const xrsfm_ba_options opt = *optp;
-    if (opt.linear_solver != XRSFM_BA_SOLVER_PCG) return XRSFM_BA_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     memset(sum, 0, sizeof(*sum));
-    const auto t_begin = std::chrono::steady_clock::now();
     Dev& d = c->d;
     hipStream_t st = c->stream;
+    int solver = opt.linear_solver;
+    if (solver == XRSFM_BA_SOLVER_AUTO) solver = (6 * d.n_cams <= kCholMaxN && c->n_ranks == 1) ? XRSFM_BA_SOLVER_CHOLESKY : XRSFM_BA_SOLVER_PCG;
+    if (solver != XRSFM_BA_SOLVER_PCG && solver != XRSFM_BA_SOLVER_CHOLESKY) return XRSFM_BA_EINVAL;
+    if (solver == XRSFM_BA_SOLVER_CHOLESKY && c->n_ranks > 1) return XRSFM_BA_EINVAL;   // block pattern is per rank so far
+    int e;
+    if (solver == XRSFM_BA_SOLVER_CHOLESKY && (e = chol_setup(c))) return e;
+    sum->linear_solver_used = solver;
+    c->profiling = opt.profile != 0;
+    for (int i = 0; i < K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+    c->recs.clear(); c->ev_used = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
     sum->num_residuals = 2 * c->pk.n_obs;
     sum->num_effective_params = 3 * (c->pk.n_var_q + c->pk.n_var_t + c->pk.n_var_p);
-    int e;
     auto finish = [&](int term, int reason, double cost) {
         sum->termination = term; sum->termination_reason = reason; sum->final_cost = cost;
-        hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st);
         sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (c->profiling) {
+            profile_collect(c);
+            int best = 0;
+            for (int i = 1; i < K_COUNT - 1; ++i) if (c->prof_ms[i] > c->prof_ms[best]) best = i;
+            sum->dom_kernel_id = best; sum->dom_kernel_ms = c->prof_ms[best]; sum->dom_kernel_launches = c->prof_n[best];
+        }
+        c->profiling = false;
         return XRSFM_BA_OK;
     };
     // iteration 0: Jacobi scaling from the unscaled column norms, then the scaled linearisation
-    hipLaunchKernelGGL(k_fill, dim3(cdiv((long long)d.n_cams * 6, kBlock) + 1), dim3(kBlock), 0, st, d.scale_c, 1.0, (size_t)d.n_cams * 6);
-    hipLaunchKernelGGL(k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, st, d.scale_p, 1.0, (size_t)d.n_pts * 3);
-    if ((e = linearize(c, opt.huber_a))) return e;
-    {
-        const long long n = std::max((long long)d.n_cams * 6, (long long)d.n_pts * 3);
-        // point norms are local to the rank that owns the track; camera norms were all-reduced in linearize()
-        hipLaunchKernelGGL(k_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, st, d);
-    }
-    if ((e = linearize(c, opt.huber_a))) return e;
-    c->linearized = true; c->scaled = true;
+    if ((e = init_scaling_and_linearize(c, opt.huber_a, true))) return e;
     double gmax = 0.0;
     if ((e = gradient_max(c, &gmax))) return e;     // also fetches the scalars
     double cost = 0.5 * c->h_scal[S_COST];
@@ -438,7 +632,6 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
     double radius = opt.initial_radius, decrease = 2.0;
     print_progress(opt, 0, cost, 0.0, gmax, 0.0, 0.0, radius);
     if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
-    double xnorm = -1.0;   // camera part is produced by k_cam_update of the first step
     int it = 0, invalid = 0;
     const double max_radius = 1e16, min_radius = 1e-32, min_rel_decrease = 1e-3;
     while (true) {
@@ -446,11 +639,16 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
         ++it;
         sum->lm_steps_attempted++;
         if ((e = prepare_step(c, radius))) return e;
-        if ((e = pcg_solve(c, opt, sum))) return e;
+        if (solver == XRSFM_BA_SOLVER_PCG) {
+            if ((e = pcg_solve(c, opt, sum))) return e;
+        } else {
+            if ((e = chol_assemble(c))) return e;
+            if ((e = chol_factor_solve(c))) return e;
+        }
         if ((e = finish_step(c, opt.huber_a))) return e;
         const double* s = c->h_scal;
         const double model_change = s[S_MODEL];
-        xnorm = std::sqrt(xnorm2_pts + s[S_XNORM2_CAMS]);
+        const double xnorm = std::sqrt(xnorm2_pts + s[S_XNORM2_CAMS]);
         if (!(model_change > 0.0) || !std::isfinite(model_change)) {
             ++invalid;
             sum->n_unsuccessful++;
@@ -488,6 +686,14 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
     }
 }
 
+int xrsfm_ba_profile_entry(xrsfm_ba_context* c, int index, const char** name, double* total_ms, int* launches) {
+    if (!c || index < 0 || index >= K_COUNT) return XRSFM_BA_EINVAL;
+    if (name) *name = kKidName[index];
+    if (total_ms) *total_ms = c->prof_ms[index];
+    if (launches) *launches = c->prof_n[index];
+    return 0;
+}
+
 int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm_ba_summary* summary) {
     if (!opt || !problem || !summary) return XRSFM_BA_EINVAL;
     xrsfm_ba_context* c = nullptr;
@@ -505,18 +711,9 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scalin
     if (!c) return XRSFM_BA_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
-    hipStream_t st = c->stream;
     int e;
-    hipLaunchKernelGGL(k_fill, dim3(cdiv((long long)d.n_cams * 6, kBlock) + 1), dim3(kBlock), 0, st, d.scale_c, 1.0, (size_t)d.n_cams * 6);
-    hipLaunchKernelGGL(k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, st, d.scale_p, 1.0, (size_t)d.n_pts * 3);
-    if ((e = linearize(c, huber_a))) return e;
-    if (use_scaling) {
-        const long long n = std::max((long long)d.n_cams * 6, (long long)d.n_pts * 3);
-        hipLaunchKernelGGL(k_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, st, d);
-        if ((e = linearize(c, huber_a))) return e;
-    }
+    if ((e = init_scaling_and_linearize(c, huber_a, use_scaling != 0))) return e;
     if ((e = fetch_scalars(c))) return e;
-    c->linearized = true;
     if (cost) *cost = 0.5 * c->h_scal[S_COST];
     const Packed& k = c->pk;
     const size_t ns = (size_t)k.n_slots;
@@ -565,17 +762,42 @@ int xrsfm_ba_debug_schur_product(xrsfm_ba_context* c, double radius, const doubl
     Dev& d = c->d;
     int e;
     if ((e = prepare_step(c, radius))) return e;
-    hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(kPcgThreads), 0, c->stream, d);   // clears st->done unless b == 0
     HIPCHK(hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream));
     const size_t n = (size_t)d.n_cams * 6;
     HIPCHK(hipMemcpyAsync(d.pp, x, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    if ((e = schur_product(c, d.pp, d.pq, false, nullptr, nullptr))) return e;
+    if ((e = schur_product(c, d.pp, d.pq, 0))) return e;
     std::vector<double> q(n), dc(n);
     HIPCHK(hipMemcpyAsync(q.data(), d.pq, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(dc.data(), d.Dc2, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     if (b) HIPCHK(hipMemcpyAsync(b, d.b, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; ++i) y[i] = q[i] + dc[i] * x[i];
+    return 0;
+}
+
+int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y, double* S_dense) {
+    if (!c || !y) return XRSFM_BA_EINVAL;
+    if (!c->linearized) return XRSFM_BA_ESTATE;
+    HIPCHK(hipSetDevice(c->device));
+    Dev& d = c->d;
+    int e;
+    if ((e = chol_setup(c))) return e;
+    if ((e = prepare_step(c, radius))) return e;
+    if ((e = chol_assemble(c))) return e;
+    const CholDev& cd = c->chol.dev;
+    if (S_dense) {
+        std::vector<double> h((size_t)cd.n_pad * cd.n_pad);
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpy(h.data(), cd.S, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int r = 0; r < cd.n; ++r)
+            for (int col = 0; col <= r; ++col) {
+                const double v = h[(size_t)r * cd.n_pad + col];
+                S_dense[(size_t)r * cd.n + col] = v; S_dense[(size_t)col * cd.n + r] = v;
+            }
+    }
+    if ((e = chol_factor_solve(c))) return e;
+    HIPCHK(hipMemcpyAsync(y, d.px, sizeof(double) * (size_t)cd.n, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

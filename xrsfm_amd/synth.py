@@ -84,8 +84,11 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     assert n_cams >= k_obs >= 1
     rng = np.random.Generator(np.random.PCG64(seed))
     intr = (KITTI_INTR[0], KITTI_INTR[1], KITTI_INTR[2], k_dist)
-    radius = 40.0
-    # closed loop for >= 100 cameras; an open arc with the 100-camera spacing below that
+    # Closed loop with a constant inter-camera spacing of 2*pi*40/100 = 2.51 units (the spacing of
+    # BASELINE.json config 2: 100 cameras on a radius-40 ring; a KITTI-like per-frame baseline), so the
+    # ring grows with the camera count (radius 400 at 1k cameras) instead of the parallax shrinking;
+    # below 100 cameras an open arc of the radius-40 ring with the same spacing.
+    radius = 40.0 * max(n_cams, 100) / 100.0
     ang = 2 * np.pi * np.arange(n_cams) / max(n_cams, 100)
     centre = np.stack([radius * np.cos(ang), rng.normal(0, 0.1, n_cams), radius * np.sin(ang)], axis=1)
     if mode == "sequential":
@@ -170,9 +173,12 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
 
     # perturbed initial state; frames 0/1 keep their translation (gauge)
     s_rot, s_t, s_p = perturb
-    q0 = _quat_plus(q_gt, rng.normal(0, s_rot, (n_cams, 3)))
-    dt = rng.normal(0, s_t, (n_cams, 3)); dt[0:2] = 0.0
-    t0 = t_gt + dt
+    # rotation and camera CENTRE are perturbed (t = -R c follows); the gauge frames 0/1 stay exact
+    drot = rng.normal(0, s_rot, (n_cams, 3)); drot[0:2] = 0.0
+    dcen = rng.normal(0, s_t, (n_cams, 3)); dcen[0:2] = 0.0
+    q0 = _quat_plus(q_gt, drot)
+    t0 = -np.einsum("nij,nj->ni", _rot_from_quat(q0), centre + dcen)
+    t0[0:2] = t_gt[0:2]; q0[0:2] = q_gt[0:2]
     P0 = P_gt + rng.normal(0, s_p, (n_points, 3))
     cam_const = np.zeros(n_cams, np.uint8); cam_const[0:2] = 2        # bit1: t constant
     return dict(
