@@ -173,42 +173,155 @@ __global__ void k_dense_fill_diag(CholDev c, Dev d) {
 }
 
 // ------------------------------------------------------------ tile Cholesky
-// Diagonal tile: L = chol(A) in LDS, also Linv (lower) for the trsm / substitution steps.
+// ---- small helpers for the in-register 16x16 diagonal-block factorisation
+__device__ __forceinline__ double readlane_d(double v, int lane) {   // lane must be wave-uniform
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fast_rcp(double u) {               // v_rcp_f64 + 2 Newton steps
+    double r = __builtin_amdgcn_rcp(u);
+    double e = fma(-u, r, 1.0); r = fma(r, e, r);
+    e = fma(-u, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f64 + 2 Newton steps
+    double y = __builtin_amdgcn_rsq(u);
+    double h = 0.5 * u;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// Diagonal tile: L = chol(A) and Linv = L^-1, blocked 16x16.
+//   per block column kb: (a) wave 0 factors the 16x16 diagonal block in registers (lane = row; column
+//   broadcasts are v_readlane, one reciprocal per column, square roots applied once at the end) and
+//   inverts it; (b) the rows below are multiplied by Linv11^T and (c) the trailing blocks are updated
+//   with 16x16x16 products on the FP64 matrix cores.  3 barriers per block column.
 __global__ __launch_bounds__(256) void k_potrf(CholDev c, int k) {
-    __shared__ double A[kNB][kNB + 1];
-    __shared__ double Li[kNB][kNB + 1];
-    const int t = threadIdx.x;
+    __shared__ double A[kNB][kLdT];
+    __shared__ double Li[kNB][kLdT];
+    __shared__ double Tb[3][16][17];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
     double* base = c.S + (size_t)(k * kNB) * c.n_pad + k * kNB;
-    for (int e = t; e < kNB * kNB; e += 256) { const int r = e / kNB, col = e % kNB; A[r][col] = (col <= r) ? base[(size_t)r * c.n_pad + col] : 0.0; }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = t + 256 * it; const int r = e >> 6, col = e & 63;
+        A[r][col] = (col <= r) ? base[(size_t)r * c.n_pad + col] : 0.0;
+        Li[r][col] = 0.0;
+    }
     __syncthreads();
-    for (int j = 0; j < kNB; ++j) {
-        const double djj = sqrt(A[j][j]);
+    for (int kb = 0; kb < 4; ++kb) {
+        const int b0 = 16 * kb;
+        if (wave == 0) {
+            // (a) lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
+            double a[16];
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc) a[cc] = A[b0 + li][b0 + cc];
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) {
+                const double ujj = readlane_d(a[jj], jj);
+                const double tl = a[jj] * fast_rcp(ujj);          // u_ij / u_jj
+#pragma unroll
+                for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-tl, readlane_d(a[jj], cc), a[cc]);
+            }
+            // column scaling by 1/sqrt(u_jj): lane i computes its own s_i
+            double si = 1.0;
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) if (li == jj) si = fast_rsqrt(a[jj]);
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) a[jj] *= readlane_d(si, jj);   // a[jj] = L[i][jj] for jj <= i
+            // inverse of the 16x16 lower-triangular block: lane = column cc
+            double sacc[16], lcol[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = (r == li) ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const double x = sacc[r] * readlane_d(si, r);
+                lcol[r] = x;
+#pragma unroll
+                for (int i = r + 1; i < 16; ++i) sacc[i] = fma(-readlane_d(a[r], i), x, sacc[i]);
+            }
+            if (lane < 16) {
+#pragma unroll
+                for (int cc = 0; cc < 16; ++cc) {
+                    A[b0 + lane][b0 + cc] = (cc <= lane) ? a[cc] : 0.0;
+                    Li[b0 + cc][b0 + lane] = lcol[cc];               // Linv[r][col]: zero above the diagonal by construction
+                }
+            }
+        }
         __syncthreads();
-        if (t >= j && t < kNB) A[t][j] = (t == j) ? djj : A[t][j] / djj;
+        // (b) rows below: X = A21 * Linv11^T, one 16-row block per wave
+        if (kb + 1 + wave < 4) {
+            const int rb = 16 * (kb + 1 + wave);
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[rb + li][b0 + k0 + lk], Li[b0 + li][b0 + k0 + lk], acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) A[rb + lk + 4 * g][b0 + li] = acc[g];
+        }
         __syncthreads();
-        // trailing update of the lower triangle: A[i][c2] -= A[i][j] * A[c2][j], j < c2 <= i
-        for (int e = t; e < kNB * kNB; e += 256) {
-            const int i = e / kNB, c2 = e % kNB;
-            if (c2 > j && c2 <= i) A[i][c2] -= A[i][j] * A[c2][j];
+        // (c) trailing update A_ij -= X_i X_j^T for kb < j <= i < 4, blocks dealt round-robin to the waves
+        {
+            int idx = 0;
+            for (int i = kb + 1; i < 4; ++i)
+                for (int j = kb + 1; j <= i; ++j, ++idx) {
+                    if ((idx & 3) != wave) continue;
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int k0 = 0; k0 < 16; k0 += 4)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * i + li][b0 + k0 + lk], A[16 * j + li][b0 + k0 + lk], acc, 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * j + li] -= acc[g];
+                }
         }
         __syncthreads();
     }
-    // Linv: column cc by forward substitution, one thread per column (threads 0..63)
-    if (t < kNB) {
-        const int cc = t;
-        for (int r = 0; r < kNB; ++r) {
-            double s = (r == cc) ? 1.0 : 0.0;
-            if (r < cc) { Li[r][cc] = 0.0; continue; }
-            for (int m = cc; m < r; ++m) s -= A[r][m] * Li[m][cc];
-            Li[r][cc] = s / A[r][r];
+    // ---- off-diagonal blocks of Linv, block rows dd = 1,2,3:  Linv_ij = -Linv_ii * sum_{kb=j}^{i-1} L_i,kb Linv_kb,j
+    for (int dd = 1; dd < 4; ++dd) {
+        const int nblk = 4 - dd;
+        double tv[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = t + 256 * q;
+            if (e < nblk * 256) {
+                const int j = e >> 8, r = (e >> 4) & 15, cc = e & 15, i = j + dd;
+                double acc = 0.0;
+                for (int kb = j; kb < i; ++kb)
+#pragma unroll
+                    for (int m = 0; m < 16; ++m) acc += A[16 * i + r][16 * kb + m] * Li[16 * kb + m][16 * j + cc];
+                tv[q] = acc;
+            }
         }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = t + 256 * q;
+            if (e < nblk * 256) { const int j = e >> 8, r = (e >> 4) & 15, cc = e & 15; Tb[j][r][cc] = tv[q]; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int e = t + 256 * q;
+            if (e < nblk * 256) {
+                const int j = e >> 8, r = (e >> 4) & 15, cc = e & 15, i = j + dd;
+                double acc = 0.0;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) acc += Li[16 * i + r][16 * i + m] * Tb[j][m][cc];
+                Li[16 * i + r][16 * j + cc] = -acc;
+            }
+        }
+        __syncthreads();
     }
-    __syncthreads();
     double* lo = c.Linv + (size_t)k * kNB * kNB;
-    for (int e = t; e < kNB * kNB; e += 256) {
-        const int r = e / kNB, col = e % kNB;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int e = t + 256 * it; const int r = e >> 6, col = e & 63;
+        lo[e] = (col <= r) ? Li[r][col] : 0.0;
         if (col <= r) base[(size_t)r * c.n_pad + col] = A[r][col];
-        lo[e] = Li[r][col];
     }
 }
 
@@ -234,7 +347,20 @@ __device__ __forceinline__ void tile_abt_mfma(const double* __restrict__ As, con
 }
 
 __device__ __forceinline__ void load_tile_lds(double* dst, const double* __restrict__ src, size_t ld) {
-    for (int e = threadIdx.x; e < kNB * kNB; e += 256) { const int r = e / kNB, col = e % kNB; dst[r * kLdT + col] = src[(size_t)r * ld + col]; }
+    // 64x64 doubles = 2048 double2, 8 per thread; issue all global loads, then store
+    double2 v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = threadIdx.x + 256 * it;          // double2 index
+        const int r = e >> 5, c2 = (e & 31) * 2;
+        v[it] = *reinterpret_cast<const double2*>(src + (size_t)r * ld + c2);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        const int r = e >> 5, c2 = (e & 31) * 2;
+        dst[r * kLdT + c2] = v[it].x; dst[r * kLdT + c2 + 1] = v[it].y;
+    }
 }
 
 // A_ik <- A_ik * Linv_k^T for the tiles i listed in rows[]
