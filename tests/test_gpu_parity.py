@@ -165,7 +165,10 @@ def test_edge_cases(lib):
 
 
 @pytest.mark.parametrize("n_cams,n_pts,k_obs,mode", [(8, 300, 4, "sequential"), (30, 500, 5, "sequential"),
-                                                     (80, 12, 70, "unordered"), (40, 800, 6, "unordered")])
+                                                     (80, 12, 70, "unordered"), (40, 800, 6, "unordered"),
+                                                     # band / ring patterns -> nested-dissection order + level schedule
+                                                     (60, 700, 2, "sequential"), (130, 1500, 4, "sequential"),
+                                                     (257, 2500, 3, "sequential")])
 def test_cholesky_reduced_system(lib, n_cams, n_pts, k_obs, mode):
     """Explicit reduced camera matrix S and the tile Cholesky solve against the oracle's dense Schur complement."""
     import scipy.linalg as sla

@@ -25,6 +25,8 @@ struct CholDev {
     double* y;        // [n_pad] forward-substituted rhs
     double* rhs;      // [n_pad] working copy of b
     double* x;        // [n_pad]
+    const int* cam_off;   // [n_cams] first scalar row of the camera's 6x6 diagonal block (tile-aligned groups)
+    const int* one_k;     // [T] identity list 0..T-1 (right-looking path: kernels read their panel from a list)
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -138,41 +140,51 @@ __global__ __launch_bounds__(kBlock) void k_block_segsum(const double* __restric
 }
 
 __global__ void k_zero_tiles(CholDev c, const int* __restrict__ tiles, int n_tiles) {
-    // tiles: pairs (ti, tj); one workgroup per tile
+    // tiles: pairs (ti, tj); one workgroup per tile.  Diagonal tiles start as identity so that padding
+    // rows (tile slots without a camera) stay decoupled with a unit pivot.
     const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
     for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
         const int r = e / kNB, col = e % kNB;
-        c.S[(size_t)(ti * kNB + r) * c.n_pad + tj * kNB + col] = 0.0;
+        c.S[(size_t)(ti * kNB + r) * c.n_pad + tj * kNB + col] = (ti == tj && r == col) ? 1.0 : 0.0;
     }
 }
 
-// Dense fill: off-diagonal blocks (lower: row block b > col block a) = -sum; diagonal = Scc + Dc2; padding diag = 1
+// Dense fill.  Sblk[b] holds sum W_rb Hinv W_ca^T for the camera pair (rb > ca); it goes to the lower triangle
+// of S in the elimination order (cam_off), transposed if rb is ordered before ca.
 __global__ void k_dense_fill_off(CholDev c, const double* __restrict__ Sblk, const int* __restrict__ blk_rc, int n_blocks) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_blocks * 36) return;
     const int b = i / 36, e = i % 36;
-    const int rb = blk_rc[2 * b], ca = blk_rc[2 * b + 1];
-    c.S[(size_t)(6 * rb + e / 6) * c.n_pad + 6 * ca + e % 6] = -Sblk[i];
+    const int orow = c.cam_off[blk_rc[2 * b]], ocol = c.cam_off[blk_rc[2 * b + 1]];
+    const int r = e / 6, col = e % 6;
+    if (orow > ocol) c.S[(size_t)(orow + r) * c.n_pad + ocol + col] = -Sblk[i];
+    else c.S[(size_t)(ocol + col) * c.n_pad + orow + r] = -Sblk[i];
 }
 
 __global__ void k_dense_fill_diag(CholDev c, Dev d) {
     const int cam = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cam < d.n_cams) {
-        const double* S = d.camS + 28 * (size_t)cam;
-        int idx = 0;
-        for (int a = 0; a < 6; ++a)
-            for (int b = a; b < 6; ++b) {
-                double v = S[idx++];
-                if (a == b) v += d.Dc2[6 * (size_t)cam + a];
-                c.S[(size_t)(6 * cam + b) * c.n_pad + 6 * cam + a] = v;   // lower
-                c.S[(size_t)(6 * cam + a) * c.n_pad + 6 * cam + b] = v;   // (upper inside the diagonal tile is ignored)
-            }
-    }
-    const int r = c.n + cam;
-    if (cam >= 0 && r < c.n_pad && cam < c.n_pad - c.n) c.S[(size_t)r * c.n_pad + r] = 1.0;
+    if (cam >= d.n_cams) return;
+    const double* S = d.camS + 28 * (size_t)cam;
+    const int o = c.cam_off[cam];
+    int idx = 0;
+    for (int a = 0; a < 6; ++a)
+        for (int b = a; b < 6; ++b) {
+            double v = S[idx++];
+            if (a == b) v += d.Dc2[6 * (size_t)cam + a];
+            c.S[(size_t)(o + b) * c.n_pad + o + a] = v;   // lower triangle (a diagonal block never straddles tiles)
+        }
 }
 
-// ------------------------------------------------------------ tile Cholesky
+// rhs in elimination order (padding rows 0), and the solution back in camera order
+__global__ void k_rhs_scatter(CholDev c, const double* __restrict__ b, int n_cams) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cams * 6) c.rhs[c.cam_off[i / 6] + i % 6] = b[i];
+}
+__global__ void k_sol_gather(CholDev c, double* __restrict__ out, int n_cams) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_cams * 6) out[i] = c.x[c.cam_off[i / 6] + i % 6];
+}
+
 // ---- small helpers for the in-register 16x16 diagonal-block factorisation
 __device__ __forceinline__ double readlane_d(double v, int lane) {   // lane must be wave-uniform
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -199,7 +211,8 @@ __device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f6
 //   broadcasts are v_readlane, one reciprocal per column, square roots applied once at the end) and
 //   inverts it; (b) the rows below are multiplied by Linv11^T and (c) the trailing blocks are updated
 //   with 16x16x16 products on the FP64 matrix cores.  3 barriers per block column.
-__global__ __launch_bounds__(256) void k_potrf(CholDev c, int k) {
+__global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict__ klist) {
+    const int k = klist[blockIdx.x];
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Tb[3][16][17];
@@ -468,6 +481,121 @@ __global__ __launch_bounds__(256) void k_bwd(CholDev c, int k, const int* __rest
 __global__ void k_copy_pad(double* dst, const double* src, int n, int n_pad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0;
+}
+
+// ------------------------------------------------------------ level-scheduled (left-looking) variants
+// Panels whose elimination-tree level is equal are independent; each launch below covers one level.
+// Targets never overlap inside a launch and every sum runs in list order, so the result is deterministic.
+
+__device__ __forceinline__ void store_acc_sub(double* Cg, size_t ld, const v4d (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
+                Cg[(size_t)r * ld + col] -= acc[m][n2][g];
+            }
+}
+
+// Target tile (i,k):  A_ik -= sum_{j in contrib} A_ij A_kj^T.   tgt: (i,k) pairs; cptr/cj: CSR of contributing j.
+__global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restrict__ tgt, const int* __restrict__ cptr,
+                                                   const int* __restrict__ cj) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem; double* Bs = smem + kNB * kLdT;
+    const int i = tgt[2 * blockIdx.x], k = tgt[2 * blockIdx.x + 1];
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    for (int q = cptr[blockIdx.x]; q < cptr[blockIdx.x + 1]; ++q) {
+        const int j = cj[q];
+        __syncthreads();
+        load_tile_lds(As, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
+        load_tile_lds(Bs, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+        __syncthreads();
+        tile_abt_mfma(As, Bs, acc);
+    }
+    store_acc_sub(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, acc);
+}
+
+// A_ik <- A_ik Linv_k^T for the (i,k) pairs of one level
+__global__ __launch_bounds__(256) void k_ll_trsm(CholDev c, const int* __restrict__ pairs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* As = smem; double* Bs = smem + kNB * kLdT;
+    const int i = pairs[2 * blockIdx.x], k = pairs[2 * blockIdx.x + 1];
+    double* Ag = c.S + (size_t)(i * kNB) * c.n_pad + k * kNB;
+    load_tile_lds(As, Ag, c.n_pad);
+    load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
+    __syncthreads();
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    tile_abt_mfma(As, Bs, acc);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
+                Ag[(size_t)r * c.n_pad + col] = acc[m][n2][g];
+            }
+}
+
+// forward, one level: y_k = Linv_k (rhs_k - sum_{j in row(k)} L_kj y_j)
+__global__ __launch_bounds__(256) void k_ll_fwd(CholDev c, const int* __restrict__ klist, const int* __restrict__ rptr,
+                                                const int* __restrict__ rj) {
+    __shared__ double v[kNB], acc[kNB], tmp[kNB];
+    const int k = klist[blockIdx.x];
+    if (threadIdx.x < kNB) acc[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
+    for (int q = rptr[blockIdx.x]; q < rptr[blockIdx.x + 1]; ++q) {
+        const int j = rj[q];
+        __syncthreads();
+        if (threadIdx.x < kNB) v[threadIdx.x] = c.y[j * kNB + threadIdx.x];
+        __syncthreads();
+        tile_gemv(c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad, v, tmp, false, nullptr);
+        __syncthreads();
+        if (threadIdx.x < kNB) acc[threadIdx.x] -= tmp[threadIdx.x];
+    }
+    __syncthreads();
+    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, acc, tmp, false, nullptr);
+    __syncthreads();
+    if (threadIdx.x < kNB) c.y[k * kNB + threadIdx.x] = tmp[threadIdx.x];
+}
+
+// backward, one level: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i)
+__global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict__ klist, const int* __restrict__ cptr,
+                                                const int* __restrict__ ci) {
+    __shared__ double v[kNB], acc[kNB], tmp[kNB];
+    const int k = klist[blockIdx.x];
+    if (threadIdx.x < kNB) acc[threadIdx.x] = c.y[k * kNB + threadIdx.x];
+    for (int q = cptr[blockIdx.x]; q < cptr[blockIdx.x + 1]; ++q) {
+        const int i = ci[q];
+        __syncthreads();
+        if (threadIdx.x < kNB) v[threadIdx.x] = c.x[i * kNB + threadIdx.x];
+        __syncthreads();
+        tile_gemv(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, v, tmp, true, nullptr);
+        __syncthreads();
+        if (threadIdx.x < kNB) acc[threadIdx.x] -= tmp[threadIdx.x];
+    }
+    __syncthreads();
+    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, acc, tmp, true, nullptr);
+    __syncthreads();
+    if (threadIdx.x < kNB) c.x[k * kNB + threadIdx.x] = tmp[threadIdx.x];
+}
+
+__global__ void k_zero_vec(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
 }
 
 }  // namespace xba

@@ -82,8 +82,17 @@ struct CholHost {
     int *slot_pair_ptr = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr;
     double *scat2 = nullptr, *Sblk = nullptr;
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
+    // right-looking schedule (dense patterns): one panel after the other
     int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
     std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
+    // level schedule (elimination-tree levels of the tile pattern; left-looking updates)
+    bool use_levels = false;
+    int n_levels = 0;
+    int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr, *lv_trsm = nullptr;
+    int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
+    std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;      // per level offsets (size n_levels+1)
+    std::vector<int> cam_off_host;
+    int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring
 };
 
 struct xrsfm_ba_context {
@@ -283,17 +292,56 @@ int chol_setup(xrsfm_ba_context* c) {
     }
     blk_ptr.push_back(n_pairs);
     const int n_blocks = (int)blk_ptr.size() - 1;
-    // tile pattern + symbolic factorisation
-    const int T = (n + kNB - 1) / kNB > 0 ? (n + kNB - 1) / kNB : 1, n_pad = T * kNB;
+    // ---- elimination order of the cameras: 10 cameras per 64-row tile (4 padding rows), groups tile-aligned.
+    // Band / ring structure (sequential SfM): nested dissection of the path so that the elimination tree of the
+    // tiles is shallow; otherwise the natural order.
+    constexpr int kCamsPerTile = 10;
+    int w = 0; bool wrap = false;
+    for (int b = 0; b < n_blocks; ++b) {
+        const int dlin = blk_rc[2 * b] - blk_rc[2 * b + 1];
+        const int dc = std::min(dlin, Nc - dlin);
+        if (dc != dlin) wrap = true;
+        w = std::max(w, dc);
+    }
+    std::vector<std::vector<int>> groups;   // each group starts on a tile boundary
+    h.ordering = 0;
+    if (w >= 1 && 16 * w <= Nc) {
+        h.ordering = 1;
+        const int leaf = 2 * kCamsPerTile;
+        struct Rec { static void run(int lo, int hi, int w_, int leaf_, std::vector<std::vector<int>>& g) {
+            if (hi <= lo) return;
+            if (hi - lo <= leaf_ + w_) { std::vector<int> v; for (int c2 = lo; c2 < hi; ++c2) v.push_back(c2); g.push_back(v); return; }
+            const int mid = lo + (hi - lo - w_) / 2;
+            run(lo, mid, w_, leaf_, g); run(mid + w_, hi, w_, leaf_, g);
+            std::vector<int> v; for (int c2 = mid; c2 < mid + w_; ++c2) v.push_back(c2); g.push_back(v);
+        } };
+        if (wrap) {
+            Rec::run(w, Nc, w, leaf, groups);
+            std::vector<int> root; for (int c2 = 0; c2 < w; ++c2) root.push_back(c2);
+            groups.push_back(root);
+        } else {
+            Rec::run(0, Nc, w, leaf, groups);
+        }
+    } else {
+        std::vector<int> all; for (int c2 = 0; c2 < Nc; ++c2) all.push_back(c2);
+        groups.push_back(all);
+    }
+    std::vector<int> cam_off(Nc, 0);
+    int T = 0;
+    for (const auto& g : groups) {
+        for (size_t q = 0; q < g.size(); ++q) cam_off[g[q]] = kNB * (T + (int)q / kCamsPerTile) + 6 * ((int)q % kCamsPerTile);
+        T += ((int)g.size() + kCamsPerTile - 1) / kCamsPerTile;
+    }
+    if (T == 0) T = 1;
+    const int n_pad = T * kNB;
+    h.cam_off_host = cam_off;
+    // ---- tile pattern + symbolic factorisation
     std::vector<char> nz((size_t)T * T, 0);
-    auto mark = [&](int r0, int r1, int c0, int c1) {   // scalar index ranges, inclusive
-        for (int ti = r0 / kNB; ti <= r1 / kNB; ++ti)
-            for (int tj = c0 / kNB; tj <= c1 / kNB; ++tj)
-                if (ti >= tj) nz[(size_t)ti * T + tj] = 1;
-    };
     for (int t = 0; t < T; ++t) nz[(size_t)t * T + t] = 1;
-    for (int cam = 0; cam < Nc; ++cam) mark(6 * cam, 6 * cam + 5, 6 * cam, 6 * cam + 5);
-    for (int b = 0; b < n_blocks; ++b) mark(6 * blk_rc[2 * b], 6 * blk_rc[2 * b] + 5, 6 * blk_rc[2 * b + 1], 6 * blk_rc[2 * b + 1] + 5);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int ti = cam_off[blk_rc[2 * b]] / kNB, tj = cam_off[blk_rc[2 * b + 1]] / kNB;
+        nz[(size_t)std::max(ti, tj) * T + std::min(ti, tj)] = 1;
+    }
     std::vector<int> rows_flat, pairs_flat;
     h.rows_off.assign(T + 1, 0); h.pairs_off.assign(T + 1, 0); h.cols_off.assign(T + 1, 0);
     for (int kk = 0; kk < T; ++kk) {
@@ -311,23 +359,71 @@ int chol_setup(xrsfm_ba_context* c) {
         h.cols_off[kk + 1] = (int)cols_flat.size();
         for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { tiles_nz.push_back(kk); tiles_nz.push_back(j); }
     }
+    // ---- elimination-tree levels of the (filled) tile pattern and the per-level work lists
+    std::vector<int> level(T, 0);
+    int n_levels = 0;
+    for (int kk = 0; kk < T; ++kk) {
+        int lv = 0;
+        for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) lv = std::max(lv, level[j] + 1);
+        level[kk] = lv;
+        n_levels = std::max(n_levels, lv + 1);
+    }
+    std::vector<int> lv_k, lv_tgt, lv_cptr(1, 0), lv_cj, lv_trsm, lv_rptr(1, 0), lv_rj, lv_bptr(1, 0), lv_bi;
+    h.lv_k_off.assign(n_levels + 1, 0); h.lv_tgt_off.assign(n_levels + 1, 0); h.lv_trsm_off.assign(n_levels + 1, 0);
+    for (int lv = 0; lv < n_levels; ++lv) {
+        for (int kk = 0; kk < T; ++kk) {
+            if (level[kk] != lv) continue;
+            lv_k.push_back(kk);
+            // forward: row tiles j < k; backward: column tiles i > k   (CSR aligned with lv_k)
+            for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) lv_rj.push_back(j);
+            lv_rptr.push_back((int)lv_rj.size());
+            for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) lv_bi.push_back(i);
+            lv_bptr.push_back((int)lv_bi.size());
+            for (int i = kk; i < T; ++i) {
+                if (!nz[(size_t)i * T + kk]) continue;
+                if (i > kk) { lv_trsm.push_back(i); lv_trsm.push_back(kk); }
+                std::vector<int> contrib;
+                for (int j = 0; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
+                if (contrib.empty()) continue;
+                lv_tgt.push_back(i); lv_tgt.push_back(kk);
+                for (int j : contrib) lv_cj.push_back(j);
+                lv_cptr.push_back((int)lv_cj.size());
+            }
+        }
+        h.lv_k_off[lv + 1] = (int)lv_k.size();
+        h.lv_tgt_off[lv + 1] = (int)lv_tgt.size() / 2;
+        h.lv_trsm_off[lv + 1] = (int)lv_trsm.size() / 2;
+    }
+    h.n_levels = n_levels;
+    h.use_levels = (2 * n_levels <= T);
+    std::vector<int> one_k(T);
+    for (int t = 0; t < T; ++t) one_k[t] = t;
     h.n_blocks = n_blocks; h.n_pairs = n_pairs; h.T = T; h.n_tiles_nz = (int)tiles_nz.size() / 2;
     int e;
+    int *d_cam_off = nullptr, *d_one_k = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     TRYC(dev_upload(c, &h.slot_pair_ptr, spp)); TRYC(dev_upload(c, &h.pair_dst, pair_dst));
     TRYC(dev_upload(c, &h.blk_ptr, blk_ptr)); TRYC(dev_upload(c, &h.blk_rc, blk_rc));
     TRYC(dev_upload(c, &h.tiles_nz, tiles_nz)); TRYC(dev_upload(c, &h.rows_flat, rows_flat));
     TRYC(dev_upload(c, &h.pairs_flat, pairs_flat)); TRYC(dev_upload(c, &h.cols_flat, cols_flat));
+    TRYC(dev_upload(c, &h.lv_k, lv_k)); TRYC(dev_upload(c, &h.lv_tgt, lv_tgt)); TRYC(dev_upload(c, &h.lv_cptr, lv_cptr));
+    TRYC(dev_upload(c, &h.lv_cj, lv_cj)); TRYC(dev_upload(c, &h.lv_trsm, lv_trsm));
+    TRYC(dev_upload(c, &h.lv_rptr, lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, lv_rj));
+    TRYC(dev_upload(c, &h.lv_bptr, lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, lv_bi));
+    TRYC(dev_upload(c, &d_cam_off, cam_off)); TRYC(dev_upload(c, &d_one_k, one_k));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(n_pairs > 0 ? n_pairs : 1) * 36));
     TRYC(dev_alloc(c, &h.Sblk, (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
-    h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T;
+    h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k;
     TRYC(dev_alloc(c, &h.dev.S, (size_t)n_pad * n_pad));
     TRYC(dev_alloc(c, &h.dev.Linv, (size_t)T * kNB * kNB));
     TRYC(dev_alloc(c, &h.dev.y, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)n_pad));
 #undef TRYC
     HIPCHK(hipMemset(h.dev.S, 0, sizeof(double) * (size_t)n_pad * n_pad));
-    (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kNB * kLdT * (int)sizeof(double));
-    (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kNB * kLdT * (int)sizeof(double));
+    const int shm = 2 * kNB * kLdT * (int)sizeof(double);
+    (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     h.ready = true;
     return 0;
 }
@@ -342,7 +438,7 @@ int chol_assemble(xrsfm_ba_context* c) {
     if (e) return e;
     if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_zero_tiles, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, h.tiles_nz, h.n_tiles_nz);
     if (h.n_blocks > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_off, dim3(cdiv((long long)h.n_blocks * 36, 256)), dim3(256), 0, h.dev, h.Sblk, h.blk_rc, h.n_blocks);
-    LAUNCH(c, K_DENSE_FILL, k_dense_fill_diag, dim3(cdiv(std::max(d.n_cams, kNB), 256)), dim3(256), 0, h.dev, d);
+    if (d.n_cams > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_diag, dim3(cdiv(d.n_cams, 256)), dim3(256), 0, h.dev, d);
     return 0;
 }
 
@@ -352,23 +448,44 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     const int T = h.T;
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
-    LAUNCH(c, K_SMALL, k_copy_pad, dim3(cdiv(h.dev.n_pad, 256)), dim3(256), 0, h.dev.rhs, d.b, h.dev.n, h.dev.n_pad);
-    for (int k = 0; k < T; ++k) {
-        LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, k);
-        const int nr = h.rows_off[k + 1] - h.rows_off[k];
-        if (nr > 0) LAUNCH(c, K_TRSM, k_trsm, dim3(nr), dim3(256), shm, h.dev, k, h.rows_flat + h.rows_off[k]);
-        const int np = h.pairs_off[k + 1] - h.pairs_off[k];
-        if (np > 0) LAUNCH(c, K_UPDATE, k_update, dim3(np), dim3(256), shm, h.dev, k, h.pairs_flat + 2 * (size_t)h.pairs_off[k]);
+    LAUNCH(c, K_SMALL, k_zero_vec, dim3(cdiv(h.dev.n_pad, 256)), dim3(256), 0, h.dev.rhs, h.dev.n_pad);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_rhs_scatter, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.b, d.n_cams);
+    if (h.use_levels) {
+        // one launch per elimination-tree level and phase
+        for (int lv = 0; lv < h.n_levels; ++lv) {
+            const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
+            if (nt > 0) LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
+            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
+            LAUNCH(c, K_POTRF, k_potrf, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv]);
+            const int ns = h.lv_trsm_off[lv + 1] - h.lv_trsm_off[lv];
+            if (ns > 0) LAUNCH(c, K_TRSM, k_ll_trsm, dim3(ns), dim3(256), shm, h.dev, h.lv_trsm + 2 * (size_t)h.lv_trsm_off[lv]);
+        }
+        for (int lv = 0; lv < h.n_levels; ++lv) {
+            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
+            LAUNCH(c, K_TRISOLVE, k_ll_fwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_rptr + h.lv_k_off[lv], h.lv_rj);
+        }
+        for (int lv = h.n_levels - 1; lv >= 0; --lv) {
+            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
+            LAUNCH(c, K_TRISOLVE, k_ll_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi);
+        }
+    } else {
+        for (int k = 0; k < T; ++k) {
+            LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, h.dev.one_k + k);
+            const int nr = h.rows_off[k + 1] - h.rows_off[k];
+            if (nr > 0) LAUNCH(c, K_TRSM, k_trsm, dim3(nr), dim3(256), shm, h.dev, k, h.rows_flat + h.rows_off[k]);
+            const int np = h.pairs_off[k + 1] - h.pairs_off[k];
+            if (np > 0) LAUNCH(c, K_UPDATE, k_update, dim3(np), dim3(256), shm, h.dev, k, h.pairs_flat + 2 * (size_t)h.pairs_off[k]);
+        }
+        for (int k = 0; k < T; ++k) {
+            const int nr = h.rows_off[k + 1] - h.rows_off[k];
+            LAUNCH(c, K_TRISOLVE, k_fwd, dim3(1 + nr), dim3(256), 0, h.dev, k, h.rows_flat + h.rows_off[k]);
+        }
+        for (int k = T - 1; k >= 0; --k) {
+            const int ncol = h.cols_off[k + 1] - h.cols_off[k];
+            LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
+        }
     }
-    for (int k = 0; k < T; ++k) {
-        const int nr = h.rows_off[k + 1] - h.rows_off[k];
-        LAUNCH(c, K_TRISOLVE, k_fwd, dim3(1 + nr), dim3(256), 0, h.dev, k, h.rows_flat + h.rows_off[k]);
-    }
-    for (int k = T - 1; k >= 0; --k) {
-        const int ncol = h.cols_off[k + 1] - h.cols_off[k];
-        LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
-    }
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_copy_pad, dim3(cdiv(h.dev.n, 256)), dim3(256), 0, d.px, h.dev.x, h.dev.n, h.dev.n);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.px, d.n_cams);
     return 0;
 }
 
@@ -789,11 +906,16 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
         std::vector<double> h((size_t)cd.n_pad * cd.n_pad);
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy(h.data(), cd.S, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-        for (int r = 0; r < cd.n; ++r)
-            for (int col = 0; col <= r; ++col) {
-                const double v = h[(size_t)r * cd.n_pad + col];
-                S_dense[(size_t)r * cd.n + col] = v; S_dense[(size_t)col * cd.n + r] = v;
-            }
+        const std::vector<int>& off = c->chol.cam_off_host;
+        const int Nc = d.n_cams;
+        for (int ca = 0; ca < Nc; ++ca)
+            for (int cb = 0; cb < Nc; ++cb)
+                for (int a = 0; a < 6; ++a)
+                    for (int b2 = 0; b2 < 6; ++b2) {
+                        const int r = off[ca] + a, col = off[cb] + b2;
+                        const double v = (r >= col) ? h[(size_t)r * cd.n_pad + col] : h[(size_t)col * cd.n_pad + r];
+                        S_dense[(size_t)(6 * ca + a) * cd.n + 6 * cb + b2] = v;
+                    }
     }
     if ((e = chol_factor_solve(c))) return e;
     HIPCHK(hipMemcpyAsync(y, d.px, sizeof(double) * (size_t)cd.n, hipMemcpyDeviceToHost, c->stream));
