@@ -226,3 +226,57 @@ def test_profile_entries(lib):
     assert prof["k_linearize"][1] == s.n_successful + 2      # two linearisations at iteration 0, one per accepted step
     assert prof["k_potrf"][1] > 0 and s.dom_kernel_ms > 0
     ctx.close()
+
+
+def _golden():
+    import glob, os
+    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", _golden(), ids=[p.split("/")[-1][:-4] for p in _golden()])
+@pytest.mark.parametrize("solver", [0, 1])
+def test_hip_path_reproduces_golden(lib, path, solver):
+    """Committed golden fixtures (tests/golden/make_golden.py): initial blocks, LM step counts, final RMSE and cameras."""
+    from xrsfm_amd import capi
+    z = np.load(path)
+    arr = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    mi, ft, pt, rad = z["opt"]
+    ctx = capi.Context(H.to_product(arr))
+    out = ctx.debug_linearize(5.99, False)
+    assert abs(out["cost"] - float(z["init_cost"])) <= 1e-12 * float(z["init_cost"])
+    assert H.rel_err(out["r"], z["init_r"]) < 1e-12 and H.rel_err(out["Jc"], z["init_Jc"]) < 1e-11 and H.rel_err(out["Jp"], z["init_Jp"]) < 1e-11
+    ctx.close()
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options(max_iterations=int(mi), function_tolerance=float(ft), parameter_tolerance=float(pt),
+                                              initial_radius=float(rad), linear_solver=solver))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (int(z["n_successful"]), int(z["n_unsuccessful"]))
+    assert abs(math.sqrt(s.final_cost / n_res) - float(z["rmse_ref_style"])) < 1e-6
+    assert np.abs(prod.cam_q - z["out_cam_q"]).max() < 1e-5 and np.abs(prod.cam_t - z["out_cam_t"]).max() < 1e-5
+
+
+def test_full_size_properties(lib):
+    """BASELINE.json config 2 (100 cams / 50k points / 200k obs): size-independent properties + C restatement."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi, synth
+    d = synth.make_problem(**synth.CONFIGS["S"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    ctx = capi.Context(H.to_product(arr))
+    s = ctx.run(capi.default_options())
+    q, t, P = ctx.download()
+    assert s.termination == 0 and s.final_cost < s.initial_cost
+    # idempotence: re-solving from the optimum takes (almost) no steps and does not move the cameras
+    prod2 = H.to_product(dict(arr, cam_q=q, cam_t=t, points=P))
+    s2 = capi.solve(prod2)
+    assert s2.n_successful <= 1 and np.abs(prod2.cam_q - q).max() < 1e-4
+    # the returned state really has the reported cost (evaluated by the oracle)
+    ref = H.to_oracle(dict(arr, cam_q=q, cam_t=t, points=P))
+    assert abs(bo.evaluate(ref, ref.cam_q, ref.cam_t, ref.points, want_jac=False) - s.final_cost) <= 1e-9 * s.final_cost
+    if ba_cpu.available():
+        prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+        sc = ba_cpu.solve(prob, threads=8)
+        n_res = 2 * arr["obs_cam"].shape[0]
+        assert (sc["n_successful"], sc["n_unsuccessful"]) == (s.n_successful, s.n_unsuccessful)
+        assert abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s.final_cost / n_res)) < 1e-6
+        assert max(np.abs(prob["cam_q"] - q).max(), np.abs(prob["cam_t"] - t).max()) < 1e-5
+    ctx.close()

@@ -1,0 +1,81 @@
+"""Oracle (numpy) and C restatement against the committed golden fixtures; C restatement against the numpy oracle."""
+import glob
+import math
+import os
+
+import numpy as np
+import pytest
+
+from oracle import ba_cpu, ba_oracle as bo
+from tests import helpers as H
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+def _load(path):
+    z = np.load(path)
+    arr = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    mi, ft, pt, rad = z["opt"]
+    return z, arr, dict(max_iterations=int(mi), function_tolerance=float(ft), parameter_tolerance=float(pt), initial_radius=float(rad))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    if not ba_cpu.available():
+        ba_cpu.build()
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_numpy_oracle_reproduces_golden(path):
+    z, arr, opt = _load(path)
+    pr = H.to_oracle(arr)
+    cost0, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    assert abs(cost0 - float(z["init_cost"])) <= 1e-12 * cost0
+    assert H.rel_err(rt, z["init_r"]) < 1e-12 and H.rel_err(Fc, z["init_Jc"]) < 1e-12 and H.rel_err(Ep, z["init_Jp"]) < 1e-12
+    s = bo.solve(pr, bo.Options(**opt))
+    assert (s.n_successful, s.n_unsuccessful) == (int(z["n_successful"]), int(z["n_unsuccessful"]))
+    assert abs(s.final_cost - float(z["final_cost"])) <= 1e-9 * s.final_cost
+    assert np.abs(pr.cam_q - z["out_cam_q"]).max() < 1e-8 and np.abs(pr.cam_t - z["out_cam_t"]).max() < 1e-8
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p)[:-4] for p in GOLD])
+def test_c_restatement_reproduces_golden(path):
+    z, arr, opt = _load(path)
+    prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+    s = ba_cpu.solve(prob, threads=2, **opt)
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s["n_successful"], s["n_unsuccessful"]) == (int(z["n_successful"]), int(z["n_unsuccessful"]))
+    assert abs(math.sqrt(s["final_cost"] / n_res) - float(z["rmse_ref_style"])) < 1e-9
+    assert np.abs(prob["cam_q"] - z["out_cam_q"]).max() < 1e-7 and np.abs(prob["cam_t"] - z["out_cam_t"]).max() < 1e-7
+
+
+@pytest.mark.parametrize("mode,n_cams,n_pts,k_obs", [("sequential", 30, 1500, 4), ("unordered", 24, 600, 5)])
+def test_c_restatement_matches_numpy_oracle(mode, n_cams, n_pts, k_obs):
+    arr = H.make(n_cams, n_pts, k_obs, seed=111, mode=mode)
+    pr = H.to_oracle(arr)
+    s = bo.solve(pr, bo.Options())
+    prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+    sc = ba_cpu.solve(prob, threads=4)
+    assert (sc["n_successful"], sc["n_unsuccessful"]) == (s.n_successful, s.n_unsuccessful)
+    assert abs(sc["final_cost"] - s.final_cost) <= 1e-9 * s.final_cost
+    assert sc["num_effective_params"] == s.num_effective_params
+    assert np.abs(prob["cam_q"] - pr.cam_q).max() < 1e-8 and np.abs(prob["cam_t"] - pr.cam_t).max() < 1e-8
+
+
+def test_oracle_pcg_equals_exact():
+    arr = H.make(10, 300, 4, seed=112)
+    a = H.to_oracle(arr); b = H.to_oracle(arr)
+    sa = bo.solve(a, bo.Options()); sb = bo.solve(b, bo.Options(linear_solver="pcg"))
+    assert (sa.n_successful, sa.n_unsuccessful) == (sb.n_successful, sb.n_unsuccessful)
+    assert np.abs(a.cam_q - b.cam_q).max() < 1e-8 and np.abs(a.cam_t - b.cam_t).max() < 1e-8
+
+
+def test_lm_properties():
+    """Size-independent properties: accepted costs decrease monotonically; a converged state re-solves in 0 steps."""
+    arr = H.make(12, 500, 4, seed=113)
+    pr = H.to_oracle(arr)
+    s = bo.solve(pr, bo.Options())
+    costs = [t["cost"] for t in s.trace if t.get("ok")]
+    assert all(b <= a for a, b in zip(costs, costs[1:]))
+    s2 = bo.solve(pr, bo.Options())
+    assert s2.n_successful <= 1

@@ -1,0 +1,79 @@
+"""N > 1 path on CPU: the point sharding bench.py uses + the all-reduce protocol of the library
+(per-camera sums and scalar partials summed over ranks), checked with world_size-2 gloo.
+
+The per-rank arithmetic here is the oracle's (the HIP kernels need a GPU); what is under test is that sharding by
+point plus SUM all-reduces of exactly the buffers the library all-reduces reproduces the single-rank quantities."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tests import helpers as H
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, arr, out):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import shard_problem
+    from oracle import ba_oracle as bo
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = shard_problem(arr, rank, world)
+    pr = H.to_oracle(local)
+    cost, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    lin = bo._Linearization(pr, rt, Fc, Ep)
+    n_c = pr.cam_q.shape[0]
+    radius = 1e4
+    Dp2 = np.clip(np.einsum("nii->ni", lin.Hpp), 1e-6, 1e32) / radius
+    Hinv = np.linalg.inv(lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3)))
+    WH = np.einsum("nij,njk->nik", lin.W, Hinv[pr.obs_pt])
+    # what the library all-reduces: cost partial, camera-side linearisation (diag Hcc + g_c), reduced rhs, S*x
+    x = np.random.default_rng(0).normal(size=(n_c, 6))
+    v = np.einsum("nki,ni->nk", lin.Fs, x[pr.obs_cam])
+    tj = bo._scatter_add(pr.points.shape[0], pr.obs_pt, np.einsum("nki,nk->ni", lin.Es, v))
+    zz = v - np.einsum("nki,ni->nk", lin.Es, np.einsum("nij,nj->ni", Hinv, tj)[pr.obs_pt])
+    bufs = dict(cost=np.array([cost]), hcc=np.einsum("nii->ni", lin.Hcc).copy(), gc=lin.gc.copy(),
+                rb=-bo._scatter_add(n_c, pr.obs_cam, np.einsum("nij,nj->ni", WH, lin.gp[pr.obs_pt])),
+                sx=bo._scatter_add(n_c, pr.obs_cam, np.einsum("nki,nk->ni", lin.Fs, zz)))
+    for k in bufs:
+        t = torch.from_numpy(np.ascontiguousarray(bufs[k])); dist.all_reduce(t); bufs[k] = t.numpy()
+    if rank == 0:
+        np.savez(out, **bufs)
+    dist.destroy_process_group()
+
+
+def test_point_sharding_and_allreduce_reproduce_single_rank(tmp_path):
+    from bench import shard_problem
+    from oracle import ba_oracle as bo
+    arr = H.make(12, 400, 4, seed=120)
+    # shards partition the observations and keep every camera
+    parts = [shard_problem(arr, r, 2) for r in range(2)]
+    assert sum(p["obs_cam"].shape[0] for p in parts) == arr["obs_cam"].shape[0]
+    assert sum(p["points"].shape[0] for p in parts) == arr["points"].shape[0]
+    assert all(p["cam_q"].shape == arr["cam_q"].shape for p in parts)
+    out = str(tmp_path / "r0.npz")
+    mp.spawn(_worker, args=(2, _free_port(), arr, out), nprocs=2, join=True)
+    z = np.load(out)
+    pr = H.to_oracle(arr)
+    cost, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    lin = bo._Linearization(pr, rt, Fc, Ep)
+    n_c = pr.cam_q.shape[0]
+    Dp2 = np.clip(np.einsum("nii->ni", lin.Hpp), 1e-6, 1e32) / 1e4
+    Hinv = np.linalg.inv(lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3)))
+    WH = np.einsum("nij,njk->nik", lin.W, Hinv[pr.obs_pt])
+    x = np.random.default_rng(0).normal(size=(n_c, 6))
+    v = np.einsum("nki,ni->nk", lin.Fs, x[pr.obs_cam])
+    tj = bo._scatter_add(pr.points.shape[0], pr.obs_pt, np.einsum("nki,nk->ni", lin.Es, v))
+    zz = v - np.einsum("nki,ni->nk", lin.Es, np.einsum("nij,nj->ni", Hinv, tj)[pr.obs_pt])
+    assert abs(z["cost"][0] - cost) <= 1e-12 * cost
+    assert H.rel_err(z["hcc"], np.einsum("nii->ni", lin.Hcc)) < 1e-12 and H.rel_err(z["gc"], lin.gc) < 1e-12
+    assert H.rel_err(z["rb"], -bo._scatter_add(n_c, pr.obs_cam, np.einsum("nij,nj->ni", WH, lin.gp[pr.obs_pt]))) < 1e-12
+    assert H.rel_err(z["sx"], bo._scatter_add(n_c, pr.obs_cam, np.einsum("nki,nk->ni", lin.Fs, zz))) < 1e-12

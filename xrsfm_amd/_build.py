@@ -1,4 +1,4 @@
-"""Build helpers: compile the HIP library (gfx950) and the C test oracle in-tree."""
+"""Build helper: compile the HIP library (gfx950) in-tree."""
 from __future__ import annotations
 
 import os
