@@ -1,0 +1,56 @@
+// Test driver for the adapter: builds a xrsfm::Map (shim types) from a flat problem dump, calls BASolver, dumps the Map.
+// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba> [frame_id]
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "optimization/ba_solver.h"
+
+template <typename T> static std::vector<T> rd(FILE *f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
+
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    auto hdr = rd<int32_t>(f, 4);
+    const int nc = hdr[0], np = hdr[1], no = hdr[2], ni = hdr[3];
+    auto q = rd<double>(f, 4 * (size_t)nc); auto t = rd<double>(f, 3 * (size_t)nc); auto cam_intr = rd<int32_t>(f, nc);
+    auto model = rd<int32_t>(f, ni); auto prm = rd<double>(f, 8 * (size_t)ni); auto P = rd<double>(f, 3 * (size_t)np);
+    auto oc = rd<int32_t>(f, no); auto op = rd<int32_t>(f, no); auto uv = rd<double>(f, 2 * (size_t)no);
+    fclose(f);
+    static const int nparams[5] = {3, 4, 4, 5, 8};
+    xrsfm::Map map;
+    for (int i = 0; i < ni; ++i) { xrsfm::Camera c; c.id_ = i; c.model_id_ = model[i]; c.params_.assign(prm.begin() + 8 * i, prm.begin() + 8 * i + nparams[model[i]]); map.camera_map_[i] = c; }
+    map.frames_.resize(nc); map.tracks_.resize(np);
+    for (int i = 0; i < nc; ++i) {
+        auto &fr = map.frames_[i]; fr.id = i; fr.camera_id = cam_intr[i]; fr.registered = true;
+        for (int k = 0; k < 4; ++k) fr.Tcw.q.coeffs().data()[k] = q[4 * i + k];
+        for (int k = 0; k < 3; ++k) fr.Tcw.t.data()[k] = t[3 * i + k];
+    }
+    for (int j = 0; j < np; ++j) for (int k = 0; k < 3; ++k) map.tracks_[j].point3d_.data()[k] = P[3 * j + k];
+    for (int i = 0; i < no; ++i) {
+        auto &fr = map.frames_[oc[i]];
+        xrsfm::vector2 p2; p2(0) = uv[2 * i]; p2(1) = uv[2 * i + 1];
+        map.tracks_[op[i]].observations_[oc[i]] = (int)fr.points.size();
+        fr.points.push_back(p2); fr.track_ids_.push_back(op[i]);
+    }
+    // an extra 2D feature without a track in every frame: must be skipped (track_ids_ == -1)
+    for (auto &fr : map.frames_) { fr.points.push_back(xrsfm::vector2()); fr.track_ids_.push_back(-1); }
+    map.init_id1 = 0; map.init_id2 = 1;
+    xrsfm::BASolver solver;
+    const std::string mode = argv[3];
+    if (mode == "gba") solver.GBA(map);
+    else if (mode == "gba_fast") solver.GBA(map, false);
+    else if (mode == "structure") solver.GBA(map, true, true);
+    else if (mode == "kgba") solver.KGBA(map, {3}, true);
+    else if (mode == "lba") solver.LBA(argc > 4 ? atoi(argv[4]) : nc - 1, map);
+    else return 2;
+    FILE *o = fopen(argv[2], "wb");
+    int32_t st = solver.last_status();
+    fwrite(&st, 4, 1, o);
+    for (auto &fr : map.frames_) { fwrite(fr.Tcw.q.coeffs().data(), 8, 4, o); fwrite(fr.Tcw.t.data(), 8, 3, o); }
+    for (auto &tr : map.tracks_) fwrite(tr.point3d_.data(), 8, 3, o);
+    fclose(o);
+    return 0;
+}

@@ -1,0 +1,308 @@
+// xrsfm::BASolver::{GBA,KGBA,LBA} on top of the C-ABI (include/xrsfm_ba.h).
+//
+// Behaviour restated from /root/reference/src/optimization/ba_solver.cc (no code shared with it):
+//   which frames enter           GBA :598-607 (registered), KGBA :647-660 (registered key frames), LBA :525-549
+//   residual blocks per frame    SetUp :330-356 / SetUpLBA :358-391 (track_ids_[i] != -1)
+//   constant blocks              intrinsics always (:602-606); gauge t of init_id1/2 (:611-614, :662-663);
+//                                fix_all_frames (:616-621); LBA points not seen by the new frame (:380-382);
+//                                LBA gauge fallbacks (:551-584)
+//   solver options               :70-77 with :586-589 (LBA), :626-634 (GBA), :667-670 (KGBA)
+//   printed summary              PrintSolverSummary :14-68, "LBA:" line :537-549, "kf: a/b" :676
+//   KGBA pre/post                KeyFrameSelection / UpdateByRefFrame stay in the reference (src/base/map.cc:428-663)
+#include "ba_solver.h"
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstdio>
+#include <iomanip>
+#include <iostream>
+#include <set>
+#include <unordered_map>
+
+#include "geometry/colmap/base/triangulation.h"
+#include "geometry/colmap/util/math.h"
+#include "xrsfm_ba.h"
+
+namespace xrsfm {
+namespace {
+
+// Flat copy of the parameter blocks of one BA call + the way back into the Map.
+class FlatProblem {
+  public:
+    explicit FlatProblem(Map &map) : map_(map) {}
+
+    // One frame = SetUp(problem, map, frame).  `lba_frame_id >= 0` selects SetUpLBA's rule for constant points.
+    void AddFrame(Frame &frame, int lba_frame_id = -1) {
+        const int cam = static_cast<int>(frames_.size());
+        const Camera &camera = map_.Camera(frame.camera_id);
+        int num_mea = 0;
+        for (size_t i = 0; i < frame.track_ids_.size(); ++i) {
+            const int tid = frame.track_ids_[i];
+            if (tid == -1) continue;
+            ++num_mea;
+            auto it = track_slot_.find(tid);
+            int slot;
+            if (it == track_slot_.end()) {
+                slot = static_cast<int>(tracks_.size());
+                track_slot_.emplace(tid, slot);
+                tracks_.push_back(tid);
+                const double *p = map_.tracks_[tid].point3d_.data();
+                points_.insert(points_.end(), p, p + 3);
+                point_const_.push_back(0);
+            } else {
+                slot = it->second;
+            }
+            if (lba_frame_id >= 0) {
+                const Track &track = map_.tracks_[tid];
+                // reference rule: `angle_ > 5 || observations_.count(frame_id) == 0` (angle_ is in radians, so only
+                // the second half can fire, ba_solver.cc:380)
+                if (track.angle_ > 5 || track.observations_.count(lba_frame_id) == 0) point_const_[slot] = 1;
+            }
+            obs_cam_.push_back(cam);
+            obs_pt_.push_back(slot);
+            obs_uv_.push_back(frame.points[i](0));
+            obs_uv_.push_back(frame.points[i](1));
+        }
+        if (num_mea == 0)
+            std::cerr << (lba_frame_id >= 0 ? "LBA" : "BA") << ": NO Measurement In Frame " << frame.id << std::endl;
+        frames_.push_back(&frame);
+        frame_slot_[static_cast<int>(frame.id)] = cam;
+        const double *q = frame.Tcw.q.coeffs().data();   // x,y,z,w
+        const double *t = frame.Tcw.t.data();
+        cam_q_.insert(cam_q_.end(), q, q + 4);
+        cam_t_.insert(cam_t_.end(), t, t + 3);
+        cam_const_.push_back(0);
+        // intrinsics: one constant block per camera_id
+        auto ci = intr_slot_.find(static_cast<int>(frame.camera_id));
+        if (ci == intr_slot_.end()) {
+            ci = intr_slot_.emplace(static_cast<int>(frame.camera_id), static_cast<int>(intr_model_.size())).first;
+            intr_model_.push_back(static_cast<int>(camera.model_id_));
+            for (size_t k = 0; k < 8; ++k) intr_params_.push_back(k < camera.params_.size() ? camera.params_[k] : 0.0);
+        }
+        cam_intr_.push_back(ci->second);
+    }
+
+    bool HasFrame(int frame_id) const { return frame_slot_.count(frame_id) != 0; }
+    void FixTranslation(int frame_id) {
+        auto it = frame_slot_.find(frame_id);
+        if (it != frame_slot_.end()) cam_const_[it->second] |= XRSFM_BA_CONST_T;
+    }
+    void FixPose(int frame_id) {
+        auto it = frame_slot_.find(frame_id);
+        if (it != frame_slot_.end()) cam_const_[it->second] |= (XRSFM_BA_CONST_Q | XRSFM_BA_CONST_T);
+    }
+    size_t NumFrames() const { return frames_.size(); }
+
+    // ceres::Solve replacement; writes the result back into the Map on success.
+    int Solve(const xrsfm_ba_options &opt, xrsfm_ba_summary *summary) {
+        xrsfm_ba_problem p;
+        p.n_cams = static_cast<int32_t>(frames_.size());
+        p.n_points = static_cast<int32_t>(tracks_.size());
+        p.n_obs = static_cast<int32_t>(obs_cam_.size());
+        p.n_intr = static_cast<int32_t>(intr_model_.size());
+        p.cam_q = cam_q_.data(); p.cam_t = cam_t_.data(); p.cam_const = cam_const_.data(); p.cam_intr = cam_intr_.data();
+        p.intr_model = intr_model_.data(); p.intr_params = intr_params_.data();
+        p.points = points_.data(); p.point_const = point_const_.data();
+        p.obs_cam = obs_cam_.data(); p.obs_pt = obs_pt_.data(); p.obs_uv = obs_uv_.data();
+        const int rc = xrsfm_ba_solve(&opt, &p, summary);
+        if (rc != XRSFM_BA_OK) {
+            std::cerr << "xrsfm_ba_solve failed with code " << rc << " (no CPU fallback); map left unchanged" << std::endl;
+            return rc;
+        }
+        for (size_t c = 0; c < frames_.size(); ++c) {
+            double *q = frames_[c]->Tcw.q.coeffs().data();
+            double *t = frames_[c]->Tcw.t.data();
+            for (int k = 0; k < 4; ++k) q[k] = cam_q_[4 * c + k];
+            for (int k = 0; k < 3; ++k) t[k] = cam_t_[3 * c + k];
+        }
+        for (size_t j = 0; j < tracks_.size(); ++j) {
+            double *p3 = map_.tracks_[tracks_[j]].point3d_.data();
+            for (int k = 0; k < 3; ++k) p3[k] = points_[3 * j + k];
+        }
+        return rc;
+    }
+
+  private:
+    Map &map_;
+    std::vector<Frame *> frames_;
+    std::unordered_map<int, int> frame_slot_, track_slot_, intr_slot_;
+    std::vector<int> tracks_;
+    std::vector<double> cam_q_, cam_t_, intr_params_, points_, obs_uv_;
+    std::vector<uint8_t> cam_const_, point_const_;
+    std::vector<int32_t> cam_intr_, intr_model_, obs_cam_, obs_pt_;
+};
+
+xrsfm_ba_options ReferenceOptions(int max_iterations, double ftol, double ptol) {
+    xrsfm_ba_options o;
+    xrsfm_ba_default_options(&o);       // Ceres defaults + SPARSE_SCHUR-equivalent exact solve
+    o.max_iterations = max_iterations;
+    o.function_tolerance = ftol;
+    o.parameter_tolerance = ptol;
+    return o;
+}
+
+// Same lines as PrintSolverSummary (ba_solver.cc:14-68).
+void PrintSummary(const xrsfm_ba_summary &s) {
+    const char *termination = s.termination == XRSFM_BA_CONVERGENCE ? "Convergence"
+                              : s.termination == XRSFM_BA_NO_CONVERGENCE ? "No convergence" : "Failure";
+    const double nres = s.num_residuals > 0 ? static_cast<double>(s.num_residuals) : 1.0;
+    std::cout << std::right << std::setw(16) << "Residuals : " << std::left << s.num_residuals << std::endl;
+    std::cout << std::right << std::setw(16) << "Parameters : " << std::left << s.num_effective_params << std::endl;
+    std::cout << std::right << std::setw(16) << "Iterations : " << std::left << s.n_successful + s.n_unsuccessful << std::endl;
+    std::cout << std::right << std::setw(16) << "Time : " << std::left << s.total_time_s << " [s]" << std::endl;
+    std::cout << std::right << std::setw(16) << "Initial cost : " << std::right << std::setprecision(6)
+              << std::sqrt(s.initial_cost / nres) << " [px]" << std::endl;
+    std::cout << std::right << std::setw(16) << "Final cost : " << std::right << std::setprecision(6)
+              << std::sqrt(s.final_cost / nres) << " [px]" << std::endl;
+    std::cout << std::right << std::setw(16) << "Termination : " << std::right << termination << std::endl << std::endl;
+}
+
+// Frames sharing tracks with `frame`, most covisible first.  include_self mirrors the difference between
+// CovisibilityNeibors (:503-505, counts the frame itself) and FindLocalBundle (:404, skips it).
+std::vector<std::pair<int, int>> CovisibleFrames(const Frame &frame, const Map &map, bool include_self, int *num_points3d) {
+    std::unordered_map<int, int> shared;
+    int n3d = 0;
+    for (const int tid : frame.track_ids_) {
+        if (tid == -1) continue;
+        ++n3d;
+        for (const auto &obs : map.tracks_[tid].observations_)
+            if (include_self || obs.first != static_cast<int>(frame.id)) shared[obs.first] += 1;
+    }
+    if (num_points3d) *num_points3d = n3d;
+    std::vector<std::pair<int, int>> out(shared.begin(), shared.end());
+    std::sort(out.begin(), out.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.second > b.second; });
+    return out;
+}
+
+// ba_solver.cc:495-521
+std::vector<int> MostCovisible(int frame_id, Map &map, size_t num_images = 4) {
+    std::vector<int> ids;
+    for (const auto &fc : CovisibleFrames(map.frames_[frame_id], map, true, nullptr)) {
+        ids.push_back(fc.first);
+        if (ids.size() == num_images) break;
+    }
+    return ids;
+}
+
+// ba_solver.cc:393-493: the frame itself plus up to num_images-1 covisible frames that pass a ladder of
+// (triangulation angle, overlap) thresholds, strictest first.
+std::vector<int> LocalBundle(int frame_id, Map &map, size_t num_images = 4) {
+    Frame &frame = map.frames_[frame_id];
+    int num_p3d = 0;
+    const auto cov = CovisibleFrames(frame, map, false, &num_p3d);
+    const size_t wanted = std::min(num_images, cov.size() + 1);
+    std::vector<int> ids;
+    ids.reserve(wanted);
+    ids.push_back(frame_id);
+    if (cov.size() + 1 == wanted) {
+        for (const auto &fc : cov) ids.push_back(fc.first);
+        return ids;
+    }
+    const double base_angle = 6 * 0.01745329;
+    const double angle_div[8] = {1.0, 1.5, 2.0, 2.5, 3.0, 4.0, 5.0, 6.0};
+    const double overlap_frac[8] = {0.6, 0.6, 0.5, 0.4, 0.3, 0.2, 0.1, 0.1};
+    const auto centre = frame.Tcw.center();
+    std::vector<double> angle(cov.size(), -1.0);
+    std::vector<char> taken(cov.size(), 0);
+    std::vector<decltype(frame.Tcw.center())> pts;
+    for (int level = 0; level < 8 && ids.size() < wanted; ++level) {
+        const double min_angle = base_angle / angle_div[level], min_overlap = overlap_frac[level] * num_p3d;
+        for (size_t k = 0; k < cov.size(); ++k) {
+            if (cov[k].second < min_overlap) break;
+            if (taken[k]) continue;
+            const Frame &other = map.frames_[cov[k].first];
+            if (angle[k] < 0.0) {
+                pts.clear();
+                for (const int tid : frame.track_ids_)
+                    if (tid != -1) pts.push_back(map.tracks_[tid].point3d_);
+                auto other_pose = other.Tcw;
+                angle[k] = colmap::Percentile(colmap::CalculateTriangulationAngles(centre, other_pose.center(), pts), 75);
+            }
+            if (angle[k] >= min_angle) {
+                ids.push_back(static_cast<int>(other.id));
+                taken[k] = 1;
+                if (ids.size() >= wanted) break;
+            }
+        }
+    }
+    return ids;
+}
+
+} // namespace
+
+void BASolver::GBA(Map &map, bool accurate, bool fix_all_frames) {
+    FlatProblem problem(map);
+    for (auto &frame : map.frames_)
+        if (frame.registered) problem.AddFrame(frame);
+    if (!fix_all_frames) {
+        problem.FixTranslation(map.init_id1);
+        problem.FixTranslation(map.init_id2);
+    } else {
+        for (auto &frame : map.frames_)
+            if (frame.registered) problem.FixPose(static_cast<int>(frame.id));
+    }
+    xrsfm_ba_options opt = accurate ? ReferenceOptions(50, 1e-5, 1e-6) : ReferenceOptions(20, 1e-4, 1e-5);
+    opt.verbose = 1;   // minimizer_progress_to_stdout = true (:625)
+    xrsfm_ba_summary summary;
+    last_status_ = problem.Solve(opt, &summary);
+    if (last_status_ == XRSFM_BA_OK) PrintSummary(summary);
+}
+
+void BASolver::KGBA(Map &map, const std::vector<int> fix_key_frame_ids, const bool is_sequential_data) {
+    KeyFrameSelection(map, fix_key_frame_ids, is_sequential_data);
+    int num_rf = 0, num_kf = 0;
+    FlatProblem problem(map);
+    for (auto &frame : map.frames_) {
+        if (!frame.registered) continue;
+        ++num_rf;
+        if (!frame.is_keyframe) continue;
+        ++num_kf;
+        problem.AddFrame(frame);
+    }
+    problem.FixTranslation(map.init_id1);
+    problem.FixTranslation(map.init_id2);
+    xrsfm_ba_options opt = ReferenceOptions(20, 1e-4, 1e-5);
+    opt.initial_radius = 1e6;
+    opt.verbose = 1;
+    xrsfm_ba_summary summary;
+    last_status_ = problem.Solve(opt, &summary);
+    if (last_status_ == XRSFM_BA_OK) PrintSummary(summary);
+    printf("kf: %d/%d\n", num_kf, num_rf);
+    UpdateByRefFrame(map);
+}
+
+void BASolver::LBA(int frame_id, Map &map) {
+    const std::vector<int> neighbours = MostCovisible(frame_id, map);
+    const std::vector<int> bundle = LocalBundle(frame_id, map);
+    std::set<int> local(neighbours.begin(), neighbours.end());
+    local.insert(bundle.begin(), bundle.end());
+
+    FlatProblem problem(map);
+    printf("LBA: ");
+    for (const int id : local) {
+        printf(" %d", id);
+        problem.AddFrame(map.frames_.at(id), frame_id);
+    }
+    printf("\n");
+
+    // gauge: the init frames if present, else the two last frames of the local bundle / neighbour list
+    int fixed = 0;
+    if (local.count(map.init_id1)) { problem.FixTranslation(map.init_id1); ++fixed; }
+    if (local.count(map.init_id2)) { problem.FixTranslation(map.init_id2); ++fixed; }
+    if (fixed == 0) {
+        const std::vector<int> *src = bundle.size() >= 2 ? &bundle : (neighbours.size() >= 2 ? &neighbours : nullptr);
+        if (src) {
+            problem.FixTranslation((*src)[src->size() - 1]);
+            problem.FixTranslation((*src)[src->size() - 2]);
+        } else {
+            printf("!!!LBA only one frame\n");
+            problem.FixTranslation(frame_id);
+        }
+    }
+    xrsfm_ba_options opt = ReferenceOptions(5, 1e-4, 1e-5);
+    xrsfm_ba_summary summary;
+    last_status_ = problem.Solve(opt, &summary);   // the reference prints nothing for LBA (:586-591)
+}
+
+} // namespace xrsfm

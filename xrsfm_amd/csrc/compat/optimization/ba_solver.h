@@ -1,0 +1,35 @@
+// Source-compatible replacement of /root/reference/src/optimization/ba_solver.h:14-30.
+//
+// Same class name, namespace and public signatures, so src/mapper/incremental_mapper.{h,cc}
+// (member `BASolver ba_solver`, calls at incremental_mapper.cc:33,71,81), src/geometry/error_corrector.cc:220,236
+// and src/run_triangulation.cc:180 compile unchanged; GBA / KGBA / LBA run on the MI355X through the C-ABI of
+// include/xrsfm_ba.h instead of ceres::Solve.  No Ceres header is needed by this file.
+//
+// ScalePoseGraphUnorder (pose graph, DOGLEG; ba_solver.cc:147-328) is not part of the BA hot path: its
+// definition stays in the reference's translation unit.
+#ifndef XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
+#define XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
+
+#include <vector>
+
+#include "base/map.h"
+
+namespace xrsfm {
+class BASolver {
+  public:
+    BASolver() {}
+
+    void ScalePoseGraphUnorder(const LoopInfo &loop_info, Map &map, bool use_key = false);
+    void KGBA(Map &map, const std::vector<int> fix_key_frame_ids, const bool is_sequential_data);
+    void GBA(Map &map, bool accurate = true, bool fix_all_frames = false);
+    void LBA(int frame_id, Map &map);
+
+    // Result of the last GBA/KGBA/LBA call (0 = ok, negative = XRSFM_BA_E* code).  The reference ignores the
+    // Ceres summary (ba_solver.cc:636-637); callers that want to know can read this.
+    int last_status() const { return last_status_; }
+
+  private:
+    int last_status_ = 0;
+};
+} // namespace xrsfm
+#endif // XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
