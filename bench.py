@@ -53,7 +53,7 @@ def shard_problem(arr: dict, rank: int, world: int) -> dict:
     return out
 
 
-def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, n_pairs: int = 0):
+def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, nnzb: int = 0):
     """ALGORITHMIC HBM bytes of one launch, J-stored accounting of SURVEY.md section 8(d) / DESIGN.md section 5
     (FP64 values, int32 indices).  None for kernels that are latency- or MFMA-bound."""
     table = {
@@ -63,13 +63,26 @@ def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, n_pairs:
         "k_schur_matvec": n_obs * 144 + n_pts * 48 + n_cams * 96,
         # read r, J; read Hpp^-1 (6) + g_p (3); write diagonal blocks of S (21) + rhs (6)      (B_prep)
         "k_schur_prep": n_obs * 160 + n_pts * 72 + n_cams * 216,
-        # explicit-S accounting: read J once, one 6x6 block written per off-diagonal pair
-        "k_schur_pairs": n_obs * 144 + n_pts * 48 + n_pairs * 288,
+        # explicit-S accounting (B_S): read J once, write the nnzb off-diagonal 6x6 blocks of S once
+        "k_schur_pairs": n_obs * 144 + n_pts * 48 + nnzb * 288,
         # back-substitute: read J, r; Hpp^-1, g_p, points in, points out                       (B_back)
         "k_backsub": n_obs * (144 + 16) + n_pts * 144 + n_cams * 48,
         "k_cost": n_obs * 24 + n_pts * 24 + n_cams * 56,
     }
     return table.get(kernel)
+
+
+def count_offdiag_blocks(arr: dict) -> int:
+    """nnzb of the strictly lower triangle of the reduced camera matrix: distinct camera pairs sharing a track."""
+    order = np.lexsort((arr["obs_cam"], arr["obs_pt"]))
+    cam = arr["obs_cam"][order].astype(np.int64); pt = arr["obs_pt"][order]
+    keys = []
+    for d in range(1, 65):
+        same = pt[d:] == pt[:-d]
+        if not same.any():
+            break
+        keys.append(cam[d:][same] * (1 << 32) + cam[:-d][same])
+    return int(np.unique(np.concatenate(keys)).shape[0]) if keys else 0
 
 
 def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
@@ -182,9 +195,7 @@ def main():
         _, dom = max(cands)
         ms, launches = kernels[dom]
         avg_s = ms * 1e-3 / launches
-        track_len = np.bincount(local["obs_pt"], minlength=prob.n_points)
-        n_pairs = int((track_len * (track_len - 1) // 2).sum())
-        alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, n_pairs)
+        alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
         ach = alg / avg_s / 1e9
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": None, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,

@@ -69,11 +69,28 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d, const int* __rest
         int maxp = npair;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, __shfl_xor(maxp, off, kWave));
+        const int stride = d.tile_stride[it.first_tile];
         for (int dd = 1; dd <= maxp; ++dd) {
             double Wb[18];
 #pragma unroll
             for (int k = 0; k < 18; ++k) Wb[k] = __shfl_down(W[k], dd, kWave);
-            if (dd <= npair) {
+            const bool has = dd <= npair;
+            if (stride > 0) {
+                // regular tile: the same camera pair in every track -> sum over the tracks first, 6 values at a time
+                const int dst = (has && lane < stride) ? pair_dst[pbase + dd - 1] : -1;
+#pragma unroll
+                for (int rb = 0; rb < 6; ++rb) {
+                    double o[6];
+#pragma unroll
+                    for (int ca = 0; ca < 6; ++ca)
+                        o[ca] = has ? Wb[3 * rb] * WH[3 * ca] + Wb[3 * rb + 1] * WH[3 * ca + 1] + Wb[3 * rb + 2] * WH[3 * ca + 2] : 0.0;
+                    strided_reduce<6>(o, stride, lane);
+                    if (dst >= 0) {
+                        double2* out = reinterpret_cast<double2*>(scat2 + 36 * (size_t)dst + 6 * rb);
+                        out[0] = make_double2(o[0], o[1]); out[1] = make_double2(o[2], o[3]); out[2] = make_double2(o[4], o[5]);
+                    }
+                }
+            } else if (has) {
                 double2* out = reinterpret_cast<double2*>(scat2 + 36 * (size_t)pair_dst[pbase + dd - 1]);
 #pragma unroll
                 for (int rb = 0; rb < 6; ++rb) {

@@ -41,6 +41,7 @@ struct Dev {
     const int* slot_cam; const int* slot_pt; const int* slot_campos;
     const double* slot_u; const double* slot_v;
     const Item* items;
+    const int* tile_stride;   // [n_tiles] L > 0 for regular tiles (all tracks share one tuple of L cameras)
     // cameras
     CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
     double* cam_act;    // [Nc] 1.0 if any rank observes the camera (cameras without observations are not in the program)
@@ -62,6 +63,7 @@ struct Dev {
     double* scat;       // camera-major scatter buffer, [n_obs][28]
     double* part;       // per-item partial sums, 4 * n_items
     double* campart;    // per-camera partials, 2 * n_cams
+    double* ptpart;     // per-workgroup partials of point kernels, cdiv(n_pts, 256)
     double* scal;       // S_COUNT scalars
     PcgStatus* st;
 };
@@ -81,6 +83,20 @@ __device__ __forceinline__ void seg_reduce(double (&v)[N], int key, int lane) {
     for (int off = 1; off < kWave; off <<= 1) {
         const int okey = __shfl_down(key, off, kWave);
         const bool take = (lane + off < kWave) && (okey == key);
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            const double o = __shfl_down(v[k], off, kWave);
+            if (take) v[k] += o;
+        }
+    }
+}
+
+// Regular tile (every track has the same L cameras, lane = track*L + rank): sum over the tracks, the lanes
+// < L end up with the per-camera totals.  Lanes without data must hold zeros.  Fixed order.
+template <int N>
+__device__ __forceinline__ void strided_reduce(double (&v)[N], int stride, int lane) {
+    for (int off = stride; off < kWave; off <<= 1) {
+        const bool take = lane + off < kWave;
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             const double o = __shfl_down(v[k], off, kWave);
@@ -128,6 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Dev d, double huber_a) {
     for (int tl = 0; tl < it.n_tiles; ++tl) {
         const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        double cs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (s.valid) {
             const CamRec& c = d.cam[s.cam];
             double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
@@ -172,18 +189,24 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Dev d, double huber_a) {
             v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[0] * E[1] + E[3] * E[4]; v[2] = E[0] * E[2] + E[3] * E[5];
             v[3] = E[1] * E[1] + E[4] * E[4]; v[4] = E[1] * E[2] + E[4] * E[5]; v[5] = E[2] * E[2] + E[5] * E[5];
             v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
-            double2* out = reinterpret_cast<double2*>(d.scat + 12 * (size_t)d.slot_campos[s.slot]);
-            double cs[12];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 cs[k] = F[k] * F[k] + F[6 + k] * F[6 + k];
                 cs[6 + k] = F[k] * r0 + F[6 + k] * r1;
             }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
             if (s.head && (!is_long || tl == 0) && !d.pt_const[s.pt])
                 xn2 += Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
             if (is_long && lane == 0 && tl == 0) long_pt = s.pt;
+        }
+        {   // camera-side terms: one partial per camera for a regular tile, one per observation otherwise
+            const int stride = d.tile_stride[it.first_tile + tl];
+            if (stride > 0) strided_reduce<12>(cs, stride, lane);
+            const int cp = d.slot_campos[s.slot];
+            if (cp >= 0) {
+                double2* out = reinterpret_cast<double2*>(d.scat + 12 * (size_t)cp);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
+            }
         }
         seg_reduce<9>(v, s.pt, lane);
         if (!is_long) {
@@ -314,44 +337,52 @@ __global__ void k_cam_prep(Dev d, double radius, double dmin, double dmax) {
 // Per observation: block-Jacobi diagonal block and reduced right-hand side terms
 //   S_cc += F^T F - (F^T E) Hinv (E^T F),   rb -= (F^T E) Hinv g_p
 __global__ __launch_bounds__(kBlock) void k_schur_prep(Dev d) {
-    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;      // blocks of 256 slots = 4 whole tiles, wave = tile
     if (slot >= d.n_slots) return;
+    const int lane = threadIdx.x & (kWave - 1);
     const int cam = d.slot_cam[slot];
-    if (cam < 0) return;
-    const int pt = d.slot_pt[slot];
-    const size_t ns = (size_t)d.n_slots;
-    double F[12], E[6];
-#pragma unroll
-    for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + slot];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + slot];
-    const double* Hi = d.Hinv + 6 * (size_t)pt;
-    const double h[6] = {Hi[0], Hi[1], Hi[2], Hi[3], Hi[4], Hi[5]};
-    const double* g = d.gp + 3 * (size_t)pt;
-    const double g0 = g[0], g1 = g[1], g2 = g[2];
-    double W[18], WH[18];
-#pragma unroll
-    for (int a = 0; a < 6; ++a) {
-#pragma unroll
-        for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[6 + a] * E[3 + b];
-        WH[3 * a + 0] = W[3 * a] * h[0] + W[3 * a + 1] * h[1] + W[3 * a + 2] * h[2];
-        WH[3 * a + 1] = W[3 * a] * h[1] + W[3 * a + 1] * h[3] + W[3 * a + 2] * h[4];
-        WH[3 * a + 2] = W[3 * a] * h[2] + W[3 * a + 1] * h[4] + W[3 * a + 2] * h[5];
-    }
     double o[28];
-    int idx = 0;
 #pragma unroll
-    for (int a = 0; a < 6; ++a)
+    for (int k = 0; k < 28; ++k) o[k] = 0.0;
+    if (cam >= 0) {
+        const int pt = d.slot_pt[slot];
+        const size_t ns = (size_t)d.n_slots;
+        double F[12], E[6];
 #pragma unroll
-        for (int c = a; c < 6; ++c)
-            o[idx++] = F[a] * F[c] + F[6 + a] * F[6 + c]
-                       - (WH[3 * a] * W[3 * c] + WH[3 * a + 1] * W[3 * c + 1] + WH[3 * a + 2] * W[3 * c + 2]);
+        for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + slot];
 #pragma unroll
-    for (int a = 0; a < 6; ++a) o[21 + a] = -(WH[3 * a] * g0 + WH[3 * a + 1] * g1 + WH[3 * a + 2] * g2);
-    o[27] = 0.0;
-    double2* out = reinterpret_cast<double2*>(d.scat + 28 * (size_t)d.slot_campos[slot]);
+        for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + slot];
+        const double* Hi = d.Hinv + 6 * (size_t)pt;
+        const double h[6] = {Hi[0], Hi[1], Hi[2], Hi[3], Hi[4], Hi[5]};
+        const double* g = d.gp + 3 * (size_t)pt;
+        const double g0 = g[0], g1 = g[1], g2 = g[2];
+        double W[18], WH[18];
 #pragma unroll
-    for (int k = 0; k < 14; ++k) out[k] = make_double2(o[2 * k], o[2 * k + 1]);
+        for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[6 + a] * E[3 + b];
+            WH[3 * a + 0] = W[3 * a] * h[0] + W[3 * a + 1] * h[1] + W[3 * a + 2] * h[2];
+            WH[3 * a + 1] = W[3 * a] * h[1] + W[3 * a + 1] * h[3] + W[3 * a + 2] * h[4];
+            WH[3 * a + 2] = W[3 * a] * h[2] + W[3 * a + 1] * h[4] + W[3 * a + 2] * h[5];
+        }
+        int idx = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = a; c < 6; ++c)
+                o[idx++] = F[a] * F[c] + F[6 + a] * F[6 + c]
+                           - (WH[3 * a] * W[3 * c] + WH[3 * a + 1] * W[3 * c + 1] + WH[3 * a + 2] * W[3 * c + 2]);
+#pragma unroll
+        for (int a = 0; a < 6; ++a) o[21 + a] = -(WH[3 * a] * g0 + WH[3 * a + 1] * g1 + WH[3 * a + 2] * g2);
+    }
+    const int stride = d.tile_stride[slot >> 6];
+    if (stride > 0) strided_reduce<28>(o, stride, lane);
+    const int cp = d.slot_campos[slot];
+    if (cp >= 0) {
+        double2* out = reinterpret_cast<double2*>(d.scat + 28 * (size_t)cp);
+#pragma unroll
+        for (int k = 0; k < 14; ++k) out[k] = make_double2(o[2 * k], o[2 * k + 1]);
+    }
 }
 
 // Per camera: M = S_cc + D_c^2, store M^-1 (symmetric, 21) via Cholesky; b = g_c + rb.
@@ -488,13 +519,19 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
         }
         const int hl = seg_head_lane(s.head || !s.valid, lane);
         u[0] = __shfl(u[0], hl, kWave); u[1] = __shfl(u[1], hl, kWave); u[2] = __shfl(u[2], hl, kWave);
+        double y[6] = {0, 0, 0, 0, 0, 0};
         if (s.valid) {
             const double z0 = v0 - (E[0] * u[0] + E[1] * u[1] + E[2] * u[2]);
             const double z1 = v1 - (E[3] * u[0] + E[4] * u[1] + E[5] * u[2]);
-            double2* out = reinterpret_cast<double2*>(d.scat + 6 * (size_t)d.slot_campos[s.slot]);
-            out[0] = make_double2(F[0] * z0 + F[6] * z1, F[1] * z0 + F[7] * z1);
-            out[1] = make_double2(F[2] * z0 + F[8] * z1, F[3] * z0 + F[9] * z1);
-            out[2] = make_double2(F[4] * z0 + F[10] * z1, F[5] * z0 + F[11] * z1);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) y[k] = F[k] * z0 + F[6 + k] * z1;
+        }
+        const int stride = d.tile_stride[it.first_tile];
+        if (stride > 0) strided_reduce<6>(y, stride, lane);
+        const int cp = d.slot_campos[s.slot];
+        if (cp >= 0) {
+            double2* out = reinterpret_cast<double2*>(d.scat + 6 * (size_t)cp);
+            out[0] = make_double2(y[0], y[1]); out[1] = make_double2(y[2], y[3]); out[2] = make_double2(y[4], y[5]);
         }
         return;
     }
@@ -747,16 +784,21 @@ __global__ void k_gradmax_cams(Dev d) {
     d.campart[c] = m;
 }
 
-__global__ void k_gradmax_pts(Dev d, double* out) {
+__global__ __launch_bounds__(kBlock) void k_gradmax_pts(Dev d, double* __restrict__ blockmax) {
+    __shared__ double lds[kWavesPerBlock];
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     double m = 0.0;
     if (p < d.n_pts && !d.pt_const[p])
         for (int k = 0; k < 3; ++k) m = fmax(m, fabs(d.gp[3 * (size_t)p + k] / d.scale_p[3 * (size_t)p + k]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
-    // non-negative doubles order like their bit patterns -> integer atomicMax is exact and order-free
-    if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(m));
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) blockmax[blockIdx.x] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
 }
+
+// Up to 8 independent reductions in one launch (one workgroup each); op 0 = sum, 1 = max.
+struct ReduceJobs { const double* in[8]; int n[8]; double* out[8]; int op[8]; };
 
 // Deterministic single-workgroup reductions of partial arrays.
 __global__ __launch_bounds__(kPcgThreads) void k_reduce_sum(const double* __restrict__ in, int n, double* out) {
@@ -765,6 +807,30 @@ __global__ __launch_bounds__(kPcgThreads) void k_reduce_sum(const double* __rest
     for (int i = threadIdx.x; i < n; i += kPcgThreads) s += in[i];
     s = block_sum<kPcgThreads>(s, lds);
     if (threadIdx.x == 0) *out = s;
+}
+
+__global__ __launch_bounds__(kPcgThreads) void k_reduce_multi(ReduceJobs jobs) {
+    __shared__ double lds[kPcgThreads / kWave];
+    const double* in = jobs.in[blockIdx.x];
+    const int n = jobs.n[blockIdx.x];
+    if (jobs.op[blockIdx.x] == 0) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += kPcgThreads) s += in[i];
+        s = block_sum<kPcgThreads>(s, lds);
+        if (threadIdx.x == 0) *jobs.out[blockIdx.x] = s;
+    } else {
+        double m = 0.0;
+        for (int i = threadIdx.x; i < n; i += kPcgThreads) m = fmax(m, in[i]);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
+        if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double r = 0.0;
+            for (int i = 0; i < kPcgThreads / kWave; ++i) r = fmax(r, lds[i]);
+            *jobs.out[blockIdx.x] = r;
+        }
+    }
 }
 
 __global__ __launch_bounds__(kPcgThreads) void k_reduce_max(const double* __restrict__ in, int n, double* out) {

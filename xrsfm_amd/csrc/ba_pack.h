@@ -17,7 +17,9 @@ struct Packed {
     std::vector<int> slot_cam, slot_pt, slot_campos, slot_obs;  // slot_obs: caller obs index (-1 pad)
     std::vector<double> slot_u, slot_v;
     std::vector<int> items;          // pairs {first_tile, n_tiles}
-    std::vector<int> cam_ptr;        // [n_cams+1]
+    std::vector<int> cam_ptr;        // [n_cams+1] into the camera-major scatter buffer (entries, not observations)
+    std::vector<int> tile_stride;    // [n_tiles] L > 0: every track of the tile has the same L cameras ("regular" tile)
+    int n_cam_entries = 0;
     std::vector<unsigned char> pt_const;
     int n_var_q = 0, n_var_t = 0, n_var_p = 0;
 };
@@ -47,16 +49,29 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     for (int j = 0; j < Np; ++j) ptr[j + 1] = ptr[j] + cnt[j + 1];
     std::vector<int> fill(ptr.begin(), ptr.end() - 1), csr(No);
     for (int i = 0; i < No; ++i) csr[fill[p.obs_pt[i]]++] = i;
-    // active points: short tracks sorted by their lowest camera (locality of the
-    // camera gathers / scatters), long tracks (> 64 obs) at the end
+    // observations of every track ordered by camera
+    for (int j = 0; j < Np; ++j)
+        std::stable_sort(csr.begin() + ptr[j], csr.begin() + ptr[j + 1], [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+    // active points: short tracks sorted by their camera tuple (tracks seeing the same cameras become neighbours:
+    // locality of the camera gathers, and whole tiles that share one tuple can be pre-reduced in the wave),
+    // long tracks (> 64 obs) at the end
     std::vector<int> order;
     order.reserve(Np);
     for (int j = 0; j < Np; ++j)
         if (cnt[j + 1] > 0) order.push_back(j);
+    auto tuple_less = [&](int a, int b) {
+        const int la = cnt[a + 1], lb = cnt[b + 1];
+        const int n = std::min(la, lb);
+        for (int k = 0; k < n; ++k) {
+            const int ca = p.obs_cam[csr[ptr[a] + k]], cb = p.obs_cam[csr[ptr[b] + k]];
+            if (ca != cb) return ca < cb;
+        }
+        return la < lb;
+    };
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
         const bool la = cnt[a + 1] > 64, lb = cnt[b + 1] > 64;
         if (la != lb) return lb;
-        return mincam[a] < mincam[b];
+        return tuple_less(a, b);
     });
     o.n_cams = Nc; o.n_pts = (int)order.size(); o.n_obs = No;
     o.pt_orig = order;
@@ -70,9 +85,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         const int j = order[pj];
         const int len = cnt[j + 1];
         o.pt_const[pj] = (p.point_const && p.point_const[j]) ? 1 : 0;
-        // observations of one track ordered by camera (deterministic)
-        std::vector<int> obs(csr.begin() + ptr[j], csr.begin() + ptr[j + 1]);
-        std::stable_sort(obs.begin(), obs.end(), [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+        const int* obs_b = csr.data() + ptr[j];
         if (len <= 64) {
             const int used = (int)(o.slot_cam.size() % 64);
             if (cur_tile_start < 0 || used + len > 64 || used == 0) {
@@ -85,7 +98,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
             cur_tile_start = -1;
             o.items.push_back((int)(o.slot_cam.size() / 64)); o.items.push_back((len + 63) / 64);
         }
-        for (int i : obs) { o.slot_cam.push_back(p.obs_cam[i]); o.slot_pt.push_back(pj); o.slot_obs.push_back(i); }
+        for (int q = 0; q < len; ++q) { const int i = obs_b[q]; o.slot_cam.push_back(p.obs_cam[i]); o.slot_pt.push_back(pj); o.slot_obs.push_back(i); }
         if (len > 64) pad_tile();
     }
     pad_tile();
@@ -94,19 +107,45 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     o.slot_u.assign(o.n_slots, 0.0); o.slot_v.assign(o.n_slots, 0.0);
     for (int s = 0; s < o.n_slots; ++s)
         if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
-    // camera-major positions (within a camera: slot order)
+    // regular tiles: >= 2 tracks, all with the same camera tuple of length L <= 32
+    o.tile_stride.assign(o.n_tiles, 0);
+    for (int t = 0; t < o.n_tiles; ++t) {
+        const int b0 = 64 * t;
+        if (o.slot_cam[b0] < 0) continue;
+        int L = 1;
+        while (L < 64 && o.slot_cam[b0 + L] >= 0 && o.slot_pt[b0 + L] == o.slot_pt[b0]) ++L;
+        if (L > 32 || L >= 64) continue;
+        bool regular = true;
+        int nvalid = L;
+        for (int s2 = b0 + L; s2 < b0 + 64 && o.slot_cam[s2] >= 0; ++s2, ++nvalid) {
+            const int r = (s2 - b0) % L;
+            if (o.slot_cam[s2] != o.slot_cam[b0 + r]) { regular = false; break; }
+            if (r > 0 ? o.slot_pt[s2] != o.slot_pt[s2 - 1] : o.slot_pt[s2] == o.slot_pt[s2 - 1]) { regular = false; break; }
+        }
+        if (regular && nvalid % L == 0 && nvalid >= 2 * L) o.tile_stride[t] = L;
+    }
+    for (size_t it = 0; it + 1 < o.items.size(); it += 2)          // long items are never regular
+        if (o.items[it + 1] > 1)
+            for (int t = o.items[it]; t < o.items[it] + o.items[it + 1]; ++t) o.tile_stride[t] = 0;
+    // camera-major positions of the lanes that write a camera-side partial: every valid lane of an irregular tile,
+    // the first track (lanes < L) of a regular one.  Within a camera: slot order.
+    auto writes = [&](int s2) { const int L = o.tile_stride[s2 / 64]; return o.slot_cam[s2] >= 0 && (L == 0 || (s2 % 64) < L); };
     o.cam_ptr.assign(Nc + 1, 0);
-    for (int s = 0; s < o.n_slots; ++s)
-        if (o.slot_cam[s] >= 0) o.cam_ptr[o.slot_cam[s] + 1]++;
+    for (int s2 = 0; s2 < o.n_slots; ++s2)
+        if (writes(s2)) o.cam_ptr[o.slot_cam[s2] + 1]++;
     for (int c = 0; c < Nc; ++c) o.cam_ptr[c + 1] += o.cam_ptr[c];
+    o.n_cam_entries = o.cam_ptr[Nc];
     std::vector<int> cf(o.cam_ptr.begin(), o.cam_ptr.end() - 1);
     o.slot_campos.assign(o.n_slots, -1);
-    for (int s = 0; s < o.n_slots; ++s)
-        if (o.slot_cam[s] >= 0) o.slot_campos[s] = cf[o.slot_cam[s]]++;
+    for (int s2 = 0; s2 < o.n_slots; ++s2)
+        if (writes(s2)) o.slot_campos[s2] = cf[o.slot_cam[s2]]++;
+    std::vector<char> cam_seen(Nc, 0);
+    for (int s2 = 0; s2 < o.n_slots; ++s2)
+        if (o.slot_cam[s2] >= 0) cam_seen[o.slot_cam[s2]] = 1;
     // effective parameter count (num_effective_parameters_reduced)
     o.n_var_q = o.n_var_t = o.n_var_p = 0;
     for (int c = 0; c < Nc; ++c) {
-        if (o.cam_ptr[c + 1] == o.cam_ptr[c]) continue;
+        if (!cam_seen[c]) continue;
         const unsigned cc = p.cam_const ? p.cam_const[c] : 0u;
         if (!(cc & XRSFM_BA_CONST_Q)) o.n_var_q++;
         if (!(cc & XRSFM_BA_CONST_T)) o.n_var_t++;

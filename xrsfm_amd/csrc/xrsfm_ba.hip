@@ -186,8 +186,12 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
     Dev& d = c->d;
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camlin, (const PcgStatus*)nullptr);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part, d.n_items, d.scal + S_COST);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part + d.n_items, d.n_items, d.scal + S_XNORM2_PTS);
+    {
+        ReduceJobs j{};
+        j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = d.scal + S_COST; j.op[0] = 0;
+        j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = d.scal + S_XNORM2_PTS; j.op[1] = 0;
+        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(2), dim3(kPcgThreads), 0, j);
+    }
     int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12, kNcclSum);
     if (e) return e;
     return allreduce(c, d.scal + S_COST, 2, kNcclSum);   // S_COST, S_XNORM2_PTS adjacent
@@ -195,10 +199,15 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
 
 int gradient_max(xrsfm_ba_context* c, double* out) {
     Dev& d = c->d;
-    HIPCHK(hipMemsetAsync(d.scal + S_GRADMAX_PTS, 0, sizeof(double), c->stream));
-    if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_gradmax_pts, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, d, d.scal + S_GRADMAX_PTS);
+    const int nb = cdiv(d.n_pts, kBlock);
+    if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_gradmax_pts, dim3(nb), dim3(kBlock), 0, d, d.ptpart);
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
-    LAUNCH(c, K_SMALL, k_reduce_max, dim3(1), dim3(kPcgThreads), 0, d.campart, d.n_cams, d.scal + S_GRADMAX_CAMS);
+    {
+        ReduceJobs j{};
+        j.in[0] = d.ptpart; j.n[0] = d.n_pts > 0 ? nb : 0; j.out[0] = d.scal + S_GRADMAX_PTS; j.op[0] = 1;
+        j.in[1] = d.campart; j.n[1] = d.n_cams; j.out[1] = d.scal + S_GRADMAX_CAMS; j.op[1] = 1;
+        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(2), dim3(kPcgThreads), 0, j);
+    }
     int e = allreduce(c, d.scal + S_GRADMAX_PTS, 1, kNcclMax);
     if (e) return e;
     e = fetch_scalars(c);
@@ -272,25 +281,30 @@ int chol_setup(xrsfm_ba_context* c) {
         for (int s = 0; s < ns; ++s) spp[s + 1] = spp[s] + rest[s];
     }
     const int n_pairs = spp[ns];
-    std::vector<std::pair<unsigned long long, int>> keyed(n_pairs);
+    // block-major destinations: every pair of an irregular tile, the pairs of the first track of a regular tile
+    // (the kernel sums the other tracks of the tile into it)
+    std::vector<std::pair<unsigned long long, int>> keyed;
+    keyed.reserve(n_pairs);
     for (int s = 0; s < ns; ++s) {
         const int np = spp[s + 1] - spp[s];
+        const int L = k.tile_stride[s / 64];
         for (int dd = 1; dd <= np; ++dd) {
             const unsigned long long cb = (unsigned)k.slot_cam[s + dd], ca = (unsigned)k.slot_cam[s];
             if (cb <= ca) return XRSFM_BA_EINVAL;   // two observations of one track in the same frame
-            keyed[spp[s] + dd - 1] = {(cb << 32) | ca, spp[s] + dd - 1};
+            if (L == 0 || (s % 64) < L) keyed.push_back({(cb << 32) | ca, spp[s] + dd - 1});
         }
     }
+    const int n_writes = (int)keyed.size();
     std::sort(keyed.begin(), keyed.end());
-    std::vector<int> pair_dst(n_pairs), blk_ptr, blk_rc;
-    for (int i = 0; i < n_pairs; ++i) {
+    std::vector<int> pair_dst(n_pairs, -1), blk_ptr, blk_rc;
+    for (int i = 0; i < n_writes; ++i) {
         if (i == 0 || keyed[i].first != keyed[i - 1].first) {
             blk_ptr.push_back(i);
             blk_rc.push_back((int)(keyed[i].first >> 32)); blk_rc.push_back((int)(keyed[i].first & 0xffffffffu));
         }
         pair_dst[keyed[i].second] = i;
     }
-    blk_ptr.push_back(n_pairs);
+    blk_ptr.push_back(n_writes);
     const int n_blocks = (int)blk_ptr.size() - 1;
     // ---- elimination order of the cameras: 10 cameras per 64-row tile (4 padding rows), groups tile-aligned.
     // Band / ring structure (sequential SfM): nested dissection of the path so that the elimination tree of the
@@ -411,7 +425,7 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.lv_rptr, lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, lv_rj));
     TRYC(dev_upload(c, &h.lv_bptr, lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, lv_bi));
     TRYC(dev_upload(c, &d_cam_off, cam_off)); TRYC(dev_upload(c, &d_one_k, one_k));
-    TRYC(dev_alloc(c, &h.scat2, (size_t)(n_pairs > 0 ? n_pairs : 1) * 36));
+    TRYC(dev_alloc(c, &h.scat2, (size_t)(n_writes > 0 ? n_writes : 1) * 36));
     TRYC(dev_alloc(c, &h.Sblk, (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
     h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k;
     TRYC(dev_alloc(c, &h.dev.S, (size_t)n_pad * n_pad));
@@ -495,11 +509,14 @@ int finish_step(xrsfm_ba_context* c, double huber_a) {
     if (d.n_items > 0) LAUNCH(c, K_BACKSUB, k_backsub, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d);
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (d.n_items > 0) LAUNCH(c, K_COST, k_cost, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part, d.n_items, d.scal + S_COST_CAND);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part + 2 * (size_t)d.n_items, d.n_items, d.scal + S_MODEL);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.part + 3 * (size_t)d.n_items, d.n_items, d.scal + S_STEP2_PTS);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.campart, d.n_cams, d.scal + S_STEP2_CAMS);
-    LAUNCH(c, K_SMALL, k_reduce_sum, dim3(1), dim3(kPcgThreads), 0, d.campart + d.n_cams, d.n_cams, d.scal + S_XNORM2_CAMS);
+    {
+        ReduceJobs j{};
+        const double* ins[5] = {d.part, d.part + 2 * (size_t)d.n_items, d.part + 3 * (size_t)d.n_items, d.campart, d.campart + d.n_cams};
+        const int ns[5] = {d.n_items, d.n_items, d.n_items, d.n_cams, d.n_cams};
+        double* outs[5] = {d.scal + S_COST_CAND, d.scal + S_MODEL, d.scal + S_STEP2_PTS, d.scal + S_STEP2_CAMS, d.scal + S_XNORM2_CAMS};
+        for (int q = 0; q < 5; ++q) { j.in[q] = ins[q]; j.n[q] = ns[q]; j.out[q] = outs[q]; j.op[q] = 0; }
+        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(5), dim3(kPcgThreads), 0, j);
+    }
     int e = allreduce(c, d.scal + S_COST_CAND, 3, kNcclSum);   // COST_CAND, MODEL, STEP2_PTS adjacent
     if (e) return e;
     return fetch_scalars(c);
@@ -614,6 +631,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &tmp_it, k.items.size() / 2));
     if (!k.items.empty() && hipMemcpy(tmp_it, k.items.data(), k.items.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
     d.items = tmp_it;
+    TRY(dev_upload(c, &tmp_i, k.tile_stride)); d.tile_stride = tmp_i;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam_cand = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); c->cam0 = tmp_c;
@@ -637,6 +655,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.scat, (size_t)(k.n_obs > 0 ? k.n_obs : 1) * 28));
     TRY(dev_alloc(c, &d.part, (size_t)d.n_items * 4));
     TRY(dev_alloc(c, &d.campart, nc * 2));
+    TRY(dev_alloc(c, &d.ptpart, np / kBlock + 2));
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));
     TRY(dev_alloc(c, &d.st, (size_t)1));
 #undef TRY
