@@ -164,6 +164,10 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context *ctx, double huber_a, int use_scal
 /* After debug_linearize: y = S(radius) * x for a caller vector x [n_cams][6]; also returns rhs b [n_cams][6]. */
 int xrsfm_ba_debug_schur_product(xrsfm_ba_context *ctx, double radius, const double *x, double *y, double *b);
 
+/* Multi-GPU emulation for tests: supply the union of all ranks' off-diagonal camera pairs (row > col) before the first
+ * Cholesky solve, exactly what xrsfm_ba_run obtains with an all-reduce when n_ranks > 1. */
+int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context *ctx, int n_pairs, const int32_t *row_col);
+
 /* After debug_linearize: solve S(radius) y = b with the Cholesky path; y [n_cams][6].  If S_dense != NULL it
  * receives the assembled reduced camera matrix before factorisation, [6 n_cams][6 n_cams] row-major, symmetric. */
 int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context *ctx, double radius, double *y, double *S_dense);

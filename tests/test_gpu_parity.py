@@ -280,3 +280,58 @@ def test_full_size_properties(lib):
         assert abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s.final_cost / n_res)) < 1e-6
         assert max(np.abs(prob["cam_q"] - q).max(), np.abs(prob["cam_t"] - t).max()) < 1e-5
     ctx.close()
+
+
+@pytest.mark.parametrize("n_cams,n_pts,k_obs", [(40, 900, 3), (130, 2000, 4)])
+def test_sharded_reduced_matrix_sums_to_full(lib, n_cams, n_pts, k_obs):
+    """Multi-GPU Cholesky path, emulated on one GPU: two shards (bench.shard_problem) with the union block pattern
+    that xrsfm_ba_run obtains by all-reduce; the shards' reduced camera matrices and right-hand sides must add up to
+    the single-rank ones (that sum is what the RCCL all-reduce of the block values produces)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import shard_problem, count_offdiag_blocks
+    from xrsfm_amd import capi
+    arr = H.make(n_cams, n_pts, k_obs, seed=140)
+    full = capi.Context(H.to_product(arr))
+    full.debug_linearize(5.99, False)
+    _, S_full = full.debug_cholesky_solve(2e3, want_S=True)
+    # union pattern from the full problem
+    order = np.lexsort((arr["obs_cam"], arr["obs_pt"]))
+    cam = arr["obs_cam"][order]; pt = arr["obs_pt"][order]
+    pairs = set()
+    for d in range(1, k_obs):
+        same = pt[d:] == pt[:-d]
+        pairs |= set(zip(cam[d:][same].tolist(), cam[:-d][same].tolist()))
+    pattern = np.array(sorted(pairs), np.int32)
+    assert pattern.shape[0] == count_offdiag_blocks(arr)
+    S_sum = np.zeros_like(S_full)
+    for r in range(2):
+        ctx = capi.Context(H.to_product(shard_problem(arr, r, 2)))
+        ctx.debug_set_block_pattern(pattern)
+        ctx.debug_linearize(5.99, False)
+        _, S = ctx.debug_cholesky_solve(2e3, want_S=True)
+        S_sum += S
+        ctx.close()
+    assert H.rel_err(S_sum, S_full) < 1e-12
+    full.close()
+
+
+def test_rccl_plumbing_single_rank(lib, monkeypatch):
+    """A real 1-rank RCCL communicator (XRSFM_BA_FORCE_COMM=1): unique id, ncclCommInitRank with the id passed by value,
+    every all-reduce of the solve issued on the library's stream.  Results must equal the communicator-free run bit for bit."""
+    from xrsfm_amd import capi
+    arr = H.make(20, 1200, 4, seed=141)
+    a = capi.Context(H.to_product(arr))
+    sa = a.run(); qa, ta, Pa = a.download(); a.close()
+    monkeypatch.setenv("XRSFM_BA_FORCE_COMM", "1")
+    uid = capi.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    for solver in (1, 0):
+        b = capi.Context(H.to_product(arr))
+        b.comm_init(1, 0, uid if solver == 1 else capi.comm_unique_id())
+        sb = b.run(capi.default_options(linear_solver=solver)); qb, tb, Pb = b.download(); b.close()
+        assert sb.n_successful == sa.n_successful
+        if solver == 1:
+            assert sb.final_cost == sa.final_cost and np.array_equal(qa, qb) and np.array_equal(ta, tb) and np.array_equal(Pa, Pb)
+        else:
+            assert abs(sb.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost

@@ -57,7 +57,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -96,6 +96,8 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_schur_product.restype = C.c_int
     lib.xrsfm_ba_debug_cholesky_solve.argtypes = [vp, C.c_double, _c_double_p, _c_double_p]
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
+    lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
+    lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
     lib.xrsfm_ba_profile_entry.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _c_double_p, C.POINTER(C.c_int)]
     lib.xrsfm_ba_profile_entry.restype = C.c_int
     _lib = lib
@@ -233,6 +235,10 @@ class Context:
         S = np.zeros((n, n)) if want_S else None
         check(self.lib.xrsfm_ba_debug_cholesky_solve(self._h, radius, _dp(y), _dp(S)), "debug_cholesky_solve")
         return y, S
+
+    def debug_set_block_pattern(self, row_col: np.ndarray):
+        rc = np.ascontiguousarray(row_col, np.int32).reshape(-1, 2)
+        check(self.lib.xrsfm_ba_debug_set_block_pattern(self._h, rc.shape[0], rc.ctypes.data_as(_c_int32_p)), "debug_set_block_pattern")
 
     def profile(self) -> dict:
         """Per-kernel HIP-event totals of the last run with options.profile != 0: name -> (ms, launches)."""

@@ -14,6 +14,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -113,6 +114,8 @@ struct xrsfm_ba_context {
     std::vector<Rec> recs;
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
     bool linearized = false;
+    std::vector<unsigned long long> pattern_keys;   // union of the ranks' off-diagonal camera pairs ((row << 32) | col), sorted
+    bool have_pattern = false;
     CholHost chol;
 };
 
@@ -138,7 +141,7 @@ int dev_upload(xrsfm_ba_context* c, T** p, const std::vector<T>& v) {
 inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 
 int allreduce(xrsfm_ba_context* c, double* buf, size_t n, int op) {
-    if (c->n_ranks <= 1) return 0;
+    if (!c->comm) return 0;
     const int e = g_rccl.AllReduce(buf, buf, n, kNcclFloat64, op, c->comm, c->stream);
     return e == 0 ? 0 : XRSFM_BA_ECOMM;
 }
@@ -296,15 +299,45 @@ int chol_setup(xrsfm_ba_context* c) {
     }
     const int n_writes = (int)keyed.size();
     std::sort(keyed.begin(), keyed.end());
-    std::vector<int> pair_dst(n_pairs, -1), blk_ptr, blk_rc;
-    for (int i = 0; i < n_writes; ++i) {
-        if (i == 0 || keyed[i].first != keyed[i - 1].first) {
-            blk_ptr.push_back(i);
-            blk_rc.push_back((int)(keyed[i].first >> 32)); blk_rc.push_back((int)(keyed[i].first & 0xffffffffu));
-        }
-        pair_dst[keyed[i].second] = i;
+    // block list: the local camera pairs, or (multi-GPU) the union over all ranks so that every rank holds the same
+    // blocks in the same order and the block values can be all-reduced
+    std::vector<unsigned long long> blk_keys;
+    if (c->n_ranks > 1 && !c->have_pattern) {
+        // union by an all-reduce(max) of an N_c x N_c occupancy map (once per problem)
+        std::vector<double> occ((size_t)Nc * Nc, 0.0);
+        for (const auto& kv : keyed) occ[(size_t)(kv.first >> 32) * Nc + (kv.first & 0xffffffffu)] = 1.0;
+        double* d_occ = nullptr;
+        if (hipMalloc((void**)&d_occ, occ.size() * sizeof(double)) != hipSuccess) return XRSFM_BA_ENOMEM;
+        int e2 = XRSFM_BA_OK;
+        if (hipMemcpy(d_occ, occ.data(), occ.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) e2 = XRSFM_BA_ENODEV;
+        if (!e2) e2 = allreduce(c, d_occ, occ.size(), kNcclMax);
+        if (!e2 && hipStreamSynchronize(c->stream) != hipSuccess) e2 = XRSFM_BA_ENODEV;
+        if (!e2 && hipMemcpy(occ.data(), d_occ, occ.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) e2 = XRSFM_BA_ENODEV;
+        (void)hipFree(d_occ);
+        if (e2) return e2;
+        c->pattern_keys.clear();
+        for (int rb = 0; rb < Nc; ++rb)
+            for (int ca = 0; ca < rb; ++ca)
+                if (occ[(size_t)rb * Nc + ca] > 0.0) c->pattern_keys.push_back(((unsigned long long)rb << 32) | (unsigned)ca);
+        c->have_pattern = true;
     }
-    blk_ptr.push_back(n_writes);
+    if (c->have_pattern) {
+        blk_keys = c->pattern_keys;
+    } else {
+        for (int i = 0; i < n_writes; ++i)
+            if (i == 0 || keyed[i].first != keyed[i - 1].first) blk_keys.push_back(keyed[i].first);
+    }
+    std::vector<int> pair_dst(n_pairs, -1), blk_ptr, blk_rc;
+    {
+        int i = 0;
+        for (const unsigned long long key : blk_keys) {
+            blk_ptr.push_back(i);
+            blk_rc.push_back((int)(key >> 32)); blk_rc.push_back((int)(key & 0xffffffffu));
+            while (i < n_writes && keyed[i].first == key) { pair_dst[keyed[i].second] = i; ++i; }
+        }
+        if (i != n_writes) return XRSFM_BA_EINVAL;    // a local pair that is missing from the supplied pattern
+        blk_ptr.push_back(n_writes);
+    }
     const int n_blocks = (int)blk_ptr.size() - 1;
     // ---- elimination order of the cameras: 10 cameras per 64-row tile (4 padding rows), groups tile-aligned.
     // Band / ring structure (sequential SfM): nested dissection of the path so that the elimination tree of the
@@ -679,7 +712,10 @@ int xrsfm_ba_comm_unique_id(unsigned char id[128]) {
 
 int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigned char id[128]) {
     if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return XRSFM_BA_EINVAL;
-    if (n_ranks == 1) { c->n_ranks = 1; c->rank = 0; return 0; }
+    // a single rank needs no communicator; XRSFM_BA_FORCE_COMM=1 creates one anyway (exercises the RCCL plumbing
+    // on a 1-GPU box: every all-reduce then really goes through ncclAllReduce)
+    const char* force = getenv("XRSFM_BA_FORCE_COMM");
+    if (n_ranks == 1 && !(force && force[0] == '1')) { c->n_ranks = 1; c->rank = 0; return 0; }
     if (!load_rccl()) return XRSFM_BA_ECOMM;
     HIPCHK(hipSetDevice(c->device));
     UniqueId u;
@@ -733,9 +769,8 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
     Dev& d = c->d;
     hipStream_t st = c->stream;
     int solver = opt.linear_solver;
-    if (solver == XRSFM_BA_SOLVER_AUTO) solver = (6 * d.n_cams <= kCholMaxN && c->n_ranks == 1) ? XRSFM_BA_SOLVER_CHOLESKY : XRSFM_BA_SOLVER_PCG;
+    if (solver == XRSFM_BA_SOLVER_AUTO) solver = (6 * d.n_cams <= kCholMaxN) ? XRSFM_BA_SOLVER_CHOLESKY : XRSFM_BA_SOLVER_PCG;
     if (solver != XRSFM_BA_SOLVER_PCG && solver != XRSFM_BA_SOLVER_CHOLESKY) return XRSFM_BA_EINVAL;
-    if (solver == XRSFM_BA_SOLVER_CHOLESKY && c->n_ranks > 1) return XRSFM_BA_EINVAL;   // block pattern is per rank so far
     int e;
     if (solver == XRSFM_BA_SOLVER_CHOLESKY && (e = chol_setup(c))) return e;
     sum->linear_solver_used = solver;
@@ -908,6 +943,21 @@ int xrsfm_ba_debug_schur_product(xrsfm_ba_context* c, double radius, const doubl
     if (b) HIPCHK(hipMemcpyAsync(b, d.b, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; ++i) y[i] = q[i] + dc[i] * x[i];
+    return 0;
+}
+
+int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context* c, int n_pairs, const int32_t* row_col) {
+    if (!c || n_pairs < 0 || (n_pairs > 0 && !row_col)) return XRSFM_BA_EINVAL;
+    if (c->chol.ready) return XRSFM_BA_ESTATE;
+    c->pattern_keys.clear();
+    for (int i = 0; i < n_pairs; ++i) {
+        const int rb = row_col[2 * i], ca = row_col[2 * i + 1];
+        if (ca < 0 || rb <= ca || rb >= c->d.n_cams) return XRSFM_BA_EINVAL;
+        c->pattern_keys.push_back(((unsigned long long)rb << 32) | (unsigned)ca);
+    }
+    std::sort(c->pattern_keys.begin(), c->pattern_keys.end());
+    c->pattern_keys.erase(std::unique(c->pattern_keys.begin(), c->pattern_keys.end()), c->pattern_keys.end());
+    c->have_pattern = true;
     return 0;
 }
 
