@@ -197,8 +197,12 @@ def main():
         avg_s = ms * 1e-3 / launches
         alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
         ach = alg / avg_s / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
+        if world == 1 and os.path.exists(pmc):      # separate rocprofv3 --pmc passes (tools/pmc_summary.py), bytes per launch
+            traffic = json.load(open(pmc)).get(dom)
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": None, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
+                    "traffic": traffic, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "algorithmic_bytes_per_launch": alg}
 
     if rank == 0:
