@@ -14,6 +14,8 @@ int main() {
     hipMalloc(&c.S, h.size() * 8); hipMalloc(&c.Linv, (size_t)T * kNB * kNB * 8);
     hipMalloc(&c.y, n_pad * 8); hipMalloc(&c.rhs, n_pad * 8); hipMalloc(&c.x, n_pad * 8);
     int* rows; hipMalloc(&rows, 64 * 4); std::vector<int> hr = {1, 2, 3, 1, 1, 2, 1, 2, 2, 3, 1, 3, 2, 3, 3}; hipMemcpy(rows, hr.data(), hr.size() * 4, hipMemcpyHostToDevice);
+    int* klist; hipMalloc(&klist, 64); std::vector<int> hk = {0, 1, 2, 3}; hipMemcpy(klist, hk.data(), 16, hipMemcpyHostToDevice);
+    int* trows; hipMalloc(&trows, 64); std::vector<int> ht(T, 64); hipMemcpy(trows, ht.data(), T * 4, hipMemcpyHostToDevice); c.tile_rows = trows;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto timeit = [&](const char* name, auto f, int reps) {
         f(); hipDeviceSynchronize();
@@ -24,9 +26,9 @@ int main() {
     hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     timeit("empty", [&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, 0); }, 1000);
-    timeit("potrf", [&] { hipMemcpyAsync(c.S, h.data(), 8, hipMemcpyHostToDevice, 0); hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, 0, c, 0); }, 200);
+    timeit("potrf", [&] { hipMemcpyAsync(c.S, h.data(), 8, hipMemcpyHostToDevice, 0); hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, 0, c, klist, (const int*)nullptr, (const int*)nullptr); }, 200);
     hipMemcpy(c.S, h.data(), h.size() * 8, hipMemcpyHostToDevice);
-    timeit("potrf_only", [&] { hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, 0, c, 1); }, 1000);
+    timeit("potrf_only", [&] { hipLaunchKernelGGL(k_potrf, dim3(1), dim3(256), 0, 0, c, klist + 1, (const int*)nullptr, (const int*)nullptr); }, 1000);
     timeit("trsm x3", [&] { hipLaunchKernelGGL(k_trsm, dim3(3), dim3(256), shm, 0, c, 0, rows); }, 1000);
     timeit("update x6", [&] { hipLaunchKernelGGL(k_update, dim3(6), dim3(256), shm, 0, c, 0, rows + 3); }, 1000);
     timeit("fwd", [&] { hipLaunchKernelGGL(k_fwd, dim3(4), dim3(256), 0, 0, c, 0, rows); }, 1000);

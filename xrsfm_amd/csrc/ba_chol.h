@@ -27,17 +27,29 @@ struct CholDev {
     double* x;        // [n_pad]
     const int* cam_off;   // [n_cams] first scalar row of the camera's 6x6 diagonal block (tile-aligned groups)
     const int* one_k;     // [T] identity list 0..T-1 (right-looking path: kernels read their panel from a list)
+    const int* tile_rows; // [T] leading rows of the tile that hold cameras (the rest is identity padding)
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------ S assembly
-// Off-diagonal blocks of one tile of tracks.  Lane = observation a; partner b = a + d
-// in the same track (b's camera id is larger).  block(b,a) = W_b * (W_a Hinv)^T.
-__global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr,
-                                                       const int* __restrict__ pair_dst, double* __restrict__ scat2) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+// Off-diagonal blocks  block(b,a) = sum_tracks W_b Hinv W_a^T  (camera b > camera a of the same track).
+// One wavefront per tile (64-thread workgroups: the staged operands of a wave live in its own LDS).
+//  * regular tile (T tracks, all with the same L cameras): the lanes stage W and W*Hinv as [6L x 3T] matrices in LDS
+//    and the wave forms G = W (W Hinv)^T with v_mfma_f64_16x16x4_f64: G holds every camera-pair block already summed
+//    over the T tracks, written once per tile;
+//  * other tiles: lane = observation a, partner b = a + d in the same track via shfl_down, one block per pair;
+//  * long tracks: lane loops over all later observations of its track.
+__device__ __forceinline__ int pairs_lds_doubles(int L, int T) {   // per operand matrix
+    const int Rp = (6 * L + 15) & ~15, Cp = ((3 * T + 3) & ~3) + 2;
+    return Rp * Cp;
+}
+
+__global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr,
+                                                      const int* __restrict__ pair_dst, double* __restrict__ scat2) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int item = blockIdx.x;
     if (item >= d.n_items) return;
     const Item it = d.items[item];
     const size_t ns = (size_t)d.n_slots;
@@ -66,31 +78,62 @@ __global__ __launch_bounds__(kBlock) void k_schur_pairs(Dev d, const int* __rest
             pbase = slot_pair_ptr[s.slot];
             npair = slot_pair_ptr[s.slot + 1] - pbase;
         }
+        const int L = d.tile_stride[it.first_tile];
+        if (L > 0) {
+            const int nvalid = __popcll(__ballot(s.valid));
+            const int T = nvalid / L;
+            const int R = 6 * L, Rp = (R + 15) & ~15, C4 = (3 * T + 3) & ~3, Cp = C4 + 2;
+            double* Wst = smem; double* Hst = smem + Rp * Cp;
+            int* dtab = reinterpret_cast<int*>(smem + 2 * Rp * Cp);       // [L][L] destination of block (rb, ra)
+            // destinations of the first track's pairs: issued first so the index loads overlap the staging
+            if (lane < L)
+                for (int dd = 1; dd <= npair; ++dd) dtab[lane * L + lane + dd] = pair_dst[pbase + dd - 1];
+            // zero only the padding: rows R..Rp-1 and columns 3T..Cp-1 (the rest is overwritten below)
+            for (int e = lane; e < (Rp - R) * Cp; e += kWave) { Wst[R * Cp + e] = 0.0; Hst[R * Cp + e] = 0.0; }
+            const int padc = Cp - 3 * T;
+            for (int e = lane; e < R * padc; e += kWave) {
+                const int row = e / padc, cc = 3 * T + (e - row * padc);
+                Wst[row * Cp + cc] = 0.0; Hst[row * Cp + cc] = 0.0;
+            }
+            if (s.valid) {
+                const int t = lane / L, r = lane - t * L;
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        Wst[(6 * r + i) * Cp + 3 * t + m] = W[3 * i + m];
+                        Hst[(6 * r + i) * Cp + 3 * t + m] = WH[3 * i + m];
+                    }
+            }
+            __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operands and dtab are in LDS
+            __builtin_amdgcn_wave_barrier();
+            const int li = lane & 15, lk = lane >> 4;
+            const int nI = Rp >> 4;
+            for (int I = 0; I < nI; ++I)
+                for (int J = 0; J <= I; ++J) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    const double* ap = Wst + (16 * I + li) * Cp + lk;
+                    const double* bp = Hst + (16 * J + li) * Cp + lk;
+                    for (int k0 = 0; k0 < C4; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
+                    const int col = 16 * J + li;
+                    const int ra = col / 6, j = col - 6 * ra;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = 16 * I + lk + 4 * g;
+                        const int rb = row / 6, i = row - 6 * rb;
+                        if (row < R && col < R && rb > ra) scat2[36 * (size_t)dtab[ra * L + rb] + 6 * i + j] = acc[g];
+                    }
+                }
+            return;
+        }
         int maxp = npair;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, __shfl_xor(maxp, off, kWave));
-        const int stride = d.tile_stride[it.first_tile];
         for (int dd = 1; dd <= maxp; ++dd) {
             double Wb[18];
 #pragma unroll
             for (int k = 0; k < 18; ++k) Wb[k] = __shfl_down(W[k], dd, kWave);
-            const bool has = dd <= npair;
-            if (stride > 0) {
-                // regular tile: the same camera pair in every track -> sum over the tracks first, 6 values at a time
-                const int dst = (has && lane < stride) ? pair_dst[pbase + dd - 1] : -1;
-#pragma unroll
-                for (int rb = 0; rb < 6; ++rb) {
-                    double o[6];
-#pragma unroll
-                    for (int ca = 0; ca < 6; ++ca)
-                        o[ca] = has ? Wb[3 * rb] * WH[3 * ca] + Wb[3 * rb + 1] * WH[3 * ca + 1] + Wb[3 * rb + 2] * WH[3 * ca + 2] : 0.0;
-                    strided_reduce<6>(o, stride, lane);
-                    if (dst >= 0) {
-                        double2* out = reinterpret_cast<double2*>(scat2 + 36 * (size_t)dst + 6 * rb);
-                        out[0] = make_double2(o[0], o[1]); out[1] = make_double2(o[2], o[3]); out[2] = make_double2(o[4], o[5]);
-                    }
-                }
-            } else if (has) {
+            if (dd <= npair) {
                 double2* out = reinterpret_cast<double2*>(scat2 + 36 * (size_t)pair_dst[pbase + dd - 1]);
 #pragma unroll
                 for (int rb = 0; rb < 6; ++rb) {
@@ -228,8 +271,12 @@ __device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f6
 //   broadcasts are v_readlane, one reciprocal per column, square roots applied once at the end) and
 //   inverts it; (b) the rows below are multiplied by Linv11^T and (c) the trailing blocks are updated
 //   with 16x16x16 products on the FP64 matrix cores.  3 barriers per block column.
-__global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict__ klist) {
+//   With rptr/rj (level schedule) the forward substitution of the panel is folded in:
+//   y_k = Linv_k (rhs_k - sum_{j in row(k)} L_kj y_j); every L_kj and y_j belongs to a lower level.
+__global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict__ klist, const int* __restrict__ rptr,
+                                               const int* __restrict__ rj) {
     const int k = klist[blockIdx.x];
+    const int nb = (c.tile_rows[k] + 15) >> 4;       // 16-row blocks that are not pure identity padding
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Tb[3][16][17];
@@ -240,10 +287,10 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
     for (int it = 0; it < 16; ++it) {
         const int e = t + 256 * it; const int r = e >> 6, col = e & 63;
         A[r][col] = (col <= r) ? base[(size_t)r * c.n_pad + col] : 0.0;
-        Li[r][col] = 0.0;
+        Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
     }
     __syncthreads();
-    for (int kb = 0; kb < 4; ++kb) {
+    for (int kb = 0; kb < nb; ++kb) {
         const int b0 = 16 * kb;
         if (wave == 0) {
             // (a) lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
@@ -284,7 +331,7 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
         }
         __syncthreads();
         // (b) rows below: X = A21 * Linv11^T, one 16-row block per wave
-        if (kb + 1 + wave < 4) {
+        if (kb + 1 + wave < nb) {
             const int rb = 16 * (kb + 1 + wave);
             v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -297,7 +344,7 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
         // (c) trailing update A_ij -= X_i X_j^T for kb < j <= i < 4, blocks dealt round-robin to the waves
         {
             int idx = 0;
-            for (int i = kb + 1; i < 4; ++i)
+            for (int i = kb + 1; i < nb; ++i)
                 for (int j = kb + 1; j <= i; ++j, ++idx) {
                     if ((idx & 3) != wave) continue;
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
@@ -311,8 +358,8 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
         __syncthreads();
     }
     // ---- off-diagonal blocks of Linv, block rows dd = 1,2,3:  Linv_ij = -Linv_ii * sum_{kb=j}^{i-1} L_i,kb Linv_kb,j
-    for (int dd = 1; dd < 4; ++dd) {
-        const int nblk = 4 - dd;
+    for (int dd = 1; dd < nb; ++dd) {
+        const int nblk = nb - dd;
         double tv[3] = {0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
@@ -352,6 +399,33 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
         const int e = t + 256 * it; const int r = e >> 6, col = e & 63;
         lo[e] = (col <= r) ? Li[r][col] : 0.0;
         if (col <= r) base[(size_t)r * c.n_pad + col] = A[r][col];
+    }
+    if (rptr) {     // forward substitution of this panel; Tb (3*16*17 doubles) is reused as 3 x 64 scratch
+        double* acc = &Tb[0][0][0]; double* v = acc + 64; double* tmp = acc + 128;
+        if (t < kNB) acc[t] = c.rhs[k * kNB + t];
+        const int o = t >> 2, part = t & 3;
+        for (int q = rptr[blockIdx.x]; q < rptr[blockIdx.x + 1]; ++q) {
+            const int j = rj[q];
+            __syncthreads();
+            if (t < kNB) v[t] = c.y[j * kNB + t];
+            __syncthreads();
+            const double* M = c.S + (size_t)(k * kNB + o) * c.n_pad + j * kNB + part * 16;
+            double sacc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) sacc += M[m] * v[part * 16 + m];
+            sacc += __shfl_xor(sacc, 1, kWave);
+            sacc += __shfl_xor(sacc, 2, kWave);
+            if (part == 0) tmp[o] = sacc;
+            __syncthreads();
+            if (t < kNB) acc[t] -= tmp[t];
+        }
+        __syncthreads();
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sacc += Li[o][part * 16 + m] * acc[part * 16 + m];
+        sacc += __shfl_xor(sacc, 1, kWave);
+        sacc += __shfl_xor(sacc, 2, kWave);
+        if (part == 0) c.y[k * kNB + o] = sacc;
     }
 }
 

@@ -83,6 +83,7 @@ struct CholHost {
     int *slot_pair_ptr = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr;
     double *scat2 = nullptr, *Sblk = nullptr;
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
+    size_t pairs_shm = 0;                         // dynamic LDS of k_schur_pairs: staged operands of the largest regular tile
     // right-looking schedule (dense patterns): one panel after the other
     int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
     std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
@@ -373,13 +374,15 @@ int chol_setup(xrsfm_ba_context* c) {
         std::vector<int> all; for (int c2 = 0; c2 < Nc; ++c2) all.push_back(c2);
         groups.push_back(all);
     }
-    std::vector<int> cam_off(Nc, 0);
+    std::vector<int> cam_off(Nc, 0), tile_rows;
     int T = 0;
     for (const auto& g : groups) {
         for (size_t q = 0; q < g.size(); ++q) cam_off[g[q]] = kNB * (T + (int)q / kCamsPerTile) + 6 * ((int)q % kCamsPerTile);
-        T += ((int)g.size() + kCamsPerTile - 1) / kCamsPerTile;
+        const int nt = ((int)g.size() + kCamsPerTile - 1) / kCamsPerTile;
+        for (int q = 0; q < nt; ++q) tile_rows.push_back(6 * std::min(kCamsPerTile, (int)g.size() - q * kCamsPerTile));
+        T += nt;
     }
-    if (T == 0) T = 1;
+    if (T == 0) { T = 1; tile_rows.push_back(0); }
     const int n_pad = T * kNB;
     h.cam_off_host = cam_off;
     // ---- tile pattern + symbolic factorisation
@@ -442,12 +445,21 @@ int chol_setup(xrsfm_ba_context* c) {
         h.lv_trsm_off[lv + 1] = (int)lv_trsm.size() / 2;
     }
     h.n_levels = n_levels;
+    h.pairs_shm = 0;
+    for (int t = 0; t < k.n_tiles; ++t) {
+        const int L = k.tile_stride[t];
+        if (L <= 0) continue;
+        int nvalid = 0;
+        for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
+        const int T2 = nvalid / L, Rp = (6 * L + 15) & ~15, Cp = ((3 * T2 + 3) & ~3) + 2;
+        h.pairs_shm = std::max(h.pairs_shm, 2 * (size_t)Rp * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
+    }
     h.use_levels = (2 * n_levels <= T);
     std::vector<int> one_k(T);
     for (int t = 0; t < T; ++t) one_k[t] = t;
     h.n_blocks = n_blocks; h.n_pairs = n_pairs; h.T = T; h.n_tiles_nz = (int)tiles_nz.size() / 2;
     int e;
-    int *d_cam_off = nullptr, *d_one_k = nullptr;
+    int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     TRYC(dev_upload(c, &h.slot_pair_ptr, spp)); TRYC(dev_upload(c, &h.pair_dst, pair_dst));
     TRYC(dev_upload(c, &h.blk_ptr, blk_ptr)); TRYC(dev_upload(c, &h.blk_rc, blk_rc));
@@ -457,10 +469,10 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.lv_cj, lv_cj)); TRYC(dev_upload(c, &h.lv_trsm, lv_trsm));
     TRYC(dev_upload(c, &h.lv_rptr, lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, lv_rj));
     TRYC(dev_upload(c, &h.lv_bptr, lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, lv_bi));
-    TRYC(dev_upload(c, &d_cam_off, cam_off)); TRYC(dev_upload(c, &d_one_k, one_k));
+    TRYC(dev_upload(c, &d_cam_off, cam_off)); TRYC(dev_upload(c, &d_one_k, one_k)); TRYC(dev_upload(c, &d_tile_rows, tile_rows));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(n_writes > 0 ? n_writes : 1) * 36));
     TRYC(dev_alloc(c, &h.Sblk, (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
-    h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k;
+    h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
     TRYC(dev_alloc(c, &h.dev.S, (size_t)n_pad * n_pad));
     TRYC(dev_alloc(c, &h.dev.Linv, (size_t)T * kNB * kNB));
     TRYC(dev_alloc(c, &h.dev.y, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)n_pad));
@@ -471,6 +483,7 @@ int chol_setup(xrsfm_ba_context* c) {
     (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.pairs_shm);
     h.ready = true;
     return 0;
 }
@@ -479,7 +492,7 @@ int chol_setup(xrsfm_ba_context* c) {
 int chol_assemble(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
-    if (d.n_items > 0 && h.n_pairs > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
+    if (d.n_items > 0 && h.n_pairs > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(d.n_items), dim3(kWave), h.pairs_shm, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
     if (h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_block_segsum, dim3(h.n_blocks), dim3(kBlock), 0, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, h.Sblk, (size_t)h.n_blocks * 36, kNcclSum);
     if (e) return e;
@@ -503,21 +516,18 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
             if (nt > 0) LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
-            LAUNCH(c, K_POTRF, k_potrf, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv]);
+            LAUNCH(c, K_POTRF, k_potrf, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_rptr + h.lv_k_off[lv], h.lv_rj);
             const int ns = h.lv_trsm_off[lv + 1] - h.lv_trsm_off[lv];
             if (ns > 0) LAUNCH(c, K_TRSM, k_ll_trsm, dim3(ns), dim3(256), shm, h.dev, h.lv_trsm + 2 * (size_t)h.lv_trsm_off[lv]);
         }
-        for (int lv = 0; lv < h.n_levels; ++lv) {
-            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
-            LAUNCH(c, K_TRISOLVE, k_ll_fwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_rptr + h.lv_k_off[lv], h.lv_rj);
-        }
+        // (the forward substitution is folded into k_potrf)
         for (int lv = h.n_levels - 1; lv >= 0; --lv) {
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
             LAUNCH(c, K_TRISOLVE, k_ll_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi);
         }
     } else {
         for (int k = 0; k < T; ++k) {
-            LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, h.dev.one_k + k);
+            LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, h.dev.one_k + k, (const int*)nullptr, (const int*)nullptr);
             const int nr = h.rows_off[k + 1] - h.rows_off[k];
             if (nr > 0) LAUNCH(c, K_TRSM, k_trsm, dim3(nr), dim3(256), shm, h.dev, k, h.rows_flat + h.rows_off[k]);
             const int np = h.pairs_off[k + 1] - h.pairs_off[k];
