@@ -146,6 +146,19 @@ void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
  * the call that replaces ceres::Solve(options, &problem, &summary). */
 int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm_ba_summary *summary);
 
+/* Post-BA track filter on the same flat arrays (Point3dProcessor::FilterPoints3d,
+ * /root/reference/src/geometry/track_processor.cc:280-332, called after every KGBA at incremental_mapper.cc:83-85).
+ * The problem here is the whole map: every registered frame and every observation of every non-outlier track.
+ *   obs_delete[i]    1: observation i has reprojection error > max_reproj_error or depth outside [1e-3, 1e3]
+ *   track_outlier[j] 0 keep; 1: at most one observation would remain; 2: max pairwise triangulation angle of the kept
+ *                    observations < min_tri_angle_rad (for 1 every observation of the track goes, like SetTrackOutlier)
+ *   track_error[j]   mean reprojection error of the kept observations (-1 if outlier 1 / no observation)   (may be NULL)
+ *   track_angle[j]   Track::angle_ as UpdateTrackAngle leaves it (early exit above the threshold)          (may be NULL)
+ *   num_filtered[2]  the two counters the reference prints ("Outlier num1 / num2")                          (may be NULL) */
+int xrsfm_ba_filter_tracks(const xrsfm_ba_problem *problem, double max_reproj_error, double min_tri_angle_rad,
+                           uint8_t *obs_delete, uint8_t *track_outlier, double *track_error, double *track_angle,
+                           int32_t *num_filtered);
+
 /* profile != 0 in the last xrsfm_ba_run: per-kernel totals measured with HIP events on the
  * library's stream.  Returns 0 and fills the outputs for index < number of kernel classes,
  * XRSFM_BA_EINVAL past the end. */

@@ -514,3 +514,66 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
                                    rel=rel, model_change=model_change))
             if radius < opt.min_radius:
                 return finish("CONVERGENCE: min trust region radius", cost)
+
+
+# ----------------------------------------------------------------------------
+# post-BA track filter
+# ----------------------------------------------------------------------------
+def filter_tracks(problem: Problem, max_re: float, min_angle: float):
+    """Restates FilterPoints3d/FilterPoint3d/UpdateTrackAngle (/root/reference/src/geometry/track_processor.cc:253-332)
+    and colmap::CalculateTriangulationAngle (geometry/colmap/base/triangulation.cc:124-147).  Pure-Python loops."""
+    ci, pi = problem.obs_cam, problem.obs_pt
+    M = rotation_from_quat(problem.cam_q)
+    centre = -np.einsum("nji,nj->ni", M, problem.cam_t)
+    Pc = np.einsum("nij,nj->ni", M[ci], problem.points[pi]) + problem.cam_t[ci]
+    z = Pc[:, 2]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xn = Pc[:, 0] / z; yn = Pc[:, 1] / z
+    intr = problem.cam_intr[ci]; model = problem.intr_model[intr]; prm = problem.intr_params[intr]
+    fx, fy, cx, cy = _intrinsics_per_obs(model, prm)
+    r2 = xn * xn + yn * yn
+    du = np.zeros_like(xn); dv = np.zeros_like(xn)
+    m = (model == 0) | (model == 1); du[m] = xn[m]; dv[m] = yn[m]
+    for mid, ik in ((2, 3), (3, 4)):
+        m = model == mid; du[m] = xn[m] * (prm[m, ik] * r2[m]); dv[m] = yn[m] * (prm[m, ik] * r2[m])
+    m = model == 4
+    if m.any():
+        k1, k2, p1, p2 = prm[m, 4], prm[m, 5], prm[m, 6], prm[m, 7]
+        rad = k1 * r2[m] + k2 * r2[m] ** 2; xy = xn[m] * yn[m]
+        du[m] = xn[m] * rad + 2 * p1 * xy + p2 * (r2[m] + 2 * xn[m] ** 2)
+        dv[m] = yn[m] * rad + 2 * p2 * xy + p1 * (r2[m] + 2 * yn[m] ** 2)
+    re = np.hypot(fx * (xn + du) + cx - problem.obs_uv[:, 0], fy * (yn + dv) + cy - problem.obs_uv[:, 1])
+    delete = (re > max_re) | (z < 1e-3) | (z > 1e3)
+    n_p = problem.points.shape[0]
+    outlier = np.zeros(n_p, np.uint8); err = np.full(n_p, -1.0); ang = np.full(n_p, -1.0); cnt = [0, 0]
+    order = np.lexsort((ci, pi)); ptr = np.searchsorted(pi[order], np.arange(n_p + 1))
+    for j in range(n_p):
+        ids = order[ptr[j]:ptr[j + 1]]
+        n = len(ids)
+        if n == 0:
+            continue
+        nd = int(delete[ids].sum())
+        if nd >= n - 1:
+            outlier[j] = 1; cnt[0] += n; continue
+        cnt[0] += nd
+        keep = ids[~delete[ids]]
+        err[j] = re[keep].sum() / len(keep)
+        best = 0.0; done = False
+        P = problem.points[j]
+        for a in range(len(keep)):
+            if done:
+                break
+            for b in range(a + 1, len(keep)):
+                c1, c2 = centre[ci[keep[a]]], centre[ci[keep[b]]]
+                b2 = ((c1 - c2) ** 2).sum(); r1 = ((P - c1) ** 2).sum(); r2_ = ((P - c2) ** 2).sum()
+                den = 2.0 * math.sqrt(r1 * r2_)
+                t = 0.0 if den == 0.0 else abs(math.acos(max(-1.0, min(1.0, (r1 + r2_ - b2) / den))))
+                t = min(t, math.pi - t)
+                if t > best:
+                    best = t
+                    if best > min_angle:
+                        done = True; break
+        ang[j] = best
+        if best < min_angle:
+            outlier[j] = 2; cnt[1] += 1
+    return dict(obs_delete=delete.astype(np.uint8), track_outlier=outlier, track_error=err, track_angle=ang, num_filtered=np.array(cnt))

@@ -335,3 +335,24 @@ def test_rccl_plumbing_single_rank(lib, monkeypatch):
             assert sb.final_cost == sa.final_cost and np.array_equal(qa, qb) and np.array_equal(ta, tb) and np.array_equal(Pa, Pb)
         else:
             assert abs(sb.final_cost - sa.final_cost) <= 1e-9 * sa.final_cost
+
+
+@pytest.mark.parametrize("variant", ["kitti", "models"])
+def test_filter_tracks_matches_reference_rules(lib, variant):
+    """FilterPoints3d on the GPU against the oracle restatement (bit-exact masks and counters)."""
+    from xrsfm_amd import capi
+    arr = H.make(12, 900, 4, seed=150, outlier_frac=0.08, min_tri_angle_deg=0.2)
+    if variant == "models":
+        arr = H.with_models(arr, seed=8)
+    arr["points"][::50] += np.array([0.0, 0.0, -70.0])        # behind the cameras: depth test
+    arr["points"][7::60] *= 40.0                              # far away: small triangulation angle / depth > 1e3
+    max_re, min_angle = 4.0, math.radians(1.5)                # rec_1dsfm.cc:90-91
+    ref = bo.filter_tracks(H.to_oracle(arr), max_re, min_angle)
+    got = capi.filter_tracks(H.to_product(arr), max_re, min_angle)
+    assert np.array_equal(got["obs_delete"], ref["obs_delete"]) and got["obs_delete"].sum() > 20
+    assert np.array_equal(got["track_outlier"], ref["track_outlier"])
+    assert set(np.unique(ref["track_outlier"])) == {0, 1, 2}
+    assert np.array_equal(got["num_filtered"], ref["num_filtered"])
+    keep = ref["track_outlier"] != 1
+    assert np.abs(got["track_error"][keep] - ref["track_error"][keep]).max() < 1e-9
+    assert np.abs(got["track_angle"][keep] - ref["track_angle"][keep]).max() < 1e-12

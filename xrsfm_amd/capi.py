@@ -56,7 +56,7 @@ class CSummary(C.Structure):
 EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
-    "xrsfm_ba_solve", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
+    "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern",
 ]
 
@@ -90,6 +90,9 @@ def load(path: str | None = None):
     lib.xrsfm_ba_download.argtypes = [vp, _c_double_p, _c_double_p, _c_double_p]; lib.xrsfm_ba_download.restype = C.c_int
     lib.xrsfm_ba_destroy.argtypes = [vp]; lib.xrsfm_ba_destroy.restype = None
     lib.xrsfm_ba_solve.argtypes = [C.POINTER(COptions), C.POINTER(CProblem), C.POINTER(CSummary)]; lib.xrsfm_ba_solve.restype = C.c_int
+    lib.xrsfm_ba_filter_tracks.argtypes = [C.POINTER(CProblem), C.c_double, C.c_double, _c_uint8_p, _c_uint8_p, _c_double_p,
+                                            _c_double_p, _c_int32_p]
+    lib.xrsfm_ba_filter_tracks.restype = C.c_int
     lib.xrsfm_ba_debug_linearize.argtypes = [vp, C.c_double, C.c_int] + [_c_double_p] * 8
     lib.xrsfm_ba_debug_linearize.restype = C.c_int
     lib.xrsfm_ba_debug_schur_product.argtypes = [vp, C.c_double, _c_double_p, _c_double_p, _c_double_p]
@@ -266,3 +269,14 @@ def solve(problem: ProblemArrays, options: COptions | None = None) -> CSummary:
     cs = problem.c_struct()
     check(load().xrsfm_ba_solve(C.byref(options), C.byref(cs), C.byref(s)), "xrsfm_ba_solve")
     return s
+
+
+def filter_tracks(problem: ProblemArrays, max_reproj_error: float, min_tri_angle_rad: float) -> dict:
+    """xrsfm_ba_filter_tracks: masks and per-track statistics of the reference's FilterPoints3d."""
+    obs_del = np.zeros(problem.n_obs, np.uint8); out = np.zeros(problem.n_points, np.uint8)
+    err = np.zeros(problem.n_points); ang = np.zeros(problem.n_points); cnt = np.zeros(2, np.int32)
+    cs = problem.c_struct()
+    check(load().xrsfm_ba_filter_tracks(C.byref(cs), max_reproj_error, min_tri_angle_rad, obs_del.ctypes.data_as(_c_uint8_p),
+                                        out.ctypes.data_as(_c_uint8_p), _dp(err), _dp(ang), cnt.ctypes.data_as(_c_int32_p)),
+          "xrsfm_ba_filter_tracks")
+    return dict(obs_delete=obs_del, track_outlier=out, track_error=err, track_angle=ang, num_filtered=cnt)

@@ -20,6 +20,7 @@
 
 #include "../../include/xrsfm_ba.h"
 #include "ba_chol.h"
+#include "ba_filter.h"
 #include "ba_kernels.h"
 #include "ba_pack.h"
 
@@ -883,6 +884,89 @@ int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm
     e = xrsfm_ba_run(c, opt, summary);
     if (!e) e = xrsfm_ba_download(c, problem->cam_q, problem->cam_t, problem->points);
     xrsfm_ba_destroy(c);
+    return e;
+}
+
+// ---------------------------------------------------------------- post-BA track filter
+int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, double min_tri_angle_rad, uint8_t* obs_delete,
+                           uint8_t* track_outlier, double* track_error, double* track_angle, int32_t* num_filtered) {
+    if (!p || !obs_delete || !track_outlier) return XRSFM_BA_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[xrsfm_ba] no HIP device visible: the track filter has no CPU fallback\n");
+        return XRSFM_BA_ENODEV;
+    }
+    const int Nc = p->n_cams, Np = p->n_points, No = p->n_obs;
+    if (Nc < 0 || Np < 0 || No < 0) return XRSFM_BA_EINVAL;
+    for (int c2 = 0; c2 < Nc; ++c2) {
+        const int ii = p->cam_intr[c2];
+        if (ii < 0 || ii >= p->n_intr || p->intr_model[ii] < 0 || p->intr_model[ii] > 4) return XRSFM_BA_EINVAL;
+    }
+    // observations by track, inside a track by camera (= frame id order of Track::observations_)
+    std::vector<int> ptr(Np + 1, 0);
+    for (int i = 0; i < No; ++i) {
+        if (p->obs_cam[i] < 0 || p->obs_cam[i] >= Nc || p->obs_pt[i] < 0 || p->obs_pt[i] >= Np) return XRSFM_BA_EINVAL;
+        ptr[p->obs_pt[i] + 1]++;
+    }
+    for (int j = 0; j < Np; ++j) ptr[j + 1] += ptr[j];
+    std::vector<int> fill(ptr.begin(), ptr.end() - 1), order(No);
+    for (int i = 0; i < No; ++i) order[fill[p->obs_pt[i]]++] = i;
+    for (int j = 0; j < Np; ++j)
+        std::stable_sort(order.begin() + ptr[j], order.begin() + ptr[j + 1], [&](int a, int b) { return p->obs_cam[a] < p->obs_cam[b]; });
+    std::vector<int> ocam(No), model(Nc);
+    std::vector<double> ouv(2 * (size_t)No);
+    for (int k2 = 0; k2 < No; ++k2) { ocam[k2] = p->obs_cam[order[k2]]; ouv[2 * (size_t)k2] = p->obs_uv[2 * (size_t)order[k2]]; ouv[2 * (size_t)k2 + 1] = p->obs_uv[2 * (size_t)order[k2] + 1]; }
+    std::vector<CamRec> cams(Nc);
+    for (int i = 0; i < Nc; ++i) {
+        for (int k2 = 0; k2 < 4; ++k2) cams[i].q[k2] = p->cam_q[4 * (size_t)i + k2];
+        for (int k2 = 0; k2 < 3; ++k2) cams[i].t[k2] = p->cam_t[3 * (size_t)i + k2];
+        cams[i].pad = 0.0;
+        for (int k2 = 0; k2 < 8; ++k2) cams[i].intr[k2] = p->intr_params[8 * (size_t)p->cam_intr[i] + k2];
+        model[i] = p->intr_model[p->cam_intr[i]];
+    }
+    HIPCHK(hipSetDevice(0));
+    std::vector<void*> bufs;
+    auto up = [&](const void* h, size_t bytes, void** dptr) -> int {
+        if (hipMalloc(dptr, bytes ? bytes : 8) != hipSuccess) return XRSFM_BA_ENOMEM;
+        bufs.push_back(*dptr);
+        if (h && bytes && hipMemcpy(*dptr, h, bytes, hipMemcpyHostToDevice) != hipSuccess) return XRSFM_BA_ENODEV;
+        return 0;
+    };
+    int e = 0;
+    void *d_cam, *d_model, *d_centre, *d_P, *d_ptr, *d_ocam, *d_ouv, *d_del, *d_out, *d_err, *d_ang, *d_cnt;
+    if (!e) e = up(cams.data(), sizeof(CamRec) * (size_t)Nc, &d_cam);
+    if (!e) e = up(model.data(), sizeof(int) * (size_t)Nc, &d_model);
+    if (!e) e = up(nullptr, sizeof(double) * 3 * (size_t)Nc, &d_centre);
+    if (!e) e = up(p->points, sizeof(double) * 3 * (size_t)Np, &d_P);
+    if (!e) e = up(ptr.data(), sizeof(int) * ((size_t)Np + 1), &d_ptr);
+    if (!e) e = up(ocam.data(), sizeof(int) * (size_t)No, &d_ocam);
+    if (!e) e = up(ouv.data(), sizeof(double) * 2 * (size_t)No, &d_ouv);
+    if (!e) e = up(nullptr, (size_t)No, &d_del);
+    if (!e) e = up(nullptr, (size_t)Np, &d_out);
+    if (!e) e = up(nullptr, sizeof(double) * (size_t)Np, &d_err);
+    if (!e) e = up(nullptr, sizeof(double) * (size_t)Np, &d_ang);
+    if (!e) e = up(nullptr, sizeof(int) * 2, &d_cnt);
+    if (!e && hipMemset(d_cnt, 0, sizeof(int) * 2) != hipSuccess) e = XRSFM_BA_ENODEV;
+    if (!e) {
+        if (Nc > 0) hipLaunchKernelGGL(k_cam_centres, dim3(cdiv(Nc, 256)), dim3(256), 0, 0, (const CamRec*)d_cam, Nc, (double*)d_centre);
+        if (Np > 0) hipLaunchKernelGGL(k_filter_tracks, dim3(cdiv(Np, 128)), dim3(128), 0, 0, (const CamRec*)d_cam, (const int*)d_model, (const double*)d_centre,
+                                       (const double*)d_P, (const int*)d_ptr, (const int*)d_ocam, (const double*)d_ouv, Np, max_reproj_error, min_tri_angle_rad,
+                                       (unsigned char*)d_del, (unsigned char*)d_out, (double*)d_err, (double*)d_ang, (int*)d_cnt);
+        std::vector<unsigned char> del(No);
+        std::vector<double> err(Np), ang(Np);
+        int cnt[2] = {0, 0};
+        if (hipDeviceSynchronize() != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e && No && hipMemcpy(del.data(), d_del, (size_t)No, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e && Np && hipMemcpy(track_outlier, d_out, (size_t)Np, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e && Np && track_error && hipMemcpy(track_error, d_err, sizeof(double) * (size_t)Np, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e && Np && track_angle && hipMemcpy(track_angle, d_ang, sizeof(double) * (size_t)Np, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e && hipMemcpy(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e) {
+            for (int k2 = 0; k2 < No; ++k2) obs_delete[order[k2]] = del[k2];
+            if (num_filtered) { num_filtered[0] = cnt[0]; num_filtered[1] = cnt[1]; }
+        }
+    }
+    for (void* b : bufs) (void)hipFree(b);
     return e;
 }
 
