@@ -1,0 +1,78 @@
+"""COLMAP-binary model I/O + BA-only replay (tools/ba_replay.cc over xrsfm_amd/csrc/io/colmap_model.h)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tools", "ba_replay")
+
+
+@pytest.fixture(scope="module")
+def exe(lib):
+    src = os.path.join(ROOT, "tools", "ba_replay.cc")
+    hdr = os.path.join(ROOT, "xrsfm_amd", "csrc", "io", "colmap_model.h")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-std=c++17", "-O2", "-o", EXE, src, "-L" + os.path.join(ROOT, "xrsfm_amd", "lib"), "-lxrsfm_ba",
+                        "-Wl,-rpath," + os.path.join(ROOT, "xrsfm_amd", "lib"), "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    return EXE
+
+
+def test_model_roundtrip_python(tmp_path):
+    from xrsfm_amd import colmap_io
+    arr = H.with_models(H.make(7, 90, 3, seed=160), seed=1)
+    colmap_io.write_model(str(tmp_path), arr)
+    m = colmap_io.read_model(str(tmp_path))
+    assert len(m["cameras"]) == 7 and len(m["images"]) == 7 and len(m["points"]) == 90
+    for c in range(7):
+        q = m["images"][c]["q_wxyz"]
+        assert np.array_equal(q, arr["cam_q"][c][[3, 0, 1, 2]]) and np.array_equal(m["images"][c]["t"], arr["cam_t"][c])
+        assert m["images"][c]["points"]["track"][-1] == colmap_io.NO_TRACK
+        mid, prm = m["cameras"][int(arr["cam_intr"][c])]
+        assert mid == arr["intr_model"][arr["cam_intr"][c]] and np.array_equal(prm, arr["intr_params"][arr["cam_intr"][c]][:len(prm)])
+    n_obs = sum(len(p["obs"]) for p in m["points"].values())
+    assert n_obs == arr["obs_cam"].shape[0]
+    # every observation of a track points back at a 2D feature carrying that track id
+    for pid, p in m["points"].items():
+        for frame, p2d in p["obs"]:
+            assert m["images"][frame]["points"]["track"][p2d] == pid
+
+
+def test_replay_without_gpu_fails_loudly(exe, tmp_path):
+    import torch
+    from xrsfm_amd import capi, colmap_io
+    if torch.cuda.is_available() and capi.device_count() > 0:
+        pytest.skip("a GPU is present")
+    colmap_io.write_model(str(tmp_path / "in"), H.make(6, 40, 3, seed=161))
+    os.makedirs(tmp_path / "out")
+    p = subprocess.run([exe, str(tmp_path / "in"), str(tmp_path / "out")], capture_output=True, text=True)
+    assert p.returncode == 1 and "xrsfm_ba_solve failed: -2" in p.stderr
+
+
+@pytest.mark.gpu
+def test_replay_equals_direct_solve(exe, tmp_path):
+    """C++ reader -> GBA through the C-ABI -> C++ writer equals capi.solve on the same flat problem; the filter pass
+    drops what xrsfm_ba_filter_tracks marks."""
+    from xrsfm_amd import capi, colmap_io
+    arr = H.with_models(H.make(9, 300, 4, seed=162, outlier_frac=0.05), seed=3)
+    colmap_io.write_model(str(tmp_path / "in"), arr)
+    os.makedirs(tmp_path / "out")
+    p = subprocess.run([exe, str(tmp_path / "in"), str(tmp_path / "out"), "--filter", "4.0", "1.5"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    m = colmap_io.read_model(str(tmp_path / "out"))
+    prod = H.to_product(arr)
+    capi.solve(prod)
+    for c in range(9):
+        assert np.abs(m["images"][c]["q_wxyz"] - prod.cam_q[c][[3, 0, 1, 2]]).max() < 1e-12
+        assert np.abs(m["images"][c]["t"] - prod.cam_t[c]).max() < 1e-12
+    flt = capi.filter_tracks(prod, 4.0, np.deg2rad(1.5))
+    kept = np.nonzero(flt["track_outlier"] == 0)[0]
+    assert sorted(m["points"].keys()) == kept.tolist()
+    for j in kept[:50]:
+        assert np.abs(m["points"][j]["xyz"] - prod.points[j]).max() < 1e-12
+        n_keep = int(((prod.obs_pt == j) & (flt["obs_delete"] == 0)).sum())
+        assert len(m["points"][j]["obs"]) == n_keep
+    assert f"Outlier num1: {flt['num_filtered'][0]} Outlier num2: {flt['num_filtered'][1]}" in p.stdout
