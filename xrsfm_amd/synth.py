@@ -196,4 +196,6 @@ CONFIGS = {
     # BASELINE.json configs 2 and 4
     "S": dict(n_cams=100, n_points=50_000, k_obs=4, seed=2),
     "L": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4),
+    # shape of BASELINE.json config 3 (KITTI-00 key-frame global BA, SURVEY 8 estimate): sequential visibility
+    "K": dict(n_cams=2000, n_points=1_000_000, k_obs=4, seed=3),
 }
