@@ -355,22 +355,35 @@ int chol_setup(xrsfm_ba_context* c) {
     std::vector<std::vector<int>> groups;   // each group starts on a tile boundary
     h.ordering = 0;
     if (w >= 1 && 16 * w <= Nc) {
+        // Multi-way nested dissection of the path/ring: a tree node cuts its range with g separators of w cameras each
+        // that share ONE tile (g*w <= 10 cameras), so the elimination tree has depth log_{g+1} instead of log_2.
         h.ordering = 1;
         const int leaf = 2 * kCamsPerTile;
-        struct Rec { static void run(int lo, int hi, int w_, int leaf_, std::vector<std::vector<int>>& g) {
-            if (hi <= lo) return;
-            if (hi - lo <= leaf_ + w_) { std::vector<int> v; for (int c2 = lo; c2 < hi; ++c2) v.push_back(c2); g.push_back(v); return; }
-            const int mid = lo + (hi - lo - w_) / 2;
-            run(lo, mid, w_, leaf_, g); run(mid + w_, hi, w_, leaf_, g);
-            std::vector<int> v; for (int c2 = mid; c2 < mid + w_; ++c2) v.push_back(c2); g.push_back(v);
+        struct Rec { static void run(int lo, int hi, int w_, int leaf_, int cap, const std::vector<int>& extra, std::vector<std::vector<int>>& g) {
+            if (hi <= lo) { if (!extra.empty()) g.push_back(extra); return; }
+            int nsep = std::max(1, (cap - (int)extra.size()) / w_);
+            while (nsep > 1 && (hi - lo - nsep * w_) < (nsep + 1) * leaf_ / 2) --nsep;
+            if (hi - lo <= leaf_ + w_) {
+                std::vector<int> v; for (int c2 = lo; c2 < hi; ++c2) v.push_back(c2);
+                g.push_back(v);
+                if (!extra.empty()) g.push_back(extra);
+                return;
+            }
+            const int total = hi - lo - nsep * w_, part = total / (nsep + 1), rem = total % (nsep + 1);
+            std::vector<int> seps;
+            int cur = lo;
+            for (int s2 = 0; s2 <= nsep; ++s2) {
+                const int len = part + (s2 < rem ? 1 : 0);
+                run(cur, cur + len, w_, leaf_, cap, std::vector<int>(), g);
+                cur += len;
+                if (s2 < nsep) { for (int c2 = cur; c2 < cur + w_; ++c2) seps.push_back(c2); cur += w_; }
+            }
+            seps.insert(seps.end(), extra.begin(), extra.end());
+            g.push_back(seps);
         } };
-        if (wrap) {
-            Rec::run(w, Nc, w, leaf, groups);
-            std::vector<int> root; for (int c2 = 0; c2 < w; ++c2) root.push_back(c2);
-            groups.push_back(root);
-        } else {
-            Rec::run(0, Nc, w, leaf, groups);
-        }
+        std::vector<int> root;
+        if (wrap) for (int c2 = 0; c2 < w; ++c2) root.push_back(c2);     // closes the ring: eliminated last, with the top separators
+        Rec::run(wrap ? w : 0, Nc, w, leaf, kCamsPerTile, root, groups);
     } else {
         std::vector<int> all; for (int c2 = 0; c2 < Nc; ++c2) all.push_back(c2);
         groups.push_back(all);
