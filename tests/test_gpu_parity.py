@@ -356,3 +356,29 @@ def test_filter_tracks_matches_reference_rules(lib, variant):
     keep = ref["track_outlier"] != 1
     assert np.abs(got["track_error"][keep] - ref["track_error"][keep]).max() < 1e-9
     assert np.abs(got["track_angle"][keep] - ref["track_angle"][keep]).max() < 1e-12
+
+
+def test_headline_config_properties(lib):
+    """BASELINE.json config 4 (1k cams / 500k points / 2M obs), the bench workload: termination, cost decrease, the
+    reported cost is the cost of the returned state, bit-reproducibility, and RMSE parity with the C restatement."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi, synth
+    d = synth.make_problem(**synth.CONFIGS["L"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    ctx = capi.Context(H.to_product(arr))
+    s = ctx.run(capi.default_options())
+    q, t, P = ctx.download()
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert s.termination == 0 and s.final_cost < 0.05 * s.initial_cost and s.linear_solver_used == 1
+    ctx.reset()
+    s2 = ctx.run(capi.default_options())
+    q2, t2, P2 = ctx.download()
+    assert s2.final_cost == s.final_cost and np.array_equal(q, q2) and np.array_equal(P, P2)
+    ref = H.to_oracle(dict(arr, cam_q=q, cam_t=t, points=P))
+    assert abs(bo.evaluate(ref, ref.cam_q, ref.cam_t, ref.points, want_jac=False) - s.final_cost) <= 1e-9 * s.final_cost
+    if ba_cpu.available():
+        prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+        sc = ba_cpu.solve(prob, threads=8)
+        assert (sc["n_successful"], sc["n_unsuccessful"]) == (s.n_successful, s.n_unsuccessful)
+        assert abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s.final_cost / n_res)) < 1e-6
+    ctx.close()
