@@ -192,14 +192,17 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camlin, (const PcgStatus*)nullptr);
     {
+        // the two scalar partial sums land behind the camera block so that ONE all-reduce covers both
+        double* tail = d.camlin + (size_t)d.n_cams * 12;
         ReduceJobs j{};
-        j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = d.scal + S_COST; j.op[0] = 0;
-        j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = d.scal + S_XNORM2_PTS; j.op[1] = 0;
+        j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = tail; j.op[0] = 0;
+        j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = tail + 1; j.op[1] = 0;
         LAUNCH(c, K_SMALL, k_reduce_multi, dim3(2), dim3(kPcgThreads), 0, j);
+        int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2, kNcclSum);
+        if (e) return e;
+        HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST, S_XNORM2_PTS adjacent
     }
-    int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12, kNcclSum);
-    if (e) return e;
-    return allreduce(c, d.scal + S_COST, 2, kNcclSum);   // S_COST, S_XNORM2_PTS adjacent
+    return 0;
 }
 
 int gradient_max(xrsfm_ba_context* c, double* out) {
@@ -222,13 +225,14 @@ int gradient_max(xrsfm_ba_context* c, double* out) {
 }
 
 // Everything that depends on the radius: D^2, Hpp^-1, diagonal blocks of S and the reduced right-hand side.
-int prepare_step(xrsfm_ba_context* c, double radius) {
+int prepare_step(xrsfm_ba_context* c, double radius, bool with_blocks = false) {
     Dev& d = c->d;
     const double dmin = 1e-6, dmax = 1e32;
     if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_point_prep, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_prep, dim3(cdiv((long long)d.n_cams * 6, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
     if (d.n_slots > 0) LAUNCH(c, K_SCHUR_PREP, k_schur_prep, dim3(cdiv(d.n_slots, kBlock)), dim3(kBlock), 0, d);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, (const PcgStatus*)nullptr);
+    if (with_blocks) return 0;      // Cholesky path: all-reduced together with the off-diagonal blocks in chol_assemble
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28, kNcclSum);
     if (e) return e;
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_factor, dim3(cdiv(d.n_cams, 64)), dim3(64), 0, d);
@@ -485,7 +489,11 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.lv_bptr, lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, lv_bi));
     TRYC(dev_upload(c, &d_cam_off, cam_off)); TRYC(dev_upload(c, &d_one_k, one_k)); TRYC(dev_upload(c, &d_tile_rows, tile_rows));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(n_writes > 0 ? n_writes : 1) * 36));
-    TRYC(dev_alloc(c, &h.Sblk, (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
+    {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
+        double* both = nullptr;
+        TRYC(dev_alloc(c, &both, (size_t)Nc * 28 + (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
+        c->d.camS = both; h.Sblk = both + (size_t)Nc * 28;
+    }
     h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
     TRYC(dev_alloc(c, &h.dev.S, (size_t)n_pad * n_pad));
     TRYC(dev_alloc(c, &h.dev.Linv, (size_t)T * kNB * kNB));
@@ -508,8 +516,9 @@ int chol_assemble(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     if (d.n_items > 0 && h.n_pairs > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(d.n_items), dim3(kWave), h.pairs_shm, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
     if (h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_block_segsum, dim3(h.n_blocks), dim3(kBlock), 0, h.scat2, h.blk_ptr, h.Sblk);
-    int e = allreduce(c, h.Sblk, (size_t)h.n_blocks * 36, kNcclSum);
+    int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_factor, dim3(cdiv(d.n_cams, 64)), dim3(64), 0, d);
     if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_zero_tiles, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, h.tiles_nz, h.n_tiles_nz);
     if (h.n_blocks > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_off, dim3(cdiv((long long)h.n_blocks * 36, 256)), dim3(256), 0, h.dev, h.Sblk, h.blk_rc, h.n_blocks);
     if (d.n_cams > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_diag, dim3(cdiv(d.n_cams, 256)), dim3(256), 0, h.dev, d);
@@ -704,7 +713,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.scale_c, nc * 6)); TRY(dev_alloc(c, &d.scale_p, np * 3));
     TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Fs, ns * 12)); TRY(dev_alloc(c, &d.Es, ns * 6));
     TRY(dev_alloc(c, &d.Hpp, np * 6)); TRY(dev_alloc(c, &d.gp, np * 3)); TRY(dev_alloc(c, &d.Hinv, np * 6));
-    TRY(dev_alloc(c, &d.camlin, nc * 12)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
+    TRY(dev_alloc(c, &d.camlin, nc * 12 + 2)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
     TRY(dev_alloc(c, &d.Minv, nc * 21)); TRY(dev_alloc(c, &d.b, nc * 6));
     TRY(dev_alloc(c, &d.px, nc * 6 + kNB)); TRY(dev_alloc(c, &d.pr, nc * 6)); TRY(dev_alloc(c, &d.pz, nc * 6));
     TRY(dev_alloc(c, &d.pp, nc * 6)); TRY(dev_alloc(c, &d.pq, nc * 6));
@@ -833,7 +842,7 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
         if (it >= opt.max_iterations) return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
         ++it;
         sum->lm_steps_attempted++;
-        if ((e = prepare_step(c, radius))) return e;
+        if ((e = prepare_step(c, radius, solver == XRSFM_BA_SOLVER_CHOLESKY))) return e;
         if (solver == XRSFM_BA_SOLVER_PCG) {
             if ((e = pcg_solve(c, opt, sum))) return e;
         } else {
@@ -1075,7 +1084,7 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
     Dev& d = c->d;
     int e;
     if ((e = chol_setup(c))) return e;
-    if ((e = prepare_step(c, radius))) return e;
+    if ((e = prepare_step(c, radius, true))) return e;
     if ((e = chol_assemble(c))) return e;
     const CholDev& cd = c->chol.dev;
     if (S_dense) {
