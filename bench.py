@@ -142,11 +142,12 @@ def main():
     local = shard_problem(arr, rank, world)
     prob = capi.ProblemArrays(**{k: np.array(v, copy=True) for k, v in local.items()})
     ctx = capi.Context(prob, device=local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("XRSFM_BA_FORCE_COMM") == "1":     # the env var exercises the RCCL path on one GPU
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = torch.tensor(list(capi.comm_unique_id()), dtype=torch.uint8, device="cuda")
-        dist.broadcast(uid, 0)
+        if world > 1:
+            dist.broadcast(uid, 0)
         ctx.comm_init(world, rank, bytes(uid.cpu().tolist()))
 
     opt = capi.default_options(verbose=1 if (args.verbose and rank == 0) else 0)

@@ -74,7 +74,7 @@ def load(path: str | None = None):
     global _lib
     if _lib is not None:
         return _lib
-    path = path or _build.LIB
+    path = path or os.environ.get("XRSFM_BA_LIB") or _build.LIB      # XRSFM_BA_LIB: developer override (ablation builds)
     if not os.path.exists(path):
         raise RuntimeError(f"{path} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
                            "the BA path has no fallback implementation")
