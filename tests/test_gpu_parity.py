@@ -382,3 +382,24 @@ def test_headline_config_properties(lib):
         assert (sc["n_successful"], sc["n_unsuccessful"]) == (s.n_successful, s.n_unsuccessful)
         assert abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s.final_cost / n_res)) < 1e-6
     ctx.close()
+
+
+def test_pose_only_refinement(lib):
+    """the pose refinement of RegisterImage (/root/reference/src/geometry/pnp.cc:38-71) is the same
+    engine with one camera, every point constant and Ceres' default options (10 iterations, ftol 1e-6, ptol 1e-8)."""
+    from xrsfm_amd import capi
+    full = H.make(8, 400, 4, seed=170)
+    keep = full["obs_cam"] == 5
+    pts, inv = np.unique(full["obs_pt"][keep], return_inverse=True)
+    rng = np.random.default_rng(3)
+    arr = dict(cam_q=bo.quat_plus(full["cam_q"][5:6], rng.normal(0, 0.02, (1, 3))), cam_t=full["cam_t"][5:6] + rng.normal(0, 0.1, (1, 3)),
+               cam_const=np.zeros(1, np.uint8), cam_intr=np.zeros(1, np.int32), intr_model=full["intr_model"], intr_params=full["intr_params"],
+               points=full["points"][pts], point_const=np.ones(len(pts), np.uint8),
+               obs_cam=np.zeros(int(keep.sum()), np.int32), obs_pt=inv.astype(np.int32), obs_uv=full["obs_uv"][keep])
+    kw = dict(max_iterations=10, function_tolerance=1e-6, parameter_tolerance=1e-8)
+    pr, s_ref, prod, s = _solve_both(arr, kw)
+    assert s.num_effective_params == 6 and s_ref.num_effective_params == 6
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-9 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-8
+    assert np.array_equal(prod.points, arr["points"])           # constant points are returned untouched
