@@ -403,3 +403,25 @@ def test_pose_only_refinement(lib):
     assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost
     assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-9 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-8
     assert np.array_equal(prod.points, arr["points"])           # constant points are returned untouched
+
+
+@pytest.mark.parametrize("solver", [0, 1])
+def test_ragged_tracks(lib, solver):
+    """Ragged input: track lengths 1..6 after dropping random observations (single-observation points enter with a rank-2
+    point block that only the LM damping regularises), mixed regular/irregular tiles, shuffled order."""
+    arr = H.make(14, 700, 6, seed=180, mode="unordered", min_tri_angle_deg=0.5)
+    rng = np.random.default_rng(9)
+    n = arr["obs_cam"].shape[0]
+    keep = rng.random(n) < 0.55
+    first = np.zeros(n, bool); first[np.unique(arr["obs_pt"], return_index=True)[1]] = True     # >= 1 observation per point
+    keep |= first
+    perm = rng.permutation(int(keep.sum()))
+    for k in ("obs_cam", "obs_pt", "obs_uv"):
+        arr[k] = np.ascontiguousarray(arr[k][keep][perm])
+    lens = np.bincount(arr["obs_pt"], minlength=700)
+    assert lens.min() == 1 and lens.max() == 6 and (lens == 1).sum() > 5
+    pr, s_ref, prod, s = _solve_both(arr, dict(linear_solver=solver, max_iterations=15))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert max(np.abs(prod.cam_q - pr.cam_q).max(), np.abs(prod.cam_t - pr.cam_t).max()) < 1e-5

@@ -179,6 +179,7 @@ void profile_collect(xrsfm_ba_context* c, int tag_limit = 1 << 30) {
 }
 
 int fetch_scalars(xrsfm_ba_context* c) {
+    HIPCHK(hipGetLastError());          // a failed launch since the last sync point
     HIPCHK(hipMemcpyAsync(c->h_scal, c->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->profiling) profile_collect(c);
