@@ -61,10 +61,7 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
         int npair = 0, pbase = 0;
         if (s.valid) {
             double F[12], E[6];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + s.slot];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + s.slot];
+            load_FE(d, s.slot, s.cam, s.pt, F, E);
             const double* h = d.Hinv + 6 * (size_t)s.pt;
             const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5];
 #pragma unroll
@@ -155,10 +152,11 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
         if (d.slot_cam[sa] < 0) continue;
         const int pt = d.slot_pt[sa];
         const double* h = d.Hinv + 6 * (size_t)pt;
-        double WH[18];
+        double Fa[12], Ea[6], WH[18];
+        load_FE(d, sa, d.slot_cam[sa], pt, Fa, Ea);
         for (int a = 0; a < 6; ++a) {
             double w[3];
-            for (int b = 0; b < 3; ++b) w[b] = d.Fs[a * ns + sa] * d.Es[b * ns + sa] + d.Fs[(6 + a) * ns + sa] * d.Es[(3 + b) * ns + sa];
+            for (int b = 0; b < 3; ++b) w[b] = Fa[a] * Ea[b] + Fa[6 + a] * Ea[3 + b];
             WH[3 * a + 0] = w[0] * h[0] + w[1] * h[1] + w[2] * h[2];
             WH[3 * a + 1] = w[0] * h[1] + w[1] * h[3] + w[2] * h[4];
             WH[3 * a + 2] = w[0] * h[2] + w[1] * h[4] + w[2] * h[5];
@@ -167,10 +165,12 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
         const int npair = slot_pair_ptr[sa + 1] - pbase;
         for (int dd = 1; dd <= npair; ++dd) {
             const int sb = sa + dd;
+            double Fb[12], Eb[6];
+            load_FE(d, sb, d.slot_cam[sb], pt, Fb, Eb);
             double* out = scat2 + 36 * (size_t)pair_dst[pbase + dd - 1];
             for (int rb = 0; rb < 6; ++rb) {
                 double wb[3];
-                for (int m = 0; m < 3; ++m) wb[m] = d.Fs[rb * ns + sb] * d.Es[m * ns + sb] + d.Fs[(6 + rb) * ns + sb] * d.Es[(3 + m) * ns + sb];
+                for (int m = 0; m < 3; ++m) wb[m] = Fb[rb] * Eb[m] + Fb[6 + rb] * Eb[3 + m];
                 for (int ca = 0; ca < 6; ++ca) out[6 * rb + ca] = wb[0] * WH[3 * ca] + wb[1] * WH[3 * ca + 1] + wb[2] * WH[3 * ca + 2];
             }
         }

@@ -35,6 +35,15 @@ enum Scal {
     S_GRADMAX_PTS, S_GRADMAX_CAMS, S_COUNT = 16
 };
 
+// Per-camera data the consumers need to rebuild the Jacobian blocks of an observation (128 bytes, one line).
+struct __attribute__((aligned(16))) CamLin {
+    double M[9];     // M(q) at the linearisation point
+    double sq[3];    // Jacobi scale of the rotation columns, 0 if q is constant
+    double st[3];    // ... of the translation columns, 0 if t is constant
+    double pad;
+};
+static_assert(sizeof(CamLin) == 128, "CamLin must be 128 bytes");
+
 struct Dev {
     int n_cams, n_pts, n_tiles, n_slots, n_items;
     // per slot
@@ -50,7 +59,9 @@ struct Dev {
     // Jacobi scaling
     double* scale_c; double* scale_p;
     // linearisation (SoA over slots: component-major)
-    double* rt; double* Fs; double* Es;
+    double* rt; double* Jp;   // rt[2][n]: robustified residual; Jp[6][n]: sqrt(rho') * d r / d Pc (2x3) — the camera (2x6)
+                              // and point (2x3) blocks are rebuilt from it by load_FE() ("compressed J": 64 instead of 160 B/obs)
+    CamLin* camrec;           // [Nc] per-camera linearisation record (rotation matrix, scale*mask of the 6 columns)
     double* Hpp; double* gp; double* Hinv;
     double* camlin;     // [Nc][12]: diag(Hcc) (6), gc (6)
     double* Dc2;        // [Nc][6]
@@ -128,6 +139,55 @@ __device__ __forceinline__ SlotCtx load_slot(const Dev& d, int tile, int lane) {
     return s;
 }
 
+
+// Rebuild the Jacobi-scaled, robustified blocks of one observation:
+//   F (2x6) = [ -2 (j x M P) * sq | j * st ],   E (2x3) = (j M) * sp        (j = rows of Jp)
+__device__ __forceinline__ void load_FE(const Dev& d, int slot, int cam, int pt, double (&F)[12], double (&E)[6]) {
+    const size_t ns = (size_t)d.n_slots;
+    double j[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) j[k] = d.Jp[k * ns + slot];
+    const CamLin& c = d.camrec[cam];
+    double M[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) M[k] = c.M[k];
+    const double* P = d.P + 3 * (size_t)pt;
+    const double P0 = P[0], P1 = P[1], P2 = P[2];
+    const double rp0 = M[0] * P0 + M[1] * P1 + M[2] * P2;
+    const double rp1 = M[3] * P0 + M[4] * P1 + M[5] * P2;
+    const double rp2 = M[6] * P0 + M[7] * P1 + M[8] * P2;
+    const double* spp = d.scale_p + 3 * (size_t)pt;
+    const double mp = d.pt_const[pt] ? 0.0 : 1.0;
+    const double sp0 = spp[0] * mp, sp1 = spp[1] * mp, sp2 = spp[2] * mp;
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        const double a = j[3 * row], b = j[3 * row + 1], cc = j[3 * row + 2];
+        F[6 * row + 0] = -2.0 * (b * rp2 - cc * rp1) * c.sq[0];
+        F[6 * row + 1] = -2.0 * (cc * rp0 - a * rp2) * c.sq[1];
+        F[6 * row + 2] = -2.0 * (a * rp1 - b * rp0) * c.sq[2];
+        F[6 * row + 3] = a * c.st[0];
+        F[6 * row + 4] = b * c.st[1];
+        F[6 * row + 5] = cc * c.st[2];
+        E[3 * row + 0] = (a * M[0] + b * M[3] + cc * M[6]) * sp0;
+        E[3 * row + 1] = (a * M[1] + b * M[4] + cc * M[7]) * sp1;
+        E[3 * row + 2] = (a * M[2] + b * M[5] + cc * M[8]) * sp2;
+    }
+}
+
+// Per-camera linearisation record (run before every linearisation: cameras, scales and masks as they are now).
+__global__ void k_cam_lin(Dev d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n_cams) return;
+    CamLin r;
+    const double q[4] = {d.cam[c].q[0], d.cam[c].q[1], d.cam[c].q[2], d.cam[c].q[3]};
+    quat_to_mat(q, r.M);
+    const unsigned cc = d.cam_const[c];
+    const double* sc = d.scale_c + 6 * (size_t)c;
+    for (int k = 0; k < 3; ++k) { r.sq[k] = (cc & 1u) ? 0.0 : sc[k]; r.st[k] = (cc & 2u) ? 0.0 : sc[3 + k]; }
+    r.pad = 0.0;
+    d.camrec[c] = r;
+}
+
 // ---------------------------------------------------------------- linearise
 // Residuals, robustified + Jacobi-scaled Jacobian blocks, per-track H_pp / g_p
 // (segmented wave reduction), per-observation camera-side terms into the
@@ -183,9 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Dev d, double huber_a) {
             const size_t ns = (size_t)d.n_slots;
             d.rt[s.slot] = r0; d.rt[ns + s.slot] = r1;
 #pragma unroll
-            for (int k = 0; k < 12; ++k) d.Fs[k * ns + s.slot] = F[k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) d.Es[k * ns + s.slot] = E[k];
+            for (int k = 0; k < 6; ++k) d.Jp[k * ns + s.slot] = pr.jp[k] * sw;
             v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[0] * E[1] + E[3] * E[4]; v[2] = E[0] * E[2] + E[3] * E[5];
             v[3] = E[1] * E[1] + E[4] * E[4]; v[4] = E[1] * E[2] + E[4] * E[5]; v[5] = E[2] * E[2] + E[5] * E[5];
             v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
@@ -292,6 +350,17 @@ __global__ __launch_bounds__(kBlock) void k_cam_segsum(const double* __restrict_
     }
 }
 
+// Diagnostics only: materialise the 2x6 / 2x3 blocks (SoA over slots) the consumers rebuild on the fly.
+__global__ void k_debug_materialize(Dev d, double* __restrict__ Fs, double* __restrict__ Es) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= d.n_slots || d.slot_cam[slot] < 0) return;
+    double F[12], E[6];
+    load_FE(d, slot, d.slot_cam[slot], d.slot_pt[slot], F, E);
+    const size_t ns = (size_t)d.n_slots;
+    for (int k = 0; k < 12; ++k) Fs[k * ns + slot] = F[k];
+    for (int k = 0; k < 6; ++k) Es[k * ns + slot] = E[k];
+}
+
 // Jacobi scaling from the column norms of the unscaled Jacobian: 1/(1+|col|).
 __global__ void k_scale_from_norms(Dev d) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,10 +417,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_prep(Dev d) {
         const int pt = d.slot_pt[slot];
         const size_t ns = (size_t)d.n_slots;
         double F[12], E[6];
-#pragma unroll
-        for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + slot];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + slot];
+        load_FE(d, slot, cam, d.slot_pt[slot], F, E);
         const double* Hi = d.Hinv + 6 * (size_t)pt;
         const double h[6] = {Hi[0], Hi[1], Hi[2], Hi[3], Hi[4], Hi[5]};
         const double* g = d.gp + 3 * (size_t)pt;
@@ -500,10 +566,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
         double F[12], E[6], v0 = 0.0, v1 = 0.0;
         double w[3] = {0, 0, 0};
         if (s.valid) {
-#pragma unroll
-            for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + s.slot];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + s.slot];
+            load_FE(d, s.slot, s.cam, s.pt, F, E);
             const double* p = pvec + 6 * (size_t)s.cam;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { const double pk = p[k]; v0 += F[k] * pk; v1 += F[6 + k] * pk; }
@@ -544,11 +607,13 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
         if (cam >= 0) {
             pt0 = d.slot_pt[slot];
             const double* p = pvec + 6 * (size_t)cam;
+            double F[12], E[6];
+            load_FE(d, slot, cam, pt0, F, E);
             double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + slot] * p[k]; v1 += d.Fs[(6 + k) * ns + slot] * p[k]; }
+            for (int k = 0; k < 6; ++k) { v0 += F[k] * p[k]; v1 += F[6 + k] * p[k]; }
 #pragma unroll
-            for (int k = 0; k < 3; ++k) wsum[k] += d.Es[k * ns + slot] * v0 + d.Es[(3 + k) * ns + slot] * v1;
+            for (int k = 0; k < 3; ++k) wsum[k] += E[k] * v0 + E[3 + k] * v1;
         }
     }
 #pragma unroll
@@ -563,10 +628,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
         const int cam = d.slot_cam[slot];
         if (cam >= 0) {
             double F[12], E[6];
-#pragma unroll
-            for (int k = 0; k < 12; ++k) F[k] = d.Fs[k * ns + slot];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + slot];
+            load_FE(d, slot, cam, d.slot_pt[slot], F, E);
             const double* p = pvec + 6 * (size_t)cam;
             double v0 = 0.0, v1 = 0.0;
 #pragma unroll
@@ -639,10 +701,10 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
         double w[3] = {0, 0, 0};
         if (s.valid) {
             const double* y = d.px + 6 * (size_t)s.cam;
+            double F[12];
+            load_FE(d, s.slot, s.cam, s.pt, F, E);
 #pragma unroll
-            for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + s.slot] * y[k]; v1 += d.Fs[(6 + k) * ns + s.slot] * y[k]; }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) E[k] = d.Es[k * ns + s.slot];
+            for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
             r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
@@ -685,11 +747,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
             if (cam >= 0) {
                 pt0 = d.slot_pt[slot];
                 const double* y = d.px + 6 * (size_t)cam;
+                double F[12], E[6];
+                load_FE(d, slot, cam, pt0, F, E);
                 double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + slot] * y[k]; v1 += d.Fs[(6 + k) * ns + slot] * y[k]; }
+                for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
 #pragma unroll
-                for (int k = 0; k < 3; ++k) wsum[k] += d.Es[k * ns + slot] * v0 + d.Es[(3 + k) * ns + slot] * v1;
+                for (int k = 0; k < 3; ++k) wsum[k] += E[k] * v0 + E[3 + k] * v1;
             }
         }
 #pragma unroll
@@ -721,11 +785,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
             const int cam = d.slot_cam[slot];
             if (cam >= 0) {
                 const double* y = d.px + 6 * (size_t)cam;
+                double F[12], E[6];
+                load_FE(d, slot, cam, pt0, F, E);
                 double v0 = 0.0, v1 = 0.0;
 #pragma unroll
-                for (int k = 0; k < 6; ++k) { v0 += d.Fs[k * ns + slot] * y[k]; v1 += d.Fs[(6 + k) * ns + slot] * y[k]; }
-                const double m0 = v0 + d.Es[slot] * u[0] + d.Es[ns + slot] * u[1] + d.Es[2 * ns + slot] * u[2];
-                const double m1 = v1 + d.Es[3 * ns + slot] * u[0] + d.Es[4 * ns + slot] * u[1] + d.Es[5 * ns + slot] * u[2];
+                for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
+                const double m0 = v0 + E[0] * u[0] + E[1] * u[1] + E[2] * u[2];
+                const double m1 = v1 + E[3] * u[0] + E[4] * u[1] + E[5] * u[2];
                 model += m0 * (d.rt[slot] - 0.5 * m0) + m1 * (d.rt[ns + slot] - 0.5 * m1);
             }
         }

@@ -190,6 +190,7 @@ int fetch_scalars(xrsfm_ba_context* c) {
 // and camlin / Hpp / gp filled.
 int linearize(xrsfm_ba_context* c, double huber_a) {
     Dev& d = c->d;
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_lin, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camlin, (const PcgStatus*)nullptr);
     {
@@ -712,7 +713,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_upload(c, &tmp_u, k.pt_const)); d.pt_const = tmp_u;
     const size_t ns = (size_t)k.n_slots, nc = (size_t)k.n_cams, np = (size_t)k.n_pts;
     TRY(dev_alloc(c, &d.scale_c, nc * 6)); TRY(dev_alloc(c, &d.scale_p, np * 3));
-    TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Fs, ns * 12)); TRY(dev_alloc(c, &d.Es, ns * 6));
+    TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Jp, ns * 6)); TRY(dev_alloc(c, &d.camrec, nc));
     TRY(dev_alloc(c, &d.Hpp, np * 6)); TRY(dev_alloc(c, &d.gp, np * 3)); TRY(dev_alloc(c, &d.Hinv, np * 6));
     TRY(dev_alloc(c, &d.camlin, nc * 12 + 2)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
     TRY(dev_alloc(c, &d.Minv, nc * 21)); TRY(dev_alloc(c, &d.b, nc * 6));
@@ -1015,13 +1016,22 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scalin
         if ((e = fetch(d.rt, ns * 2, h))) return e;
         for (size_t s = 0; s < ns; ++s) if (k.slot_obs[s] >= 0) { r[2 * (size_t)k.slot_obs[s]] = h[s]; r[2 * (size_t)k.slot_obs[s] + 1] = h[ns + s]; }
     }
-    if (Jc) {
-        if ((e = fetch(d.Fs, ns * 12, h))) return e;
-        for (size_t s = 0; s < ns; ++s) if (k.slot_obs[s] >= 0) for (int q = 0; q < 12; ++q) Jc[12 * (size_t)k.slot_obs[s] + q] = h[q * ns + s];
-    }
-    if (Jp) {
-        if ((e = fetch(d.Es, ns * 6, h))) return e;
-        for (size_t s = 0; s < ns; ++s) if (k.slot_obs[s] >= 0) for (int q = 0; q < 6; ++q) Jp[6 * (size_t)k.slot_obs[s] + q] = h[q * ns + s];
+    if (Jc || Jp) {
+        double *dF = nullptr, *dE = nullptr;
+        if (hipMalloc((void**)&dF, (ns ? ns : 1) * 12 * sizeof(double)) != hipSuccess) return XRSFM_BA_ENOMEM;
+        if (hipMalloc((void**)&dE, (ns ? ns : 1) * 6 * sizeof(double)) != hipSuccess) { (void)hipFree(dF); return XRSFM_BA_ENOMEM; }
+        if (ns) hipLaunchKernelGGL(k_debug_materialize, dim3(cdiv((long long)ns, kBlock)), dim3(kBlock), 0, c->stream, d, dF, dE);
+        (void)hipStreamSynchronize(c->stream);
+        std::vector<double> hF, hE;
+        e = fetch(dF, ns * 12, hF);
+        if (!e) e = fetch(dE, ns * 6, hE);
+        (void)hipFree(dF); (void)hipFree(dE);
+        if (e) return e;
+        for (size_t s2 = 0; s2 < ns; ++s2) {
+            if (k.slot_obs[s2] < 0) continue;
+            if (Jc) for (int q = 0; q < 12; ++q) Jc[12 * (size_t)k.slot_obs[s2] + q] = hF[q * ns + s2];
+            if (Jp) for (int q = 0; q < 6; ++q) Jp[6 * (size_t)k.slot_obs[s2] + q] = hE[q * ns + s2];
+        }
     }
     if (Hpp) {
         if ((e = fetch(d.Hpp, (size_t)k.n_pts * 6, h))) return e;
