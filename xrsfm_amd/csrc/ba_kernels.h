@@ -51,6 +51,7 @@ struct Dev {
     const double* slot_u; const double* slot_v;
     const Item* items;
     const int* tile_stride;   // [n_tiles] L > 0 for regular tiles (all tracks share one tuple of L cameras)
+    const int* tile_maxlen;   // [n_tiles] longest track of the tile (bounds the segmented reductions)
     // cameras
     CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
     double* cam_act;    // [Nc] 1.0 if any rank observes the camera (cameras without observations are not in the program)
@@ -89,9 +90,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 // Segmented suffix-sum over contiguous segments (key = track id); the head lane
 // of each segment ends up with the segment total.  Fixed tree order.
 template <int N>
-__device__ __forceinline__ void seg_reduce(double (&v)[N], int key, int lane) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
+__device__ __forceinline__ void seg_reduce(double (&v)[N], int key, int lane, int maxlen = kWave) {
+    // maxlen: wave-uniform upper bound of the segment length (longest track of the tile): offsets >= maxlen cannot
+    // stay inside a segment, so log2(maxlen) steps suffice (2 instead of 6 for 4-observation tracks)
+    for (int off = 1; off < maxlen; off <<= 1) {
         const int okey = __shfl_down(key, off, kWave);
         const bool take = (lane + off < kWave) && (okey == key);
 #pragma unroll
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize(Dev d, double huber_a) {
                 for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
             }
         }
-        seg_reduce<9>(v, s.pt, lane);
+        seg_reduce<9>(v, s.pt, lane, d.tile_maxlen[it.first_tile + tl]);
         if (!is_long) {
             if (s.head) {
                 double* H = d.Hpp + 6 * (size_t)s.pt;
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
             for (int k = 0; k < 6; ++k) { const double pk = p[k]; v0 += F[k] * pk; v1 += F[6 + k] * pk; }
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
-        seg_reduce<3>(w, s.pt, lane);
+        seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);
         double u[3] = {0, 0, 0};
         if (s.head) {
             const double* h = d.Hinv + 6 * (size_t)s.pt;
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
             r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
-        seg_reduce<3>(w, s.pt, lane);
+        seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);
         double u[3] = {0, 0, 0};
         if (s.head) {
             const double* h = d.Hinv + 6 * (size_t)s.pt;

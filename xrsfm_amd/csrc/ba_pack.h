@@ -18,6 +18,7 @@ struct Packed {
     std::vector<double> slot_u, slot_v;
     std::vector<int> items;          // pairs {first_tile, n_tiles}
     std::vector<int> cam_ptr;        // [n_cams+1] into the camera-major scatter buffer (entries, not observations)
+    std::vector<int> tile_maxlen;    // [n_tiles] longest track in the tile (<= 64)
     std::vector<int> tile_stride;    // [n_tiles] L > 0: every track of the tile has the same L cameras ("regular" tile)
     int n_cam_entries = 0;
     std::vector<unsigned char> pt_const;
@@ -107,6 +108,17 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     o.slot_u.assign(o.n_slots, 0.0); o.slot_v.assign(o.n_slots, 0.0);
     for (int s = 0; s < o.n_slots; ++s)
         if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
+    o.tile_maxlen.assign(o.n_tiles, 1);
+    for (int t = 0; t < o.n_tiles; ++t) {
+        int run = 0, best = 1;
+        for (int q = 0; q < 64; ++q) {
+            const int s2 = 64 * t + q;
+            if (o.slot_cam[s2] < 0) break;
+            run = (q > 0 && o.slot_pt[s2] == o.slot_pt[s2 - 1]) ? run + 1 : 1;
+            best = std::max(best, run);
+        }
+        o.tile_maxlen[t] = best;
+    }
     // regular tiles: >= 2 tracks, all with the same camera tuple of length L <= 32
     o.tile_stride.assign(o.n_tiles, 0);
     for (int t = 0; t < o.n_tiles; ++t) {

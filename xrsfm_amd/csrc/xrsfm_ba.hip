@@ -700,6 +700,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     if (!k.items.empty() && hipMemcpy(tmp_it, k.items.data(), k.items.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
     d.items = tmp_it;
     TRY(dev_upload(c, &tmp_i, k.tile_stride)); d.tile_stride = tmp_i;
+    TRY(dev_upload(c, &tmp_i, k.tile_maxlen)); d.tile_maxlen = tmp_i;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam_cand = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); c->cam0 = tmp_c;
