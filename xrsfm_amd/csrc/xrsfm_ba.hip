@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "../../include/xrsfm_ba.h"
@@ -104,6 +106,7 @@ struct xrsfm_ba_context {
     Packed pk;
     Dev d{};
     std::vector<void*> allocs;
+    std::vector<size_t> alloc_class;
     CamRec* cam0 = nullptr; double* P0 = nullptr;   // pristine copies for reset
     int n_points_caller = 0;
     double* h_scal = nullptr;       // pinned
@@ -123,12 +126,83 @@ struct xrsfm_ba_context {
 
 namespace {
 
+// Process-wide cache of device allocations: BASolver::LBA runs once per registered frame (thousands of small problems per
+// reconstruction, incremental_mapper.cc:71) and hipMalloc/hipFree of ~50 buffers would dominate such a call.  Blocks are
+// rounded up to size classes, returned to the cache by xrsfm_ba_destroy and reused by the next xrsfm_ba_create on the same device.
+struct DevCache {
+    std::mutex mu;
+    std::map<std::pair<int, size_t>, std::vector<void*>> free_blocks;     // (device, class bytes) -> blocks
+    size_t cached_bytes = 0;
+    static size_t size_class(size_t bytes) {
+        size_t c = 256;
+        while (c < bytes) c += (c < (1u << 20)) ? c : c / 4;     // x2 up to 1 MiB, then +25 % steps
+        return c;
+    }
+    void* get(int dev, size_t bytes, size_t* cls) {
+        *cls = size_class(bytes);
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto it = free_blocks.find({dev, *cls});
+            if (it != free_blocks.end() && !it->second.empty()) { void* p = it->second.back(); it->second.pop_back(); cached_bytes -= *cls; return p; }
+        }
+        void* p = nullptr;
+        if (hipMalloc(&p, *cls) != hipSuccess) {          // out of memory: drop the cache and retry once
+            release_all();
+            if (hipMalloc(&p, *cls) != hipSuccess) return nullptr;
+        }
+        return p;
+    }
+    void put(int dev, void* p, size_t cls) {
+        std::lock_guard<std::mutex> g(mu);
+        if (cached_bytes + cls > (size_t)16 << 30) { (void)hipFree(p); return; }       // keep at most 16 GiB around
+        free_blocks[{dev, cls}].push_back(p); cached_bytes += cls;
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& kv : free_blocks) for (void* p : kv.second) (void)hipFree(p);
+        free_blocks.clear(); cached_bytes = 0;
+    }
+};
+DevCache g_cache;
+
+// stream + pinned scalar buffers are recycled too (hipStreamCreate/Destroy and hipHostMalloc/Free cost ~0.5 ms per call)
+struct HostBundle { hipStream_t stream; double* h_scal; PcgStatus* h_st; };
+struct BundleCache {
+    std::mutex mu;
+    std::map<int, std::vector<HostBundle>> free_bundles;
+    bool get(int dev, HostBundle* b) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            auto& v = free_bundles[dev];
+            if (!v.empty()) { *b = v.back(); v.pop_back(); return true; }
+        }
+        b->stream = nullptr; b->h_scal = nullptr; b->h_st = nullptr;
+        if (hipStreamCreate(&b->stream) != hipSuccess) return false;
+        if (hipHostMalloc((void**)&b->h_scal, sizeof(double) * S_COUNT) != hipSuccess ||
+            hipHostMalloc((void**)&b->h_st, sizeof(PcgStatus)) != hipSuccess) {
+            if (b->h_scal) (void)hipHostFree(b->h_scal);
+            (void)hipStreamDestroy(b->stream);
+            return false;
+        }
+        return true;
+    }
+    void put(int dev, const HostBundle& b) {
+        std::lock_guard<std::mutex> g(mu);
+        auto& v = free_bundles[dev];
+        if (v.size() >= 8) { (void)hipHostFree(b.h_scal); (void)hipHostFree(b.h_st); (void)hipStreamDestroy(b.stream); return; }
+        v.push_back(b);
+    }
+};
+BundleCache g_bundles;
+
 template <typename T>
 int dev_alloc(xrsfm_ba_context* c, T** p, size_t n) {
-    void* q = nullptr;
     if (n == 0) n = 1;
-    if (hipMalloc(&q, n * sizeof(T)) != hipSuccess) return XRSFM_BA_ENOMEM;
+    size_t cls = 0;
+    void* q = g_cache.get(c->device, n * sizeof(T), &cls);
+    if (!q) return XRSFM_BA_ENOMEM;
     c->allocs.push_back(q);
+    c->alloc_class.push_back(cls);
     *p = (T*)q;
     return 0;
 }
@@ -646,10 +720,9 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
-    for (void* p : c->allocs) (void)hipFree(p);
-    if (c->h_scal) (void)hipHostFree(c->h_scal);
-    if (c->h_st) (void)hipHostFree(c->h_st);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
+    if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st});
     delete c;
 }
 
@@ -666,7 +739,11 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     c->device = device;
     int e = pack_problem(*p, c->pk);
     if (e) { delete c; return e; }
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&c->stream) != hipSuccess) { delete c; return XRSFM_BA_ENODEV; }
+    {
+        HostBundle hb;
+        if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
+        c->stream = hb.stream; c->h_scal = hb.h_scal; c->h_st = hb.h_st;
+    }
     const Packed& k = c->pk;
     Dev& d = c->d;
     c->n_points_caller = p->n_points;
@@ -728,11 +805,9 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));
     TRY(dev_alloc(c, &d.st, (size_t)1));
 #undef TRY
-    if (hipHostMalloc((void**)&c->h_scal, sizeof(double) * S_COUNT) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_st, sizeof(PcgStatus)) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENOMEM; }
-    if (hipMemset(d.scal, 0, sizeof(double) * S_COUNT) != hipSuccess || hipMemset(d.st, 0, sizeof(PcgStatus)) != hipSuccess ||
-        hipMemset(d.scat, 0, sizeof(double) * 28 * (size_t)(k.n_obs > 0 ? k.n_obs : 1)) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
-    if (hipDeviceSynchronize() != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
+    // (the scatter buffers need no clearing: every entry is written before it is read)
+    if (hipMemsetAsync(d.scal, 0, sizeof(double) * S_COUNT, c->stream) != hipSuccess || hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
     *out = c;
     return XRSFM_BA_OK;
 }
