@@ -450,21 +450,28 @@ __device__ __forceinline__ void tile_abt_mfma(const double* __restrict__ As, con
     }
 }
 
-__device__ __forceinline__ void load_tile_lds(double* dst, const double* __restrict__ src, size_t ld) {
-    // 64x64 doubles = 2048 double2, 8 per thread; issue all global loads, then store
-    double2 v[8];
+// 64x64 doubles = 2048 double2, 8 per thread: global -> registers and registers -> LDS as two steps, so that the loads
+// of the next tile can be in flight while the matrix cores work on the current one
+__device__ __forceinline__ void load_tile_regs(double2 (&v)[8], const double* __restrict__ src, size_t ld) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int e = threadIdx.x + 256 * it;          // double2 index
         const int r = e >> 5, c2 = (e & 31) * 2;
         v[it] = *reinterpret_cast<const double2*>(src + (size_t)r * ld + c2);
     }
+}
+__device__ __forceinline__ void store_tile_lds(double* dst, const double2 (&v)[8]) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int e = threadIdx.x + 256 * it;
         const int r = e >> 5, c2 = (e & 31) * 2;
         dst[r * kLdT + c2] = v[it].x; dst[r * kLdT + c2 + 1] = v[it].y;
     }
+}
+__device__ __forceinline__ void load_tile_lds(double* dst, const double* __restrict__ src, size_t ld) {
+    double2 v[8];
+    load_tile_regs(v, src, ld);
+    store_tile_lds(dst, v);
 }
 
 // A_ik <- A_ik * Linv_k^T for the tiles i listed in rows[]
@@ -603,12 +610,23 @@ __global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restr
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    for (int q = cptr[blockIdx.x]; q < cptr[blockIdx.x + 1]; ++q) {
-        const int j = cj[q];
+    const int q0 = cptr[blockIdx.x], q1 = cptr[blockIdx.x + 1];
+    double2 ra[8], rb[8];
+    if (q0 < q1) {
+        const int j = cj[q0];
+        load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
+        load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+    }
+    for (int q = q0; q < q1; ++q) {
+        __syncthreads();                       // the previous product no longer reads LDS
+        store_tile_lds(As, ra);
+        store_tile_lds(Bs, rb);
         __syncthreads();
-        load_tile_lds(As, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
-        load_tile_lds(Bs, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
-        __syncthreads();
+        if (q + 1 < q1) {                      // next contribution: loads in flight during the MFMAs below
+            const int j = cj[q + 1];
+            load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
+            load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+        }
         tile_abt_mfma(As, Bs, acc);
     }
     store_acc_sub(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, acc);
