@@ -177,6 +177,13 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context *ctx, double huber_a, int use_scal
 /* After debug_linearize: y = S(radius) * x for a caller vector x [n_cams][6]; also returns rhs b [n_cams][6]. */
 int xrsfm_ba_debug_schur_product(xrsfm_ba_context *ctx, double radius, const double *x, double *y, double *b);
 
+/* Host-side packing only (no GPU needed): runs the track-tile packing of xrsfm_ba_create and reports
+ * stats[0] tiles, [1] slots (= 64*tiles), [2] work items, [3] regular tiles, [4] long items (tracks > 64 observations),
+ * [5] camera-major partial entries, [6] longest track, [7] active points.  slot_obs (may be NULL) receives, for each of
+ * the `slots` slots, the caller's observation index stored there or -1 for padding; it must hold n_obs + 64*(n_points+1)
+ * entries at most (upper bound of the slot count). */
+int xrsfm_ba_debug_pack(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *slot_obs);
+
 /* Multi-GPU emulation for tests: supply the union of all ranks' off-diagonal camera pairs (row > col) before the first
  * Cholesky solve, exactly what xrsfm_ba_run obtains with an all-reduce when n_ranks > 1. */
 int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context *ctx, int n_pairs, const int32_t *row_col);

@@ -1,0 +1,75 @@
+"""Host logic without a GPU: the track-tile packing of xrsfm_ba_create (xrsfm_amd/csrc/ba_pack.h) through xrsfm_ba_debug_pack."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+def _check_invariants(arr, st):
+    n_obs = arr["obs_cam"].shape[0]
+    so = st["slot_obs"]
+    assert st["slots"] == 64 * st["tiles"] == so.shape[0]
+    used = so[so >= 0]
+    assert np.array_equal(np.sort(used), np.arange(n_obs))                   # every observation exactly once
+    pt = np.where(so >= 0, arr["obs_pt"][np.clip(so, 0, None)], -1)
+    cam = np.where(so >= 0, arr["obs_cam"][np.clip(so, 0, None)], -1)
+    # a track is contiguous, ordered by camera, and never straddles a tile unless it is a long item of whole tiles
+    for j in np.unique(arr["obs_pt"]):
+        idx = np.nonzero(pt == j)[0]
+        assert idx[-1] - idx[0] + 1 == len(idx)
+        assert np.all(np.diff(cam[idx]) > 0)
+        if len(idx) <= 64:
+            assert idx[0] // 64 == idx[-1] // 64
+        else:
+            assert idx[0] % 64 == 0
+    # padding only at the end of a tile
+    for t in range(st["tiles"]):
+        v = so[64 * t:64 * t + 64] >= 0
+        assert v[0] and not np.any(v[1:] & ~v[:-1])
+    assert st["active_points"] == len(np.unique(arr["obs_pt"]))
+
+
+@pytest.mark.parametrize("case", ["sequential", "unordered", "ragged", "long"])
+def test_packing_invariants(lib, case):
+    from xrsfm_amd import capi
+    if case == "sequential":
+        arr = H.make(40, 3000, 4, seed=190)
+    elif case == "unordered":
+        arr = H.make(25, 800, 5, seed=191, mode="unordered")
+    elif case == "ragged":
+        arr = H.make(14, 700, 6, seed=192, mode="unordered", min_tri_angle_deg=0.5)
+        rng = np.random.default_rng(1)
+        keep = rng.random(arr["obs_cam"].shape[0]) < 0.6
+        keep[np.unique(arr["obs_pt"], return_index=True)[1]] = True
+        perm = rng.permutation(int(keep.sum()))
+        for k in ("obs_cam", "obs_pt", "obs_uv"):
+            arr[k] = np.ascontiguousarray(arr[k][keep][perm])
+    else:
+        arr = H.make(150, 9, 140, seed=193, mode="unordered", min_tri_angle_deg=0.5)
+    st = capi.debug_pack(H.to_product(arr))
+    _check_invariants(arr, st)
+    if case == "sequential":
+        assert st["regular_tiles"] > 0.8 * st["tiles"] and st["long_items"] == 0 and st["longest_track"] == 4
+        assert st["cam_entries"] < 0.3 * arr["obs_cam"].shape[0]            # regular tiles emit one partial per camera
+    if case == "long":
+        assert st["long_items"] == 9 and st["longest_track"] == 140 and st["items"] == 9 and st["tiles"] == 27
+        assert st["cam_entries"] == arr["obs_cam"].shape[0]
+
+
+def test_packing_edge_cases(lib):
+    from xrsfm_amd import capi
+    empty = capi.ProblemArrays(cam_q=np.zeros((0, 4)), cam_t=np.zeros((0, 3)), cam_intr=np.zeros(0, np.int32),
+                               intr_model=np.zeros(0, np.int32), intr_params=np.zeros((0, 8)), points=np.zeros((0, 3)),
+                               obs_cam=np.zeros(0, np.int32), obs_pt=np.zeros(0, np.int32), obs_uv=np.zeros((0, 2)))
+    st = capi.debug_pack(empty)
+    assert st["tiles"] == 0 and st["items"] == 0
+    arr = H.make(6, 40, 3, seed=194)
+    bad = H.to_product(arr); bad.obs_pt[3] = 10 ** 6
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.debug_pack(bad)
+    bad = H.to_product(arr); bad.intr_model[0] = 7
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.debug_pack(bad)
+    # points without observations are not active
+    arr["points"] = np.concatenate([arr["points"], np.zeros((3, 3))]); arr["point_const"] = np.zeros(43, np.uint8)
+    assert capi.debug_pack(H.to_product(arr))["active_points"] == 40

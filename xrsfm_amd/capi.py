@@ -57,7 +57,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -101,6 +101,8 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
+    lib.xrsfm_ba_debug_pack.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
+    lib.xrsfm_ba_debug_pack.restype = C.c_int
     lib.xrsfm_ba_profile_entry.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _c_double_p, C.POINTER(C.c_int)]
     lib.xrsfm_ba_profile_entry.restype = C.c_int
     _lib = lib
@@ -280,3 +282,15 @@ def filter_tracks(problem: ProblemArrays, max_reproj_error: float, min_tri_angle
                                         out.ctypes.data_as(_c_uint8_p), _dp(err), _dp(ang), cnt.ctypes.data_as(_c_int32_p)),
           "xrsfm_ba_filter_tracks")
     return dict(obs_delete=obs_del, track_outlier=out, track_error=err, track_angle=ang, num_filtered=cnt)
+
+
+def debug_pack(problem: ProblemArrays) -> dict:
+    """Host-side packing statistics and the slot -> observation map (works without a GPU)."""
+    stats = np.zeros(8, np.int32)
+    slot_obs = np.full(problem.n_obs + 64 * (problem.n_points + 1), -2, np.int32)
+    cs = problem.c_struct()
+    check(load().xrsfm_ba_debug_pack(C.byref(cs), stats.ctypes.data_as(_c_int32_p), slot_obs.ctypes.data_as(_c_int32_p)), "xrsfm_ba_debug_pack")
+    keys = ("tiles", "slots", "items", "regular_tiles", "long_items", "cam_entries", "longest_track", "active_points")
+    out = dict(zip(keys, (int(v) for v in stats)))
+    out["slot_obs"] = slot_obs[:out["slots"]].copy()
+    return out

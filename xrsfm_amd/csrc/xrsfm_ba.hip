@@ -1149,6 +1149,21 @@ int xrsfm_ba_debug_schur_product(xrsfm_ba_context* c, double radius, const doubl
     return 0;
 }
 
+int xrsfm_ba_debug_pack(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* slot_obs) {
+    if (!p || !stats) return XRSFM_BA_EINVAL;
+    Packed k;
+    const int e = pack_problem(*p, k);
+    if (e) return e;
+    int regular = 0, longs = 0, maxlen = 0;
+    for (int t = 0; t < k.n_tiles; ++t) { regular += k.tile_stride[t] > 0; maxlen = std::max(maxlen, k.tile_maxlen[t]); }
+    for (size_t i = 0; i + 1 < k.items.size(); i += 2)
+        if (k.items[i + 1] > 1) { ++longs; int len = 0; for (int s2 = 64 * k.items[i]; s2 < 64 * (k.items[i] + k.items[i + 1]); ++s2) len += k.slot_cam[s2] >= 0; maxlen = std::max(maxlen, len); }
+    stats[0] = k.n_tiles; stats[1] = k.n_slots; stats[2] = (int32_t)k.items.size() / 2; stats[3] = regular; stats[4] = longs;
+    stats[5] = k.n_cam_entries; stats[6] = maxlen; stats[7] = k.n_pts;
+    if (slot_obs) for (int s2 = 0; s2 < k.n_slots; ++s2) slot_obs[s2] = k.slot_obs[s2];
+    return 0;
+}
+
 int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context* c, int n_pairs, const int32_t* row_col) {
     if (!c || n_pairs < 0 || (n_pairs > 0 && !row_col)) return XRSFM_BA_EINVAL;
     if (c->chol.ready) return XRSFM_BA_ESTATE;
