@@ -63,8 +63,9 @@ def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, nnzb: in
         "k_schur_matvec": n_obs * 144 + n_pts * 48 + n_cams * 96,
         # read r, J; read Hpp^-1 (6) + g_p (3); write diagonal blocks of S (21) + rhs (6)      (B_prep)
         "k_schur_prep": n_obs * 160 + n_pts * 72 + n_cams * 216,
-        # explicit-S accounting (B_S): read J once, write the nnzb off-diagonal 6x6 blocks of S once
-        "k_schur_pairs": n_obs * 144 + n_pts * 48 + nnzb * 288,
+        # fused S assembly of the Cholesky path = B_prep + the nnzb off-diagonal 6x6 blocks of S written once
+        # (explicit-S accounting of SURVEY 8d; r and J are read once for both)
+        "k_schur_pairs": n_obs * 160 + n_pts * 72 + n_cams * 216 + nnzb * 288,
         # back-substitute: read J, r; Hpp^-1, g_p, points in, points out                       (B_back)
         "k_backsub": n_obs * (144 + 16) + n_pts * 144 + n_cams * 48,
         "k_cost": n_obs * 24 + n_pts * 24 + n_cams * 56,

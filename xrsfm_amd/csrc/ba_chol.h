@@ -33,7 +33,9 @@ struct CholDev {
 typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------ S assembly
-// Off-diagonal blocks  block(b,a) = sum_tracks W_b Hinv W_a^T  (camera b > camera a of the same track).
+// Off-diagonal blocks  block(b,a) = sum_tracks W_b Hinv W_a^T  (camera b > camera a of the same track), plus — fused,
+// because they need the same loads and the same W, W*Hinv — the per-observation diagonal-block and reduced-rhs terms
+// (the 28 values k_schur_prep produces on the PCG path), written to the camera-major scatter buffer.
 // One wavefront per tile (64-thread workgroups: the staged operands of a wave live in its own LDS).
 //  * regular tile (T tracks, all with the same L cameras): the lanes stage W and W*Hinv as [6L x 3T] matrices in LDS
 //    and the wave forms G = W (W Hinv)^T with v_mfma_f64_16x16x4_f64: G holds every camera-pair block already summed
@@ -55,9 +57,11 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
     const size_t ns = (size_t)d.n_slots;
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
-        double W[18], WH[18];
+        double W[18], WH[18], o28[28];
 #pragma unroll
         for (int k = 0; k < 18; ++k) { W[k] = 0.0; WH[k] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 28; ++k) o28[k] = 0.0;
         int npair = 0, pbase = 0;
         if (s.valid) {
             double F[12], E[6];
@@ -74,19 +78,39 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
             }
             pbase = slot_pair_ptr[s.slot];
             npair = slot_pair_ptr[s.slot + 1] - pbase;
+            // diagonal block of S and reduced rhs of this observation (what k_schur_prep computes on the PCG path)
+            const double* g = d.gp + 3 * (size_t)s.pt;
+            const double g0 = g[0], g1 = g[1], g2 = g[2];
+            int idx = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int c2 = a; c2 < 6; ++c2)
+                    o28[idx++] = F[a] * F[c2] + F[6 + a] * F[6 + c2]
+                                 - (WH[3 * a] * W[3 * c2] + WH[3 * a + 1] * W[3 * c2 + 1] + WH[3 * a + 2] * W[3 * c2 + 2]);
+#pragma unroll
+            for (int a = 0; a < 6; ++a) o28[21 + a] = -(WH[3 * a] * g0 + WH[3 * a + 1] * g1 + WH[3 * a + 2] * g2);
         }
         const int L = d.tile_stride[it.first_tile];
+        {
+            if (L > 0) strided_reduce<28>(o28, L, lane);
+            const int cp = d.slot_campos[s.slot];
+            if (cp >= 0) {
+                double2* out = reinterpret_cast<double2*>(d.scat + 28 * (size_t)cp);
+#pragma unroll
+                for (int k = 0; k < 14; ++k) out[k] = make_double2(o28[2 * k], o28[2 * k + 1]);
+            }
+        }
         if (L > 0) {
             const int nvalid = __popcll(__ballot(s.valid));
             const int T = nvalid / L;
             const int R = 6 * L, Rp = (R + 15) & ~15, C4 = (3 * T + 3) & ~3, Cp = C4 + 2;
-            double* Wst = smem; double* Hst = smem + Rp * Cp;
-            int* dtab = reinterpret_cast<int*>(smem + 2 * Rp * Cp);       // [L][L] destination of block (rb, ra)
+            double* Wst = smem; double* Hst = smem + R * Cp;               // only the R rows that hold data are staged
+            int* dtab = reinterpret_cast<int*>(smem + 2 * R * Cp);          // [L][L] destination of block (rb, ra)
             // destinations of the first track's pairs: issued first so the index loads overlap the staging
             if (lane < L)
                 for (int dd = 1; dd <= npair; ++dd) dtab[lane * L + lane + dd] = pair_dst[pbase + dd - 1];
-            // zero only the padding: rows R..Rp-1 and columns 3T..Cp-1 (the rest is overwritten below)
-            for (int e = lane; e < (Rp - R) * Cp; e += kWave) { Wst[R * Cp + e] = 0.0; Hst[R * Cp + e] = 0.0; }
+            // zero the K padding columns 3T..Cp-1 (rows beyond R are never staged: reads are clamped, results discarded)
             const int padc = Cp - 3 * T;
             for (int e = lane; e < R * padc; e += kWave) {
                 const int row = e / padc, cc = 3 * T + (e - row * padc);
@@ -109,8 +133,8 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
             for (int I = 0; I < nI; ++I)
                 for (int J = 0; J <= I; ++J) {
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
-                    const double* ap = Wst + (16 * I + li) * Cp + lk;
-                    const double* bp = Hst + (16 * J + li) * Cp + lk;
+                    const double* ap = Wst + min(16 * I + li, R - 1) * Cp + lk;
+                    const double* bp = Hst + min(16 * J + li, R - 1) * Cp + lk;
                     for (int k0 = 0; k0 < C4; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
                     const int col = 16 * J + li;
                     const int ra = col / 6, j = col - 6 * ra;
@@ -160,6 +184,19 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
             WH[3 * a + 0] = w[0] * h[0] + w[1] * h[1] + w[2] * h[2];
             WH[3 * a + 1] = w[0] * h[1] + w[1] * h[3] + w[2] * h[4];
             WH[3 * a + 2] = w[0] * h[2] + w[1] * h[4] + w[2] * h[5];
+        }
+        {   // diagonal block / rhs terms of observation a
+            const double* g = d.gp + 3 * (size_t)pt;
+            double* out = d.scat + 28 * (size_t)d.slot_campos[sa];
+            int idx = 0;
+            for (int a = 0; a < 6; ++a)
+                for (int c2 = a; c2 < 6; ++c2) {
+                    double wc[3];
+                    for (int b = 0; b < 3; ++b) wc[b] = Fa[c2] * Ea[b] + Fa[6 + c2] * Ea[3 + b];
+                    out[idx++] = Fa[a] * Fa[c2] + Fa[6 + a] * Fa[6 + c2] - (WH[3 * a] * wc[0] + WH[3 * a + 1] * wc[1] + WH[3 * a + 2] * wc[2]);
+                }
+            for (int a = 0; a < 6; ++a) out[21 + a] = -(WH[3 * a] * g[0] + WH[3 * a + 1] * g[1] + WH[3 * a + 2] * g[2]);
+            out[27] = 0.0;
         }
         const int pbase = slot_pair_ptr[sa];
         const int npair = slot_pair_ptr[sa + 1] - pbase;

@@ -306,9 +306,9 @@ int prepare_step(xrsfm_ba_context* c, double radius, bool with_blocks = false) {
     const double dmin = 1e-6, dmax = 1e32;
     if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_point_prep, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_prep, dim3(cdiv((long long)d.n_cams * 6, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
+    if (with_blocks) return 0;      // Cholesky path: k_schur_pairs also produces the diagonal blocks / rhs (chol_assemble)
     if (d.n_slots > 0) LAUNCH(c, K_SCHUR_PREP, k_schur_prep, dim3(cdiv(d.n_slots, kBlock)), dim3(kBlock), 0, d);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, (const PcgStatus*)nullptr);
-    if (with_blocks) return 0;      // Cholesky path: all-reduced together with the off-diagonal blocks in chol_assemble
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28, kNcclSum);
     if (e) return e;
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_factor, dim3(cdiv(d.n_cams, 64)), dim3(64), 0, d);
@@ -546,7 +546,8 @@ int chol_setup(xrsfm_ba_context* c) {
         int nvalid = 0;
         for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
         const int T2 = nvalid / L, Rp = (6 * L + 15) & ~15, Cp = ((3 * T2 + 3) & ~3) + 2;
-        h.pairs_shm = std::max(h.pairs_shm, 2 * (size_t)Rp * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
+        (void)Rp;
+        h.pairs_shm = std::max(h.pairs_shm, 2 * (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
     }
     h.use_levels = (2 * n_levels <= T);
     std::vector<int> one_k(T);
@@ -590,7 +591,8 @@ int chol_setup(xrsfm_ba_context* c) {
 int chol_assemble(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
-    if (d.n_items > 0 && h.n_pairs > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(d.n_items), dim3(kWave), h.pairs_shm, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
+    if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(d.n_items), dim3(kWave), h.pairs_shm, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
+    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, (const PcgStatus*)nullptr);
     if (h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_block_segsum, dim3(h.n_blocks), dim3(kBlock), 0, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
