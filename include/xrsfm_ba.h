@@ -184,6 +184,12 @@ int xrsfm_ba_debug_schur_product(xrsfm_ba_context *ctx, double radius, const dou
  * entries at most (upper bound of the slot count). */
 int xrsfm_ba_debug_pack(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *slot_obs);
 
+/* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
+ * (0 natural, 1 nested dissection of a band/ring), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
+ * [6] level schedule used (else right-looking), [7] structurally non-zero tiles after fill.  cam_offset (may be NULL):
+ * [n_cams] first row of each camera in the elimination order. */
+int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *cam_offset);
+
 /* Multi-GPU emulation for tests: supply the union of all ranks' off-diagonal camera pairs (row > col) before the first
  * Cholesky solve, exactly what xrsfm_ba_run obtains with an all-reduce when n_ranks > 1. */
 int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context *ctx, int n_pairs, const int32_t *row_col);

@@ -425,3 +425,35 @@ def test_ragged_tracks(lib, solver):
     assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
     assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
     assert max(np.abs(prod.cam_q - pr.cam_q).max(), np.abs(prod.cam_t - pr.cam_t).max()) < 1e-5
+
+
+def test_band_with_loop_closures(lib):
+    """A sequential problem with a few long-range camera pairs (loop closures): the band ordering must survive them (level
+    schedule still shallow) and the solve must still match the oracle."""
+    from xrsfm_amd import capi
+    arr = H.make(160, 3000, 4, seed=200)
+    rng = np.random.default_rng(4)
+    # 6 extra tracks, each seen by two far-apart camera pairs (geometry does not matter for the structure: observations
+    # that end up behind a camera take the clamp branch of the cost functor)
+    n_p = arr["points"].shape[0]
+    extra_cam, extra_pt, extra_uv, extra_P = [], [], [], []
+    for e in range(6):
+        a, b = int(rng.integers(0, 60)), int(rng.integers(90, 150))
+        for cidx in (a, a + 1, b, b + 1):
+            extra_cam.append(cidx); extra_pt.append(n_p + e); extra_uv.append(rng.uniform([100, 50], [1100, 300]))
+        extra_P.append(arr["points"][int(rng.integers(0, n_p))] + rng.normal(0, 0.5, 3))
+    arr["points"] = np.concatenate([arr["points"], np.array(extra_P)])
+    arr["point_const"] = np.zeros(arr["points"].shape[0], np.uint8)
+    arr["obs_cam"] = np.concatenate([arr["obs_cam"], np.array(extra_cam, np.int32)])
+    arr["obs_pt"] = np.concatenate([arr["obs_pt"], np.array(extra_pt, np.int32)])
+    arr["obs_uv"] = np.concatenate([arr["obs_uv"], np.array(extra_uv)])
+    ctx = capi.Context(H.to_product(arr))
+    s = ctx.run(capi.default_options(profile=1, max_iterations=8))
+    prof = ctx.profile()
+    levels = prof["k_potrf"][1] / (s.lm_steps_attempted)
+    assert levels <= 12, levels                      # 96 tiles would be ~96 sequential panels with the natural order
+    ctx.close()
+    pr, s_ref, prod, s2 = _solve_both(arr, dict(max_iterations=8))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s2.n_successful, s2.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(math.sqrt(s2.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6

@@ -1,0 +1,90 @@
+"""Host-side plan of the reduced-camera Cholesky (ba_plan.h) through xrsfm_ba_debug_chol_plan: no GPU needed."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+from xrsfm_amd import capi
+
+
+def _check_layout(plan, n_cams):
+    off = plan["cam_offset"]
+    assert len(set(off.tolist())) == n_cams                       # every camera has its own 6 rows
+    assert np.all(off % 64 % 6 == 0) and np.all(off % 64 <= 54)   # 10 cameras per 64-row tile, never straddling a tile
+    assert off.max() < 64 * plan["tiles"]
+    assert 1 <= plan["levels"] <= plan["tiles"]
+    assert plan["tiles_nz"] <= plan["tiles"] * (plan["tiles"] + 1) // 2
+
+
+def _add_closures(arr, n_extra, seed=4):
+    rng = np.random.default_rng(seed)
+    n_p = arr["points"].shape[0]
+    n_c = arr["cam_q"].shape[0]
+    ec, ep, eu, eP = [], [], [], []
+    for e in range(n_extra):
+        a, b = int(rng.integers(0, n_c // 3)), int(rng.integers(n_c // 2, n_c - 10))
+        for cidx in (a, a + 1, b, b + 1):
+            ec.append(cidx); ep.append(n_p + e); eu.append(rng.uniform([100, 50], [1100, 300]))
+        eP.append(arr["points"][int(rng.integers(0, n_p))] + rng.normal(0, 0.5, 3))
+    arr["points"] = np.concatenate([arr["points"], np.array(eP)])
+    arr["point_const"] = np.zeros(arr["points"].shape[0], np.uint8)
+    arr["obs_cam"] = np.concatenate([arr["obs_cam"], np.array(ec, np.int32)])
+    arr["obs_pt"] = np.concatenate([arr["obs_pt"], np.array(ep, np.int32)])
+    arr["obs_uv"] = np.concatenate([arr["obs_uv"], np.array(eu)])
+    return arr
+
+
+def test_band_gets_nested_dissection():
+    arr = H.make(160, 3000, 4, seed=200)
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, 160)
+    assert plan["ordering"] == 1 and plan["hubs"] == 0 and plan["band"] == 3
+    assert plan["level_schedule"] == 1 and plan["levels"] <= 5
+    assert plan["blocks"] == 160 * 3                               # ring of 160 cameras, each sharing tracks with 3 successors
+
+
+def test_loop_closures_become_hubs():
+    arr = _add_closures(H.make(160, 3000, 4, seed=200), 6)
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, 160)
+    assert plan["ordering"] == 1 and plan["band"] == 3
+    assert 0 < plan["hubs"] <= 24
+    assert plan["level_schedule"] == 1 and plan["levels"] <= 9
+    off = plan["cam_offset"]
+    # hub cameras are eliminated last: the ends of a long-range pair sit in the last tiles
+    ec = arr["obs_cam"][-24:]
+    assert off[ec].min() // 64 >= plan["tiles"] - 3
+
+
+def test_too_many_closures_fall_back_to_natural_order():
+    arr = _add_closures(H.make(160, 3000, 4, seed=200), 40)
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, 160)
+    assert plan["ordering"] == 0 and plan["hubs"] == 0
+    assert plan["tiles"] == 16
+    assert np.array_equal(plan["cam_offset"], 64 * (np.arange(160) // 10) + 6 * (np.arange(160) % 10))
+
+
+def test_dense_visibility_keeps_natural_order():
+    arr = H.make(30, 400, 12, seed=3, mode="unordered")
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, 30)
+    assert plan["tiles"] == 3
+
+
+def test_duplicate_frame_in_track_is_rejected():
+    arr = H.make(12, 60, 3, seed=1)
+    arr["obs_cam"] = arr["obs_cam"].copy()
+    pt0 = arr["obs_pt"][0]
+    idx = np.nonzero(arr["obs_pt"] == pt0)[0]
+    arr["obs_cam"][idx[1]] = arr["obs_cam"][idx[0]]
+    with pytest.raises(Exception):
+        capi.debug_chol_plan(H.to_product(arr))
+
+
+def test_empty_problem_plan():
+    arr = H.make(12, 60, 3, seed=1)
+    for k in ("obs_cam", "obs_pt"):
+        arr[k] = arr[k][:0]
+    arr["obs_uv"] = arr["obs_uv"][:0]
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["blocks"] == 0 and plan["tiles"] >= 1

@@ -57,7 +57,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -101,6 +101,8 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
+    lib.xrsfm_ba_debug_chol_plan.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
+    lib.xrsfm_ba_debug_chol_plan.restype = C.c_int
     lib.xrsfm_ba_debug_pack.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
     lib.xrsfm_ba_debug_pack.restype = C.c_int
     lib.xrsfm_ba_profile_entry.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), _c_double_p, C.POINTER(C.c_int)]
@@ -293,4 +295,16 @@ def debug_pack(problem: ProblemArrays) -> dict:
     keys = ("tiles", "slots", "items", "regular_tiles", "long_items", "cam_entries", "longest_track", "active_points")
     out = dict(zip(keys, (int(v) for v in stats)))
     out["slot_obs"] = slot_obs[:out["slots"]].copy()
+    return out
+
+
+def debug_chol_plan(problem: ProblemArrays) -> dict:
+    """Host-side plan of the Cholesky path: tiles, elimination-tree levels, ordering (works without a GPU)."""
+    stats = np.zeros(8, np.int32)
+    off = np.zeros(max(problem.n_cams, 1), np.int32)
+    cs = problem.c_struct()
+    check(load().xrsfm_ba_debug_chol_plan(C.byref(cs), stats.ctypes.data_as(_c_int32_p), off.ctypes.data_as(_c_int32_p)), "xrsfm_ba_debug_chol_plan")
+    keys = ("tiles", "levels", "ordering", "hubs", "band", "blocks", "level_schedule", "tiles_nz")
+    out = dict(zip(keys, (int(v) for v in stats)))
+    out["cam_offset"] = off[:problem.n_cams].copy()
     return out

@@ -15,7 +15,7 @@
 
 namespace xba {
 
-constexpr int kNB = 64;          // tile size
+constexpr int kNB = 64;          // tile size (ba_plan.h: kPlanTile)
 constexpr int kLdT = 66;         // LDS row stride (doubles): conflict-free ds_read_b64 for MFMA operands
 
 struct CholDev {

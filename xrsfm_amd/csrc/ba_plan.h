@@ -1,0 +1,257 @@
+// Host-side plan of the explicit reduced-camera solve (no device calls: testable without a GPU through
+// xrsfm_ba_debug_chol_plan): camera-pair blocks and their scatter destinations, elimination order of the cameras,
+// symbolic factorisation of the 64x64 tile pattern, elimination-tree levels and the per-level work lists.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <utility>
+#include <vector>
+
+#include "ba_pack.h"
+
+namespace xba {
+
+constexpr int kPlanTile = 64;        // tile size (must equal kNB of ba_chol.h)
+constexpr int kCamsPerTile = 10;     // 10 cameras = 60 rows per tile + 4 identity padding rows
+
+struct CholPlan {
+    int n = 0, n_pad = 0, T = 0, n_blocks = 0, n_pairs = 0, n_writes = 0, n_tiles_nz = 0, n_levels = 0;
+    int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring
+    int n_hubs = 0, band = 0;
+    bool use_levels = false;
+    size_t pairs_shm = 0;            // dynamic LDS of k_schur_pairs: staged operands of the largest regular tile
+    std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, one_k, tiles_nz;
+    std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
+    std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_trsm, lv_rptr, lv_rj, lv_bptr, lv_bi;     // level schedule
+    std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;
+};
+
+typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
+
+// Pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a.  `keyed` lists the pairs
+// that WRITE a partial block: every pair of an irregular tile, the pairs of the first track of a regular tile.
+inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& keyed) {
+    const int ns = k.n_slots;
+    spp.assign(ns + 1, 0);
+    {
+        int run = 0;
+        std::vector<int> rest(ns, 0);
+        for (int s = ns - 1; s >= 0; --s) {
+            if (k.slot_cam[s] < 0) { run = 0; rest[s] = 0; continue; }
+            run = (s + 1 < ns && k.slot_cam[s + 1] >= 0 && k.slot_pt[s + 1] == k.slot_pt[s]) ? run + 1 : 0;
+            rest[s] = run;
+        }
+        for (int s = 0; s < ns; ++s) spp[s + 1] = spp[s] + rest[s];
+    }
+    keyed.clear();
+    keyed.reserve(spp[ns]);
+    for (int s = 0; s < ns; ++s) {
+        const int np = spp[s + 1] - spp[s];
+        const int L = k.tile_stride[s / 64];
+        for (int dd = 1; dd <= np; ++dd) {
+            const unsigned long long cb = (unsigned)k.slot_cam[s + dd], ca = (unsigned)k.slot_cam[s];
+            if (cb <= ca) return XRSFM_BA_EINVAL;   // two observations of one track in the same frame
+            if (L == 0 || (s % 64) < L) keyed.push_back({(cb << 32) | ca, spp[s] + dd - 1});
+        }
+    }
+    std::sort(keyed.begin(), keyed.end());
+    return 0;
+}
+
+namespace plan_detail {
+inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<int>& extra, const std::vector<int>& keep,
+                    std::vector<std::vector<int>>& g) {
+    if (hi <= lo) { if (!extra.empty()) g.push_back(extra); return; }
+    int nsep = std::max(1, (cap - (int)extra.size()) / w);
+    while (nsep > 1 && (hi - lo - nsep * w) < (nsep + 1) * leaf / 2) --nsep;
+    if (hi - lo <= leaf + w) {
+        std::vector<int> v;
+        for (int c = lo; c < hi; ++c) v.push_back(keep[c]);
+        g.push_back(v);
+        if (!extra.empty()) g.push_back(extra);
+        return;
+    }
+    const int total = hi - lo - nsep * w, part = total / (nsep + 1), rem = total % (nsep + 1);
+    std::vector<int> seps;
+    int cur = lo;
+    for (int s = 0; s <= nsep; ++s) {
+        const int len = part + (s < rem ? 1 : 0);
+        dissect(cur, cur + len, w, leaf, cap, std::vector<int>(), keep, g);
+        cur += len;
+        if (s < nsep) { for (int c = cur; c < cur + w; ++c) seps.push_back(keep[c]); cur += w; }
+    }
+    seps.insert(seps.end(), extra.begin(), extra.end());
+    g.push_back(seps);
+}
+}  // namespace plan_detail
+
+// `pattern`: union of all ranks' camera pairs (sorted, unique) or nullptr for the local pairs.
+inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const PairKeys& keyed,
+                           const std::vector<unsigned long long>* pattern, CholPlan& P) {
+    const int Nc = k.n_cams, ns = k.n_slots;
+    P = CholPlan();
+    P.spp = spp;
+    P.n = 6 * Nc;
+    P.n_pairs = spp[ns];
+    P.n_writes = (int)keyed.size();
+    std::vector<unsigned long long> blk_keys;
+    if (pattern) blk_keys = *pattern;
+    else
+        for (int i = 0; i < P.n_writes; ++i)
+            if (i == 0 || keyed[i].first != keyed[i - 1].first) blk_keys.push_back(keyed[i].first);
+    P.pair_dst.assign(P.n_pairs, -1);
+    {
+        int i = 0;
+        for (const unsigned long long key : blk_keys) {
+            P.blk_ptr.push_back(i);
+            P.blk_rc.push_back((int)(key >> 32)); P.blk_rc.push_back((int)(key & 0xffffffffu));
+            while (i < P.n_writes && keyed[i].first == key) { P.pair_dst[keyed[i].second] = i; ++i; }
+        }
+        if (i != P.n_writes) return XRSFM_BA_EINVAL;    // a local pair that is missing from the supplied pattern
+        P.blk_ptr.push_back(P.n_writes);
+    }
+    const int n_blocks = P.n_blocks = (int)P.blk_ptr.size() - 1;
+    const std::vector<int>& blk_rc = P.blk_rc;
+
+    // ---- elimination order.  Band width w of the camera graph (circular distance of the camera pairs).  A few
+    // long-range pairs (loop closures, re-observed landmarks) must not destroy the band structure of a sequential
+    // reconstruction: w covers all but 0.5 % of the pairs, the cameras at the ends of the remaining pairs become "hubs"
+    // that are eliminated last (at most max(24, Nc/16) of them, else the natural order is kept); every other dependency they cause is handled exactly by the symbolic factorisation.
+    int w = 0; bool wrap = false;
+    std::vector<char> is_hub(Nc, 0);
+    {
+        std::vector<int> dist(n_blocks);
+        for (int b = 0; b < n_blocks; ++b) {
+            const int dlin = blk_rc[2 * b] - blk_rc[2 * b + 1];
+            dist[b] = std::min(dlin, Nc - dlin);
+        }
+        std::vector<int> sorted_d = dist;
+        std::sort(sorted_d.begin(), sorted_d.end());
+        if (n_blocks > 0) w = sorted_d[(size_t)((n_blocks - 1) * 0.995)];
+        // ... or, on small problems where a handful of closures is more than 0.5 % of the pairs: the smallest band that
+        // leaves at most `cap` hub cameras
+        std::vector<int> reach(Nc, 0);
+        for (int b = 0; b < n_blocks; ++b) {
+            reach[blk_rc[2 * b]] = std::max(reach[blk_rc[2 * b]], dist[b]);
+            reach[blk_rc[2 * b + 1]] = std::max(reach[blk_rc[2 * b + 1]], dist[b]);
+        }
+        std::sort(reach.begin(), reach.end());
+        const int cap = std::max(24, Nc / 16);
+        if (Nc > cap) w = std::min(w, reach[Nc - 1 - cap]);
+        for (int b = 0; b < n_blocks; ++b) {
+            const int dlin = blk_rc[2 * b] - blk_rc[2 * b + 1];
+            if (dist[b] > w) { is_hub[blk_rc[2 * b]] = 1; is_hub[blk_rc[2 * b + 1]] = 1; }
+            else if (dist[b] != dlin) wrap = true;                   // a band pair that closes the ring
+        }
+        for (int c = 0; c < Nc; ++c) P.n_hubs += is_hub[c];
+    }
+    P.band = w;
+    std::vector<std::vector<int>> groups;   // each group starts on a tile boundary
+    if (w >= 1 && 16 * w <= Nc && P.n_hubs <= std::max(24, Nc / 16)) {
+        // multi-way nested dissection of the path/ring: a tree node cuts its range with g separators of w cameras each
+        // that share ONE tile (g*w <= 10 cameras), so the elimination tree has depth log_{g+1} instead of log_2
+        P.ordering = 1;
+        std::vector<int> keep;
+        for (int c = 0; c < Nc; ++c) if (!is_hub[c]) keep.push_back(c);
+        const int nk = (int)keep.size();
+        std::vector<int> root;
+        const int wr = std::min(w, nk);
+        if (wrap) for (int c = 0; c < wr; ++c) root.push_back(keep[c]);   // closes the ring: eliminated with the top separators
+        plan_detail::dissect(wrap ? wr : 0, nk, w, 2 * kCamsPerTile, kCamsPerTile, root, keep, groups);
+        if (P.n_hubs > 0) {
+            std::vector<int> hubs;
+            for (int c = 0; c < Nc; ++c) if (is_hub[c]) hubs.push_back(c);
+            groups.push_back(hubs);
+        }
+    } else {
+        P.n_hubs = 0;
+        std::vector<int> all;
+        for (int c = 0; c < Nc; ++c) all.push_back(c);
+        groups.push_back(all);
+    }
+    P.cam_off.assign(Nc, 0);
+    int T = 0;
+    for (const auto& g : groups) {
+        for (size_t q = 0; q < g.size(); ++q) P.cam_off[g[q]] = kPlanTile * (T + (int)q / kCamsPerTile) + 6 * ((int)q % kCamsPerTile);
+        const int nt = ((int)g.size() + kCamsPerTile - 1) / kCamsPerTile;
+        for (int q = 0; q < nt; ++q) P.tile_rows.push_back(6 * std::min(kCamsPerTile, (int)g.size() - q * kCamsPerTile));
+        T += nt;
+    }
+    if (T == 0) { T = 1; P.tile_rows.push_back(0); }
+    P.T = T; P.n_pad = T * kPlanTile;
+
+    // ---- tile pattern + symbolic factorisation
+    std::vector<char> nz((size_t)T * T, 0);
+    for (int t = 0; t < T; ++t) nz[(size_t)t * T + t] = 1;
+    for (int b = 0; b < n_blocks; ++b) {
+        const int ti = P.cam_off[blk_rc[2 * b]] / kPlanTile, tj = P.cam_off[blk_rc[2 * b + 1]] / kPlanTile;
+        nz[(size_t)std::max(ti, tj) * T + std::min(ti, tj)] = 1;
+    }
+    P.rows_off.assign(T + 1, 0); P.pairs_off.assign(T + 1, 0); P.cols_off.assign(T + 1, 0);
+    for (int kk = 0; kk < T; ++kk) {
+        std::vector<int> R;
+        for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) R.push_back(i);
+        for (int i : R) P.rows_flat.push_back(i);
+        for (size_t a = 0; a < R.size(); ++a)
+            for (size_t b2 = 0; b2 <= a; ++b2) { nz[(size_t)R[a] * T + R[b2]] = 1; P.pairs_flat.push_back(R[a]); P.pairs_flat.push_back(R[b2]); }
+        P.rows_off[kk + 1] = (int)P.rows_flat.size();
+        P.pairs_off[kk + 1] = (int)P.pairs_flat.size() / 2;
+    }
+    for (int kk = 0; kk < T; ++kk) {
+        for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.cols_flat.push_back(j);
+        P.cols_off[kk + 1] = (int)P.cols_flat.size();
+        for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { P.tiles_nz.push_back(kk); P.tiles_nz.push_back(j); }
+    }
+    P.n_tiles_nz = (int)P.tiles_nz.size() / 2;
+
+    // ---- elimination-tree levels of the (filled) tile pattern and the per-level work lists
+    std::vector<int> level(T, 0);
+    int n_levels = 0;
+    for (int kk = 0; kk < T; ++kk) {
+        int lv = 0;
+        for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) lv = std::max(lv, level[j] + 1);
+        level[kk] = lv;
+        n_levels = std::max(n_levels, lv + 1);
+    }
+    P.lv_cptr.assign(1, 0); P.lv_rptr.assign(1, 0); P.lv_bptr.assign(1, 0);
+    P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0); P.lv_trsm_off.assign(n_levels + 1, 0);
+    for (int lv = 0; lv < n_levels; ++lv) {
+        for (int kk = 0; kk < T; ++kk) {
+            if (level[kk] != lv) continue;
+            P.lv_k.push_back(kk);
+            // forward: row tiles j < k; backward: column tiles i > k   (CSR aligned with lv_k)
+            for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.lv_rj.push_back(j);
+            P.lv_rptr.push_back((int)P.lv_rj.size());
+            for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) P.lv_bi.push_back(i);
+            P.lv_bptr.push_back((int)P.lv_bi.size());
+            for (int i = kk; i < T; ++i) {
+                if (!nz[(size_t)i * T + kk]) continue;
+                if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
+                std::vector<int> contrib;
+                for (int j = 0; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
+                if (contrib.empty()) continue;
+                P.lv_tgt.push_back(i); P.lv_tgt.push_back(kk);
+                for (int j : contrib) P.lv_cj.push_back(j);
+                P.lv_cptr.push_back((int)P.lv_cj.size());
+            }
+        }
+        P.lv_k_off[lv + 1] = (int)P.lv_k.size();
+        P.lv_tgt_off[lv + 1] = (int)P.lv_tgt.size() / 2;
+        P.lv_trsm_off[lv + 1] = (int)P.lv_trsm.size() / 2;
+    }
+    P.n_levels = n_levels;
+    P.use_levels = (2 * n_levels <= T);
+    P.one_k.resize(T);
+    for (int t = 0; t < T; ++t) P.one_k[t] = t;
+    for (int t = 0; t < k.n_tiles; ++t) {
+        const int L = k.tile_stride[t];
+        if (L <= 0) continue;
+        int nvalid = 0;
+        for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
+        const int T2 = nvalid / L, Cp = ((3 * T2 + 3) & ~3) + 2;
+        P.pairs_shm = std::max(P.pairs_shm, 2 * (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
+    }
+    return 0;
+}
+
+}  // namespace xba

@@ -25,6 +25,7 @@
 #include "ba_filter.h"
 #include "ba_kernels.h"
 #include "ba_pack.h"
+#include "ba_plan.h"
 
 using namespace xba;
 
@@ -349,43 +350,15 @@ int chol_setup(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     if (h.ready) return 0;
     const Packed& k = c->pk;
-    const int Nc = k.n_cams, ns = k.n_slots;
-    const int n = 6 * Nc;
-    if (n > kCholMaxN) return XRSFM_BA_EINVAL;
-    // pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a
-    std::vector<int> spp(ns + 1, 0);
-    {
-        // length of the run of equal slot_pt starting at s, computed right-to-left
-        int run = 0;
-        std::vector<int> rest(ns, 0);
-        for (int s = ns - 1; s >= 0; --s) {
-            if (k.slot_cam[s] < 0) { run = 0; rest[s] = 0; continue; }
-            run = (s + 1 < ns && k.slot_cam[s + 1] >= 0 && k.slot_pt[s + 1] == k.slot_pt[s]) ? run + 1 : 0;
-            rest[s] = run;
-        }
-        for (int s = 0; s < ns; ++s) spp[s + 1] = spp[s] + rest[s];
-    }
-    const int n_pairs = spp[ns];
-    // block-major destinations: every pair of an irregular tile, the pairs of the first track of a regular tile
-    // (the kernel sums the other tracks of the tile into it)
-    std::vector<std::pair<unsigned long long, int>> keyed;
-    keyed.reserve(n_pairs);
-    for (int s = 0; s < ns; ++s) {
-        const int np = spp[s + 1] - spp[s];
-        const int L = k.tile_stride[s / 64];
-        for (int dd = 1; dd <= np; ++dd) {
-            const unsigned long long cb = (unsigned)k.slot_cam[s + dd], ca = (unsigned)k.slot_cam[s];
-            if (cb <= ca) return XRSFM_BA_EINVAL;   // two observations of one track in the same frame
-            if (L == 0 || (s % 64) < L) keyed.push_back({(cb << 32) | ca, spp[s] + dd - 1});
-        }
-    }
-    const int n_writes = (int)keyed.size();
-    std::sort(keyed.begin(), keyed.end());
-    // block list: the local camera pairs, or (multi-GPU) the union over all ranks so that every rank holds the same
-    // blocks in the same order and the block values can be all-reduced
-    std::vector<unsigned long long> blk_keys;
+    const int Nc = k.n_cams;
+    if (6 * Nc > kCholMaxN) return XRSFM_BA_EINVAL;
+    std::vector<int> spp;
+    PairKeys keyed;
+    int e = chol_local_keys(k, spp, keyed);
+    if (e) return e;
+    // multi-GPU: every rank must hold the same blocks in the same order so that the block values can be all-reduced:
+    // union of the ranks' camera pairs by an all-reduce(max) of an N_c x N_c occupancy map (once per problem)
     if (c->n_ranks > 1 && !c->have_pattern) {
-        // union by an all-reduce(max) of an N_c x N_c occupancy map (once per problem)
         std::vector<double> occ((size_t)Nc * Nc, 0.0);
         for (const auto& kv : keyed) occ[(size_t)(kv.first >> 32) * Nc + (kv.first & 0xffffffffu)] = 1.0;
         double* d_occ = nullptr;
@@ -403,180 +376,35 @@ int chol_setup(xrsfm_ba_context* c) {
                 if (occ[(size_t)rb * Nc + ca] > 0.0) c->pattern_keys.push_back(((unsigned long long)rb << 32) | (unsigned)ca);
         c->have_pattern = true;
     }
-    if (c->have_pattern) {
-        blk_keys = c->pattern_keys;
-    } else {
-        for (int i = 0; i < n_writes; ++i)
-            if (i == 0 || keyed[i].first != keyed[i - 1].first) blk_keys.push_back(keyed[i].first);
-    }
-    std::vector<int> pair_dst(n_pairs, -1), blk_ptr, blk_rc;
-    {
-        int i = 0;
-        for (const unsigned long long key : blk_keys) {
-            blk_ptr.push_back(i);
-            blk_rc.push_back((int)(key >> 32)); blk_rc.push_back((int)(key & 0xffffffffu));
-            while (i < n_writes && keyed[i].first == key) { pair_dst[keyed[i].second] = i; ++i; }
-        }
-        if (i != n_writes) return XRSFM_BA_EINVAL;    // a local pair that is missing from the supplied pattern
-        blk_ptr.push_back(n_writes);
-    }
-    const int n_blocks = (int)blk_ptr.size() - 1;
-    // ---- elimination order of the cameras: 10 cameras per 64-row tile (4 padding rows), groups tile-aligned.
-    // Band / ring structure (sequential SfM): nested dissection of the path so that the elimination tree of the
-    // tiles is shallow; otherwise the natural order.
-    constexpr int kCamsPerTile = 10;
-    int w = 0; bool wrap = false;
-    for (int b = 0; b < n_blocks; ++b) {
-        const int dlin = blk_rc[2 * b] - blk_rc[2 * b + 1];
-        const int dc = std::min(dlin, Nc - dlin);
-        if (dc != dlin) wrap = true;
-        w = std::max(w, dc);
-    }
-    std::vector<std::vector<int>> groups;   // each group starts on a tile boundary
-    h.ordering = 0;
-    if (w >= 1 && 16 * w <= Nc) {
-        // Multi-way nested dissection of the path/ring: a tree node cuts its range with g separators of w cameras each
-        // that share ONE tile (g*w <= 10 cameras), so the elimination tree has depth log_{g+1} instead of log_2.
-        h.ordering = 1;
-        const int leaf = 2 * kCamsPerTile;
-        struct Rec { static void run(int lo, int hi, int w_, int leaf_, int cap, const std::vector<int>& extra, std::vector<std::vector<int>>& g) {
-            if (hi <= lo) { if (!extra.empty()) g.push_back(extra); return; }
-            int nsep = std::max(1, (cap - (int)extra.size()) / w_);
-            while (nsep > 1 && (hi - lo - nsep * w_) < (nsep + 1) * leaf_ / 2) --nsep;
-            if (hi - lo <= leaf_ + w_) {
-                std::vector<int> v; for (int c2 = lo; c2 < hi; ++c2) v.push_back(c2);
-                g.push_back(v);
-                if (!extra.empty()) g.push_back(extra);
-                return;
-            }
-            const int total = hi - lo - nsep * w_, part = total / (nsep + 1), rem = total % (nsep + 1);
-            std::vector<int> seps;
-            int cur = lo;
-            for (int s2 = 0; s2 <= nsep; ++s2) {
-                const int len = part + (s2 < rem ? 1 : 0);
-                run(cur, cur + len, w_, leaf_, cap, std::vector<int>(), g);
-                cur += len;
-                if (s2 < nsep) { for (int c2 = cur; c2 < cur + w_; ++c2) seps.push_back(c2); cur += w_; }
-            }
-            seps.insert(seps.end(), extra.begin(), extra.end());
-            g.push_back(seps);
-        } };
-        std::vector<int> root;
-        if (wrap) for (int c2 = 0; c2 < w; ++c2) root.push_back(c2);     // closes the ring: eliminated last, with the top separators
-        Rec::run(wrap ? w : 0, Nc, w, leaf, kCamsPerTile, root, groups);
-    } else {
-        std::vector<int> all; for (int c2 = 0; c2 < Nc; ++c2) all.push_back(c2);
-        groups.push_back(all);
-    }
-    std::vector<int> cam_off(Nc, 0), tile_rows;
-    int T = 0;
-    for (const auto& g : groups) {
-        for (size_t q = 0; q < g.size(); ++q) cam_off[g[q]] = kNB * (T + (int)q / kCamsPerTile) + 6 * ((int)q % kCamsPerTile);
-        const int nt = ((int)g.size() + kCamsPerTile - 1) / kCamsPerTile;
-        for (int q = 0; q < nt; ++q) tile_rows.push_back(6 * std::min(kCamsPerTile, (int)g.size() - q * kCamsPerTile));
-        T += nt;
-    }
-    if (T == 0) { T = 1; tile_rows.push_back(0); }
-    const int n_pad = T * kNB;
-    h.cam_off_host = cam_off;
-    // ---- tile pattern + symbolic factorisation
-    std::vector<char> nz((size_t)T * T, 0);
-    for (int t = 0; t < T; ++t) nz[(size_t)t * T + t] = 1;
-    for (int b = 0; b < n_blocks; ++b) {
-        const int ti = cam_off[blk_rc[2 * b]] / kNB, tj = cam_off[blk_rc[2 * b + 1]] / kNB;
-        nz[(size_t)std::max(ti, tj) * T + std::min(ti, tj)] = 1;
-    }
-    std::vector<int> rows_flat, pairs_flat;
-    h.rows_off.assign(T + 1, 0); h.pairs_off.assign(T + 1, 0); h.cols_off.assign(T + 1, 0);
-    for (int kk = 0; kk < T; ++kk) {
-        std::vector<int> R;
-        for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) R.push_back(i);
-        for (int i : R) rows_flat.push_back(i);
-        for (size_t a = 0; a < R.size(); ++a)
-            for (size_t b2 = 0; b2 <= a; ++b2) { nz[(size_t)R[a] * T + R[b2]] = 1; pairs_flat.push_back(R[a]); pairs_flat.push_back(R[b2]); }
-        h.rows_off[kk + 1] = (int)rows_flat.size();
-        h.pairs_off[kk + 1] = (int)pairs_flat.size() / 2;
-    }
-    std::vector<int> cols_flat, tiles_nz;
-    for (int kk = 0; kk < T; ++kk) {
-        for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) cols_flat.push_back(j);
-        h.cols_off[kk + 1] = (int)cols_flat.size();
-        for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { tiles_nz.push_back(kk); tiles_nz.push_back(j); }
-    }
-    // ---- elimination-tree levels of the (filled) tile pattern and the per-level work lists
-    std::vector<int> level(T, 0);
-    int n_levels = 0;
-    for (int kk = 0; kk < T; ++kk) {
-        int lv = 0;
-        for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) lv = std::max(lv, level[j] + 1);
-        level[kk] = lv;
-        n_levels = std::max(n_levels, lv + 1);
-    }
-    std::vector<int> lv_k, lv_tgt, lv_cptr(1, 0), lv_cj, lv_trsm, lv_rptr(1, 0), lv_rj, lv_bptr(1, 0), lv_bi;
-    h.lv_k_off.assign(n_levels + 1, 0); h.lv_tgt_off.assign(n_levels + 1, 0); h.lv_trsm_off.assign(n_levels + 1, 0);
-    for (int lv = 0; lv < n_levels; ++lv) {
-        for (int kk = 0; kk < T; ++kk) {
-            if (level[kk] != lv) continue;
-            lv_k.push_back(kk);
-            // forward: row tiles j < k; backward: column tiles i > k   (CSR aligned with lv_k)
-            for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) lv_rj.push_back(j);
-            lv_rptr.push_back((int)lv_rj.size());
-            for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) lv_bi.push_back(i);
-            lv_bptr.push_back((int)lv_bi.size());
-            for (int i = kk; i < T; ++i) {
-                if (!nz[(size_t)i * T + kk]) continue;
-                if (i > kk) { lv_trsm.push_back(i); lv_trsm.push_back(kk); }
-                std::vector<int> contrib;
-                for (int j = 0; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
-                if (contrib.empty()) continue;
-                lv_tgt.push_back(i); lv_tgt.push_back(kk);
-                for (int j : contrib) lv_cj.push_back(j);
-                lv_cptr.push_back((int)lv_cj.size());
-            }
-        }
-        h.lv_k_off[lv + 1] = (int)lv_k.size();
-        h.lv_tgt_off[lv + 1] = (int)lv_tgt.size() / 2;
-        h.lv_trsm_off[lv + 1] = (int)lv_trsm.size() / 2;
-    }
-    h.n_levels = n_levels;
-    h.pairs_shm = 0;
-    for (int t = 0; t < k.n_tiles; ++t) {
-        const int L = k.tile_stride[t];
-        if (L <= 0) continue;
-        int nvalid = 0;
-        for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
-        const int T2 = nvalid / L, Rp = (6 * L + 15) & ~15, Cp = ((3 * T2 + 3) & ~3) + 2;
-        (void)Rp;
-        h.pairs_shm = std::max(h.pairs_shm, 2 * (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
-    }
-    h.use_levels = (2 * n_levels <= T);
-    std::vector<int> one_k(T);
-    for (int t = 0; t < T; ++t) one_k[t] = t;
-    h.n_blocks = n_blocks; h.n_pairs = n_pairs; h.T = T; h.n_tiles_nz = (int)tiles_nz.size() / 2;
-    int e;
+    CholPlan P;
+    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P))) return e;
+    h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
+    h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.cam_off_host = P.cam_off;
+    h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
+    h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
     int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
-    TRYC(dev_upload(c, &h.slot_pair_ptr, spp)); TRYC(dev_upload(c, &h.pair_dst, pair_dst));
-    TRYC(dev_upload(c, &h.blk_ptr, blk_ptr)); TRYC(dev_upload(c, &h.blk_rc, blk_rc));
-    TRYC(dev_upload(c, &h.tiles_nz, tiles_nz)); TRYC(dev_upload(c, &h.rows_flat, rows_flat));
-    TRYC(dev_upload(c, &h.pairs_flat, pairs_flat)); TRYC(dev_upload(c, &h.cols_flat, cols_flat));
-    TRYC(dev_upload(c, &h.lv_k, lv_k)); TRYC(dev_upload(c, &h.lv_tgt, lv_tgt)); TRYC(dev_upload(c, &h.lv_cptr, lv_cptr));
-    TRYC(dev_upload(c, &h.lv_cj, lv_cj)); TRYC(dev_upload(c, &h.lv_trsm, lv_trsm));
-    TRYC(dev_upload(c, &h.lv_rptr, lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, lv_rj));
-    TRYC(dev_upload(c, &h.lv_bptr, lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, lv_bi));
-    TRYC(dev_upload(c, &d_cam_off, cam_off)); TRYC(dev_upload(c, &d_one_k, one_k)); TRYC(dev_upload(c, &d_tile_rows, tile_rows));
-    TRYC(dev_alloc(c, &h.scat2, (size_t)(n_writes > 0 ? n_writes : 1) * 36));
+    TRYC(dev_upload(c, &h.slot_pair_ptr, P.spp)); TRYC(dev_upload(c, &h.pair_dst, P.pair_dst));
+    TRYC(dev_upload(c, &h.blk_ptr, P.blk_ptr)); TRYC(dev_upload(c, &h.blk_rc, P.blk_rc));
+    TRYC(dev_upload(c, &h.tiles_nz, P.tiles_nz)); TRYC(dev_upload(c, &h.rows_flat, P.rows_flat));
+    TRYC(dev_upload(c, &h.pairs_flat, P.pairs_flat)); TRYC(dev_upload(c, &h.cols_flat, P.cols_flat));
+    TRYC(dev_upload(c, &h.lv_k, P.lv_k)); TRYC(dev_upload(c, &h.lv_tgt, P.lv_tgt)); TRYC(dev_upload(c, &h.lv_cptr, P.lv_cptr));
+    TRYC(dev_upload(c, &h.lv_cj, P.lv_cj)); TRYC(dev_upload(c, &h.lv_trsm, P.lv_trsm));
+    TRYC(dev_upload(c, &h.lv_rptr, P.lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, P.lv_rj));
+    TRYC(dev_upload(c, &h.lv_bptr, P.lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, P.lv_bi));
+    TRYC(dev_upload(c, &d_cam_off, P.cam_off)); TRYC(dev_upload(c, &d_one_k, P.one_k)); TRYC(dev_upload(c, &d_tile_rows, P.tile_rows));
+    TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
         double* both = nullptr;
-        TRYC(dev_alloc(c, &both, (size_t)Nc * 28 + (size_t)(n_blocks > 0 ? n_blocks : 1) * 36));
+        TRYC(dev_alloc(c, &both, (size_t)Nc * 28 + (size_t)(P.n_blocks > 0 ? P.n_blocks : 1) * 36));
         c->d.camS = both; h.Sblk = both + (size_t)Nc * 28;
     }
-    h.dev.n = n; h.dev.n_pad = n_pad; h.dev.T = T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
-    TRYC(dev_alloc(c, &h.dev.S, (size_t)n_pad * n_pad));
-    TRYC(dev_alloc(c, &h.dev.Linv, (size_t)T * kNB * kNB));
-    TRYC(dev_alloc(c, &h.dev.y, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)n_pad));
+    h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
+    TRYC(dev_alloc(c, &h.dev.S, (size_t)P.n_pad * P.n_pad));
+    TRYC(dev_alloc(c, &h.dev.Linv, (size_t)P.T * kNB * kNB));
+    TRYC(dev_alloc(c, &h.dev.y, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)P.n_pad));
 #undef TRYC
-    HIPCHK(hipMemset(h.dev.S, 0, sizeof(double) * (size_t)n_pad * n_pad));
+    HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * (size_t)P.n_pad * P.n_pad, c->stream));
     const int shm = 2 * kNB * kLdT * (int)sizeof(double);
     (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
@@ -1163,6 +991,22 @@ int xrsfm_ba_debug_pack(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* sl
     stats[0] = k.n_tiles; stats[1] = k.n_slots; stats[2] = (int32_t)k.items.size() / 2; stats[3] = regular; stats[4] = longs;
     stats[5] = k.n_cam_entries; stats[6] = maxlen; stats[7] = k.n_pts;
     if (slot_obs) for (int s2 = 0; s2 < k.n_slots; ++s2) slot_obs[s2] = k.slot_obs[s2];
+    return 0;
+}
+
+int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* cam_offset) {
+    if (!p || !stats) return XRSFM_BA_EINVAL;
+    Packed k;
+    int e = pack_problem(*p, k);
+    if (e) return e;
+    std::vector<int> spp;
+    PairKeys keyed;
+    if ((e = chol_local_keys(k, spp, keyed))) return e;
+    CholPlan P;
+    if ((e = chol_plan_build(k, spp, keyed, nullptr, P))) return e;
+    stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
+    stats[6] = P.use_levels ? 1 : 0; stats[7] = P.n_tiles_nz;
+    if (cam_offset) for (int i = 0; i < k.n_cams; ++i) cam_offset[i] = P.cam_off[i];
     return 0;
 }
 
