@@ -34,65 +34,71 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 // ------------------------------------------------------------ S assembly
 // Off-diagonal blocks  block(b,a) = sum_tracks W_b Hinv W_a^T  (camera b > camera a of the same track), plus — fused,
-// because they need the same loads and the same W, W*Hinv — the per-observation diagonal-block and reduced-rhs terms
-// (the 28 values k_schur_prep produces on the PCG path), written to the camera-major scatter buffer.
-// One wavefront per tile (64-thread workgroups: the staged operands of a wave live in its own LDS).
-//  * regular tile (T tracks, all with the same L cameras): the lanes stage W and W*Hinv as [6L x 3T] matrices in LDS
-//    and the wave forms G = W (W Hinv)^T with v_mfma_f64_16x16x4_f64: G holds every camera-pair block already summed
-//    over the T tracks, written once per tile;
+// because they need the same loads and the same W — the per-observation diagonal-block and reduced-rhs terms (the 28
+// values k_schur_prep produces on the PCG path), written to the camera-major scatter buffer.
+// With Hinv = C C^T (k_point_prep) every term is a product of V = W C with itself:  W_b Hinv W_a^T = V_b V_a^T.
+// One wavefront per tile (64-thread workgroups: the staged operand of a wave lives in its own LDS; the kernel is
+// latency-bound, so LDS and VGPR footprints are sized for 4 waves per SIMD).
+//  * regular tile (T tracks, all with the same L cameras): the lanes stage V as a [6L x 3T] matrix in LDS and the wave
+//    forms the Gram matrix G = V V^T with v_mfma_f64_16x16x4_f64: G holds every camera-pair block already summed over
+//    the T tracks, written once per tile;
 //  * other tiles: lane = observation a, partner b = a + d in the same track via shfl_down, one block per pair;
 //  * long tracks: lane loops over all later observations of its track.
-__device__ __forceinline__ int pairs_lds_doubles(int L, int T) {   // per operand matrix
-    const int Rp = (6 * L + 15) & ~15, Cp = ((3 * T + 3) & ~3) + 2;
-    return Rp * Cp;
+__device__ __forceinline__ void pairs_V(const double* F, const double* E, const double* __restrict__ hc, double* V) {
+    const double c00 = hc[0], c10 = hc[1], c20 = hc[2], c11 = hc[3], c21 = hc[4], c22 = hc[5];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const double w0 = F[a] * E[0] + F[6 + a] * E[3], w1 = F[a] * E[1] + F[6 + a] * E[4], w2 = F[a] * E[2] + F[6 + a] * E[5];
+        V[3 * a + 0] = w0 * c00 + w1 * c10 + w2 * c20;
+        V[3 * a + 1] = w1 * c11 + w2 * c21;
+        V[3 * a + 2] = w2 * c22;
+    }
 }
 
-__global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr,
-                                                      const int* __restrict__ pair_dst, double* __restrict__ scat2) {
+// diagonal block of S and reduced rhs of one observation:  F^T F - V V^T (upper triangle, 21) | -V C^T g (6) | 0
+__device__ __forceinline__ void pairs_diag(const double* F, const double* V, const double* __restrict__ hc,
+                                           const double* __restrict__ g, double* o28) {
+    int idx = 0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int c2 = a; c2 < 6; ++c2)
+            o28[idx++] = F[a] * F[c2] + F[6 + a] * F[6 + c2]
+                         - (V[3 * a] * V[3 * c2] + V[3 * a + 1] * V[3 * c2 + 1] + V[3 * a + 2] * V[3 * c2 + 2]);
+    const double g0 = g[0], g1 = g[1], g2 = g[2];
+    const double u0 = hc[0] * g0 + hc[1] * g1 + hc[2] * g2, u1 = hc[3] * g1 + hc[4] * g2, u2 = hc[5] * g2;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) o28[21 + a] = -(V[3 * a] * u0 + V[3 * a + 1] * u1 + V[3 * a + 2] * u2);
+    o28[27] = 0.0;
+}
+
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst, double* __restrict__ scat2) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     const int item = blockIdx.x;
     if (item >= d.n_items) return;
     const Item it = d.items[item];
-    const size_t ns = (size_t)d.n_slots;
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
-        double W[18], WH[18], o28[28];
-#pragma unroll
-        for (int k = 0; k < 18; ++k) { W[k] = 0.0; WH[k] = 0.0; }
-#pragma unroll
-        for (int k = 0; k < 28; ++k) o28[k] = 0.0;
-        int npair = 0, pbase = 0;
-        if (s.valid) {
-            double F[12], E[6];
-            load_FE(d, s.slot, s.cam, s.pt, F, E);
-            const double* h = d.Hinv + 6 * (size_t)s.pt;
-            const double h0 = h[0], h1 = h[1], h2 = h[2], h3 = h[3], h4 = h[4], h5 = h[5];
-#pragma unroll
-            for (int a = 0; a < 6; ++a) {
-#pragma unroll
-                for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[6 + a] * E[3 + b];
-                WH[3 * a + 0] = W[3 * a] * h0 + W[3 * a + 1] * h1 + W[3 * a + 2] * h2;
-                WH[3 * a + 1] = W[3 * a] * h1 + W[3 * a + 1] * h3 + W[3 * a + 2] * h4;
-                WH[3 * a + 2] = W[3 * a] * h2 + W[3 * a + 1] * h4 + W[3 * a + 2] * h5;
-            }
-            pbase = slot_pair_ptr[s.slot];
-            npair = slot_pair_ptr[s.slot + 1] - pbase;
-            // diagonal block of S and reduced rhs of this observation (what k_schur_prep computes on the PCG path)
-            const double* g = d.gp + 3 * (size_t)s.pt;
-            const double g0 = g[0], g1 = g[1], g2 = g[2];
-            int idx = 0;
-#pragma unroll
-            for (int a = 0; a < 6; ++a)
-#pragma unroll
-                for (int c2 = a; c2 < 6; ++c2)
-                    o28[idx++] = F[a] * F[c2] + F[6 + a] * F[6 + c2]
-                                 - (WH[3 * a] * W[3 * c2] + WH[3 * a + 1] * W[3 * c2 + 1] + WH[3 * a + 2] * W[3 * c2 + 2]);
-#pragma unroll
-            for (int a = 0; a < 6; ++a) o28[21 + a] = -(WH[3 * a] * g0 + WH[3 * a + 1] * g1 + WH[3 * a + 2] * g2);
-        }
         const int L = d.tile_stride[it.first_tile];
+        double V[18];
+#pragma unroll
+        for (int k = 0; k < 18; ++k) V[k] = 0.0;
+        int npair = 0, pbase = 0;
         {
+            double o28[28];
+#pragma unroll
+            for (int k = 0; k < 28; ++k) o28[k] = 0.0;
+            if (s.valid) {
+                double F[12], E[6];
+                load_FE(d, s.slot, s.cam, s.pt, F, E);
+                const double* hc = d.Hc + 6 * (size_t)s.pt;
+                pairs_V(F, E, hc, V);
+                pbase = slot_pair_ptr[s.slot];
+                npair = slot_pair_ptr[s.slot + 1] - pbase;
+                pairs_diag(F, V, hc, d.gp + 3 * (size_t)s.pt, o28);
+            }
             if (L > 0) strided_reduce<28>(o28, L, lane);
             const int cp = d.slot_campos[s.slot];
             if (cp >= 0) {
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
             const int nvalid = __popcll(__ballot(s.valid));
             const int T = nvalid / L;
             const int R = 6 * L, Rp = (R + 15) & ~15, C4 = (3 * T + 3) & ~3, Cp = C4 + 2;
-            double* Wst = smem; double* Hst = smem + R * Cp;               // only the R rows that hold data are staged
-            int* dtab = reinterpret_cast<int*>(smem + 2 * R * Cp);          // [L][L] destination of block (rb, ra)
+            double* Vst = smem;                                             // only the R rows that hold data are staged
+            int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [L][L] destination of block (rb, ra)
             // destinations of the first track's pairs: issued first so the index loads overlap the staging
             if (lane < L)
                 for (int dd = 1; dd <= npair; ++dd) dtab[lane * L + lane + dd] = pair_dst[pbase + dd - 1];
@@ -114,27 +120,24 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
             const int padc = Cp - 3 * T;
             for (int e = lane; e < R * padc; e += kWave) {
                 const int row = e / padc, cc = 3 * T + (e - row * padc);
-                Wst[row * Cp + cc] = 0.0; Hst[row * Cp + cc] = 0.0;
+                Vst[row * Cp + cc] = 0.0;
             }
             if (s.valid) {
                 const int t = lane / L, r = lane - t * L;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        Wst[(6 * r + i) * Cp + 3 * t + m] = W[3 * i + m];
-                        Hst[(6 * r + i) * Cp + 3 * t + m] = WH[3 * i + m];
-                    }
+                    for (int m = 0; m < 3; ++m) Vst[(6 * r + i) * Cp + 3 * t + m] = V[3 * i + m];
             }
-            __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operands and dtab are in LDS
+            __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand and dtab are in LDS
             __builtin_amdgcn_wave_barrier();
             const int li = lane & 15, lk = lane >> 4;
             const int nI = Rp >> 4;
             for (int I = 0; I < nI; ++I)
                 for (int J = 0; J <= I; ++J) {
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
-                    const double* ap = Wst + min(16 * I + li, R - 1) * Cp + lk;
-                    const double* bp = Hst + min(16 * J + li, R - 1) * Cp + lk;
+                    const double* ap = Vst + min(16 * I + li, R - 1) * Cp + lk;
+                    const double* bp = Vst + min(16 * J + li, R - 1) * Cp + lk;
                     for (int k0 = 0; k0 < C4; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
                     const int col = 16 * J + li;
                     const int ra = col / 6, j = col - 6 * ra;
@@ -151,9 +154,9 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) maxp = max(maxp, __shfl_xor(maxp, off, kWave));
         for (int dd = 1; dd <= maxp; ++dd) {
-            double Wb[18];
+            double Vb[18];
 #pragma unroll
-            for (int k = 0; k < 18; ++k) Wb[k] = __shfl_down(W[k], dd, kWave);
+            for (int k = 0; k < 18; ++k) Vb[k] = __shfl_down(V[k], dd, kWave);
             if (dd <= npair) {
                 double2* out = reinterpret_cast<double2*>(scat2 + 36 * (size_t)pair_dst[pbase + dd - 1]);
 #pragma unroll
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
                     double o[6];
 #pragma unroll
                     for (int ca = 0; ca < 6; ++ca)
-                        o[ca] = Wb[3 * rb] * WH[3 * ca] + Wb[3 * rb + 1] * WH[3 * ca + 1] + Wb[3 * rb + 2] * WH[3 * ca + 2];
+                        o[ca] = Vb[3 * rb] * V[3 * ca] + Vb[3 * rb + 1] * V[3 * ca + 1] + Vb[3 * rb + 2] * V[3 * ca + 2];
                     out[3 * rb + 0] = make_double2(o[0], o[1]);
                     out[3 * rb + 1] = make_double2(o[2], o[3]);
                     out[3 * rb + 2] = make_double2(o[4], o[5]);
@@ -175,41 +178,27 @@ __global__ __launch_bounds__(kWave) void k_schur_pairs(Dev d, const int* __restr
     for (int sa = s_begin + lane; sa < s_end; sa += kWave) {
         if (d.slot_cam[sa] < 0) continue;
         const int pt = d.slot_pt[sa];
-        const double* h = d.Hinv + 6 * (size_t)pt;
-        double Fa[12], Ea[6], WH[18];
-        load_FE(d, sa, d.slot_cam[sa], pt, Fa, Ea);
-        for (int a = 0; a < 6; ++a) {
-            double w[3];
-            for (int b = 0; b < 3; ++b) w[b] = Fa[a] * Ea[b] + Fa[6 + a] * Ea[3 + b];
-            WH[3 * a + 0] = w[0] * h[0] + w[1] * h[1] + w[2] * h[2];
-            WH[3 * a + 1] = w[0] * h[1] + w[1] * h[3] + w[2] * h[4];
-            WH[3 * a + 2] = w[0] * h[2] + w[1] * h[4] + w[2] * h[5];
-        }
-        {   // diagonal block / rhs terms of observation a
-            const double* g = d.gp + 3 * (size_t)pt;
+        const double* hc = d.Hc + 6 * (size_t)pt;
+        double Va[18];
+        {
+            double Fa[12], Ea[6], o28[28];
+            load_FE(d, sa, d.slot_cam[sa], pt, Fa, Ea);
+            pairs_V(Fa, Ea, hc, Va);
+            pairs_diag(Fa, Va, hc, d.gp + 3 * (size_t)pt, o28);
             double* out = d.scat + 28 * (size_t)d.slot_campos[sa];
-            int idx = 0;
-            for (int a = 0; a < 6; ++a)
-                for (int c2 = a; c2 < 6; ++c2) {
-                    double wc[3];
-                    for (int b = 0; b < 3; ++b) wc[b] = Fa[c2] * Ea[b] + Fa[6 + c2] * Ea[3 + b];
-                    out[idx++] = Fa[a] * Fa[c2] + Fa[6 + a] * Fa[6 + c2] - (WH[3 * a] * wc[0] + WH[3 * a + 1] * wc[1] + WH[3 * a + 2] * wc[2]);
-                }
-            for (int a = 0; a < 6; ++a) out[21 + a] = -(WH[3 * a] * g[0] + WH[3 * a + 1] * g[1] + WH[3 * a + 2] * g[2]);
-            out[27] = 0.0;
+            for (int k = 0; k < 28; ++k) out[k] = o28[k];
         }
         const int pbase = slot_pair_ptr[sa];
         const int npair = slot_pair_ptr[sa + 1] - pbase;
         for (int dd = 1; dd <= npair; ++dd) {
             const int sb = sa + dd;
-            double Fb[12], Eb[6];
+            double Fb[12], Eb[6], Vb[18];
             load_FE(d, sb, d.slot_cam[sb], pt, Fb, Eb);
+            pairs_V(Fb, Eb, hc, Vb);
             double* out = scat2 + 36 * (size_t)pair_dst[pbase + dd - 1];
-            for (int rb = 0; rb < 6; ++rb) {
-                double wb[3];
-                for (int m = 0; m < 3; ++m) wb[m] = Fb[rb] * Eb[m] + Fb[6 + rb] * Eb[3 + m];
-                for (int ca = 0; ca < 6; ++ca) out[6 * rb + ca] = wb[0] * WH[3 * ca] + wb[1] * WH[3 * ca + 1] + wb[2] * WH[3 * ca + 2];
-            }
+            for (int rb = 0; rb < 6; ++rb)
+                for (int ca = 0; ca < 6; ++ca)
+                    out[6 * rb + ca] = Vb[3 * rb] * Va[3 * ca] + Vb[3 * rb + 1] * Va[3 * ca + 1] + Vb[3 * rb + 2] * Va[3 * ca + 2];
         }
     }
 }

@@ -64,6 +64,7 @@ struct Dev {
                               // and point (2x3) blocks are rebuilt from it by load_FE() ("compressed J": 64 instead of 160 B/obs)
     CamLin* camrec;           // [Nc] per-camera linearisation record (rotation matrix, scale*mask of the 6 columns)
     double* Hpp; double* gp; double* Hinv;
+    double* Hc;          // [n_pts][6] lower Cholesky factor of Hinv (c00 c10 c20 c11 c21 c22): S assembly uses V = W Hc
     double* camlin;     // [Nc][12]: diag(Hcc) (6), gc (6)
     double* Dc2;        // [Nc][6]
     double* camS;       // [Nc][28]: Scc upper (21), rb (6), pad
@@ -396,6 +397,15 @@ __global__ void k_point_prep(Dev d, double radius, double dmin, double dmax) {
     double* o = d.Hinv + 6 * (size_t)p;
 #pragma unroll
     for (int k = 0; k < 6; ++k) o[k] = inv[k];
+    // Hinv = C C^T (Hinv is SPD: the damped point block is): W Hinv W^T = (W C)(W C)^T, so the S assembly stages ONE
+    // operand matrix for its Gram products
+    const double c00 = sqrt(fmax(inv[0], 0.0)), r0 = c00 > 0.0 ? 1.0 / c00 : 0.0;
+    const double c10 = inv[1] * r0, c20 = inv[2] * r0;
+    const double c11 = sqrt(fmax(inv[3] - c10 * c10, 0.0)), r1 = c11 > 0.0 ? 1.0 / c11 : 0.0;
+    const double c21 = (inv[4] - c20 * c10) * r1;
+    const double c22 = sqrt(fmax(inv[5] - c20 * c20 - c21 * c21, 0.0));
+    double* oc = d.Hc + 6 * (size_t)p;
+    oc[0] = c00; oc[1] = c10; oc[2] = c20; oc[3] = c11; oc[4] = c21; oc[5] = c22;
 }
 
 __global__ void k_cam_prep(Dev d, double radius, double dmin, double dmax) {

@@ -19,7 +19,7 @@ struct CholPlan {
     int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring
     int n_hubs = 0, band = 0;
     bool use_levels = false;
-    size_t pairs_shm = 0;            // dynamic LDS of k_schur_pairs: staged operands of the largest regular tile
+    size_t pairs_shm = 0;            // dynamic LDS of k_schur_pairs: staged operand of the largest regular tile
     std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, one_k, tiles_nz;
     std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
     std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_trsm, lv_rptr, lv_rj, lv_bptr, lv_bi;     // level schedule
@@ -249,7 +249,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         int nvalid = 0;
         for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
         const int T2 = nvalid / L, Cp = ((3 * T2 + 3) & ~3) + 2;
-        P.pairs_shm = std::max(P.pairs_shm, 2 * (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
+        P.pairs_shm = std::max(P.pairs_shm, (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
     }
     return 0;
 }
