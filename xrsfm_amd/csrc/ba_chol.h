@@ -658,6 +658,90 @@ __global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restr
     store_acc_sub(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, acc);
 }
 
+// Thin levels near the root of the elimination tree have few targets with long lists: one workgroup per CHUNK [q0,q1) of a
+// target's list writes its partial sum (a full tile, + for a diagonal target (k,k) the 64 values sum_j L_kj y_j of the
+// forward substitution, formed from the tile that is in LDS anyway) to the workspace Wp; k_ll_update_reduce adds the
+// partials of every target in list order: deterministic, no atomics.
+constexpr int kPartStride = kNB * kNB + kNB;
+
+__global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr,
+                                                        const int* __restrict__ cj, double* __restrict__ Wp) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double yv[kNB];
+    double* As = smem; double* Bs = smem + kNB * kLdT;
+    const int i = tgt[2 * blockIdx.x], k = tgt[2 * blockIdx.x + 1];
+    const bool diag = (i == k);
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int q0 = qr[2 * blockIdx.x], q1 = qr[2 * blockIdx.x + 1];
+    const int t = threadIdx.x, o = t >> 2, part = t & 3;
+    double sv = 0.0;
+    double2 ra[8], rb[8];
+    {
+        const int j = cj[q0];
+        load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
+        load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+    }
+    for (int q = q0; q < q1; ++q) {
+        __syncthreads();                       // the previous product no longer reads LDS
+        store_tile_lds(As, ra);
+        store_tile_lds(Bs, rb);
+        if (diag && t < kNB) yv[t] = c.y[cj[q] * kNB + t];
+        __syncthreads();
+        if (q + 1 < q1) {
+            const int j = cj[q + 1];
+            load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
+            load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+        }
+        if (diag) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) sv += As[o * kLdT + part * 16 + m] * yv[part * 16 + m];
+        }
+        tile_abt_mfma(As, Bs, acc);
+    }
+    double* out = Wp + (size_t)blockIdx.x * kPartStride;
+    {
+        const int lane = t & 63, wave = t >> 6;
+        const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
+                    out[r * kNB + col] = acc[m][n2][g];
+                }
+    }
+    if (diag) {
+        sv += __shfl_xor(sv, 1, kWave);
+        sv += __shfl_xor(sv, 2, kWave);
+        if (part == 0) out[kNB * kNB + o] = sv;
+    }
+}
+
+// grid (targets, 8): 512 tile elements per workgroup
+__global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* __restrict__ rt, const int* __restrict__ rp,
+                                                          const double* __restrict__ Wp) {
+    const int i = rt[2 * blockIdx.x], k = rt[2 * blockIdx.x + 1];
+    const int p0 = rp[2 * blockIdx.x], p1 = rp[2 * blockIdx.x + 1];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = blockIdx.y * 512 + h * 256 + threadIdx.x;
+        double s = 0.0;
+        for (int p = p0; p < p1; ++p) s += Wp[(size_t)p * kPartStride + e];
+        c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] -= s;
+    }
+    if (i == k && blockIdx.y == 0 && threadIdx.x < kNB) {
+        double s = 0.0;
+        for (int p = p0; p < p1; ++p) s += Wp[(size_t)p * kPartStride + kNB * kNB + threadIdx.x];
+        c.rhs[k * kNB + threadIdx.x] -= s;
+    }
+}
+
 // A_ik <- A_ik Linv_k^T for the (i,k) pairs of one level
 __global__ __launch_bounds__(256) void k_ll_trsm(CholDev c, const int* __restrict__ pairs) {
     extern __shared__ __attribute__((aligned(16))) double smem[];

@@ -24,6 +24,12 @@ struct CholPlan {
     std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
     std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_trsm, lv_rptr, lv_rj, lv_bptr, lv_bi;     // level schedule
     std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;
+    // thin upper levels (few targets with long contribution lists): the lists are cut into chunks, one workgroup per
+    // chunk writes a partial tile, a second launch adds the partials of a target in list order
+    std::vector<int> sp_tgt, sp_q;      // per chunk: (i,k) and the [q0,q1) range in lv_cj
+    std::vector<int> sp_rt, sp_rp;      // per split target: (i,k) and its [p0,p1) range of partials (level-relative)
+    std::vector<int> sp_chunk_off, sp_rt_off;   // per level (size n_levels+1)
+    int sp_max_chunks = 0;
 };
 
 typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
@@ -215,15 +221,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     }
     P.lv_cptr.assign(1, 0); P.lv_rptr.assign(1, 0); P.lv_bptr.assign(1, 0);
     P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0); P.lv_trsm_off.assign(n_levels + 1, 0);
+    P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
     for (int lv = 0; lv < n_levels; ++lv) {
         for (int kk = 0; kk < T; ++kk) {
             if (level[kk] != lv) continue;
-            P.lv_k.push_back(kk);
-            // forward: row tiles j < k; backward: column tiles i > k   (CSR aligned with lv_k)
-            for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.lv_rj.push_back(j);
-            P.lv_rptr.push_back((int)P.lv_rj.size());
-            for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) P.lv_bi.push_back(i);
-            P.lv_bptr.push_back((int)P.lv_bi.size());
             for (int i = kk; i < T; ++i) {
                 if (!nz[(size_t)i * T + kk]) continue;
                 if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
@@ -235,9 +236,40 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 P.lv_cptr.push_back((int)P.lv_cj.size());
             }
         }
-        P.lv_k_off[lv + 1] = (int)P.lv_k.size();
         P.lv_tgt_off[lv + 1] = (int)P.lv_tgt.size() / 2;
         P.lv_trsm_off[lv + 1] = (int)P.lv_trsm.size() / 2;
+        // split this level?  (few workgroups, each with a long serial list)
+        const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
+        const int nt = g1 - g0, nc = nt > 0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0;
+        const bool split = nt > 0 && nt <= 128 && nc > 2 * nt;
+        if (split) {
+            const int cs = std::max(1, (nc + 511) / 512);
+            int np = 0;
+            for (int g = g0; g < g1; ++g) {
+                const int p0 = np;
+                for (int q = P.lv_cptr[g]; q < P.lv_cptr[g + 1]; q += cs, ++np) {
+                    P.sp_tgt.push_back(P.lv_tgt[2 * g]); P.sp_tgt.push_back(P.lv_tgt[2 * g + 1]);
+                    P.sp_q.push_back(q); P.sp_q.push_back(std::min(q + cs, P.lv_cptr[g + 1]));
+                }
+                P.sp_rt.push_back(P.lv_tgt[2 * g]); P.sp_rt.push_back(P.lv_tgt[2 * g + 1]);
+                P.sp_rp.push_back(p0); P.sp_rp.push_back(np);
+            }
+            P.sp_max_chunks = std::max(P.sp_max_chunks, np);
+        }
+        P.sp_chunk_off[lv + 1] = (int)P.sp_tgt.size() / 2;
+        P.sp_rt_off[lv + 1] = (int)P.sp_rt.size() / 2;
+        for (int kk = 0; kk < T; ++kk) {
+            if (level[kk] != lv) continue;
+            P.lv_k.push_back(kk);
+            // forward: row tiles j < k (none on a split level: the diagonal target's chunks form L_kj y_j with the tile
+            // they already hold); backward: column tiles i > k   (CSR aligned with lv_k)
+            if (!split)
+                for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.lv_rj.push_back(j);
+            P.lv_rptr.push_back((int)P.lv_rj.size());
+            for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) P.lv_bi.push_back(i);
+            P.lv_bptr.push_back((int)P.lv_bi.size());
+        }
+        P.lv_k_off[lv + 1] = (int)P.lv_k.size();
     }
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);

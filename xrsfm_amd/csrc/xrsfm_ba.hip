@@ -97,6 +97,9 @@ struct CholHost {
     int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr, *lv_trsm = nullptr;
     int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
     std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;      // per level offsets (size n_levels+1)
+    int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
+    std::vector<int> sp_chunk_off, sp_rt_off;
+    double* sp_work = nullptr;
     std::vector<int> cam_off_host;
     int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring
 };
@@ -382,6 +385,7 @@ int chol_setup(xrsfm_ba_context* c) {
     h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
+    h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off;
     int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     TRYC(dev_upload(c, &h.slot_pair_ptr, P.spp)); TRYC(dev_upload(c, &h.pair_dst, P.pair_dst));
@@ -392,6 +396,9 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.lv_cj, P.lv_cj)); TRYC(dev_upload(c, &h.lv_trsm, P.lv_trsm));
     TRYC(dev_upload(c, &h.lv_rptr, P.lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, P.lv_rj));
     TRYC(dev_upload(c, &h.lv_bptr, P.lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, P.lv_bi));
+    TRYC(dev_upload(c, &h.sp_tgt, P.sp_tgt)); TRYC(dev_upload(c, &h.sp_q, P.sp_q));
+    TRYC(dev_upload(c, &h.sp_rt, P.sp_rt)); TRYC(dev_upload(c, &h.sp_rp, P.sp_rp));
+    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
     TRYC(dev_upload(c, &d_cam_off, P.cam_off)); TRYC(dev_upload(c, &d_one_k, P.one_k)); TRYC(dev_upload(c, &d_tile_rows, P.tile_rows));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
@@ -410,6 +417,7 @@ int chol_setup(xrsfm_ba_context* c) {
     (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+    (void)hipFuncSetAttribute((const void*)k_ll_update_part, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.pairs_shm);
     h.ready = true;
     return 0;
@@ -443,7 +451,14 @@ int chol_factor_solve(xrsfm_ba_context* c) {
         // one launch per elimination-tree level and phase
         for (int lv = 0; lv < h.n_levels; ++lv) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
-            if (nt > 0) LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
+            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv];
+            if (nch > 0) {      // thin level: chunks of the contribution lists in parallel, then a fixed-order sum
+                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), shm, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
+                       h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
+                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nt, 8), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
+                       h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
+            } else if (nt > 0)
+                LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
             LAUNCH(c, K_POTRF, k_potrf, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_rptr + h.lv_k_off[lv], h.lv_rj);
             const int ns = h.lv_trsm_off[lv + 1] - h.lv_trsm_off[lv];
