@@ -225,47 +225,54 @@ __global__ __launch_bounds__(kBlock) void k_block_segsum(const double* __restric
     }
 }
 
-__global__ void k_zero_tiles(CholDev c, const int* __restrict__ tiles, int n_tiles) {
-    // tiles: pairs (ti, tj); one workgroup per tile.  Diagonal tiles start as identity so that padding
-    // rows (tile slots without a camera) stay decoupled with a unit pivot.
+// Dense fill, one workgroup per structurally non-zero tile (ti,tj): the tile is composed in LDS — zeros (fill-in), the
+// off-diagonal blocks -Sblk[b] (block (rb > ca) goes to the lower triangle in the elimination order cam_off, transposed if
+// rb is ordered before ca), on diagonal tiles the camera blocks S_cc + D_c^2 and a unit pivot on the padding rows (tile slots
+// without a camera stay decoupled) — and written once.  Diagonal tiles also write their 64 rows of the right-hand side
+// b = g_c + rb in elimination order (padding rows 0).
+__global__ __launch_bounds__(256) void k_tile_fill(CholDev c, Dev d, const int* __restrict__ tiles, const int* __restrict__ tptr,
+                                                   const int* __restrict__ tent, const double* __restrict__ Sblk,
+                                                   const int* __restrict__ blk_rc) {
+    __shared__ double A[kNB][kNB + 1];
+    __shared__ double rl[kNB];
     const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
-    for (int e = threadIdx.x; e < kNB * kNB; e += blockDim.x) {
-        const int r = e / kNB, col = e % kNB;
-        c.S[(size_t)(ti * kNB + r) * c.n_pad + tj * kNB + col] = (ti == tj && r == col) ? 1.0 : 0.0;
+    const int t = threadIdx.x;
+    const int nrows = c.tile_rows[ti];
+    for (int e = t; e < kNB * kNB; e += 256) {
+        const int r = e >> 6, col = e & 63;
+        A[r][col] = (ti == tj && r == col && r >= nrows) ? 1.0 : 0.0;
     }
-}
-
-// Dense fill.  Sblk[b] holds sum W_rb Hinv W_ca^T for the camera pair (rb > ca); it goes to the lower triangle
-// of S in the elimination order (cam_off), transposed if rb is ordered before ca.
-__global__ void k_dense_fill_off(CholDev c, const double* __restrict__ Sblk, const int* __restrict__ blk_rc, int n_blocks) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_blocks * 36) return;
-    const int b = i / 36, e = i % 36;
-    const int orow = c.cam_off[blk_rc[2 * b]], ocol = c.cam_off[blk_rc[2 * b + 1]];
-    const int r = e / 6, col = e % 6;
-    if (orow > ocol) c.S[(size_t)(orow + r) * c.n_pad + ocol + col] = -Sblk[i];
-    else c.S[(size_t)(ocol + col) * c.n_pad + orow + r] = -Sblk[i];
-}
-
-__global__ void k_dense_fill_diag(CholDev c, Dev d) {
-    const int cam = blockIdx.x * blockDim.x + threadIdx.x;
-    if (cam >= d.n_cams) return;
-    const double* S = d.camS + 28 * (size_t)cam;
-    const int o = c.cam_off[cam];
-    int idx = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) {
-            double v = S[idx++];
-            if (a == b) v += d.Dc2[6 * (size_t)cam + a];
-            c.S[(size_t)(o + b) * c.n_pad + o + a] = v;   // lower triangle (a diagonal block never straddles tiles)
+    if (t < kNB) rl[t] = 0.0;
+    __syncthreads();
+    const int q0 = tptr[blockIdx.x], q1 = tptr[blockIdx.x + 1];
+    for (int w = t; w < (q1 - q0) * 36; w += 256) {
+        const int ent = tent[q0 + w / 36], e = w % 36, r = e / 6, col = e % 6;
+        if (ent >= 0) {
+            const int orow = c.cam_off[blk_rc[2 * ent]], ocol = c.cam_off[blk_rc[2 * ent + 1]];
+            const double v = -Sblk[36 * (size_t)ent + e];
+            if (orow > ocol) A[(orow & 63) + r][(ocol & 63) + col] = v;
+            else A[(ocol & 63) + col][(orow & 63) + r] = v;
+        } else {
+            const int cam = -ent - 1, o = c.cam_off[cam] & 63;
+            const double* S = d.camS + 28 * (size_t)cam;
+            if (col >= r) {
+                double v = S[6 * r - r * (r - 1) / 2 + (col - r)];      // packed upper triangle (r, col)
+                if (r == col) v += d.Dc2[6 * (size_t)cam + r];
+                A[o + col][o + r] = v;
+            }
+            if (e < 6) rl[o + e] = d.camlin[12 * (size_t)cam + 6 + e] + S[21 + e];
         }
+    }
+    __syncthreads();
+    double* base = c.S + (size_t)(ti * kNB) * c.n_pad + tj * kNB;
+    for (int e = t; e < kNB * kNB; e += 256) {
+        const int r = e >> 6, col = e & 63;
+        base[(size_t)r * c.n_pad + col] = A[r][col];
+    }
+    if (ti == tj && t < kNB) c.rhs[ti * kNB + t] = rl[t];
 }
 
-// rhs in elimination order (padding rows 0), and the solution back in camera order
-__global__ void k_rhs_scatter(CholDev c, const double* __restrict__ b, int n_cams) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cams * 6) c.rhs[c.cam_off[i / 6] + i % 6] = b[i];
-}
+// the solution back in camera order
 __global__ void k_sol_gather(CholDev c, double* __restrict__ out, int n_cams) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_cams * 6) out[i] = c.x[c.cam_off[i / 6] + i % 6];

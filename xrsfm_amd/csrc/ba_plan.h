@@ -30,6 +30,9 @@ struct CholPlan {
     std::vector<int> sp_rt, sp_rp;      // per split target: (i,k) and its [p0,p1) range of partials (level-relative)
     std::vector<int> sp_chunk_off, sp_rt_off;   // per level (size n_levels+1)
     int sp_max_chunks = 0;
+    // fill lists: per structurally non-zero tile (tiles_nz order) its 6x6 blocks: entry >= 0 off-diagonal block id,
+    // entry < 0 the diagonal block of camera -(entry+1)
+    std::vector<int> tf_ptr, tf_ent;
 };
 
 typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
@@ -209,6 +212,24 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { P.tiles_nz.push_back(kk); P.tiles_nz.push_back(j); }
     }
     P.n_tiles_nz = (int)P.tiles_nz.size() / 2;
+    {
+        std::vector<int> tile_id((size_t)T * T, -1);
+        for (int q = 0; q < P.n_tiles_nz; ++q) tile_id[(size_t)P.tiles_nz[2 * q] * T + P.tiles_nz[2 * q + 1]] = q;
+        std::vector<int> cnt(P.n_tiles_nz + 1, 0);
+        auto tile_of_block = [&](int b) {
+            const int ti = P.cam_off[blk_rc[2 * b]] / kPlanTile, tj = P.cam_off[blk_rc[2 * b + 1]] / kPlanTile;
+            return tile_id[(size_t)std::max(ti, tj) * T + std::min(ti, tj)];
+        };
+        auto tile_of_cam = [&](int c) { const int t = P.cam_off[c] / kPlanTile; return tile_id[(size_t)t * T + t]; };
+        for (int b = 0; b < n_blocks; ++b) cnt[tile_of_block(b) + 1]++;
+        for (int c = 0; c < Nc; ++c) cnt[tile_of_cam(c) + 1]++;
+        for (int q = 0; q < P.n_tiles_nz; ++q) cnt[q + 1] += cnt[q];
+        P.tf_ptr = cnt;
+        P.tf_ent.assign(cnt[P.n_tiles_nz], 0);
+        std::vector<int> fill(cnt.begin(), cnt.end() - 1);
+        for (int c = 0; c < Nc; ++c) P.tf_ent[fill[tile_of_cam(c)]++] = -(c + 1);
+        for (int b = 0; b < n_blocks; ++b) P.tf_ent[fill[tile_of_block(b)]++] = b;
+    }
 
     // ---- elimination-tree levels of the (filled) tile pattern and the per-level work lists
     std::vector<int> level(T, 0);

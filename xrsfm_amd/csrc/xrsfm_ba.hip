@@ -100,6 +100,7 @@ struct CholHost {
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off;
     double* sp_work = nullptr;
+    int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
     int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring
 };
@@ -398,6 +399,7 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.lv_bptr, P.lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, P.lv_bi));
     TRYC(dev_upload(c, &h.sp_tgt, P.sp_tgt)); TRYC(dev_upload(c, &h.sp_q, P.sp_q));
     TRYC(dev_upload(c, &h.sp_rt, P.sp_rt)); TRYC(dev_upload(c, &h.sp_rp, P.sp_rp));
+    TRYC(dev_upload(c, &h.tf_ptr, P.tf_ptr)); TRYC(dev_upload(c, &h.tf_ent, P.tf_ent));
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
     TRYC(dev_upload(c, &d_cam_off, P.cam_off)); TRYC(dev_upload(c, &d_one_k, P.one_k)); TRYC(dev_upload(c, &d_tile_rows, P.tile_rows));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
@@ -432,21 +434,16 @@ int chol_assemble(xrsfm_ba_context* c) {
     if (h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_block_segsum, dim3(h.n_blocks), dim3(kBlock), 0, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_factor, dim3(cdiv(d.n_cams, 64)), dim3(64), 0, d);
-    if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_zero_tiles, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, h.tiles_nz, h.n_tiles_nz);
-    if (h.n_blocks > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_off, dim3(cdiv((long long)h.n_blocks * 36, 256)), dim3(256), 0, h.dev, h.Sblk, h.blk_rc, h.n_blocks);
-    if (d.n_cams > 0) LAUNCH(c, K_DENSE_FILL, k_dense_fill_diag, dim3(cdiv(d.n_cams, 256)), dim3(256), 0, h.dev, d);
+    if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc);
     return 0;
 }
 
-// Factor S = L L^T and solve S x = b; the solution lands in d.px
+// Factor S = L L^T and solve S x = b (S and b from chol_assemble); the solution lands in d.px
 int chol_factor_solve(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
     const int T = h.T;
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
-    LAUNCH(c, K_SMALL, k_zero_vec, dim3(cdiv(h.dev.n_pad, 256)), dim3(256), 0, h.dev.rhs, h.dev.n_pad);
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_rhs_scatter, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.b, d.n_cams);
     if (h.use_levels) {
         // one launch per elimination-tree level and phase
         for (int lv = 0; lv < h.n_levels; ++lv) {
