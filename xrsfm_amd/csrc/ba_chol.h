@@ -203,28 +203,6 @@ void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __re
     }
 }
 
-// Sum the contributions of one block (fixed order): out[block][36]
-__global__ __launch_bounds__(kBlock) void k_block_segsum(const double* __restrict__ scat2, const int* __restrict__ blk_ptr,
-                                                         double* __restrict__ out) {
-    constexpr int K = 36, G = kBlock / K;
-    __shared__ double lds[G * K];
-    const int b = blockIdx.x, t = threadIdx.x;
-    const int beg = blk_ptr[b], n = blk_ptr[b + 1] - beg;
-    if (t < G * K) {
-        const int g = t / K;
-        double acc = 0.0;
-        const double* base = scat2 + (size_t)beg * K + t;
-        for (int o = g; o < n; o += G) { acc += *base; base += (size_t)G * K; }
-        lds[t] = acc;
-    }
-    __syncthreads();
-    if (t < K) {
-        double s = 0.0;
-        for (int g = 0; g < G; ++g) s += lds[g * K + t];
-        out[(size_t)b * K + t] = s;
-    }
-}
-
 // Dense fill, one workgroup per structurally non-zero tile (ti,tj): the tile is composed in LDS — zeros (fill-in), the
 // off-diagonal blocks -Sblk[b] (block (rb > ca) goes to the lower triangle in the elimination order cam_off, transposed if
 // rb is ordered before ca), on diagonal tiles the camera blocks S_cc + D_c^2 and a unit pivot on the padding rows (tile slots

@@ -203,7 +203,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
     const Item it = d.items[item];
     const bool is_long = it.n_tiles > 1;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double cost = 0.0, xn2 = 0.0;
+    double cost = 0.0, xn2 = 0.0, gm = 0.0;
     int long_pt = -1;
     for (int tl = 0; tl < it.n_tiles; ++tl) {
         const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
@@ -278,6 +278,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
                 for (int k = 0; k < 6; ++k) H[k] = v[k];
                 double* g = d.gp + 3 * (size_t)s.pt;
                 g[0] = v[6]; g[1] = v[7]; g[2] = v[8];
+                const double* sp = d.scale_p + 3 * (size_t)s.pt;       // max-norm of the unscaled point gradient
+                gm = fmax(gm, fmax(fabs(v[6] / sp[0]), fmax(fabs(v[7] / sp[1]), fabs(v[8] / sp[2]))));
             }
         } else if (lane == 0) {
 #pragma unroll
@@ -290,10 +292,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
         for (int k = 0; k < 6; ++k) H[k] = acc[k];
         double* g = d.gp + 3 * (size_t)long_pt;
         g[0] = acc[6]; g[1] = acc[7]; g[2] = acc[8];
+        const double* sp = d.scale_p + 3 * (size_t)long_pt;
+        gm = fmax(fabs(acc[6] / sp[0]), fmax(fabs(acc[7] / sp[1]), fabs(acc[8] / sp[2])));
     }
     cost = wave_sum(cost);
     xn2 = wave_sum(xn2);
-    if (lane == 0) { d.part[item] = cost; d.part[d.n_items + item] = xn2; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, kWave));
+    if (lane == 0) { d.part[item] = cost; d.part[d.n_items + item] = xn2; d.part[2 * (size_t)d.n_items + item] = gm; }
 }
 
 // Cost only (1/2 sum rho is formed on the host side of the reduction), candidate state.
@@ -329,14 +335,11 @@ __global__ __launch_bounds__(kBlock) void k_cost(Dev d, double huber_a) {
 // order.  Thread (g,k) accumulates component k over observations g, g+G, ...;
 // the G partials are then added in fixed order.
 template <int K>
-__global__ __launch_bounds__(kBlock) void k_cam_segsum(const double* __restrict__ scat, const int* __restrict__ cam_ptr,
-                                                       double* __restrict__ out, const PcgStatus* st) {
-    if (st && st->done) return;
+__device__ __forceinline__ void segsum_body(const double* __restrict__ scat, const int* __restrict__ ptr, double* __restrict__ out, int c) {
     constexpr int G = kBlock / K;
     __shared__ double lds[G * K];
-    const int c = blockIdx.x;
     const int t = threadIdx.x;
-    const int beg = cam_ptr[c], end = cam_ptr[c + 1];
+    const int beg = ptr[c], end = ptr[c + 1];
     if (t < G * K) {
         const int g = t / K;
         double acc = 0.0;
@@ -352,6 +355,22 @@ __global__ __launch_bounds__(kBlock) void k_cam_segsum(const double* __restrict_
         for (int g = 0; g < G; ++g) s += lds[g * K + t];
         out[(size_t)c * K + t] = s;
     }
+}
+
+template <int K>
+__global__ __launch_bounds__(kBlock) void k_cam_segsum(const double* __restrict__ scat, const int* __restrict__ cam_ptr,
+                                                       double* __restrict__ out, const PcgStatus* st) {
+    if (st && st->done) return;
+    segsum_body<K>(scat, cam_ptr, out, blockIdx.x);
+}
+
+// Cholesky path, one launch: workgroups [0, n_cams) sum the 28 diagonal-block / rhs values of a camera, workgroups
+// [n_cams, n_cams + n_blocks) the 36 values of an off-diagonal block of S (both in list order: deterministic)
+__global__ __launch_bounds__(kBlock) void k_chol_segsum(const double* __restrict__ scat, const int* __restrict__ cam_ptr,
+                                                        double* __restrict__ camS, int n_cams, const double* __restrict__ scat2,
+                                                        const int* __restrict__ blk_ptr, double* __restrict__ Sblk) {
+    if ((int)blockIdx.x < n_cams) segsum_body<28>(scat, cam_ptr, camS, blockIdx.x);
+    else segsum_body<36>(scat2, blk_ptr, Sblk, blockIdx.x - n_cams);
 }
 
 // Diagnostics only: materialise the 2x6 / 2x3 blocks (SoA over slots) the consumers rebuild on the fly.
@@ -385,7 +404,13 @@ __global__ void k_fill(double* p, double v, size_t n) {
 }
 
 // ---------------------------------------------------------------- LM damping + point block inverse
-__global__ void k_point_prep(Dev d, double radius, double dmin, double dmax) {
+// (workgroups >= n_pt_blocks: the LM diagonal of the camera blocks)
+__global__ void k_point_prep(Dev d, double radius, double dmin, double dmax, int n_pt_blocks) {
+    if ((int)blockIdx.x >= n_pt_blocks) {
+        const int i = (blockIdx.x - n_pt_blocks) * blockDim.x + threadIdx.x;
+        if (i < d.n_cams * 6) d.Dc2[i] = clampd(d.camlin[12 * (size_t)(i / 6) + i % 6], dmin, dmax) / radius;
+        return;
+    }
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= d.n_pts) return;
     const double* H = d.Hpp + 6 * (size_t)p;
@@ -407,13 +432,6 @@ __global__ void k_point_prep(Dev d, double radius, double dmin, double dmax) {
     const double c22 = sqrt(fmax(inv[5] - c20 * c20 - c21 * c21, 0.0));
     double* oc = d.Hc + 6 * (size_t)p;
     oc[0] = c00; oc[1] = c10; oc[2] = c20; oc[3] = c11; oc[4] = c21; oc[5] = c22;
-}
-
-__global__ void k_cam_prep(Dev d, double radius, double dmin, double dmax) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= d.n_cams * 6) return;
-    const int c = i / 6, k = i % 6;
-    d.Dc2[i] = clampd(d.camlin[12 * (size_t)c + k], dmin, dmax) / radius;
 }
 
 // Per observation: block-Jacobi diagonal block and reduced right-hand side terms
@@ -842,38 +860,34 @@ __global__ void k_cam_update(Dev d) {
 }
 
 // Ceres' gradient max-norm |x - Plus(x, -g)|_inf with the unscaled gradient.
-__global__ void k_gradmax_cams(Dev d) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.n_cams) return;
-    const unsigned cc = d.cam_const[c];
-    const bool active = d.cam_act[c] > 0.0;
-    const double* g = d.camlin + 12 * (size_t)c + 6;
-    const double* sc = d.scale_c + 6 * (size_t)c;
+__global__ __launch_bounds__(kPcgThreads) void k_gradmax_cams(Dev d, double* __restrict__ out) {     // one workgroup
+    __shared__ double lds[kPcgThreads / kWave];
     double m = 0.0;
-    if (active && !(cc & 1u)) {
-        const CamRec& cur = d.cam[c];
-        const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
-        const double dl[3] = {-g[0] / sc[0], -g[1] / sc[1], -g[2] / sc[2]};
-        double qn[4];
-        quat_plus(q, dl, qn);
-        for (int k = 0; k < 4; ++k) m = fmax(m, fabs(q[k] - qn[k]));
+    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
+        const unsigned cc = d.cam_const[c];
+        const bool active = d.cam_act[c] > 0.0;
+        const double* g = d.camlin + 12 * (size_t)c + 6;
+        const double* sc = d.scale_c + 6 * (size_t)c;
+        if (active && !(cc & 1u)) {
+            const CamRec& cur = d.cam[c];
+            const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
+            const double dl[3] = {-g[0] / sc[0], -g[1] / sc[1], -g[2] / sc[2]};
+            double qn[4];
+            quat_plus(q, dl, qn);
+            for (int k = 0; k < 4; ++k) m = fmax(m, fabs(q[k] - qn[k]));
+        }
+        if (active && !(cc & 2u))
+            for (int k = 0; k < 3; ++k) m = fmax(m, fabs(g[3 + k] / sc[3 + k]));
     }
-    if (active && !(cc & 2u))
-        for (int k = 0; k < 3; ++k) m = fmax(m, fabs(g[3 + k] / sc[3 + k]));
-    d.campart[c] = m;
-}
-
-__global__ __launch_bounds__(kBlock) void k_gradmax_pts(Dev d, double* __restrict__ blockmax) {
-    __shared__ double lds[kWavesPerBlock];
-    const int p = blockIdx.x * blockDim.x + threadIdx.x;
-    double m = 0.0;
-    if (p < d.n_pts && !d.pt_const[p])
-        for (int k = 0; k < 3; ++k) m = fmax(m, fabs(d.gp[3 * (size_t)p + k] / d.scale_p[3 * (size_t)p + k]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) blockmax[blockIdx.x] = fmax(fmax(lds[0], lds[1]), fmax(lds[2], lds[3]));
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int i = 0; i < kPcgThreads / kWave; ++i) r = fmax(r, lds[i]);
+        *out = r;
+    }
 }
 
 // Up to 8 independent reductions in one launch (one workgroup each); op 0 = sum, 1 = max.

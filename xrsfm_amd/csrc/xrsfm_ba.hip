@@ -278,25 +278,25 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
         ReduceJobs j{};
         j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = tail; j.op[0] = 0;
         j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = tail + 1; j.op[1] = 0;
-        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(2), dim3(kPcgThreads), 0, j);
-        int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2, kNcclSum);
-        if (e) return e;
-        HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST, S_XNORM2_PTS adjacent
+        j.in[2] = d.part + 2 * (size_t)d.n_items; j.n[2] = d.n_items; j.out[2] = d.scal + S_GRADMAX_PTS; j.op[2] = 1;   // points are rank-local
+        if (!c->comm) {     // single rank: the sums go straight to the scalar block as well
+            j.in[3] = j.in[0]; j.n[3] = j.n[0]; j.out[3] = d.scal + S_COST; j.op[3] = 0;
+            j.in[4] = j.in[1]; j.n[4] = j.n[1]; j.out[4] = d.scal + S_XNORM2_PTS; j.op[4] = 0;
+        }
+        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(c->comm ? 3 : 5), dim3(kPcgThreads), 0, j);
+        if (c->comm) {
+            int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2, kNcclSum);
+            if (e) return e;
+            HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST, S_XNORM2_PTS adjacent
+        }
     }
     return 0;
 }
 
+// after linearize(), which leaves the point part in S_GRADMAX_PTS
 int gradient_max(xrsfm_ba_context* c, double* out) {
     Dev& d = c->d;
-    const int nb = cdiv(d.n_pts, kBlock);
-    if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_gradmax_pts, dim3(nb), dim3(kBlock), 0, d, d.ptpart);
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
-    {
-        ReduceJobs j{};
-        j.in[0] = d.ptpart; j.n[0] = d.n_pts > 0 ? nb : 0; j.out[0] = d.scal + S_GRADMAX_PTS; j.op[0] = 1;
-        j.in[1] = d.campart; j.n[1] = d.n_cams; j.out[1] = d.scal + S_GRADMAX_CAMS; j.op[1] = 1;
-        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(2), dim3(kPcgThreads), 0, j);
-    }
+    LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, d.scal + S_GRADMAX_CAMS);
     int e = allreduce(c, d.scal + S_GRADMAX_PTS, 1, kNcclMax);
     if (e) return e;
     e = fetch_scalars(c);
@@ -309,8 +309,10 @@ int gradient_max(xrsfm_ba_context* c, double* out) {
 int prepare_step(xrsfm_ba_context* c, double radius, bool with_blocks = false) {
     Dev& d = c->d;
     const double dmin = 1e-6, dmax = 1e32;
-    if (d.n_pts > 0) LAUNCH(c, K_SMALL, k_point_prep, dim3(cdiv(d.n_pts, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_prep, dim3(cdiv((long long)d.n_cams * 6, kBlock)), dim3(kBlock), 0, d, radius, dmin, dmax);
+    {
+        const int nbp = cdiv(d.n_pts, kBlock), nbc = cdiv((long long)d.n_cams * 6, kBlock);
+        if (nbp + nbc > 0) LAUNCH(c, K_SMALL, k_point_prep, dim3(nbp + nbc), dim3(kBlock), 0, d, radius, dmin, dmax, nbp);
+    }
     if (with_blocks) return 0;      // Cholesky path: k_schur_pairs also produces the diagonal blocks / rhs (chol_assemble)
     if (d.n_slots > 0) LAUNCH(c, K_SCHUR_PREP, k_schur_prep, dim3(cdiv(d.n_slots, kBlock)), dim3(kBlock), 0, d);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, (const PcgStatus*)nullptr);
@@ -430,8 +432,7 @@ int chol_assemble(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
     if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(d.n_items), dim3(kWave), h.pairs_shm, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
-    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<28>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, (const PcgStatus*)nullptr);
-    if (h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_block_segsum, dim3(h.n_blocks), dim3(kBlock), 0, h.scat2, h.blk_ptr, h.Sblk);
+    if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
     if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc);
