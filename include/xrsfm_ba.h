@@ -146,6 +146,21 @@ void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
  * the call that replaces ceres::Solve(options, &problem, &summary). */
 int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm_ba_summary *summary);
 
+/* Pose-only refinement of one frame against fixed 3-D points: the "pose estimate [refine]" block of RegisterImage
+ * (/root/reference/src/geometry/pnp.cc:38-71): one ReProjectionCost + HuberLoss(5.99) per inlier correspondence, points
+ * and intrinsics constant, EigenQuaternionParameterization on q, ceres::Solver::Options defaults with
+ * max_num_iterations = 10.  xrsfm_ba_refine_pose_options fills exactly those settings (function_tolerance 1e-6,
+ * parameter_tolerance 1e-8, gradient_tolerance 1e-10, initial radius 1e4).
+ *   model, intr_params[8]   camera model id 0..4 and its parameters (unused tail ignored)
+ *   points3d [n][3], uv [n][2], inlier_mask [n] (NULL = all inliers; only non-zero entries enter, like pnp.cc:43-45)
+ *   q[4] (x,y,z,w), t[3]    in: the RANSAC pose; out: the refined pose
+ * summary->initial_cost / final_cost with num_residuals give the two "[px]" values the reference prints (pnp.cc:63-70).
+ * Runs the same device LM path as xrsfm_ba_solve (a one-camera problem whose Schur complement is the 6x6 normal matrix). */
+void xrsfm_ba_refine_pose_options(xrsfm_ba_options *opt);
+int xrsfm_ba_refine_pose(const xrsfm_ba_options *opt, int32_t model, const double *intr_params, int32_t n,
+                         const double *points3d, const double *uv, const uint8_t *inlier_mask, double *q, double *t,
+                         xrsfm_ba_summary *summary);
+
 /* Post-BA track filter on the same flat arrays (Point3dProcessor::FilterPoints3d,
  * /root/reference/src/geometry/track_processor.cc:280-332, called after every KGBA at incremental_mapper.cc:83-85).
  * The problem here is the whole map: every registered frame and every observation of every non-outlier track.

@@ -37,6 +37,11 @@ def case(name, arr, opt):
 
 
 def main():
+    only = sys.argv[1:]     # optional: names of the cases to (re)generate
+    global case
+    if only:
+        _case = case
+        case = lambda name, arr, opt: _case(name, arr, opt) if name in only else None   # noqa: E731
     # GBA accurate (ba_solver.cc:626-629), KITTI SIMPLE_RADIAL intrinsics
     case("gba_kitti", H.make(6, 60, 4, seed=100), bo.Options())
     # all five camera models of camera_model.hpp, one per camera (cycled)
@@ -56,6 +61,9 @@ def main():
     # structure-only GBA(map, true, true) (ba_solver.cc:616-621)
     arr = H.make(6, 60, 4, seed=105); arr["cam_const"][:] = 3
     case("structure_only", arr, bo.Options())
+    # pose-only refinement of RegisterImage (pnp.cc:38-71): one camera, every point constant, Ceres defaults, 10 iterations
+    case("pose_refine", H.make_pose_problem(150, seed=106, model=2),
+         bo.Options(max_iterations=10, function_tolerance=1e-6, parameter_tolerance=1e-8))
 
 
 if __name__ == "__main__":

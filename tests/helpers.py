@@ -44,3 +44,36 @@ def with_models(arr, seed=0):
 def rel_err(a, b):
     a = np.asarray(a); b = np.asarray(b)
     return float(np.abs(a - b).max() / max(1e-300, np.abs(b).max()))
+
+
+def make_pose_problem(n=200, seed=0, model=2, outlier_frac=0.1, noise=0.5):
+    """One frame against fixed 3-D points: the input of the reference's pose refinement (pnp.cc:38-71).  Returns the flat
+    problem dict (one camera, every point constant) with a perturbed initial pose."""
+    rng = np.random.default_rng(seed)
+    f, cx, cy = 718.856, 607.1928, 185.27157
+    prm = {0: [f / 2, cx, cy], 1: [f / 2, f / 2, cx, cy], 2: [f, cx, cy, -0.01], 3: [f, f, cx, cy, 0.01],
+           4: [f, f, cx, cy, 0.01, -0.005, 1e-4, -2e-4]}[model]
+    intr = np.zeros((1, 8)); intr[0, :len(prm)] = prm
+    axis = rng.normal(size=3); axis /= np.linalg.norm(axis)
+    ang = 0.4
+    q_true = np.concatenate([np.sin(ang / 2) * axis, [np.cos(ang / 2)]])
+    t_true = rng.normal(0, 1.0, 3)
+    R = bo.rotation_from_quat(q_true[None])[0]
+    # points in front of the camera: sample in the camera frame, move to the world frame
+    pc = np.stack([rng.uniform(-8, 8, n), rng.uniform(-2.5, 2.5, n), rng.uniform(8, 40, n)], 1)
+    pw = (pc - t_true) @ R          # R^T (pc - t)
+    arr = dict(cam_q=q_true[None].copy(), cam_t=t_true[None].copy(), cam_const=np.zeros(1, np.uint8), cam_intr=np.zeros(1, np.int32),
+               intr_model=np.array([model], np.int32), intr_params=intr, points=pw, point_const=np.ones(n, np.uint8),
+               obs_cam=np.zeros(n, np.int32), obs_pt=np.arange(n, dtype=np.int32), obs_uv=np.zeros((n, 2)))
+    r0, _ = bo.project(to_oracle(arr), want_jac=False)       # residual = uv_est - uv with uv = 0  ->  uv_est
+    uv = r0 + rng.normal(0, noise, (n, 2))
+    bad = rng.random(n) < outlier_frac
+    uv[bad] += rng.uniform(-40, 40, (int(bad.sum()), 2))
+    arr["obs_uv"] = uv
+    # RANSAC-quality initial pose
+    dq = np.concatenate([rng.normal(0, 0.01, 3), [1.0]]); dq /= np.linalg.norm(dq)
+    x1, y1, z1, w1 = dq; x2, y2, z2, w2 = q_true
+    arr["cam_q"] = np.array([[w1 * x2 + x1 * w2 + y1 * z2 - z1 * y2, w1 * y2 - x1 * z2 + y1 * w2 + z1 * x2,
+                              w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2]])
+    arr["cam_t"] = (t_true + rng.normal(0, 0.05, 3))[None]
+    return arr

@@ -1,5 +1,5 @@
 // Test driver for the adapter: builds a xrsfm::Map (shim types) from a flat problem dump, calls BASolver, dumps the Map.
-// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba> [frame_id]
+// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba|refine> [frame_id]
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -39,15 +39,26 @@ int main(int argc, char **argv) {
     for (auto &fr : map.frames_) { fr.points.push_back(xrsfm::vector2()); fr.track_ids_.push_back(-1); }
     map.init_id1 = 0; map.init_id2 = 1;
     xrsfm::BASolver solver;
+    int refine_status = 0;
     const std::string mode = argv[3];
     if (mode == "gba") solver.GBA(map);
     else if (mode == "gba_fast") solver.GBA(map, false);
     else if (mode == "structure") solver.GBA(map, true, true);
     else if (mode == "kgba") solver.KGBA(map, {3}, true);
     else if (mode == "lba") solver.LBA(argc > 4 ? atoi(argv[4]) : nc - 1, map);
+    else if (mode == "refine") {
+        // RegisterImage's refinement on frame 0: correspondences = its tracked features, every 7th one a RANSAC outlier
+        auto &fr = map.frames_[0];
+        std::vector<xrsfm::vector3> p3; std::vector<std::pair<int, int>> ids; std::vector<char> inl;
+        for (size_t i = 0; i < fr.track_ids_.size(); ++i) {
+            if (fr.track_ids_[i] == -1) continue;
+            p3.push_back(map.tracks_[fr.track_ids_[i]].point3d_); ids.push_back({(int)i, fr.track_ids_[i]}); inl.push_back(ids.size() % 7 != 0);
+        }
+        refine_status = xrsfm::RefineFramePose(fr, map.Camera(fr.camera_id), p3, ids, inl);
+    }
     else return 2;
     FILE *o = fopen(argv[2], "wb");
-    int32_t st = solver.last_status();
+    int32_t st = mode == "refine" ? refine_status : solver.last_status();
     fwrite(&st, 4, 1, o);
     for (auto &fr : map.frames_) { fwrite(fr.Tcw.q.coeffs().data(), 8, 4, o); fwrite(fr.Tcw.t.data(), 8, 3, o); }
     for (auto &tr : map.tracks_) fwrite(tr.point3d_.data(), 8, 3, o);

@@ -115,3 +115,19 @@ def test_adapter_equals_direct_c_abi(exe, tmp_path, mode):
     assert np.array_equal(q[others], arr["cam_q"][others])            # frames outside the problem are untouched
     if mode in ("gba", "kgba"):
         assert "Residuals : " in out and "Termination : " in out and f"{2 * sub['obs_cam'].shape[0]}" in out
+
+
+@pytest.mark.gpu
+def test_adapter_refine_pose_equals_c_abi(exe, tmp_path):
+    """RefineFramePose (compat header; replaces the Ceres block of pnp.cc:38-71) = xrsfm_ba_refine_pose on the same inliers."""
+    from xrsfm_amd import capi
+    arr = H.make_pose_problem(120, seed=77, model=2)
+    status, q, t, P, out, err = _run(exe, arr, tmp_path, "refine")
+    assert status == 0, err
+    mask = (np.arange(1, 121) % 7 != 0).astype(np.uint8)
+    q2, t2, s = capi.refine_pose(2, arr["intr_params"][0], arr["points"], arr["obs_uv"], arr["cam_q"][0], arr["cam_t"][0], inlier_mask=mask)
+    assert np.array_equal(q[0], q2) and np.array_equal(t[0], t2)
+    assert np.array_equal(P, arr["points"])                     # points are constant
+    m = re.search(r"Initial cost : ([0-9.eE+-]+) \[px\]\nFinal cost : ([0-9.eE+-]+) \[px\]", out)
+    assert m, out
+    assert abs(float(m.group(2)) - np.sqrt(s.final_cost / s.num_residuals)) < 1e-4 * max(1.0, float(m.group(2)))

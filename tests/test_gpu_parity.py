@@ -457,3 +457,41 @@ def test_band_with_loop_closures(lib):
     n_res = 2 * arr["obs_cam"].shape[0]
     assert (s2.n_successful, s2.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
     assert abs(math.sqrt(s2.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4])
+def test_refine_pose_matches_oracle(lib, model):
+    """xrsfm_ba_refine_pose (RegisterImage's refinement, pnp.cc:38-71) against the oracle on the same one-camera problem;
+    correspondences masked out by the inlier mask must not enter (pnp.cc:43-45)."""
+    from xrsfm_amd import capi
+    arr = H.make_pose_problem(180, seed=300 + model, model=model)
+    rng = np.random.default_rng(model)
+    mask = (rng.random(180) < 0.85).astype(np.uint8)
+    keep = np.nonzero(mask)[0]
+    sub = dict(arr)
+    sub["points"] = arr["points"][keep]; sub["point_const"] = arr["point_const"][keep]
+    sub["obs_cam"] = arr["obs_cam"][keep]; sub["obs_pt"] = np.arange(keep.size, dtype=np.int32); sub["obs_uv"] = arr["obs_uv"][keep]
+    pr = H.to_oracle(sub)
+    s_ref = bo.solve(pr, bo.Options(max_iterations=10, function_tolerance=1e-6, parameter_tolerance=1e-8))
+    q, t, s = capi.refine_pose(model, arr["intr_params"][0], arr["points"], arr["obs_uv"], arr["cam_q"][0], arr["cam_t"][0], inlier_mask=mask)
+    assert s.num_residuals == 2 * keep.size and s.num_effective_params == 6
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(s.initial_cost - s_ref.initial_cost) <= 1e-9 * s_ref.initial_cost
+    n_res = 2 * keep.size
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert np.abs(q - pr.cam_q[0]).max() < 1e-5 and np.abs(t - pr.cam_t[0]).max() < 1e-5
+    # the refinement must have moved the pose towards a lower cost
+    assert s.final_cost < s.initial_cost
+
+
+@pytest.mark.gpu
+def test_refine_pose_edge_cases(lib):
+    from xrsfm_amd import capi
+    arr = H.make_pose_problem(40, seed=9, model=2)
+    # nothing selected: no residuals, pose untouched, CONVERGENCE by the gradient test like an empty Ceres problem
+    q, t, s = capi.refine_pose(2, arr["intr_params"][0], arr["points"], arr["obs_uv"], arr["cam_q"][0], arr["cam_t"][0],
+                               inlier_mask=np.zeros(40, np.uint8))
+    assert s.num_residuals == 0 and np.array_equal(q, arr["cam_q"][0]) and np.array_equal(t, arr["cam_t"][0])
+    with pytest.raises(Exception):
+        capi.refine_pose(7, arr["intr_params"][0], arr["points"], arr["obs_uv"], arr["cam_q"][0], arr["cam_t"][0])

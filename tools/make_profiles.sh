@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collect the round's judged measurements on the GPU box (run through gpurun from the repo root):
+#   gpurun --timeout 1500 -- 'bash tools/make_profiles.sh r01'
+# Outputs land in gpurun_out/prof_<tag>/; tools/finish_profiles.sh <tag> turns them into profiles/*.md afterwards.
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+# 1. kernel trace + stats of the default bench command (no CPU leg: it would only add host time)
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py --config L --no-cpu --steps 2 > $OUT/stats_bench.log 2>&1
+# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (counters only, with --kernel-trace)
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python $ROOT/bench.py --config L --no-cpu --steps 1 --warmup 0 > $OUT/fetch_bench.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python $ROOT/bench.py --config L --no-cpu --steps 1 --warmup 0 > $OUT/write_bench.log 2>&1
+# 3. summaries while the databases are at hand (the .db files are too big to bring back)
+python $ROOT/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats_table.md > /dev/null
+python $ROOT/tools/pmc_summary.py $(find $OUT/fetch -name "*.db" | head -1) $(find $OUT/write -name "*.db" | head -1) $OUT/pmc_table.md $OUT/pmc_traffic_L.json > /dev/null
+tail -1 $OUT/stats_bench.log > $OUT/stats_bench_line.json
+rm -rf $OUT/stats $OUT/fetch $OUT/write
+# 4. bench lines with the CPU leg
+cd $ROOT
+for cfg in L S K; do
+  python bench.py --config $cfg --steps 5 --warmup 2 2> $OUT/bench_$cfg.err | tail -1 > $OUT/bench_$cfg.json
+done
+nproc > $OUT/nproc.txt
+ls -la $OUT

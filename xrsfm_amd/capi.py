@@ -57,7 +57,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -101,6 +101,11 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
+    lib.xrsfm_ba_refine_pose_options.argtypes = [C.POINTER(COptions)]
+    lib.xrsfm_ba_refine_pose_options.restype = None
+    lib.xrsfm_ba_refine_pose.argtypes = [C.POINTER(COptions), C.c_int32, _c_double_p, C.c_int32, _c_double_p, _c_double_p, _c_uint8_p,
+                                         _c_double_p, _c_double_p, C.POINTER(CSummary)]
+    lib.xrsfm_ba_refine_pose.restype = C.c_int
     lib.xrsfm_ba_debug_chol_plan.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
     lib.xrsfm_ba_debug_chol_plan.restype = C.c_int
     lib.xrsfm_ba_debug_pack.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
@@ -308,3 +313,25 @@ def debug_chol_plan(problem: ProblemArrays) -> dict:
     out = dict(zip(keys, (int(v) for v in stats)))
     out["cam_offset"] = off[:problem.n_cams].copy()
     return out
+
+
+def refine_pose_options(**overrides) -> "COptions":
+    """Settings of the reference's pose refinement (pnp.cc:57-60): Ceres defaults, 10 iterations."""
+    o = COptions()
+    load().xrsfm_ba_refine_pose_options(C.byref(o))
+    for k, v in overrides.items():
+        setattr(o, k, v)
+    return o
+
+
+def refine_pose(model: int, intr_params, points3d, uv, q, t, inlier_mask=None, options=None):
+    """xrsfm_ba_refine_pose: returns (q, t, summary); inputs are not modified."""
+    prm = np.zeros(8); prm[:len(intr_params)] = np.asarray(intr_params, float)[:8]
+    P = np.ascontiguousarray(points3d, float).reshape(-1, 3); UV = np.ascontiguousarray(uv, float).reshape(-1, 2)
+    q = np.array(q, float).reshape(4).copy(); t = np.array(t, float).reshape(3).copy()
+    mask = None if inlier_mask is None else np.ascontiguousarray(inlier_mask, np.uint8)
+    s = CSummary()
+    check(load().xrsfm_ba_refine_pose(C.byref(options) if options is not None else None, int(model), _dp(prm), P.shape[0], _dp(P), _dp(UV),
+                                      mask.ctypes.data_as(_c_uint8_p) if mask is not None else None, _dp(q), _dp(t), C.byref(s)),
+          "xrsfm_ba_refine_pose")
+    return q, t, s

@@ -305,4 +305,34 @@ void BASolver::LBA(int frame_id, Map &map) {
     last_status_ = problem.Solve(opt, &summary);   // the reference prints nothing for LBA (:586-591)
 }
 
+int RefineFramePose(Frame &frame, const Camera &camera, const std::vector<vector3> &points3ds,
+                    const std::vector<std::pair<int, int>> &id_pair_vec, const std::vector<char> &inlier_mask) {
+    const size_t n = inlier_mask.size();          // the reference loops over inlier_mask (pnp.cc:43)
+    std::vector<double> P(3 * n), uv(2 * n);
+    std::vector<uint8_t> mask(n);
+    for (size_t id = 0; id < n; ++id) {
+        mask[id] = inlier_mask[id] ? 1 : 0;
+        const vector2 &p2d = frame.points[id_pair_vec[id].first];
+        for (int k = 0; k < 3; ++k) P[3 * id + k] = points3ds[id].data()[k];
+        uv[2 * id] = p2d.data()[0]; uv[2 * id + 1] = p2d.data()[1];
+    }
+    double prm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (size_t k = 0; k < camera.params_.size() && k < 8; ++k) prm[k] = camera.params_[k];
+    double q[4], t[3];
+    for (int k = 0; k < 4; ++k) q[k] = frame.Tcw.q.coeffs().data()[k];
+    for (int k = 0; k < 3; ++k) t[k] = frame.Tcw.t.data()[k];
+    xrsfm_ba_summary s;
+    const int e = xrsfm_ba_refine_pose(nullptr, static_cast<int32_t>(camera.model_id_), prm, static_cast<int32_t>(n), P.data(), uv.data(),
+                                       mask.data(), q, t, &s);
+    if (e != XRSFM_BA_OK) {
+        fprintf(stderr, "[xrsfm_ba] pose refinement failed with code %d; pose left unchanged\n", e);
+        return e;
+    }
+    for (int k = 0; k < 4; ++k) frame.Tcw.q.coeffs().data()[k] = q[k];
+    for (int k = 0; k < 3; ++k) frame.Tcw.t.data()[k] = t[k];
+    std::cout << "Initial cost : " << std::setprecision(6) << std::sqrt(s.initial_cost / s.num_residuals) << " [px]" << std::endl;
+    std::cout << "Final cost : " << std::setprecision(6) << std::sqrt(s.final_cost / s.num_residuals) << " [px]" << std::endl;
+    return e;
+}
+
 } // namespace xrsfm

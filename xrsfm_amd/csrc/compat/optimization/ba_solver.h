@@ -10,11 +10,20 @@
 #ifndef XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
 #define XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
 
+#include <utility>
 #include <vector>
 
 #include "base/map.h"
 
 namespace xrsfm {
+// The "pose estimate [refine]" block of RegisterImage (/root/reference/src/geometry/pnp.cc:38-71) without Ceres: refines
+// frame.Tcw against the inlier 2D-3D correspondences (frame.points[p2d_id] <-> points3ds[id], id_pair_vec[id] = (p2d_id,
+// track_id), inlier_mask from SolvePnP_colmap) on the GPU, prints the same two "[px]" lines.  pnp.cc includes this header
+// already; the block there becomes the single call  RefineFramePose(frame, camera, points3ds, id_pair_vec, inlier_mask);
+// Returns 0 or a negative XRSFM_BA_E* code (the pose is left untouched on error).
+int RefineFramePose(Frame &frame, const Camera &camera, const std::vector<vector3> &points3ds,
+                    const std::vector<std::pair<int, int>> &id_pair_vec, const std::vector<char> &inlier_mask);
+
 class BASolver {
   public:
     BASolver() {}

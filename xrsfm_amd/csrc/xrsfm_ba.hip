@@ -830,6 +830,48 @@ int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm
     return e;
 }
 
+// ---------------------------------------------------------------- pose-only refinement
+void xrsfm_ba_refine_pose_options(xrsfm_ba_options* o) {
+    if (!o) return;
+    xrsfm_ba_default_options(o);
+    o->max_iterations = 10;             // pnp.cc:59
+    o->function_tolerance = 1e-6;       // ceres::Solver::Options defaults
+    o->parameter_tolerance = 1e-8;
+    o->gradient_tolerance = 1e-10;
+    o->initial_radius = 1e4;
+    o->huber_a = 5.99;                  // pnp.cc:49
+}
+
+int xrsfm_ba_refine_pose(const xrsfm_ba_options* opt, int32_t model, const double* intr_params, int32_t n, const double* points3d,
+                         const double* uv, const uint8_t* inlier_mask, double* q, double* t, xrsfm_ba_summary* summary) {
+    if (!intr_params || !q || !t || !summary || n < 0 || model < 0 || model > 4) return XRSFM_BA_EINVAL;
+    if (n > 0 && (!points3d || !uv)) return XRSFM_BA_EINVAL;
+    xrsfm_ba_options o;
+    if (opt) o = *opt; else xrsfm_ba_refine_pose_options(&o);
+    std::vector<double> P, UV;
+    std::vector<int32_t> ocam, opt_idx;
+    for (int i = 0; i < n; ++i) {
+        if (inlier_mask && !inlier_mask[i]) continue;
+        opt_idx.push_back((int32_t)(P.size() / 3));
+        for (int k = 0; k < 3; ++k) P.push_back(points3d[3 * (size_t)i + k]);
+        UV.push_back(uv[2 * (size_t)i]); UV.push_back(uv[2 * (size_t)i + 1]);
+        ocam.push_back(0);
+    }
+    const int m = (int)ocam.size();
+    std::vector<uint8_t> pconst(m > 0 ? m : 1, 1);
+    uint8_t cconst = 0;
+    int32_t cam_intr = 0, intr_model = model;
+    double prm[8];
+    for (int k = 0; k < 8; ++k) prm[k] = intr_params[k];
+    xrsfm_ba_problem pr{};
+    pr.n_cams = 1; pr.n_points = m; pr.n_obs = m; pr.n_intr = 1;
+    pr.cam_q = q; pr.cam_t = t; pr.cam_const = &cconst; pr.cam_intr = &cam_intr;
+    pr.intr_model = &intr_model; pr.intr_params = prm;
+    pr.points = P.data(); pr.point_const = pconst.data();
+    pr.obs_cam = ocam.data(); pr.obs_pt = opt_idx.data(); pr.obs_uv = UV.data();
+    return xrsfm_ba_solve(&o, &pr, summary);
+}
+
 // ---------------------------------------------------------------- post-BA track filter
 int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, double min_tri_angle_rad, uint8_t* obs_delete,
                            uint8_t* track_outlier, double* track_error, double* track_angle, int32_t* num_filtered) {
