@@ -130,6 +130,13 @@ int xrsfm_ba_create(const xrsfm_ba_problem *problem, int device, xrsfm_ba_contex
 int xrsfm_ba_comm_unique_id(unsigned char id[128]);
 int xrsfm_ba_comm_init(xrsfm_ba_context *ctx, int n_ranks, int rank, const unsigned char id[128]);
 
+/* TEST HOOK: replace the RCCL all-reduce of this context by a caller-supplied one working on a HOST copy of the buffer
+ * (op 0 = sum, 1 = max; return 0 on success).  Lets several ranks share ONE GPU — RCCL refuses two ranks on one device — so the
+ * multi-rank logic (sharded points, replicated cameras, union block pattern, identical LM decisions on every rank) can be
+ * verified on a 1-GPU box with any host transport (the tests use torch.distributed/gloo).  Not a production path. */
+typedef int (*xrsfm_ba_allreduce_fn)(void *user, double *host_buf, uint64_t n, int op);
+int xrsfm_ba_debug_comm_hook(xrsfm_ba_context *ctx, int n_ranks, int rank, xrsfm_ba_allreduce_fn fn, void *user);
+
 /* Run Levenberg-Marquardt on the device-resident state (blocking). */
 int xrsfm_ba_run(xrsfm_ba_context *ctx, const xrsfm_ba_options *opt, xrsfm_ba_summary *summary);
 

@@ -27,6 +27,9 @@ class CProblem(C.Structure):
     ]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_int)
+
+
 class COptions(C.Structure):
     _fields_ = [
         ("max_iterations", C.c_int32), ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
@@ -57,7 +60,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -101,6 +104,8 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
+    lib.xrsfm_ba_debug_comm_hook.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
+    lib.xrsfm_ba_debug_comm_hook.restype = C.c_int
     lib.xrsfm_ba_refine_pose_options.argtypes = [C.POINTER(COptions)]
     lib.xrsfm_ba_refine_pose_options.restype = None
     lib.xrsfm_ba_refine_pose.argtypes = [C.POINTER(COptions), C.c_int32, _c_double_p, C.c_int32, _c_double_p, _c_double_p, _c_uint8_p,
@@ -206,6 +211,17 @@ class Context:
 
     def comm_init(self, n_ranks: int, rank: int, unique_id: bytes):
         check(self.lib.xrsfm_ba_comm_init(self._h, n_ranks, rank, unique_id), "xrsfm_ba_comm_init")
+
+    def comm_hook(self, n_ranks: int, rank: int, allreduce):
+        """TEST transport: `allreduce(array, op)` reduces a host float64 array in place across the ranks (op 0 sum, 1 max)."""
+        def _cb(user, buf, n, op):
+            try:
+                allreduce(np.ctypeslib.as_array(buf, shape=(int(n),)), int(op))
+                return 0
+            except Exception:      # noqa: BLE001  (must not unwind through the C frame)
+                return 1
+        self._hook = ALLREDUCE_FN(_cb)       # keep the trampoline alive as long as the context
+        check(self.lib.xrsfm_ba_debug_comm_hook(self._h, n_ranks, rank, self._hook, None), "xrsfm_ba_debug_comm_hook")
 
     def run(self, options: COptions | None = None) -> CSummary:
         options = options or default_options()

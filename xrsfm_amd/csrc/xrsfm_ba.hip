@@ -117,6 +117,8 @@ struct xrsfm_ba_context {
     double* h_scal = nullptr;       // pinned
     PcgStatus* h_st = nullptr;      // pinned
     void* comm = nullptr; int n_ranks = 1, rank = 0;
+    xrsfm_ba_allreduce_fn hook = nullptr; void* hook_user = nullptr; std::vector<double> hook_buf;   // test transport (host copy)
+    bool multi() const { return comm != nullptr || hook != nullptr; }
     // profiling
     bool profiling = false;
     std::vector<hipEvent_t> ev_pool; size_t ev_used = 0;
@@ -222,6 +224,15 @@ int dev_upload(xrsfm_ba_context* c, T** p, const std::vector<T>& v) {
 inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 
 int allreduce(xrsfm_ba_context* c, double* buf, size_t n, int op) {
+    if (c->hook) {
+        c->hook_buf.resize(n);
+        if (hipMemcpyAsync(c->hook_buf.data(), buf, n * sizeof(double), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (c->hook(c->hook_user, c->hook_buf.data(), (uint64_t)n, op == kNcclSum ? 0 : 1) != 0) return XRSFM_BA_ECOMM;
+        if (hipMemcpyAsync(buf, c->hook_buf.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return XRSFM_BA_ENODEV;
+        return 0;
+    }
     if (!c->comm) return 0;
     const int e = g_rccl.AllReduce(buf, buf, n, kNcclFloat64, op, c->comm, c->stream);
     return e == 0 ? 0 : XRSFM_BA_ECOMM;
@@ -279,12 +290,12 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
         j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = tail; j.op[0] = 0;
         j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = tail + 1; j.op[1] = 0;
         j.in[2] = d.part + 2 * (size_t)d.n_items; j.n[2] = d.n_items; j.out[2] = d.scal + S_GRADMAX_PTS; j.op[2] = 1;   // points are rank-local
-        if (!c->comm) {     // single rank: the sums go straight to the scalar block as well
+        if (!c->multi()) {     // single rank: the sums go straight to the scalar block as well
             j.in[3] = j.in[0]; j.n[3] = j.n[0]; j.out[3] = d.scal + S_COST; j.op[3] = 0;
             j.in[4] = j.in[1]; j.n[4] = j.n[1]; j.out[4] = d.scal + S_XNORM2_PTS; j.op[4] = 0;
         }
-        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(c->comm ? 3 : 5), dim3(kPcgThreads), 0, j);
-        if (c->comm) {
+        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(c->multi() ? 3 : 5), dim3(kPcgThreads), 0, j);
+        if (c->multi()) {
             int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2, kNcclSum);
             if (e) return e;
             HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST, S_XNORM2_PTS adjacent
@@ -679,6 +690,16 @@ int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigne
     c->comm = comm; c->n_ranks = n_ranks; c->rank = rank;
     // a camera is part of the program if ANY rank holds an observation of it
     int e = allreduce(c, c->d.cam_act, (size_t)c->d.n_cams, kNcclMax);
+    if (e) return e;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+int xrsfm_ba_debug_comm_hook(xrsfm_ba_context* c, int n_ranks, int rank, xrsfm_ba_allreduce_fn fn, void* user) {
+    if (!c || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks || c->comm) return XRSFM_BA_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    c->hook = fn; c->hook_user = user; c->n_ranks = n_ranks; c->rank = rank;
+    int e = allreduce(c, c->d.cam_act, (size_t)c->d.n_cams, kNcclMax);      // as in xrsfm_ba_comm_init
     if (e) return e;
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
