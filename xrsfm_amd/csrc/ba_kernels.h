@@ -860,7 +860,9 @@ __global__ void k_cam_update(Dev d) {
 }
 
 // Ceres' gradient max-norm |x - Plus(x, -g)|_inf with the unscaled gradient.
-__global__ __launch_bounds__(kPcgThreads) void k_gradmax_cams(Dev d, double* __restrict__ out) {     // one workgroup
+// rank_max (multi-rank only): the ranks' point-gradient maxima, folded to *out_pts here.
+__global__ __launch_bounds__(kPcgThreads) void k_gradmax_cams(Dev d, double* __restrict__ out, const double* __restrict__ rank_max,
+                                                           int n_ranks, double* __restrict__ out_pts) {     // one workgroup
     __shared__ double lds[kPcgThreads / kWave];
     double m = 0.0;
     for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
@@ -887,6 +889,11 @@ __global__ __launch_bounds__(kPcgThreads) void k_gradmax_cams(Dev d, double* __r
         double r = 0.0;
         for (int i = 0; i < kPcgThreads / kWave; ++i) r = fmax(r, lds[i]);
         *out = r;
+        if (rank_max) {
+            double m2 = 0.0;
+            for (int i = 0; i < n_ranks; ++i) m2 = fmax(m2, rank_max[i]);
+            *out_pts = m2;
+        }
     }
 }
 

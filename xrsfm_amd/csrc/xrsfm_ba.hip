@@ -76,6 +76,7 @@ const char* kKidName[K_COUNT] = {
     "k_linearize", "k_cost", "k_cam_segsum", "k_schur_prep", "k_schur_matvec", "k_pcg_update", "k_backsub", "k_schur_pairs",
     "k_block_segsum", "k_dense_fill", "k_potrf", "k_trsm", "k_update", "k_fwd_bwd", "small_kernels"};
 
+constexpr int kMaxRanks = 64;          // slots for the per-rank point-gradient maxima behind camlin
 constexpr int kCholMaxN = 12288;
 }  // namespace
 
@@ -289,14 +290,19 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
         ReduceJobs j{};
         j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = tail; j.op[0] = 0;
         j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = tail + 1; j.op[1] = 0;
-        j.in[2] = d.part + 2 * (size_t)d.n_items; j.n[2] = d.n_items; j.out[2] = d.scal + S_GRADMAX_PTS; j.op[2] = 1;   // points are rank-local
+        // max-norm of the point gradient: points are rank-local, so with several ranks every rank writes its maximum to its own
+        // slot behind the sums (the other slots are 0): the SUM all-reduce then hands every rank all the maxima
+        j.in[2] = d.part + 2 * (size_t)d.n_items; j.n[2] = d.n_items; j.op[2] = 1;
+        j.out[2] = c->multi() ? tail + 2 + c->rank : d.scal + S_GRADMAX_PTS;
         if (!c->multi()) {     // single rank: the sums go straight to the scalar block as well
             j.in[3] = j.in[0]; j.n[3] = j.n[0]; j.out[3] = d.scal + S_COST; j.op[3] = 0;
             j.in[4] = j.in[1]; j.n[4] = j.n[1]; j.out[4] = d.scal + S_XNORM2_PTS; j.op[4] = 0;
+        } else {
+            HIPCHK(hipMemsetAsync(tail + 2, 0, sizeof(double) * (size_t)c->n_ranks, c->stream));
         }
         LAUNCH(c, K_SMALL, k_reduce_multi, dim3(c->multi() ? 3 : 5), dim3(kPcgThreads), 0, j);
         if (c->multi()) {
-            int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2, kNcclSum);
+            int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2 + (size_t)c->n_ranks, kNcclSum);
             if (e) return e;
             HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST, S_XNORM2_PTS adjacent
         }
@@ -304,12 +310,12 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
     return 0;
 }
 
-// after linearize(), which leaves the point part in S_GRADMAX_PTS
+// after linearize(), which leaves the point part in S_GRADMAX_PTS (one rank) or in the per-rank slots behind camlin
 int gradient_max(xrsfm_ba_context* c, double* out) {
     Dev& d = c->d;
-    LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, d.scal + S_GRADMAX_CAMS);
-    int e = allreduce(c, d.scal + S_GRADMAX_PTS, 1, kNcclMax);
-    if (e) return e;
+    const double* rank_max = c->multi() ? d.camlin + (size_t)d.n_cams * 12 + 2 : nullptr;
+    LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, d.scal + S_GRADMAX_CAMS, rank_max, c->n_ranks, d.scal + S_GRADMAX_PTS);
+    int e;
     e = fetch_scalars(c);
     if (e) return e;
     *out = std::fmax(c->h_scal[S_GRADMAX_PTS], c->h_scal[S_GRADMAX_CAMS]);
@@ -647,7 +653,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.scale_c, nc * 6)); TRY(dev_alloc(c, &d.scale_p, np * 3));
     TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Jp, ns * 6)); TRY(dev_alloc(c, &d.camrec, nc));
     TRY(dev_alloc(c, &d.Hpp, np * 6)); TRY(dev_alloc(c, &d.gp, np * 3)); TRY(dev_alloc(c, &d.Hinv, np * 6)); TRY(dev_alloc(c, &d.Hc, np * 6));
-    TRY(dev_alloc(c, &d.camlin, nc * 12 + 2)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
+    TRY(dev_alloc(c, &d.camlin, nc * 12 + 2 + kMaxRanks)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
     TRY(dev_alloc(c, &d.Minv, nc * 21)); TRY(dev_alloc(c, &d.b, nc * 6));
     TRY(dev_alloc(c, &d.px, nc * 6 + kNB)); TRY(dev_alloc(c, &d.pr, nc * 6)); TRY(dev_alloc(c, &d.pz, nc * 6));
     TRY(dev_alloc(c, &d.pp, nc * 6)); TRY(dev_alloc(c, &d.pq, nc * 6));
@@ -676,7 +682,7 @@ int xrsfm_ba_comm_unique_id(unsigned char id[128]) {
 }
 
 int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigned char id[128]) {
-    if (!c || !id || n_ranks < 1 || rank < 0 || rank >= n_ranks) return XRSFM_BA_EINVAL;
+    if (!c || !id || n_ranks < 1 || n_ranks > kMaxRanks || rank < 0 || rank >= n_ranks) return XRSFM_BA_EINVAL;
     // a single rank needs no communicator; XRSFM_BA_FORCE_COMM=1 creates one anyway (exercises the RCCL plumbing
     // on a 1-GPU box: every all-reduce then really goes through ncclAllReduce)
     const char* force = getenv("XRSFM_BA_FORCE_COMM");
@@ -696,7 +702,7 @@ int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigne
 }
 
 int xrsfm_ba_debug_comm_hook(xrsfm_ba_context* c, int n_ranks, int rank, xrsfm_ba_allreduce_fn fn, void* user) {
-    if (!c || !fn || n_ranks < 1 || rank < 0 || rank >= n_ranks || c->comm) return XRSFM_BA_EINVAL;
+    if (!c || !fn || n_ranks < 1 || n_ranks > kMaxRanks || rank < 0 || rank >= n_ranks || c->comm) return XRSFM_BA_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     c->hook = fn; c->hook_user = user; c->n_ranks = n_ranks; c->rank = rank;
     int e = allreduce(c, c->d.cam_act, (size_t)c->d.n_cams, kNcclMax);      // as in xrsfm_ba_comm_init
