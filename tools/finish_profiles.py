@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_<tag>/ (written by tools/make_profiles.sh on the GPU box) into the committed profiles/ files.
+
+usage: python tools/finish_profiles.py r01
+"""
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+    dst = os.path.join(ROOT, "profiles")
+    rd = lambda n: open(os.path.join(src, n)).read()        # noqa: E731
+    line = rd("stats_bench_line.json").strip()
+    if not line.startswith("{"):
+        line = [l for l in rd("stats_bench.log").splitlines() if l.startswith('{"metric"')][-1]
+    nproc = rd("nproc.txt").strip()
+    with open(os.path.join(dst, f"{tag}_L_kernel_stats.md"), "w") as f:
+        f.write(f"# Round {tag[1:]} — rocprofv3 kernel-trace summary, bench.py --config L --no-cpu --steps 2 (MI355X, 1 GPU)\n\n"
+                "Command (tools/make_profiles.sh): `rocprofv3 --kernel-trace --stats -d DIR -o stats -- python bench.py --config L --no-cpu --steps 2`\n"
+                "(4 solves: 1 warm-up, 2 timed, 1 profiled with HIP events; 13 LM iterations each).  Per-kernel table from the rocpd\n"
+                "database with `tools/rocprof_summary.py`.\n\nbench.py line of the same (profiled) run:\n\n```\n" + line + "\n```\n\n" + rd("kernel_stats_table.md"))
+    with open(os.path.join(dst, f"{tag}_L_pmc_traffic.md"), "w") as f:
+        f.write(f"# Round {tag[1:]} — HBM traffic per kernel from rocprofv3 PMC counters, bench.py --config L (MI355X, 1 GPU)\n\n"
+                "Two separate passes (tools/make_profiles.sh; TCC slots do not fit both counters):\n"
+                "`rocprofv3 --pmc FETCH_SIZE --kernel-trace -- python bench.py --config L --no-cpu --steps 1 --warmup 0` and the same with `--pmc WRITE_SIZE`.\n"
+                "Corrections and their calibration: see the docstring of `tools/pmc_summary.py`.  Averages per launch.\n\n" + rd("pmc_table.md"))
+    shutil.copy(os.path.join(src, "pmc_traffic_L.json"), os.path.join(dst, "pmc_traffic_L.json"))
+    with open(os.path.join(dst, f"{tag}_bench_lines.md"), "w") as f:
+        f.write(f"# Round {tag[1:]} — bench.py lines (MI355X, 1 GPU, host with {nproc} cores), `python bench.py --config C --steps 5 --warmup 2`\n")
+        for cfg, note in (("L", "default workload"), ("S", ""), ("K", "KITTI-00-sized sequential problem")):
+            f.write(f"\n## config {cfg}" + (f" ({note})" if note else "") + "\n```\n" + rd(f"bench_{cfg}.json").strip() + "\n```\n")
+            d = json.loads(rd(f"bench_{cfg}.json"))
+            b = d.get("cpu_baseline") or {}
+            f.write(f"\n{d['ms_per_step']:.2f} ms per solve, {d['value']:.3e} {d['unit']}; CPU port {b.get('cores')} threads: "
+                    f"{b.get('value', 0):.3e} ({b.get('gpu_vs_cpu', 0):.0f}x)")
+            if "more_threads" in b:
+                m = b["more_threads"]
+                f.write(f", {m['cores']} threads: {m['value']:.3e} ({m['gpu_vs_cpu']:.0f}x)")
+            f.write(f"; final RMSE difference to the CPU port {b.get('rmse_diff_px', float('nan')):.1e} px.\n")
+    print("profiles written for", tag)
+
+
+if __name__ == "__main__":
+    main()

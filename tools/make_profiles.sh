@@ -16,7 +16,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python $ROOT
 # 3. summaries while the databases are at hand (the .db files are too big to bring back)
 python $ROOT/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats_table.md > /dev/null
 python $ROOT/tools/pmc_summary.py $(find $OUT/fetch -name "*.db" | head -1) $(find $OUT/write -name "*.db" | head -1) $OUT/pmc_table.md $OUT/pmc_traffic_L.json > /dev/null
-tail -1 $OUT/stats_bench.log > $OUT/stats_bench_line.json
+grep "^{\"metric\"" $OUT/stats_bench.log | tail -1 > $OUT/stats_bench_line.json
 rm -rf $OUT/stats $OUT/fetch $OUT/write
 # 4. bench lines with the CPU leg
 cd $ROOT
