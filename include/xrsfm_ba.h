@@ -168,6 +168,45 @@ int xrsfm_ba_refine_pose(const xrsfm_ba_options *opt, int32_t model, const doubl
                          const double *points3d, const double *uv, const uint8_t *inlier_mask, double *q, double *t,
                          xrsfm_ba_summary *summary);
 
+/* ---- Scaled pose graph of BASolver::ScalePoseGraphUnorder (/root/reference/src/optimization/ba_solver.cc:147-328; SURVEY 8f
+ * row f4).  HOST code (O(frames) unknowns; no GPU needed or used): it completes the BASolver interface without Ceres.
+ * Poses are T_wc (twc_vec of the reference).  Rotations are constant (ba_solver.cc:248-249), positions and scales are the
+ * unknowns.  An edge is one PoseGraphCost(q_mea, p_mea, weight_o) residual block (cost_factor_ceres.h:117-198) between
+ * pose1 = frame edge_a (scale edge_sa) and pose2 = frame edge_b (scale edge_sb); a scale cost is one ScaleCost(s12)
+ * (cost_factor_ceres.h:200-221).  n_scales >= n_frames: scale i < n_frames belongs to frame i, the rest are the loop
+ * scales (s_vec_loop). */
+typedef struct xrsfm_pg_problem {
+    int32_t n_frames, n_scales, n_edges, n_scale_costs;
+    const double *rot_q;        /* [n_frames][4] x,y,z,w, constant */
+    double *pos;                /* [n_frames][3] in/out */
+    double *scale;              /* [n_scales]    in/out */
+    const uint8_t *pos_const;   /* [n_frames] 1 = constant (NULL: none) */
+    const uint8_t *scale_const; /* [n_scales] */
+    const double *scale_lower;  /* [n_scales] lower bounds (-HUGE_VAL = none); NULL = unconstrained problem */
+    const int32_t *edge_a, *edge_b, *edge_sa, *edge_sb;   /* [n_edges] */
+    const double *edge_q_mea;   /* [n_edges][4] x,y,z,w */
+    const double *edge_p_mea;   /* [n_edges][3] */
+    double weight_o;            /* weight of the scale prior row (ba_solver.cc:221-229) */
+    const int32_t *sc_a, *sc_b; /* [n_scale_costs] scale indices */
+    const double *sc_s12;       /* [n_scale_costs] */
+} xrsfm_pg_problem;
+
+typedef struct xrsfm_pg_options {
+    int32_t max_iterations;     /* 100 (InitSolverOptions, ba_solver.cc:73) */
+    double function_tolerance, parameter_tolerance, gradient_tolerance;   /* Ceres defaults 1e-6, 1e-8, 1e-10 */
+    double initial_radius;      /* 1e16 (ba_solver.cc:261) */
+    int32_t verbose;
+} xrsfm_pg_options;
+
+typedef struct xrsfm_pg_summary {
+    double initial_cost, final_cost;
+    int32_t iterations, n_successful, n_unsuccessful;
+    int32_t termination;        /* 1 gradient, 2 parameter, 3 function tolerance, 4 radius, 5 max iterations, 6 linear solver failure */
+} xrsfm_pg_summary;
+
+void xrsfm_pg_default_options(xrsfm_pg_options *opt);
+int xrsfm_pg_solve(const xrsfm_pg_options *opt, xrsfm_pg_problem *problem, xrsfm_pg_summary *summary);
+
 /* Post-BA track filter on the same flat arrays (Point3dProcessor::FilterPoints3d,
  * /root/reference/src/geometry/track_processor.cc:280-332, called after every KGBA at incremental_mapper.cc:83-85).
  * The problem here is the whole map: every registered frame and every observation of every non-outlier track.

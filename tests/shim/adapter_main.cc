@@ -1,5 +1,6 @@
 // Test driver for the adapter: builds a xrsfm::Map (shim types) from a flat problem dump, calls BASolver, dumps the Map.
-// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba|refine> [frame_id]
+// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba|refine|posegraph> [frame_id | loop.bin]
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -55,6 +56,41 @@ int main(int argc, char **argv) {
             p3.push_back(map.tracks_[fr.track_ids_[i]].point3d_); ids.push_back({(int)i, fr.track_ids_[i]}); inl.push_back(ids.size() % 7 != 0);
         }
         refine_status = xrsfm::RefineFramePose(fr, map.Camera(fr.camera_id), p3, ids, inl);
+    }
+    else if (mode == "posegraph") {
+        // loop.bin: i32 frame_id, i32 n_components, per component {i32 n, i32 ids[n], f64 twc[7] (q xyzw, t)}, f64 scale_obs, i32 use_key
+        FILE *lf = fopen(argv[4], "rb");
+        if (!lf) return 2;
+        xrsfm::LoopInfo li;
+        li.frame_id = rd<int32_t>(lf, 1)[0];
+        const int ncomp = rd<int32_t>(lf, 1)[0];
+        for (int c = 0; c < ncomp; ++c) {
+            const int m = rd<int32_t>(lf, 1)[0];
+            auto ids = rd<int32_t>(lf, m);
+            auto pose = rd<double>(lf, 7);
+            li.cor_frame_ids_vec.emplace_back(ids.begin(), ids.end());
+            xrsfm::Pose tw;
+            for (int k = 0; k < 4; ++k) tw.q.coeffs().data()[k] = pose[k];
+            for (int k = 0; k < 3; ++k) tw.t.data()[k] = pose[4 + k];
+            li.twc_vec.push_back(tw);
+        }
+        li.scale_obs = rd<double>(lf, 1)[0];
+        const bool use_key = rd<int32_t>(lf, 1)[0] != 0;
+        fclose(lf);
+        // covisibility = frames sharing a track (ascending ids), key frames = even ids + init frames, ref = previous key frame
+        for (auto &tr : map.tracks_)
+            for (auto &o1 : tr.observations_)
+                for (auto &o2 : tr.observations_)
+                    if (o1.first != o2.first) {
+                        auto &v = map.frameid2covisible_frameids_[o1.first];
+                        if (std::find(v.begin(), v.end(), o2.first) == v.end()) v.push_back(o2.first);
+                    }
+        for (auto &kv : map.frameid2covisible_frameids_) std::sort(kv.second.begin(), kv.second.end());
+        for (auto &fr : map.frames_) {
+            fr.is_keyframe = !use_key || fr.id % 2 == 0 || (int)fr.id == map.init_id1 || (int)fr.id == map.init_id2 || (int)fr.id == li.frame_id;
+            fr.ref_id = fr.is_keyframe ? (int)fr.id : (int)fr.id - 1;
+        }
+        solver.ScalePoseGraphUnorder(li, map, use_key);
     }
     else return 2;
     FILE *o = fopen(argv[2], "wb");

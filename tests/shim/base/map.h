@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdint>
 #include <map>
+#include <set>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -58,6 +59,8 @@ class Track {
     vector3 point3d_;
     double angle_ = -1;
     bool outlier = false;
+    int ref_id = -1;
+    double depth = -1;
 };
 
 class Frame {
@@ -72,7 +75,13 @@ class Frame {
     int ref_id = -1;
 };
 
-struct LoopInfo {};
+struct LoopInfo {
+    int frame_id;
+    std::vector<std::set<int>> cor_frame_ids_vec;
+    std::vector<Pose> twc_vec;
+    std::vector<int> num_inlier_vec;
+    double scale_obs = -1;
+};
 
 class Map {
   public:
@@ -83,6 +92,17 @@ class Map {
     int init_id2 = -1;
     inline const class Camera &Camera(int camera_id) const { return camera_map_.at(camera_id); }
     inline class Camera &Camera(int camera_id) { return camera_map_.at(camera_id); }
+    std::unordered_map<int, std::vector<int>> frameid2covisible_frameids_;
+    // shim: undistorted pinhole normalisation with the camera's first parameters (f, cx, cy); the reference inverts the
+    // full distortion model (camera_model.hpp ImageToNormalized)
+    inline vector2 GetNormalizedPoint(const int frame_id, const int p2d_id) {
+        const auto &frame = frames_.at(frame_id);
+        const auto &cam = Camera(frame.camera_id);
+        vector2 r;
+        r.v[0] = (frame.points.at(p2d_id).v[0] - cam.params_[1]) / cam.params_[0];
+        r.v[1] = (frame.points.at(p2d_id).v[1] - cam.params_[2]) / cam.params_[0];
+        return r;
+    }
 };
 
 void KeyFrameSelection(Map &map, std::vector<int> loop_matched_frame_id, const bool is_sequential_data = false);

@@ -131,3 +131,131 @@ def test_adapter_refine_pose_equals_c_abi(exe, tmp_path):
     m = re.search(r"Initial cost : ([0-9.eE+-]+) \[px\]\nFinal cost : ([0-9.eE+-]+) \[px\]", out)
     assert m, out
     assert abs(float(m.group(2)) - np.sqrt(s.final_cost / s.num_residuals)) < 1e-4 * max(1.0, float(m.group(2)))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ScalePoseGraphUnorder (host code: these run without a GPU)
+def _quat_rot(q, v):
+    from scipy.spatial.transform import Rotation
+    return Rotation.from_quat(q).apply(v)
+
+
+def _pose_inv(q, t):
+    qi = np.array([-q[0], -q[1], -q[2], q[3]]) / np.dot(q, q)
+    return qi, -_quat_rot(qi, t)
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _write_loop(path, frame_id, comps, scale_obs, use_key):
+    with open(path, "wb") as f:
+        f.write(struct.pack("2i", frame_id, len(comps)))
+        for ids, (q, t) in comps:
+            f.write(struct.pack("i", len(ids))); f.write(np.asarray(ids, "i4").tobytes())
+            f.write(np.concatenate([q, t]).astype("f8").tobytes())
+        f.write(struct.pack("d", scale_obs)); f.write(struct.pack("i", int(use_key)))
+
+
+def _pose_graph_python(arr, loop_frame, comps, scale_obs):
+    """The routine restated in numpy for use_key = false (ba_solver.cc:147-328), on top of capi.pose_graph_solve."""
+    from xrsfm_amd import capi
+    nc = arr["cam_q"].shape[0]
+    q, t, P = arr["cam_q"], arr["cam_t"], arr["points"]
+    f, cx, cy = arr["intr_params"][0][:3]
+    obs_of = {}
+    for i, (c, j) in enumerate(zip(arr["obs_cam"], arr["obs_pt"])):
+        obs_of.setdefault(int(j), []).append((int(c), i))
+    ref, depth = {}, {}
+    for j, lst in obs_of.items():
+        best, bd = -1, -1.0
+        for c, i in sorted(lst):
+            if c == loop_frame:
+                continue
+            d = (_quat_rot(q[c], P[j]) + t[c])[2]
+            if best == -1:
+                best, bd = c, d
+            elif d >= 0 and (bd < 0 or d < bd):
+                best, bd = c, d
+        ref[j], depth[j] = best, bd
+    twc = [_pose_inv(q[i], t[i]) for i in range(nc)]
+    cov = {i: set() for i in range(nc)}
+    for lst in obs_of.values():
+        for c1, _ in lst:
+            for c2, _ in lst:
+                if c1 != c2:
+                    cov[c1].add(c2)
+    E = dict(a=[], b=[], sa=[], sb=[], q_mea=[], p_mea=[])
+
+    def add(p1, p2, a, b, sa, sb):
+        qi = _pose_inv(p1[0], np.zeros(3))[0]
+        E["a"].append(a); E["b"].append(b); E["sa"].append(sa); E["sb"].append(sb)
+        E["q_mea"].append(_qmul(qi, p2[0])); E["p_mea"].append(_quat_rot(qi, p2[1] - p1[1]))
+    for i in range(nc):
+        for c in sorted(cov[i]):
+            if i > c:
+                add(twc[i], twc[c], i, c, i, c)
+    for k, (ids, pose) in enumerate(comps):
+        for c in sorted(set(ids)):
+            add(pose, twc[c], loop_frame, c, nc + k, c)
+    weight_o = 1 - abs(scale_obs - 1) / 0.1 if abs(scale_obs - 1) < 0.1 else 0.0
+    lower = np.full(nc + len(comps), 0.2); lower[loop_frame] = -np.inf
+    pc = np.zeros(nc, np.uint8); pc[[0, 1]] = 1
+    scn = np.zeros(nc + len(comps), np.uint8); scn[[0, 1]] = 1
+    sc = [(nc, nc + 1, scale_obs)] if scale_obs != -1 and len(comps) >= 2 else []
+    E = {k: np.array(v) for k, v in E.items()}
+    pos, scale, s = capi.pose_graph_solve(np.array([p[0] for p in twc]), np.array([p[1] for p in twc]), np.ones(nc + len(comps)), E,
+                                          weight_o=weight_o, scale_costs=sc, pos_const=pc, scale_const=scn, scale_lower=lower)
+    q2, t2 = np.empty_like(q), np.empty_like(t)
+    for i in range(nc):
+        q2[i], t2[i] = _pose_inv(twc[i][0], pos[i])
+    P2 = P.copy()
+    for j, lst in obs_of.items():
+        c = ref[j]
+        oi = dict(lst)[c]
+        uv = arr["obs_uv"][oi]
+        v = scale[c] * depth[j] * np.array([(uv[0] - cx) / f, (uv[1] - cy) / f, 1.0]) - t2[c]
+        P2[j] = _quat_rot(_pose_inv(q2[c], np.zeros(3))[0], v)
+    return q2, t2, P2, scale, s
+
+
+@pytest.mark.parametrize("drift,scale_obs", [(0.0, 1.0), (0.05, 1.02)])
+def test_adapter_pose_graph_equals_python_restatement(exe, tmp_path, drift, scale_obs):
+    arr = H.make(30, 600, 4, seed=150)                  # open arc of 30 frames, 4-frame tracks
+    nc = 30
+    # loop closure for the last frame against two components at the start of the sequence: its "measured" pose is the
+    # current one moved by `drift` along the trajectory; drift 0 with scale_obs 1 = a consistent map that must come back unchanged
+    tw = _pose_inv(arr["cam_q"][nc - 1], arr["cam_t"][nc - 1])
+    comps = [([0, 1, 2], (tw[0], tw[1] + drift * np.array([1.0, 0.0, 0.5]))), ([3, 4, 5], (tw[0], tw[1] + drift * np.array([1.0, 0.0, 0.5])))]
+    # the loop frame must be covisible with the components for the graph to be connected through the loop edges only
+    loop = str(tmp_path / "loop.bin")
+    _write_loop(loop, nc - 1, comps, scale_obs, False)
+    status, q, t, P, out, err = _run(exe, arr, tmp_path, "posegraph", loop)
+    assert status == 0, err
+    assert "loop_cor: 0 num_edge: 3" in out and "weight scale" in out and "Pose graph report" in out
+    q2, t2, P2, scale, s = _pose_graph_python(arr, nc - 1, comps, scale_obs)
+    assert np.abs(q - q2).max() < 1e-9 and np.abs(t - t2).max() < 1e-7
+    seen = np.zeros(P.shape[0], bool); seen[arr["obs_pt"]] = True
+    assert np.abs(P[seen] - P2[seen]).max() < 1e-6
+    if drift == 0.0:                                     # nothing to correct: poses stay, points are re-expressed through their observation
+        assert np.abs(t - arr["cam_t"]).max() < 1e-6 and np.abs(scale - 1).max() < 1e-6
+    else:
+        assert np.abs(t - arr["cam_t"]).max() > 1e-3
+
+
+def test_adapter_pose_graph_keyframe_mode(exe, tmp_path):
+    """use_key = true: only key frames enter the graph, the others follow their reference key frame (ba_solver.cc:275-303);
+    on a consistent map everything must come back unchanged."""
+    arr = H.make(30, 600, 4, seed=151)
+    nc = 30
+    tw = _pose_inv(arr["cam_q"][nc - 1], arr["cam_t"][nc - 1])
+    comps = [([0, 2, 4], tw), ([6, 8], tw)]
+    loop = str(tmp_path / "loop.bin")
+    _write_loop(loop, nc - 1, comps, 1.0, True)
+    status, q, t, P, out, err = _run(exe, arr, tmp_path, "posegraph", loop)
+    assert status == 0, err
+    assert "loop_cor: 1 num_edge: 2" in out
+    assert np.abs(q - arr["cam_q"]).max() < 1e-9 and np.abs(t - arr["cam_t"]).max() < 1e-6

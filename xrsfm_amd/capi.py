@@ -27,6 +27,24 @@ class CProblem(C.Structure):
     ]
 
 
+class CPgProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("n_scales", C.c_int32), ("n_edges", C.c_int32), ("n_scale_costs", C.c_int32),
+                ("rot_q", _c_double_p), ("pos", _c_double_p), ("scale", _c_double_p), ("pos_const", _c_uint8_p),
+                ("scale_const", _c_uint8_p), ("scale_lower", _c_double_p), ("edge_a", _c_int32_p), ("edge_b", _c_int32_p),
+                ("edge_sa", _c_int32_p), ("edge_sb", _c_int32_p), ("edge_q_mea", _c_double_p), ("edge_p_mea", _c_double_p),
+                ("weight_o", C.c_double), ("sc_a", _c_int32_p), ("sc_b", _c_int32_p), ("sc_s12", _c_double_p)]
+
+
+class CPgOptions(C.Structure):
+    _fields_ = [("max_iterations", C.c_int32), ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
+                ("gradient_tolerance", C.c_double), ("initial_radius", C.c_double), ("verbose", C.c_int32)]
+
+
+class CPgSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int32), ("n_successful", C.c_int32),
+                ("n_unsuccessful", C.c_int32), ("termination", C.c_int32)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_int)
 
 
@@ -60,7 +78,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -104,6 +122,10 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
+    lib.xrsfm_pg_default_options.argtypes = [C.POINTER(CPgOptions)]
+    lib.xrsfm_pg_default_options.restype = None
+    lib.xrsfm_pg_solve.argtypes = [C.POINTER(CPgOptions), C.POINTER(CPgProblem), C.POINTER(CPgSummary)]
+    lib.xrsfm_pg_solve.restype = C.c_int
     lib.xrsfm_ba_debug_comm_hook.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
     lib.xrsfm_ba_debug_comm_hook.restype = C.c_int
     lib.xrsfm_ba_refine_pose_options.argtypes = [C.POINTER(COptions)]
@@ -351,3 +373,43 @@ def refine_pose(model: int, intr_params, points3d, uv, q, t, inlier_mask=None, o
                                       mask.ctypes.data_as(_c_uint8_p) if mask is not None else None, _dp(q), _dp(t), C.byref(s)),
           "xrsfm_ba_refine_pose")
     return q, t, s
+
+
+def pose_graph_solve(rot_q, pos, scale, edges, weight_o=0.0, scale_costs=(), pos_const=None, scale_const=None, scale_lower=None,
+                     **opt_overrides):
+    """xrsfm_pg_solve (host code).  edges: dict(a, b, sa, sb, q_mea [n,4], p_mea [n,3]); scale_costs:
+    iterable of (sa, sb, s12).  Returns (pos, scale, summary); inputs are not modified."""
+    rot_q = np.ascontiguousarray(rot_q, float); pos = np.array(pos, float, copy=True); scale = np.array(scale, float, copy=True)
+    keep = [rot_q, pos, scale]
+    p = CPgProblem()
+    p.n_frames, p.n_scales = rot_q.shape[0], scale.shape[0]
+    p.rot_q, p.pos, p.scale = _dp(rot_q), _dp(pos), _dp(scale)
+
+    def u8(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, np.uint8); keep.append(a); return a.ctypes.data_as(_c_uint8_p)
+
+    def i32(a):
+        a = np.ascontiguousarray(a, np.int32); keep.append(a); return a.ctypes.data_as(_c_int32_p)
+
+    def f64(a):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, float); keep.append(a); return _dp(a)
+
+    p.pos_const, p.scale_const, p.scale_lower = u8(pos_const), u8(scale_const), f64(scale_lower)
+    p.n_edges = len(edges["a"])
+    p.edge_a, p.edge_b, p.edge_sa, p.edge_sb = i32(edges["a"]), i32(edges["b"]), i32(edges["sa"]), i32(edges["sb"])
+    p.edge_q_mea, p.edge_p_mea = f64(edges["q_mea"]), f64(edges["p_mea"])
+    p.weight_o = float(weight_o)
+    sc = list(scale_costs)
+    p.n_scale_costs = len(sc)
+    p.sc_a, p.sc_b, p.sc_s12 = i32([c[0] for c in sc]), i32([c[1] for c in sc]), f64([c[2] for c in sc])
+    o = CPgOptions()
+    load().xrsfm_pg_default_options(C.byref(o))
+    for k, v in opt_overrides.items():
+        setattr(o, k, v)
+    s = CPgSummary()
+    check(load().xrsfm_pg_solve(C.byref(o), C.byref(p), C.byref(s)), "xrsfm_pg_solve")
+    return pos, scale, s

@@ -9,6 +9,7 @@
 //   solver options               :70-77 with :586-589 (LBA), :626-634 (GBA), :667-670 (KGBA)
 //   printed summary              PrintSolverSummary :14-68, "LBA:" line :537-549, "kf: a/b" :676
 //   KGBA pre/post                KeyFrameSelection / UpdateByRefFrame stay in the reference (src/base/map.cc:428-663)
+//   pose graph                   ScalePoseGraphUnorder :147-328 with AddCovisibilityEdge :79-115, AddLoopEdge :117-145
 #include "ba_solver.h"
 
 #include <algorithm>
@@ -333,6 +334,253 @@ int RefineFramePose(Frame &frame, const Camera &camera, const std::vector<vector
     std::cout << "Initial cost : " << std::setprecision(6) << std::sqrt(s.initial_cost / s.num_residuals) << " [px]" << std::endl;
     std::cout << "Final cost : " << std::setprecision(6) << std::sqrt(s.final_cost / s.num_residuals) << " [px]" << std::endl;
     return e;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pose graph with per-frame scale (loop closing).  Pose algebra on raw arrays (q = x,y,z,w; the Map's Eigen types are only
+// touched through .coeffs().data() / .data(), which the reference's types and the test shim share).
+namespace {
+struct RawPose { double q[4] = {0, 0, 0, 1}; double t[3] = {0, 0, 0}; };
+
+inline void QMul(const double *a, const double *b, double *o) {
+    const double ax = a[0], ay = a[1], az = a[2], aw = a[3], bx = b[0], by = b[1], bz = b[2], bw = b[3];
+    o[0] = aw * bx + ax * bw + ay * bz - az * by;
+    o[1] = aw * by - ax * bz + ay * bw + az * bx;
+    o[2] = aw * bz + ax * by - ay * bx + az * bw;
+    o[3] = aw * bw - ax * bx - ay * by - az * bz;
+}
+inline void QInv(const double *a, double *o) {       // Eigen::Quaternion::inverse: conjugate / squaredNorm
+    const double n = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    o[0] = -a[0] / n; o[1] = -a[1] / n; o[2] = -a[2] / n; o[3] = a[3] / n;
+}
+inline void QRot(const double *q, const double *v, double *o) {     // Eigen's q * v:  v + w*uv + q.vec x uv,  uv = 2 q.vec x v
+    const double ux = 2 * (q[1] * v[2] - q[2] * v[1]), uy = 2 * (q[2] * v[0] - q[0] * v[2]), uz = 2 * (q[0] * v[1] - q[1] * v[0]);
+    o[0] = v[0] + q[3] * ux + (q[1] * uz - q[2] * uy);
+    o[1] = v[1] + q[3] * uy + (q[2] * ux - q[0] * uz);
+    o[2] = v[2] + q[3] * uz + (q[0] * uy - q[1] * ux);
+}
+inline RawPose PInv(const RawPose &p) {              // Pose::inverse (types.h:47-52)
+    RawPose r;
+    QInv(p.q, r.q);
+    double v[3];
+    QRot(r.q, p.t, v);
+    for (int k = 0; k < 3; ++k) r.t[k] = -v[k];
+    return r;
+}
+inline RawPose PMul(const RawPose &a, const RawPose &b) {   // a.mul(b) (types.h:54-58)
+    RawPose r;
+    double v[3];
+    QRot(a.q, b.t, v);
+    for (int k = 0; k < 3; ++k) r.t[k] = v[k] + a.t[k];
+    QMul(a.q, b.q, r.q);
+    return r;
+}
+template <typename P> inline RawPose Load(const P &pose) {
+    RawPose r;
+    for (int k = 0; k < 4; ++k) r.q[k] = pose.q.coeffs().data()[k];
+    for (int k = 0; k < 3; ++k) r.t[k] = pose.t.data()[k];
+    return r;
+}
+template <typename P> inline void Store(const RawPose &r, P &pose) {
+    for (int k = 0; k < 4; ++k) pose.q.coeffs().data()[k] = r.q[k];
+    for (int k = 0; k < 3; ++k) pose.t.data()[k] = r.t[k];
+}
+} // namespace
+
+void BASolver::ScalePoseGraphUnorder(const LoopInfo &loop_info, Map &map, bool use_key) {
+    // the frame every map point is re-expressed in afterwards: prefer key frames, then the smallest positive depth (:150-196)
+    for (auto &track : map.tracks_) {
+        if (track.outlier) continue;
+        int best_frame_id = -1;
+        double best_depth = -1.0;
+        bool is_key = false;
+        for (const auto &obs : track.observations_) {
+            const int frame_id = obs.first;
+            if (frame_id == loop_info.frame_id) continue;
+            const auto &frame = map.frames_[frame_id];
+            const RawPose tcw = Load(frame.Tcw);
+            double pc[3];
+            QRot(tcw.q, track.point3d_.data(), pc);
+            const double depth = pc[2] + tcw.t[2];
+            if (best_frame_id == -1) {
+                best_frame_id = frame_id; best_depth = depth; is_key = frame.is_keyframe;
+            } else {
+                if (depth < 0) continue;
+                if ((!is_key && frame.is_keyframe) || best_depth < 0 || (depth < best_depth && !(is_key && !frame.is_keyframe))) {
+                    best_frame_id = frame_id; best_depth = depth; is_key = frame.is_keyframe;
+                }
+            }
+        }
+        track.ref_id = best_frame_id;
+        track.depth = best_depth;
+        if (track.depth < 0) {
+            std::cout << "!!! negative depth\n";
+            if (!track.observations_.empty()) {
+                const auto &it = track.observations_.begin();
+                const int track_id = map.frames_[it->first].track_ids_[it->second];
+                printf("-%d %d %lf\n", track_id, track.ref_id, track.depth);
+                for (const auto &obs : track.observations_) {
+                    const RawPose tcw = Load(map.frames_[obs.first].Tcw);
+                    double pc[3];
+                    QRot(tcw.q, track.point3d_.data(), pc);
+                    printf("%d %d %lf\n", track_id, obs.first, pc[2] + tcw.t[2]);
+                }
+            }
+        }
+        if (track.ref_id == -1) std::cout << "!!! no frame_id\n";
+    }
+
+    const size_t num_frames = map.frames_.size();
+    const size_t num_loop = loop_info.cor_frame_ids_vec.size();
+    std::vector<RawPose> twc(num_frames);
+    for (auto &frame : map.frames_)
+        if (frame.registered) twc[frame.id] = PInv(Load(frame.Tcw));
+    std::vector<double> scale(num_frames + num_loop, 1.0);       // s_vec | s_vec_loop
+
+    double weight_o = 0.0;
+    constexpr double max_th = 0.1;
+    if (std::fabs(loop_info.scale_obs - 1) < max_th) {
+        weight_o = 1 - std::fabs(loop_info.scale_obs - 1) / max_th;
+        printf("weight scale: %lf\n", weight_o);
+    }
+
+    std::vector<int32_t> ea, eb, esa, esb;
+    std::vector<double> q_mea, p_mea;
+    std::vector<int> num_cov(num_frames, 0);
+    auto add_edge = [&](const RawPose &pose1_mea, const RawPose &pose2, int a, int b, int sa, int sb) {
+        double qi[4], q[4], d[3], p[3];
+        QInv(pose1_mea.q, qi);
+        QMul(qi, pose2.q, q);
+        for (int k = 0; k < 3; ++k) d[k] = pose2.t[k] - pose1_mea.t[k];
+        QRot(qi, d, p);
+        ea.push_back(a); eb.push_back(b); esa.push_back(sa); esb.push_back(sb);
+        q_mea.insert(q_mea.end(), q, q + 4); p_mea.insert(p_mea.end(), p, p + 3);
+    };
+    // covisibility edges, measured on the current estimate (:79-115)
+    for (auto &frame : map.frames_) {
+        if (!frame.registered) continue;
+        if (use_key && !frame.is_keyframe) continue;
+        const auto it = map.frameid2covisible_frameids_.find(frame.id);
+        if (it == map.frameid2covisible_frameids_.end()) continue;
+        for (const auto &cor_id : it->second) {
+            if (static_cast<int>(frame.id) <= cor_id) continue;
+            if (use_key && !map.frames_[cor_id].is_keyframe) continue;
+            add_edge(twc[frame.id], twc[cor_id], frame.id, cor_id, frame.id, cor_id);
+            num_cov[frame.id]++; num_cov[cor_id]++;
+        }
+    }
+    // loop edges: the loop frame against every matched component, measured with that component's pose estimate (:117-145)
+    for (size_t i = 0; i < num_loop; ++i) {
+        const RawPose pose1_mea = Load(loop_info.twc_vec[i]);
+        int count = 0;
+        for (const auto &cor_id : loop_info.cor_frame_ids_vec[i]) {
+            if (use_key && !map.frames_[cor_id].is_keyframe) continue;
+            add_edge(pose1_mea, twc[cor_id], loop_info.frame_id, cor_id, static_cast<int>(num_frames + i), cor_id);
+            count++;
+            num_cov[cor_id]++; num_cov[loop_info.frame_id]++;
+        }
+        printf("loop_cor: %d num_edge: %d\n", static_cast<int>(i), count);
+    }
+    std::vector<int32_t> sca, scb;
+    std::vector<double> s12;
+    if (loop_info.scale_obs != -1 && num_loop >= 2) {
+        printf("s12:%lf %zu %zu\n", loop_info.scale_obs, loop_info.cor_frame_ids_vec[0].size(), loop_info.cor_frame_ids_vec[1].size());
+        sca.push_back(static_cast<int32_t>(num_frames)); scb.push_back(static_cast<int32_t>(num_frames + 1)); s12.push_back(loop_info.scale_obs);
+    }
+
+    // bounds and constants (:233-256): scales >= 0.2 except the loop frame's own; gauge = position and scale of the init frames
+    std::vector<double> lower(num_frames + num_loop, -HUGE_VAL);
+    std::vector<uint8_t> pos_const(num_frames, 0), scale_const(num_frames + num_loop, 0);
+    for (auto &frame : map.frames_) {
+        if (!frame.registered) continue;
+        if (use_key && !frame.is_keyframe) continue;
+        if (num_cov[frame.id] == 0) { printf("%d no covisiblity\n", frame.id); continue; }
+        if (static_cast<int>(frame.id) != loop_info.frame_id) lower[frame.id] = 0.2;
+    }
+    for (size_t i = 0; i < num_loop && i < 2; ++i) lower[num_frames + i] = 0.2;
+    for (const int id : {map.init_id1, map.init_id2})
+        if (id >= 0 && id < static_cast<int>(num_frames)) { pos_const[id] = 1; scale_const[id] = 1; }
+
+    std::vector<double> rot(4 * num_frames), pos(3 * num_frames);
+    for (size_t i = 0; i < num_frames; ++i) {
+        for (int k = 0; k < 4; ++k) rot[4 * i + k] = twc[i].q[k];
+        for (int k = 0; k < 3; ++k) pos[3 * i + k] = twc[i].t[k];
+    }
+    xrsfm_pg_problem pg{};
+    pg.n_frames = static_cast<int32_t>(num_frames); pg.n_scales = static_cast<int32_t>(num_frames + num_loop);
+    pg.n_edges = static_cast<int32_t>(ea.size()); pg.n_scale_costs = static_cast<int32_t>(sca.size());
+    pg.rot_q = rot.data(); pg.pos = pos.data(); pg.scale = scale.data();
+    pg.pos_const = pos_const.data(); pg.scale_const = scale_const.data(); pg.scale_lower = lower.data();
+    pg.edge_a = ea.data(); pg.edge_b = eb.data(); pg.edge_sa = esa.data(); pg.edge_sb = esb.data();
+    pg.edge_q_mea = q_mea.data(); pg.edge_p_mea = p_mea.data(); pg.weight_o = weight_o;
+    pg.sc_a = sca.data(); pg.sc_b = scb.data(); pg.sc_s12 = s12.data();
+    xrsfm_pg_options opt;
+    xrsfm_pg_default_options(&opt);           // 100 iterations, DOGLEG, radius 1e16 (:258-262)
+    opt.verbose = 1;                          // minimizer_progress_to_stdout (:260)
+    xrsfm_pg_summary summary;
+    last_status_ = xrsfm_pg_solve(&opt, &pg, &summary);
+    if (last_status_ != XRSFM_BA_OK) {
+        fprintf(stderr, "[xrsfm_ba] pose graph failed with code %d; map left unchanged\n", last_status_);
+        return;
+    }
+    static const char *const kTerm[] = {"", "CONVERGENCE", "CONVERGENCE", "CONVERGENCE", "CONVERGENCE", "NO_CONVERGENCE", "FAILURE"};
+    std::cout << "Pose graph report: Iterations: " << summary.iterations << ", Initial cost: " << summary.initial_cost
+              << ", Final cost: " << summary.final_cost << ", Termination: " << kTerm[summary.termination] << "\n";
+    for (size_t i = 0; i < num_frames; ++i)
+        for (int k = 0; k < 3; ++k) twc[i].t[k] = pos[3 * i + k];
+    const std::vector<double> &s_vec = scale;
+
+    const size_t stride = std::max<size_t>(1, num_frames / 10);
+    if (!use_key) {
+        for (size_t i = 0; i < num_frames; ++i)
+            if (i % stride == 0 || s_vec[i] < 0) std::cout << i << " " << s_vec[i] << std::endl;
+        for (size_t i = 0; i < num_frames; ++i) Store(PInv(twc[i]), map.frames_[i].Tcw);        // every frame (:271-273)
+    } else {
+        int num_keyframe = 0;
+        for (const auto &frame : map.frames_)
+            if (frame.registered && frame.is_keyframe) num_keyframe++;
+        const int kstride = std::max(1, num_keyframe / 10);
+        int count = 0;
+        for (size_t i = 0; i < num_frames; ++i) {
+            auto &frame = map.frames_[i];
+            if (frame.registered && frame.is_keyframe) {
+                if (count % kstride == 0 || s_vec[i] < 0) std::cout << i << " " << s_vec[i] << std::endl;
+                count++;
+            }
+        }
+        for (size_t i = 0; i < num_frames; ++i) {
+            auto &frame = map.frames_[i];
+            if (frame.registered && frame.is_keyframe) { frame.tcw_old = frame.Tcw; Store(PInv(twc[i]), frame.Tcw); }
+        }
+        // non-key frames follow their reference key frame, their relative pose scaled by its scale (:293-303)
+        for (size_t i = 0; i < num_frames; ++i) {
+            auto &frame = map.frames_[i];
+            if (frame.registered && !frame.is_keyframe) {
+                const auto &ref_frame = map.frames_[frame.ref_id];
+                scale[i] = scale[frame.ref_id];
+                RawPose tcc2 = PMul(Load(frame.Tcw), PInv(Load(ref_frame.tcw_old)));
+                for (int k = 0; k < 3; ++k) tcc2.t[k] *= scale[frame.ref_id];
+                Store(PMul(tcc2, Load(ref_frame.Tcw)), frame.Tcw);
+            }
+        }
+    }
+    for (size_t i = 0; i < num_loop && i < 2; ++i) std::cout << scale[num_frames + i] << std::endl;
+
+    // re-express every map point through its reference frame: depth scaled by that frame's scale (:311-327)
+    for (auto &track : map.tracks_) {
+        if (track.outlier) continue;
+        const int frame_id = track.ref_id;
+        if (frame_id < 0) continue;
+        const int p2d_id = track.observations_[frame_id];
+        const RawPose tcw = Load(map.frames_[frame_id].Tcw);
+        const vector2 p2d = map.GetNormalizedPoint(frame_id, p2d_id);
+        const double sd = scale[frame_id] * track.depth;
+        const double v[3] = {sd * p2d.data()[0] - tcw.t[0], sd * p2d.data()[1] - tcw.t[1], sd - tcw.t[2]};
+        double qi[4], pw[3];
+        QInv(tcw.q, qi);
+        QRot(qi, v, pw);
+        for (int k = 0; k < 3; ++k) track.point3d_.data()[k] = pw[k];
+    }
 }
 
 } // namespace xrsfm

@@ -5,8 +5,8 @@
 // and src/run_triangulation.cc:180 compile unchanged; GBA / KGBA / LBA run on the MI355X through the C-ABI of
 // include/xrsfm_ba.h instead of ceres::Solve.  No Ceres header is needed by this file.
 //
-// ScalePoseGraphUnorder (pose graph, DOGLEG; ba_solver.cc:147-328) is not part of the BA hot path: its
-// definition stays in the reference's translation unit.
+// ScalePoseGraphUnorder (pose graph, DOGLEG; ba_solver.cc:147-328) is not part of the BA hot path; it is restated on top of
+// the host-side xrsfm_pg_solve so that this class needs no Ceres at all.
 #ifndef XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
 #define XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
 

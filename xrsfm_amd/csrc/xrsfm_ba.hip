@@ -26,6 +26,7 @@
 #include "ba_kernels.h"
 #include "ba_pack.h"
 #include "ba_plan.h"
+#include "pose_graph.h"
 
 using namespace xba;
 
@@ -855,6 +856,32 @@ int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm
     if (!e) e = xrsfm_ba_download(c, problem->cam_q, problem->cam_t, problem->points);
     xrsfm_ba_destroy(c);
     return e;
+}
+
+// ---------------------------------------------------------------- scaled pose graph, host only
+void xrsfm_pg_default_options(xrsfm_pg_options* o) {
+    if (!o) return;
+    o->max_iterations = 100; o->function_tolerance = 1e-6; o->parameter_tolerance = 1e-8; o->gradient_tolerance = 1e-10;
+    o->initial_radius = 1e16; o->verbose = 0;
+}
+
+int xrsfm_pg_solve(const xrsfm_pg_options* opt, xrsfm_pg_problem* p, xrsfm_pg_summary* summary) {
+    if (!p || !summary) return XRSFM_BA_EINVAL;
+    if (p->n_frames < 0 || p->n_scales < p->n_frames || p->n_edges < 0 || p->n_scale_costs < 0) return XRSFM_BA_EINVAL;
+    if (p->n_frames > 0 && (!p->rot_q || !p->pos)) return XRSFM_BA_EINVAL;
+    if (p->n_scales > 0 && !p->scale) return XRSFM_BA_EINVAL;
+    if (p->n_edges > 0 && (!p->edge_a || !p->edge_b || !p->edge_sa || !p->edge_sb || !p->edge_q_mea || !p->edge_p_mea)) return XRSFM_BA_EINVAL;
+    if (p->n_scale_costs > 0 && (!p->sc_a || !p->sc_b || !p->sc_s12)) return XRSFM_BA_EINVAL;
+    for (int e = 0; e < p->n_edges; ++e) {
+        if (p->edge_a[e] < 0 || p->edge_a[e] >= p->n_frames || p->edge_b[e] < 0 || p->edge_b[e] >= p->n_frames) return XRSFM_BA_EINVAL;
+        if (p->edge_sa[e] < 0 || p->edge_sa[e] >= p->n_scales || p->edge_sb[e] < 0 || p->edge_sb[e] >= p->n_scales) return XRSFM_BA_EINVAL;
+    }
+    for (int e = 0; e < p->n_scale_costs; ++e)
+        if (p->sc_a[e] < 0 || p->sc_a[e] >= p->n_scales || p->sc_b[e] < 0 || p->sc_b[e] >= p->n_scales) return XRSFM_BA_EINVAL;
+    xrsfm_pg_options o;
+    if (opt) o = *opt; else xrsfm_pg_default_options(&o);
+    xpg::Solver solver(*p);
+    return solver.run(o, summary);
 }
 
 // ---------------------------------------------------------------- pose-only refinement

@@ -198,4 +198,7 @@ CONFIGS = {
     "L": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4),
     # shape of BASELINE.json config 3 (KITTI-00 key-frame global BA, SURVEY 8 estimate): sequential visibility
     "K": dict(n_cams=2000, n_points=1_000_000, k_obs=4, seed=3),
+    # shape of BASELINE.json config 5 (1DSfM internet collection): cameras around a scene, random visibility ->
+    # a dense reduced camera matrix, no regular tiles
+    "U": dict(n_cams=500, n_points=100_000, k_obs=5, seed=5, mode="unordered"),
 }
