@@ -107,15 +107,36 @@ __device__ __forceinline__ void seg_reduce(double (&v)[N], int key, int lane, in
 
 // Regular tile (every track has the same L cameras, lane = track*L + rank): sum over the tracks, the lanes
 // < L end up with the per-camera totals.  Lanes without data must hold zeros.  Fixed order.
+// A lane whose partner lane + off lies outside the wave must not add (__shfl_down hands it its own value): the partner
+// is multiplied by a 0/1 mask inside the fma that does the addition (fma(o, 1, v) == v + o exactly), which costs nothing,
+// where a select would cost two v_cndmask per value.  For power-of-two strides the steps that stay inside a row of 16
+// lanes (off < 16) are DPP row shifts (v_mov_b32 row_shl, zero past the row end: no LDS traffic) — there the summation
+// tree of a lane l < L never leaves its row, and what the other lanes accumulate is never used.
+template <int SHIFT>
+__device__ __forceinline__ double row_shl_d(double v) {     // lane i <- lane i + SHIFT of the same 16-lane row (0 past its end)
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x100 + SHIFT, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x100 + SHIFT, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int N, int SHIFT>
+__device__ __forceinline__ void row_step(double (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] += row_shl_d<SHIFT>(v[k]);
+}
 template <int N>
 __device__ __forceinline__ void strided_reduce(double (&v)[N], int stride, int lane) {
-    for (int off = stride; off < kWave; off <<= 1) {
-        const bool take = lane + off < kWave;
+    int off = stride;
+    if ((stride & (stride - 1)) == 0) {          // wave-uniform
+        if (off == 1) { row_step<N, 1>(v); off = 2; }
+        if (off == 2) { row_step<N, 2>(v); off = 4; }
+        if (off == 4) { row_step<N, 4>(v); off = 8; }
+        if (off == 8) { row_step<N, 8>(v); off = 16; }
+    }
+    for (; off < kWave; off <<= 1) {
+        const double m = (lane + off < kWave) ? 1.0 : 0.0;
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double o = __shfl_down(v[k], off, kWave);
-            if (take) v[k] += o;
-        }
+        for (int k = 0; k < N; ++k) v[k] = fma(__shfl_down(v[k], off, kWave), m, v[k]);
     }
 }
 
@@ -195,17 +216,15 @@ __global__ void k_cam_lin(Dev d) {
 // Residuals, robustified + Jacobi-scaled Jacobian blocks, per-track H_pp / g_p
 // (segmented wave reduction), per-observation camera-side terms into the
 // camera-major scatter buffer, cost and |x_points|^2 partials.
-// 128 VGPRs: 4 waves per SIMD (measured 118 -> 98 us at config L; 5 waves spill and are slower)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_linearize(Dev d, double huber_a) {
-    const int lane = threadIdx.x & (kWave - 1);
-    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
-    if (item >= d.n_items) return;
-    const Item it = d.items[item];
-    const bool is_long = it.n_tiles > 1;
+// LONG = the item is one track of more than 64 observations spread over several tiles; the accumulators that carries across
+// tiles exist only in that instantiation (they would cost the common single-tile path ~20 VGPRs).
+template <bool LONG>
+__device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int item, int lane, double huber_a) {
+    constexpr bool is_long = LONG;
     double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     double cost = 0.0, xn2 = 0.0, gm = 0.0;
     int long_pt = -1;
-    for (int tl = 0; tl < it.n_tiles; ++tl) {
+    for (int tl = 0; tl < (LONG ? it.n_tiles : 1); ++tl) {
         const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double cs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -300,6 +319,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, kWave));
     if (lane == 0) { d.part[item] = cost; d.part[d.n_items + item] = xn2; d.part[2 * (size_t)d.n_items + item] = gm; }
+}
+
+// 128 VGPRs: 4 waves per SIMD (measured 118 -> 98 us at config L; 5 waves spill and are slower)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_linearize(Dev d, double huber_a) {
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    if (it.n_tiles > 1) linearize_item<true>(d, it, item, lane, huber_a);
+    else linearize_item<false>(d, it, item, lane, huber_a);
 }
 
 // Cost only (1/2 sum rho is formed on the host side of the reduction), candidate state.
