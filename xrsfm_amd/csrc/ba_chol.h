@@ -313,10 +313,13 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
     const int li = lane & 15, lk = lane >> 4;
     double* base = c.S + (size_t)(k * kNB) * c.n_pad + k * kNB;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = t + 256 * it; const int r = e >> 6, col = e & 63;
-        A[r][col] = (col <= r) ? base[(size_t)r * c.n_pad + col] : 0.0;
+    for (int it = 0; it < 8; ++it) {           // 2048 double2 of the tile, 8 per thread; the upper triangle is masked to 0
+        const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
+        const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * c.n_pad + col);
+        A[r][col] = (col <= r) ? v.x : 0.0;
+        A[r][col + 1] = (col + 1 <= r) ? v.y : 0.0;
         Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
+        Li[r][col + 1] = (r == col + 1 && r >= 16 * nb) ? 1.0 : 0.0;
     }
     __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
@@ -414,10 +417,12 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
     }
     double* lo = c.Linv + (size_t)k * kNB * kNB;
 #pragma unroll
-    for (int it = 0; it < 16; ++it) {
-        const int e = t + 256 * it; const int r = e >> 6, col = e & 63;
-        lo[e] = (col <= r) ? Li[r][col] : 0.0;
-        if (col <= r) base[(size_t)r * c.n_pad + col] = A[r][col];
+    for (int it = 0; it < 8; ++it) {
+        const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
+        reinterpret_cast<double2*>(lo)[e] = make_double2((col <= r) ? Li[r][col] : 0.0, (col + 1 <= r) ? Li[r][col + 1] : 0.0);
+        double* dst = base + (size_t)r * c.n_pad + col;
+        if (col + 1 <= r) *reinterpret_cast<double2*>(dst) = make_double2(A[r][col], A[r][col + 1]);
+        else if (col <= r) dst[0] = A[r][col];
     }
     if (rptr) {     // forward substitution of this panel; Tb (3*16*17 doubles) is reused as 3 x 64 scratch
         double* acc = &Tb[0][0][0]; double* v = acc + 64; double* tmp = acc + 128;
