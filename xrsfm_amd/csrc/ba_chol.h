@@ -329,31 +329,29 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
             double a[16];
 #pragma unroll
             for (int cc = 0; cc < 16; ++cc) a[cc] = A[b0 + li][b0 + cc];
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const double ujj = row_bcast(a[jj], jj);
-                const double tl = a[jj] * fast_rcp(ujj);          // u_ij / u_jj
-#pragma unroll
-                for (int cc = jj + 1; cc < 16; ++cc) a[cc] = fma(-tl, row_bcast(a[jj], cc), a[cc]);
-                __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later steps from being hoisted (register pressure)
-            }
-            // column scaling by 1/sqrt(u_jj): lane i computes its own s_i
-            double si = 1.0;
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) if (li == jj) si = fast_rsqrt(a[jj]);
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) a[jj] *= row_bcast(si, jj);   // a[jj] = L[i][jj] for jj <= i
-            // inverse of the 16x16 lower-triangular block: lane = column cc
-            double lcol[16];          // running right-hand side; entry r becomes Linv[r][lane] at step r
+            // Right-looking elimination and the inverse of the triangular factor in ONE sweep: at step jj the pivot u_jj and
+            // column jj of the (unscaled) factor are final, so step jj of the forward substitution L X = I (lane = column of
+            // X) can run next to the elimination step — both use the same 15-jj broadcasts, and the two fma streams are
+            // independent.  L[i][jj] = a[jj]_i * s_jj with s_jj = 1/sqrt(u_jj).
+            double lcol[16];          // running right-hand side of column `li`; entry r becomes Linv[r][li] at step r
 #pragma unroll
             for (int r = 0; r < 16; ++r) lcol[r] = (r == li) ? 1.0 : 0.0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const double x = lcol[r] * row_bcast(si, r);
-                lcol[r] = x;
+            for (int jj = 0; jj < 16; ++jj) {
+                const double ujj = row_bcast(a[jj], jj);
+                const double sj = fast_rsqrt(ujj);
+                const double tl = a[jj] * (sj * sj);              // u_ij / u_jj
+                const double x = lcol[jj] * sj;
+                const double xs = x * sj;
+                lcol[jj] = x;
 #pragma unroll
-                for (int i = r + 1; i < 16; ++i) lcol[i] = fma(-row_bcast(a[r], i), x, lcol[i]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int cc = jj + 1; cc < 16; ++cc) {
+                    const double bv = row_bcast(a[jj], cc);       // u_{cc,jj}
+                    a[cc] = fma(-tl, bv, a[cc]);
+                    lcol[cc] = fma(-bv, xs, lcol[cc]);
+                }
+                a[jj] *= sj;                                       // column jj of L (rows >= jj)
+                __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later steps from being hoisted (register pressure)
             }
             if (lane < 16) {
 #pragma unroll
