@@ -719,21 +719,32 @@ __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __
     }
 }
 
-// grid (targets, 8): 512 tile elements per workgroup
+// Fixed-order sum of strided values with 8 loads in flight (a plain s += load loop is one L2 round trip per term).
+__device__ __forceinline__ double sum_strided(const double* __restrict__ base, size_t stride, int n) {
+    double s = 0.0;
+    int p = 0;
+    for (; p + 8 <= n; p += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = base[(size_t)(p + u) * stride];
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; p < n; ++p) s += base[(size_t)p * stride];
+    return s;
+}
+
+// grid (targets, 16): 256 tile elements per workgroup
 __global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* __restrict__ rt, const int* __restrict__ rp,
                                                           const double* __restrict__ Wp) {
     const int i = rt[2 * blockIdx.x], k = rt[2 * blockIdx.x + 1];
     const int p0 = rp[2 * blockIdx.x], p1 = rp[2 * blockIdx.x + 1];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int e = blockIdx.y * 512 + h * 256 + threadIdx.x;
-        double s = 0.0;
-        for (int p = p0; p < p1; ++p) s += Wp[(size_t)p * kPartStride + e];
+    {
+        const int e = blockIdx.y * 256 + threadIdx.x;
+        const double s = sum_strided(Wp + (size_t)p0 * kPartStride + e, kPartStride, p1 - p0);
         c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] -= s;
     }
     if (i == k && blockIdx.y == 0 && threadIdx.x < kNB) {
-        double s = 0.0;
-        for (int p = p0; p < p1; ++p) s += Wp[(size_t)p * kPartStride + kNB * kNB + threadIdx.x];
+        const double s = sum_strided(Wp + (size_t)p0 * kPartStride + kNB * kNB + threadIdx.x, kPartStride, p1 - p0);
         c.rhs[k * kNB + threadIdx.x] -= s;
     }
 }

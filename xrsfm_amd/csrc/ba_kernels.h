@@ -944,19 +944,34 @@ __global__ __launch_bounds__(kPcgThreads) void k_reduce_multi(ReduceJobs jobs) {
     const int n = jobs.n[blockIdx.x];
     if (jobs.op[blockIdx.x] == 0) {
         double s = 0.0;
-        for (int i = threadIdx.x; i < n; i += kPcgThreads) s += in[i];
+        int i = threadIdx.x;
+        for (; i + 7 * kPcgThreads < n; i += 8 * kPcgThreads) {     // 8 loads in flight, fixed order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[i + u * kPcgThreads];
+            s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+        for (; i < n; i += kPcgThreads) s += in[i];
         s = block_sum<kPcgThreads>(s, lds);
         if (threadIdx.x == 0) *jobs.out[blockIdx.x] = s;
     } else {
         double m = 0.0;
-        for (int i = threadIdx.x; i < n; i += kPcgThreads) m = fmax(m, in[i]);
+        int i = threadIdx.x;
+        for (; i + 7 * kPcgThreads < n; i += 8 * kPcgThreads) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = in[i + u * kPcgThreads];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) m = fmax(m, v[u]);
+        }
+        for (; i < n; i += kPcgThreads) m = fmax(m, in[i]);
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
         if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
         __syncthreads();
         if (threadIdx.x == 0) {
             double r = 0.0;
-            for (int i = 0; i < kPcgThreads / kWave; ++i) r = fmax(r, lds[i]);
+            for (int i2 = 0; i2 < kPcgThreads / kWave; ++i2) r = fmax(r, lds[i2]);
             *jobs.out[blockIdx.x] = r;
         }
     }

@@ -471,7 +471,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             if (nch > 0) {      // thin level: chunks of the contribution lists in parallel, then a fixed-order sum
                 LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), shm, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
                        h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nt, 8), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
+                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
             } else if (nt > 0)
                 LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
