@@ -759,6 +759,16 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         double E[6], v0 = 0.0, v1 = 0.0, r0 = 0.0, r1 = 0.0;
         double w[3] = {0, 0, 0};
+        // what the head lane of a track needs after the reduction depends on the point only: every lane of the track requests
+        // it now (same addresses: one transaction), so that it does not cost a third memory round trip after the shuffles
+        double hh[6] = {0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0};
+        if (s.valid) {
+            const double* h = d.Hinv + 6 * (size_t)s.pt;
+            const double* g = d.gp + 3 * (size_t)s.pt;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) hh[k] = h[k];
+            gg[0] = g[0]; gg[1] = g[1]; gg[2] = g[2];
+        }
         if (s.valid) {
             const double* y = d.px + 6 * (size_t)s.cam;
             double F[12];
@@ -771,12 +781,10 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
         seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);
         double u[3] = {0, 0, 0};
         if (s.head) {
-            const double* h = d.Hinv + 6 * (size_t)s.pt;
-            const double* g = d.gp + 3 * (size_t)s.pt;
-            const double a0 = g[0] - w[0], a1 = g[1] - w[1], a2 = g[2] - w[2];
-            u[0] = h[0] * a0 + h[1] * a1 + h[2] * a2;
-            u[1] = h[1] * a0 + h[3] * a1 + h[4] * a2;
-            u[2] = h[2] * a0 + h[4] * a1 + h[5] * a2;
+            const double a0 = gg[0] - w[0], a1 = gg[1] - w[1], a2 = gg[2] - w[2];
+            u[0] = hh[0] * a0 + hh[1] * a1 + hh[2] * a2;
+            u[1] = hh[1] * a0 + hh[3] * a1 + hh[4] * a2;
+            u[2] = hh[2] * a0 + hh[4] * a1 + hh[5] * a2;
             const double* sp = d.scale_p + 3 * (size_t)s.pt;
             const double* P = d.P + 3 * (size_t)s.pt;
             double* Pc = d.P_cand + 3 * (size_t)s.pt;
