@@ -116,7 +116,9 @@ struct xrsfm_ba_context {
     std::vector<size_t> alloc_class;
     CamRec* cam0 = nullptr; double* P0 = nullptr;   // pristine copies for reset
     int n_points_caller = 0;
-    double* h_scal = nullptr;       // pinned
+    double* h_scal = nullptr;       // pinned, coherent, device-visible: S_COUNT scalars + a sequence word
+    double* h_scal_dev = nullptr;   // its device address
+    unsigned long long seq = 0;
     PcgStatus* h_st = nullptr;      // pinned
     void* comm = nullptr; int n_ranks = 1, rank = 0;
     xrsfm_ba_allreduce_fn hook = nullptr; void* hook_user = nullptr; std::vector<double> hook_buf;   // test transport (host copy)
@@ -187,7 +189,8 @@ struct BundleCache {
         }
         b->stream = nullptr; b->h_scal = nullptr; b->h_st = nullptr;
         if (hipStreamCreate(&b->stream) != hipSuccess) return false;
-        if (hipHostMalloc((void**)&b->h_scal, sizeof(double) * S_COUNT) != hipSuccess ||
+        // coherent + mapped: the device publishes the LM scalars straight into this buffer (k_publish) and the host polls
+        if (hipHostMalloc((void**)&b->h_scal, sizeof(double) * (S_COUNT + 2), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
             hipHostMalloc((void**)&b->h_st, sizeof(PcgStatus)) != hipSuccess) {
             if (b->h_scal) (void)hipHostFree(b->h_scal);
             (void)hipStreamDestroy(b->stream);
@@ -270,11 +273,37 @@ void profile_collect(xrsfm_ba_context* c, int tag_limit = 1 << 30) {
     c->ev_used = 0;
 }
 
+// The LM controller needs ~10 scalars on the host twice per iteration.  A D2H copy + hipStreamSynchronize costs 20-30 us of
+// idle GPU each time; instead one tiny kernel stores the scalars and then a sequence number (system-scope release) into
+// coherent host memory and the host spins on the sequence number.
+__global__ void k_publish(const double* __restrict__ scal, double* __restrict__ host, unsigned long long seq) {
+    if (threadIdx.x < S_COUNT) host[threadIdx.x] = scal[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + S_COUNT), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 int fetch_scalars(xrsfm_ba_context* c) {
     HIPCHK(hipGetLastError());          // a failed launch since the last sync point
-    HIPCHK(hipMemcpyAsync(c->h_scal, c->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->profiling) profile_collect(c);
+    if (c->profiling || !c->h_scal_dev) {
+        HIPCHK(hipMemcpyAsync(c->h_scal, c->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        if (c->profiling) profile_collect(c);
+        return 0;
+    }
+    const unsigned long long want = ++c->seq;
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->d.scal, c->h_scal_dev, want);
+    HIPCHK(hipGetLastError());
+    const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(c->h_scal + S_COUNT);
+    for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want; ++spins) {
+        if ((spins & 0xfffff) == 0xfffff) {                 // every ~1M polls: has the stream died?
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) break; return XRSFM_BA_ENODEV; }
+            if (q != hipErrorNotReady) return XRSFM_BA_ENODEV;
+        }
+        __builtin_ia32_pause();
+    }
     return 0;
 }
 
@@ -604,6 +633,10 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
         HostBundle hb;
         if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
         c->stream = hb.stream; c->h_scal = hb.h_scal; c->h_st = hb.h_st;
+        c->seq = 0;
+        *reinterpret_cast<unsigned long long*>(c->h_scal + S_COUNT) = 0;
+        void* dp = nullptr;
+        c->h_scal_dev = (hipHostGetDevicePointer(&dp, c->h_scal, 0) == hipSuccess) ? static_cast<double*>(dp) : nullptr;
     }
     const Packed& k = c->pk;
     Dev& d = c->d;
