@@ -495,3 +495,24 @@ def test_refine_pose_edge_cases(lib):
     assert s.num_residuals == 0 and np.array_equal(q, arr["cam_q"][0]) and np.array_equal(t, arr["cam_t"][0])
     with pytest.raises(Exception):
         capi.refine_pose(7, arr["intr_params"][0], arr["points"], arr["obs_uv"], arr["cam_q"][0], arr["cam_t"][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [1, 0], ids=["cholesky", "pcg"])
+def test_gradient_tolerance_exit_matches_oracle(lib, solver):
+    """Exit by the gradient tolerance after an accepted step.  The product learns the gradient norm of a new linearisation
+    one solve late (it travels with the next step's scalars); that extra solve must be neither counted nor applied."""
+    arr = H.make(8, 300, 4, seed=410, noise=0.0, outlier_frac=0.0)
+    kw = dict(gradient_tolerance=1e-3, function_tolerance=1e-30, parameter_tolerance=1e-30, max_iterations=30)
+    pr, s_ref, prod, s = _solve_both(dict(arr), dict(kw, linear_solver=solver))
+    assert s_ref.termination.startswith("CONVERGENCE: gradient"), s_ref.termination
+    assert s.termination_reason == 1
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert s.lm_steps_attempted == s.n_successful + s.n_unsuccessful
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * max(s_ref.final_cost, 1e-12) + 1e-14
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
+    # max_iterations hit while a linearisation is still pending: same counts as the oracle as well
+    kw2 = dict(max_iterations=2)
+    pr, s_ref, prod, s = _solve_both(dict(arr), dict(kw2, linear_solver=solver))
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful) and s.termination_reason == 5
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost

@@ -341,11 +341,15 @@ int linearize(xrsfm_ba_context* c, double huber_a) {
 }
 
 // after linearize(), which leaves the point part in S_GRADMAX_PTS (one rank) or in the per-rank slots behind camlin
-int gradient_max(xrsfm_ba_context* c, double* out) {
+int gradient_max_enqueue(xrsfm_ba_context* c) {
     Dev& d = c->d;
     const double* rank_max = c->multi() ? d.camlin + (size_t)d.n_cams * 12 + 2 : nullptr;
     LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, d.scal + S_GRADMAX_CAMS, rank_max, c->n_ranks, d.scal + S_GRADMAX_PTS);
-    int e;
+    return 0;
+}
+int gradient_max(xrsfm_ba_context* c, double* out) {
+    int e = gradient_max_enqueue(c);
+    if (e) return e;
     e = fetch_scalars(c);
     if (e) return e;
     *out = std::fmax(c->h_scal[S_GRADMAX_PTS], c->h_scal[S_GRADMAX_CAMS]);
@@ -820,8 +824,25 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
     if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
     int it = 0, invalid = 0;
     const double max_radius = 1e16, min_radius = 1e-32, min_rel_decrease = 1e-3;
+    // After an accepted step the new linearisation is only ENQUEUED: its cost, |x|^2 and gradient max-norm stay in the device
+    // scalar block and reach the host together with the scalars of the next step (one host round trip per LM iteration
+    // instead of two).  The gradient-tolerance exit is then detected one solve late; that solve is discarded and not counted.
+    bool pending = false;
+    auto take_pending = [&]() {
+        cost = 0.5 * c->h_scal[S_COST];
+        xnorm2_pts = c->h_scal[S_XNORM2_PTS];
+        gmax = std::fmax(c->h_scal[S_GRADMAX_PTS], c->h_scal[S_GRADMAX_CAMS]);
+        pending = false;
+    };
     while (true) {
-        if (it >= opt.max_iterations) return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
+        if (it >= opt.max_iterations) {
+            if (pending) {
+                if ((e = fetch_scalars(c))) return e;
+                take_pending();
+                if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
+            }
+            return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
+        }
         ++it;
         sum->lm_steps_attempted++;
         if ((e = prepare_step(c, radius, solver == XRSFM_BA_SOLVER_CHOLESKY))) return e;
@@ -832,6 +853,13 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
             if ((e = chol_factor_solve(c))) return e;
         }
         if ((e = finish_step(c, opt.huber_a))) return e;
+        if (pending) {
+            take_pending();
+            if (gmax <= opt.gradient_tolerance) {     // the solve above started from a converged point: discard it
+                --it; sum->lm_steps_attempted--;
+                return finish(XRSFM_BA_CONVERGENCE, 1, cost);
+            }
+        }
         const double* s = c->h_scal;
         const double model_change = s[S_MODEL];
         const double xnorm = std::sqrt(xnorm2_pts + s[S_XNORM2_CAMS]);
@@ -855,14 +883,19 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
             std::swap(d.cam, d.cam_cand);
             std::swap(d.P, d.P_cand);
             if ((e = linearize(c, opt.huber_a))) return e;
-            if ((e = gradient_max(c, &gmax))) return e;
-            cost = 0.5 * c->h_scal[S_COST];
-            xnorm2_pts = c->h_scal[S_XNORM2_PTS];
             radius = std::fmin(max_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
             decrease = 2.0;
             sum->n_successful++;
-            print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
-            if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
+            if (opt.verbose || c->profiling) {     // the progress line needs the numbers now; profiling drains its event pool at every fetch
+                if ((e = gradient_max(c, &gmax))) return e;
+                cost = 0.5 * c->h_scal[S_COST];
+                xnorm2_pts = c->h_scal[S_XNORM2_PTS];
+                print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
+                if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
+            } else {
+                if ((e = gradient_max_enqueue(c))) return e;
+                pending = true;
+            }
         } else {
             radius /= decrease; decrease *= 2.0;
             sum->n_unsuccessful++;
