@@ -303,6 +303,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
         const int T2 = nvalid / L, Cp = ((3 * T2 + 3) & ~3) + 2;
         P.pairs_shm = std::max(P.pairs_shm, (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
+        P.pairs_shm = std::max(P.pairs_shm, (size_t)64 * 15 * sizeof(double));      // reduction buffer of the diagonal terms (kRedLd)
     }
     return 0;
 }
