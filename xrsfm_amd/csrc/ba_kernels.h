@@ -96,12 +96,9 @@ __device__ __forceinline__ void seg_reduce(double (&v)[N], int key, int lane, in
     // stay inside a segment, so log2(maxlen) steps suffice (2 instead of 6 for 4-observation tracks)
     for (int off = 1; off < maxlen; off <<= 1) {
         const int okey = __shfl_down(key, off, kWave);
-        const bool take = (lane + off < kWave) && (okey == key);
+        const double m = ((lane + off < kWave) && (okey == key)) ? 1.0 : 0.0;    // 0/1 mask inside the fma: no selects
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            const double o = __shfl_down(v[k], off, kWave);
-            if (take) v[k] += o;
-        }
+        for (int k = 0; k < N; ++k) v[k] = fma(__shfl_down(v[k], off, kWave), m, v[k]);
     }
 }
 
