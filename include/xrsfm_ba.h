@@ -36,6 +36,7 @@ extern "C" {
 #define XRSFM_BA_ENOMEM (-3)
 #define XRSFM_BA_ECOMM (-4)    /* RCCL unavailable or a collective failed         */
 #define XRSFM_BA_ESTATE (-5)   /* call order violated                            */
+#define XRSFM_BA_ETOOBIG (-6)  /* explicit reduced camera matrix requested (CHOLESKY) but it does not fit: use AUTO or PCG */
 
 /* camera models: ids of /root/reference/src/base/camera_model.hpp:93-209 */
 #define XRSFM_BA_SIMPLE_PINHOLE 0 /* {f,cx,cy}             uv = 2f*xn + c (reference quirk, :102-105) */
@@ -70,9 +71,11 @@ typedef struct xrsfm_ba_problem {
 } xrsfm_ba_problem;
 
 #define XRSFM_BA_SOLVER_PCG 0      /* implicit-Schur PCG on the reduced camera system (any size)            */
-#define XRSFM_BA_SOLVER_CHOLESKY 1 /* explicit reduced camera matrix + tile-sparse dense Cholesky (exact,
-                                      what Ceres SPARSE_SCHUR computes); needs 6*n_cams <= 12288            */
-#define XRSFM_BA_SOLVER_AUTO 2     /* CHOLESKY when it fits, else PCG                                       */
+#define XRSFM_BA_SOLVER_CHOLESKY 1 /* explicit reduced camera matrix + tile Cholesky (exact, what Ceres SPARSE_SCHUR
+                                      computes).  Any camera graph up to 6*n_cams <= 12288; beyond that only band /
+                                      ring graphs (sequential data: shallow elimination tree) while the tile storage
+                                      fits (XRSFM_BA_ETOOBIG otherwise)                                      */
+#define XRSFM_BA_SOLVER_AUTO 2     /* CHOLESKY whenever the rule above allows it, else PCG                  */
 
 typedef struct xrsfm_ba_options {
     int32_t max_iterations;      /* GBA accurate 50 / fast 20 / KGBA 20 / LBA 5        */

@@ -516,3 +516,31 @@ def test_gradient_tolerance_exit_matches_oracle(lib, solver):
     pr, s_ref, prod, s = _solve_both(dict(arr), dict(kw2, linear_solver=solver))
     assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful) and s.termination_reason == 5
     assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost
+
+
+@pytest.mark.gpu
+def test_auto_solver_beyond_the_dense_limit(lib):
+    """More than 12288 camera unknowns: a sequential (band) problem still gets the exact tile Cholesky through AUTO (shallow
+    elimination tree, S in tile storage) and matches the C restatement; random visibility at that size falls back to PCG, and an
+    explicit CHOLESKY request is refused with ETOOBIG instead of running a 200-panel dense factorisation."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi
+    arr = H.make(2100, 9000, 4, seed=420)
+    assert 6 * 2100 > 12288
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["ordering"] == 1 and plan["level_schedule"] == 1 and plan["levels"] <= 8
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options(max_iterations=10))
+    assert s.linear_solver_used == capi.SOLVER_CHOLESKY and s.final_cost < s.initial_cost
+    if ba_cpu.available():
+        prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+        sc = ba_cpu.solve(prob, max_iterations=10, threads=8)
+        n_res = 2 * arr["obs_cam"].shape[0]
+        assert (sc["n_successful"], sc["n_unsuccessful"]) == (s.n_successful, s.n_unsuccessful)
+        assert abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s.final_cost / n_res)) < 1e-6
+    arr_u = H.make(2100, 6000, 4, seed=421, mode="unordered")
+    prod_u = H.to_product(arr_u)
+    s_u = capi.solve(prod_u, capi.default_options(max_iterations=3, pcg_tolerance=1e-6))
+    assert s_u.linear_solver_used == capi.SOLVER_PCG and s_u.final_cost < s_u.initial_cost
+    with pytest.raises(Exception, match="ETOOBIG"):
+        capi.solve(H.to_product(arr_u), capi.default_options(max_iterations=1, linear_solver=capi.SOLVER_CHOLESKY))

@@ -78,7 +78,8 @@ const char* kKidName[K_COUNT] = {
     "k_block_segsum", "k_dense_fill", "k_potrf", "k_trsm", "k_update", "k_fwd_bwd", "small_kernels"};
 
 constexpr int kMaxRanks = 64;          // slots for the per-rank point-gradient maxima behind camlin
-constexpr int kCholMaxN = 12288;
+constexpr int kCholMaxN = 12288;          // dense-pattern reduced systems (right-looking schedule) up to this many unknowns
+constexpr size_t kCholMaxBytes = (size_t)96 << 30;   // tile storage of S for band-ordered problems (level schedule): sized for 288 GB
 }  // namespace
 
 // ---------------------------------------------------------------- context
@@ -408,7 +409,6 @@ int chol_setup(xrsfm_ba_context* c) {
     if (h.ready) return 0;
     const Packed& k = c->pk;
     const int Nc = k.n_cams;
-    if (6 * Nc > kCholMaxN) return XRSFM_BA_EINVAL;
     std::vector<int> spp;
     PairKeys keyed;
     int e = chol_local_keys(k, spp, keyed);
@@ -435,6 +435,9 @@ int chol_setup(xrsfm_ba_context* c) {
     }
     CholPlan P;
     if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P))) return e;
+    // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
+    // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
+    if (6 * Nc > kCholMaxN && (!P.use_levels || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
@@ -788,9 +791,16 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
     Dev& d = c->d;
     hipStream_t st = c->stream;
     int solver = opt.linear_solver;
-    if (solver == XRSFM_BA_SOLVER_AUTO) solver = (6 * d.n_cams <= kCholMaxN) ? XRSFM_BA_SOLVER_CHOLESKY : XRSFM_BA_SOLVER_PCG;
-    if (solver != XRSFM_BA_SOLVER_PCG && solver != XRSFM_BA_SOLVER_CHOLESKY) return XRSFM_BA_EINVAL;
     int e;
+    if (solver == XRSFM_BA_SOLVER_AUTO) {
+        // exact tile Cholesky whenever its plan is feasible (always up to kCholMaxN unknowns; larger problems when the camera
+        // graph is a band / ring), implicit-Schur PCG otherwise
+        e = chol_setup(c);
+        if (e == XRSFM_BA_ETOOBIG || e == XRSFM_BA_ENOMEM) solver = XRSFM_BA_SOLVER_PCG;
+        else if (e) return e;
+        else solver = XRSFM_BA_SOLVER_CHOLESKY;
+    }
+    if (solver != XRSFM_BA_SOLVER_PCG && solver != XRSFM_BA_SOLVER_CHOLESKY) return XRSFM_BA_EINVAL;
     if (solver == XRSFM_BA_SOLVER_CHOLESKY && (e = chol_setup(c))) return e;
     sum->linear_solver_used = solver;
     c->profiling = opt.profile != 0;

@@ -200,5 +200,7 @@ CONFIGS = {
     "K": dict(n_cams=2000, n_points=1_000_000, k_obs=4, seed=3),
     # shape of BASELINE.json config 5 (1DSfM internet collection): cameras around a scene, random visibility ->
     # a dense reduced camera matrix, no regular tiles
+    # a long sequential trajectory: 30 000 camera unknowns, still on the exact (band-ordered) Cholesky path
+    "X": dict(n_cams=5000, n_points=1_000_000, k_obs=4, seed=6),
     "U": dict(n_cams=500, n_points=100_000, k_obs=5, seed=5, mode="unordered"),
 }
