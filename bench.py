@@ -86,6 +86,26 @@ def count_offdiag_blocks(arr: dict) -> int:
     return int(np.unique(np.concatenate(keys)).shape[0]) if keys else 0
 
 
+def gauge_aligned_centre_diff(q1, t1, q2, t2):
+    """max |c1 - (s R c2 + T)| over the camera centres after the best similarity alignment (Umeyama).  Fixing the translations
+    of two frames (the reference's gauge, ba_solver.cc:611-614) leaves a similarity direction almost free, along which two exact
+    FP64 solvers with different summation orders drift apart without any effect on the cost; this removes that component."""
+    def centres(q, t):
+        x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        R = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                      2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                      2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        return -np.einsum("nji,nj->ni", R, t)
+    c1, c2 = centres(q1, t1), centres(q2, t2)
+    m1, m2 = c1.mean(0), c2.mean(0)
+    a, b = c1 - m1, c2 - m2
+    U, S, Vt = np.linalg.svd(a.T @ b / len(a))
+    D = np.diag([1.0, 1.0, np.sign(np.linalg.det(U @ Vt))])
+    R = U @ D @ Vt
+    sc = np.trace(np.diag(S) @ D) / (b ** 2).sum(1).mean()
+    return float(np.abs(c1 - (sc * (R @ c2.T).T + m1 - sc * R @ m2)).max())
+
+
 def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
     """oracle/ C restatement (kind "port") timed on the host cores; None if it is not built."""
     try:
@@ -243,6 +263,7 @@ def main():
                     base["more_threads"]["gpu_vs_cpu"] = out["value"] / base["more_threads"]["value"]
                 base["rmse_diff_px"] = abs(base["final_rmse_px"] - out["final_rmse_px"])
                 base["max_cam_param_diff"] = float(max(np.abs(cpu_prob["cam_q"] - q).max(), np.abs(cpu_prob["cam_t"] - t).max()))
+                base["max_centre_diff_gauge_aligned"] = gauge_aligned_centre_diff(cpu_prob["cam_q"], cpu_prob["cam_t"], q, t)
                 out["cpu_baseline"] = base
         print(json.dumps(out))
     ctx.close()
