@@ -69,15 +69,55 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         }
         return la < lb;
     };
-    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        const bool la = cnt[a + 1] > 64, lb = cnt[b + 1] > 64;
-        if (la != lb) return lb;
-        return tuple_less(a, b);
-    });
+    {
+        // The comparator walks two tuples through three indirections per element; sorting 64-bit keys built from the
+        // first cameras (4 x 15 bits, or 3 x 20 bits for more than 32k cameras; +1 so that a shorter tuple sorts before its
+        // extensions; long tracks last) and falling back to the comparator only inside groups of equal keys whose tuples
+        // are longer than the key is several times faster on a million tracks.
+        struct KI { unsigned long long key; int idx; };
+        std::vector<KI> ki(order.size());
+        const int kbits = (Nc + 1 < (1 << 15)) ? 15 : 20, kcams = (kbits == 15) ? 4 : 3;
+        const bool wide = Nc + 1 >= (1 << 20);         // camera ids do not fit the key: plain comparator sort
+        for (size_t n = 0; n < order.size(); ++n) {
+            const int j = order[n];
+            const int len = cnt[j + 1];
+            unsigned long long key = (len > 64) ? (1ull << 63) : 0ull;
+            for (int q = 0; q < kcams; ++q) {
+                const unsigned long long c = (q < len) ? (unsigned long long)p.obs_cam[csr[ptr[j] + q]] + 1ull : 0ull;
+                key |= c << (kbits * (kcams - 1 - q));
+            }
+            ki[n] = {key, j};
+        }
+        auto full_less = [&](int a, int b) {
+            const bool la = cnt[a + 1] > 64, lb = cnt[b + 1] > 64;
+            if (la != lb) return lb;
+            return tuple_less(a, b);
+        };
+        if (wide) {
+            std::stable_sort(order.begin(), order.end(), full_less);
+        } else {
+            std::sort(ki.begin(), ki.end(), [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; });
+            for (size_t n = 0; n < ki.size(); ++n) order[n] = ki[n].idx;
+            for (size_t b = 0; b < ki.size();) {       // equal leading cameras: finish with the full comparison (stable)
+                size_t e = b + 1;
+                while (e < ki.size() && ki[e].key == ki[b].key) ++e;
+                if (e - b > 1) {
+                    bool longer = false;                // tuples that extend beyond the key can still differ
+                    for (size_t n = b; n < e && !longer; ++n) longer = cnt[order[n] + 1] > kcams;
+                    if (longer) std::stable_sort(order.begin() + b, order.begin() + e, full_less);
+                }
+                b = e;
+            }
+        }
+    }
     o.n_cams = Nc; o.n_pts = (int)order.size(); o.n_obs = No;
     o.pt_orig = order;
     o.pt_const.assign(o.n_pts, 0);
     o.items.clear(); o.slot_cam.clear(); o.slot_pt.clear(); o.slot_obs.clear();
+    {
+        const size_t cap = (size_t)No + (size_t)No / 8 + 4096;      // slots incl. tile padding (grows if a pathological input needs more)
+        o.slot_cam.reserve(cap); o.slot_pt.reserve(cap); o.slot_obs.reserve(cap); o.items.reserve(2 * (cap / 64 + 1));
+    }
     auto pad_tile = [&]() {
         while (o.slot_cam.size() % 64) { o.slot_cam.push_back(-1); o.slot_pt.push_back(-1); o.slot_obs.push_back(-1); }
     };
