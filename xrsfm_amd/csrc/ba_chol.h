@@ -521,20 +521,38 @@ __device__ __forceinline__ void load_tile_lds(double* dst, const double* __restr
 }
 
 // A_ik <- A_ik * Linv_k^T for the tiles i listed in rows[]
+__device__ __forceinline__ void tile_gemv(const double* __restrict__ M, size_t ld, const double* v, double* out, bool transpose, double* red) {
+    // 4 threads per output element
+    const int t = threadIdx.x, o = t >> 2, part = t & 3;
+    double s = 0.0;
+    for (int m = part * 16; m < part * 16 + 16; ++m) s += (transpose ? M[(size_t)m * ld + o] : M[(size_t)o * ld + m]) * v[m];
+    s += __shfl_xor(s, 1, kWave);
+    s += __shfl_xor(s, 2, kWave);
+    if (part == 0) out[o] = s;
+    (void)red;
+}
+
+// (right-looking schedule) ... and the forward substitution of the panel rides along: with y_k = Linv_k rhs_k (k_potrf wrote
+// the same vector to c.y) every block updates its own row tile of the right-hand side, rhs_i -= L_ik y_k, from the tile it
+// has just formed — no separate forward launches.
 __global__ __launch_bounds__(256) void k_trsm(CholDev c, int k, const int* __restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ double vr[kNB], yk[kNB], tmp[kNB];
     double* As = smem; double* Bs = smem + kNB * kLdT;
     const int i = rows[blockIdx.x];
     double* Ag = c.S + (size_t)(i * kNB) * c.n_pad + k * kNB;
     load_tile_lds(As, Ag, c.n_pad);
     load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
+    if (threadIdx.x < kNB) vr[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
     __syncthreads();
+    tile_gemv(Bs, kLdT, vr, yk, false, nullptr);
     v4d acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
     tile_abt_mfma(As, Bs, acc);
+    __syncthreads();                              // all reads of As / Bs done, yk complete
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
 #pragma unroll
@@ -545,7 +563,12 @@ __global__ __launch_bounds__(256) void k_trsm(CholDev c, int k, const int* __res
             for (int g = 0; g < 4; ++g) {
                 const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
                 Ag[(size_t)r * c.n_pad + col] = acc[m][n2][g];
+                As[r * kLdT + col] = acc[m][n2][g];
             }
+    __syncthreads();
+    tile_gemv(As, kLdT, yk, tmp, false, nullptr);
+    __syncthreads();
+    if (threadIdx.x < kNB) c.rhs[i * kNB + threadIdx.x] -= tmp[threadIdx.x];
 }
 
 // A_ij -= A_ik * A_jk^T for the tile pairs (i,j) listed in pairs[]
@@ -577,17 +600,6 @@ __global__ __launch_bounds__(256) void k_update(CholDev c, int k, const int* __r
 }
 
 // 64x64 matrix-vector helpers (one workgroup of 256 threads): out = M v or M^T v, M row-major ld
-__device__ __forceinline__ void tile_gemv(const double* __restrict__ M, size_t ld, const double* v, double* out, bool transpose, double* red) {
-    // 4 threads per output element
-    const int t = threadIdx.x, o = t >> 2, part = t & 3;
-    double s = 0.0;
-    for (int m = part * 16; m < part * 16 + 16; ++m) s += (transpose ? M[(size_t)m * ld + o] : M[(size_t)o * ld + m]) * v[m];
-    s += __shfl_xor(s, 1, kWave);
-    s += __shfl_xor(s, 2, kWave);
-    if (part == 0) out[o] = s;
-    (void)red;
-}
-
 // forward substitution, panel k: y_k = Linv_k rhs_k;  rhs_i -= L_ik y_k for i in rows[]
 __global__ __launch_bounds__(256) void k_fwd(CholDev c, int k, const int* __restrict__ rows) {
     __shared__ double v[kNB], yk[kNB], tmp[kNB];

@@ -103,6 +103,7 @@ struct CholHost {
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off;
     double* sp_work = nullptr;
+    int* zero2 = nullptr;                                    // two zeros: an empty CSR row list
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
     int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring
@@ -456,6 +457,7 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.sp_tgt, P.sp_tgt)); TRYC(dev_upload(c, &h.sp_q, P.sp_q));
     TRYC(dev_upload(c, &h.sp_rt, P.sp_rt)); TRYC(dev_upload(c, &h.sp_rp, P.sp_rp));
     TRYC(dev_upload(c, &h.tf_ptr, P.tf_ptr)); TRYC(dev_upload(c, &h.tf_ent, P.tf_ent));
+    TRYC(dev_upload(c, &h.zero2, std::vector<int>(2, 0)));
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
     TRYC(dev_upload(c, &d_cam_off, P.cam_off)); TRYC(dev_upload(c, &d_one_k, P.one_k)); TRYC(dev_upload(c, &d_tile_rows, P.tile_rows));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
@@ -523,16 +525,13 @@ int chol_factor_solve(xrsfm_ba_context* c) {
         }
     } else {
         for (int k = 0; k < T; ++k) {
-            LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, h.dev.one_k + k, (const int*)nullptr, (const int*)nullptr);
+            LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, h.dev.one_k + k, (const int*)h.zero2, (const int*)h.zero2);   // empty row list: y_k = Linv_k rhs_k
             const int nr = h.rows_off[k + 1] - h.rows_off[k];
             if (nr > 0) LAUNCH(c, K_TRSM, k_trsm, dim3(nr), dim3(256), shm, h.dev, k, h.rows_flat + h.rows_off[k]);
             const int np = h.pairs_off[k + 1] - h.pairs_off[k];
             if (np > 0) LAUNCH(c, K_UPDATE, k_update, dim3(np), dim3(256), shm, h.dev, k, h.pairs_flat + 2 * (size_t)h.pairs_off[k]);
         }
-        for (int k = 0; k < T; ++k) {
-            const int nr = h.rows_off[k + 1] - h.rows_off[k];
-            LAUNCH(c, K_TRISOLVE, k_fwd, dim3(1 + nr), dim3(256), 0, h.dev, k, h.rows_flat + h.rows_off[k]);
-        }
+        // (forward substitution: folded into k_potrf / k_trsm)
         for (int k = T - 1; k >= 0; --k) {
             const int ncol = h.cols_off[k + 1] - h.cols_off[k];
             LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
