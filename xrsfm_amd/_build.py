@@ -33,7 +33,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libxrsfm_ba.so")
     os.makedirs(LIBDIR, exist_ok=True)
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value",
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-deprecated-declarations",
            "-o", LIB, os.path.join(CSRC, "xrsfm_ba.hip"), "-ldl"]
     if verbose:
         print(" ".join(cmd))
