@@ -39,10 +39,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 // With Hinv = C C^T (k_point_prep) every term is a product of V = W C with itself:  W_b Hinv W_a^T = V_b V_a^T.
 // One wavefront per tile (64-thread workgroups: the staged operand of a wave lives in its own LDS; the kernel is
 // latency-bound, so LDS and VGPR footprints are sized for 4 waves per SIMD).
-//  * regular tile (T tracks, all with the same L cameras): the lanes stage V as a [6L x 3T] matrix in LDS and the wave
-//    forms the Gram matrix G = V V^T with v_mfma_f64_16x16x4_f64: G holds every camera-pair block already summed over
-//    the T tracks, written once per tile;
-//  * other tiles: lane = observation a, partner b = a + d in the same track via shfl_down, one block per pair;
+//  * Gram tile (T tracks that together see C <= 10 distinct cameras; ba_pack.h): the lanes stage V as a [6C x 3T] matrix in
+//    LDS (zero where a track does not see a camera) and the wave forms the Gram matrix G = V V^T with
+//    v_mfma_f64_16x16x4_f64: G holds every camera-pair block already summed over the T tracks, written once per tile
+//    (a regular tile, every track with the same L cameras, is the dense special case);
+//  * other tiles (more distinct cameras): lane = observation a, partner b = a + d in the same track via shfl_down, one
+//    block per pair;
 //  * long tracks: lane loops over all later observations of its track.
 constexpr int kRedLd = 15;      // row stride (doubles) of the LDS reduction buffer of k_schur_pairs: 64 x 15 x 8 B
 
@@ -74,14 +76,18 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
     o28[27] = 0.0;
 }
 
+// GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
+// needs do not shape its allocation: 118 VGPRs, no spills); GRAM = false: per-pair tiles and long tracks.  The two
+// instantiations write disjoint outputs and run concurrently on two streams.
+template <bool GRAM>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst, double* __restrict__ scat2) {
+void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
+                   int n_obs_pairs, double* __restrict__ scat2) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
-    const int item = blockIdx.x;
-    if (item >= d.n_items) return;
+    const int item = item_list[blockIdx.x];          // one launch per LDS class (ba_plan.h)
     const Item it = d.items[item];
-    if (it.n_tiles == 1) {
+    if (GRAM || it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int L = d.tile_stride[it.first_tile];
         double V[18];
@@ -97,8 +103,6 @@ void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __re
                 load_FE(d, s.slot, s.cam, s.pt, F, E);
                 const double* hc = d.Hc + 6 * (size_t)s.pt;
                 pairs_V(F, E, hc, V);
-                pbase = slot_pair_ptr[s.slot];
-                npair = slot_pair_ptr[s.slot + 1] - pbase;
                 pairs_diag(F, V, hc, d.gp + 3 * (size_t)s.pt, o28);
             }
             const int cp = d.slot_campos[s.slot];
@@ -131,27 +135,38 @@ void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __re
                 for (int k = 0; k < 14; ++k) out[k] = make_double2(o28[2 * k], o28[2 * k + 1]);
             }
         }
-        if (L > 0) {
+        const int C = d.tile_ncam[it.first_tile];
+        if (GRAM) {
+            // Gram tile: rows = (distinct camera of the tile, 6), columns = (track, 3); cells of cameras a track does not see
+            // stay zero.  G = V V^T then holds every camera-pair block of the tile summed over its tracks.
+            const unsigned long long headmask = __ballot(s.head);
+            const int T = __popcll(headmask);
             const int nvalid = __popcll(__ballot(s.valid));
-            const int T = nvalid / L;
-            const int R = 6 * L, Rp = (R + 15) & ~15, C4 = (3 * T + 3) & ~3, Cp = C4 + 2;
+            const int t = __popcll(headmask & ((2ull << lane) - 1ull)) - 1;        // rank of the lane's track in the tile
+            const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : 0;
+            const int R = 6 * C, Rp = (R + 15) & ~15, C4 = (3 * T + 3) & ~3, Cp = C4 + 2;
             double* Vst = smem;                                             // only the R rows that hold data are staged
-            int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [L][L] destination of block (rb, ra)
-            // destinations of the first track's pairs: issued first so the index loads overlap the staging
-            if (lane < L)
-                for (int dd = 1; dd <= npair; ++dd) dtab[lane * L + lane + dd] = pair_dst[pbase + dd - 1];
-            // zero the K padding columns 3T..Cp-1 (rows beyond R are never staged: reads are clamped, results discarded)
-            const int padc = Cp - 3 * T;
-            for (int e = lane; e < R * padc; e += kWave) {
-                const int row = e / padc, cc = 3 * T + (e - row * padc);
-                Vst[row * Cp + cc] = 0.0;
+            int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [C][C] destination of block (cb > ca) at [ca][cb], -1 none
+            {
+                const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[it.first_tile];
+                for (int e = lane; e < C * C; e += kWave) dtab[e] = src[e];
+            }
+            if (nvalid == T * C) {
+                // dense (regular) tile: only the K padding columns 3T..Cp-1 need zeros (rows beyond R are never staged: reads
+                // are clamped, results discarded)
+                const int padc = Cp - 3 * T;
+                for (int e = lane; e < R * padc; e += kWave) {
+                    const int row = e / padc, cc = 3 * T + (e - row * padc);
+                    Vst[row * Cp + cc] = 0.0;
+                }
+            } else {
+                for (int e = lane; e < R * Cp; e += kWave) Vst[e] = 0.0;       // LDS operations of one wave complete in order
             }
             if (s.valid) {
-                const int t = lane / L, r = lane - t * L;
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m) Vst[(6 * r + i) * Cp + 3 * t + m] = V[3 * i + m];
+                    for (int m = 0; m < 3; ++m) Vst[(6 * cidx + i) * Cp + 3 * t + m] = V[3 * i + m];
             }
             __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand and dtab are in LDS
             __builtin_amdgcn_wave_barrier();
@@ -169,10 +184,18 @@ void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __re
                     for (int g = 0; g < 4; ++g) {
                         const int row = 16 * I + lk + 4 * g;
                         const int rb = row / 6, i = row - 6 * rb;
-                        if (row < R && col < R && rb > ra) scat2[36 * (size_t)dtab[ra * L + rb] + 6 * i + j] = acc[g];
+                        if (row < R && col < R && rb > ra) {
+                            const int dst = dtab[ra * C + rb];
+                            if (dst >= 0) scat2[36 * (size_t)dst + 6 * i + j] = acc[g];
+                        }
                     }
                 }
             return;
+        }
+        if (GRAM) return;           // (not reached: keeps the per-pair code out of the Gram instantiation)
+        if (s.valid) {
+            pbase = slot_pair_ptr[s.slot];
+            npair = slot_pair_ptr[s.slot + 1] - pbase;
         }
         int maxp = npair;
 #pragma unroll
@@ -197,6 +220,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ slot_pair_ptr, const int* __re
         }
         return;
     }
+    if (GRAM) return;
     // long track: lane handles observation a, loops over all later observations b of the track
     const int s_begin = it.first_tile * kWave, s_end = s_begin + it.n_tiles * kWave;
     for (int sa = s_begin + lane; sa < s_end; sa += kWave) {

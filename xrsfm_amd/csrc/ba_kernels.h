@@ -52,6 +52,9 @@ struct Dev {
     const Item* items;
     const int* tile_stride;   // [n_tiles] L > 0 for regular tiles (all tracks share one tuple of L cameras)
     const int* tile_maxlen;   // [n_tiles] longest track of the tile (bounds the segmented reductions)
+    const int* tile_ncam;     // [n_tiles] C > 0: Gram tile with C distinct cameras (ba_pack.h)
+    const int* tile_gt_off;   // [n_tiles] offset of its C x C destination table behind the observation pairs in pair_dst
+    const unsigned char* slot_cidx;   // [n_slots] index of the slot's camera among the tile's distinct cameras
     // cameras
     CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
     double* cam_act;    // [Nc] 1.0 if any rank observes the camera (cameras without observations are not in the program)

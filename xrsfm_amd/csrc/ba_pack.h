@@ -11,6 +11,10 @@
 
 namespace xba {
 
+constexpr int kGramMaxCams = 10;         // 60 operand rows: 4 MFMA row tiles
+constexpr int kGramMaxLds = 20 * 1024;   // staged operand of one tile (bytes); larger tiles use the per-pair path
+constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly launches: 160 KB / 16 workgroups
+
 struct Packed {
     int n_cams = 0, n_pts = 0, n_obs = 0, n_tiles = 0, n_slots = 0;
     std::vector<int> pt_orig;        // packed point -> caller point index
@@ -21,6 +25,14 @@ struct Packed {
     std::vector<int> tile_maxlen;    // [n_tiles] longest track in the tile (<= 64)
     std::vector<int> tile_stride;    // [n_tiles] L > 0: every track of the tile has the same L cameras ("regular" tile)
     int n_cam_entries = 0;
+    // "Gram tiles" (S assembly): a single tile whose tracks see at most kGramMaxCams distinct cameras.  Its camera-pair blocks
+    // come out of ONE Gram product V V^T, V = [6 x distinct camera] x [3 x track] (zero where a track does not see a camera),
+    // already summed over the tracks; a regular tile is the dense special case.
+    std::vector<int> tile_ncam;          // [n_tiles] distinct cameras C (0: not a Gram tile)
+    std::vector<int> tile_gt_off;        // [n_tiles] offset of the tile's C x C destination table (cell (a,b), a < b: block of the pair)
+    std::vector<unsigned char> slot_cidx;// [n_slots] index of the slot's camera in the tile's ascending camera list
+    std::vector<unsigned char> gt_cell;  // [n_gt_cells] 1: some track of the tile sees both cameras of the cell
+    int n_gt_cells = 0;
     std::vector<unsigned char> pt_const;
     int n_var_q = 0, n_var_t = 0, n_var_p = 0;
 };
@@ -121,6 +133,16 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     auto pad_tile = [&]() {
         while (o.slot_cam.size() % 64) { o.slot_cam.push_back(-1); o.slot_pt.push_back(-1); o.slot_obs.push_back(-1); }
     };
+    // A group of tracks with one camera tuple that fills at least a tile by itself starts on a tile boundary: its tiles are
+    // then all regular (one dense Gram product each, small LDS footprint) instead of the first one mixing two tuples.
+    std::vector<char> big_group_start(o.n_pts, 0);
+    for (int b = 0; b < o.n_pts;) {
+        int e = b + 1;
+        while (e < o.n_pts && !tuple_less(order[b], order[e]) && !tuple_less(order[e], order[b])) ++e;
+        const int len = cnt[order[b] + 1];
+        if (len <= 64 && (long long)(e - b) * len >= 64) big_group_start[b] = 1;
+        b = e;
+    }
     int cur_tile_start = -1;  // tile index of the open short tile, -1 if none
     for (int pj = 0; pj < o.n_pts; ++pj) {
         const int j = order[pj];
@@ -129,7 +151,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         const int* obs_b = csr.data() + ptr[j];
         if (len <= 64) {
             const int used = (int)(o.slot_cam.size() % 64);
-            if (cur_tile_start < 0 || used + len > 64 || used == 0) {
+            if (cur_tile_start < 0 || used + len > 64 || used == 0 || big_group_start[pj]) {
                 pad_tile();
                 cur_tile_start = (int)(o.slot_cam.size() / 64);
                 o.items.push_back(cur_tile_start); o.items.push_back(1);
@@ -179,6 +201,55 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     for (size_t it = 0; it + 1 < o.items.size(); it += 2)          // long items are never regular
         if (o.items[it + 1] > 1)
             for (int t = o.items[it]; t < o.items[it] + o.items[it + 1]; ++t) o.tile_stride[t] = 0;
+    // Gram tiles
+    o.tile_ncam.assign(o.n_tiles, 0); o.tile_gt_off.assign(o.n_tiles, -1);
+    o.slot_cidx.assign(o.n_slots, 255); o.gt_cell.clear();
+    {
+        std::vector<char> single(o.n_tiles, 0);
+        for (size_t it = 0; it + 1 < o.items.size(); it += 2)
+            if (o.items[it + 1] == 1) single[o.items[it]] = 1;
+        int cams[64];
+        for (int t = 0; t < o.n_tiles; ++t) {
+            if (!single[t]) continue;
+            const int b0 = 64 * t;
+            int nc = 0, ntrk = 0;
+            for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q) {
+                cams[nc++] = o.slot_cam[b0 + q];
+                ntrk += (q == 0 || o.slot_pt[b0 + q] != o.slot_pt[b0 + q - 1]);
+            }
+            if (nc == 0) continue;
+            std::sort(cams, cams + nc);
+            const int C = (int)(std::unique(cams, cams + nc) - cams);
+            const int Cp = ((3 * ntrk + 3) & ~3) + 2;
+            if (C < 2 || C > kGramMaxCams || (size_t)(6 * C) * Cp * sizeof(double) > (size_t)kGramMaxLds) continue;
+            o.tile_ncam[t] = C;
+            o.tile_gt_off[t] = (int)o.gt_cell.size();
+            o.gt_cell.resize(o.gt_cell.size() + (size_t)C * C, 0);
+            unsigned char* cell = o.gt_cell.data() + o.tile_gt_off[t];
+            for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)
+                o.slot_cidx[b0 + q] = (unsigned char)(std::lower_bound(cams, cams + C, o.slot_cam[b0 + q]) - cams);
+            for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)         // pairs inside a track (cameras ascend in a track)
+                for (int q2 = q + 1; q2 < 64 && o.slot_cam[b0 + q2] >= 0 && o.slot_pt[b0 + q2] == o.slot_pt[b0 + q]; ++q2)
+                    cell[o.slot_cidx[b0 + q] * C + o.slot_cidx[b0 + q2]] = 1;
+        }
+        // The S-assembly kernel runs once per LDS class (<= 10 KB: 16 workgroups per CU; larger).  A handful of large tiles
+        // is not worth a second launch (its duration is one tile's latency, ~15 us): they take the per-pair path instead.
+        auto lds_need = [&](int t) {
+            int ntrk = 0;
+            for (int q = 0; q < 64 && o.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || o.slot_pt[64 * t + q] != o.slot_pt[64 * t + q - 1]);
+            return (size_t)(6 * o.tile_ncam[t]) * (((3 * ntrk + 3) & ~3) + 2) * sizeof(double) + (size_t)o.tile_ncam[t] * o.tile_ncam[t] * sizeof(int);
+        };
+        int n_big = 0;
+        for (int t = 0; t < o.n_tiles; ++t) n_big += (o.tile_ncam[t] > 0 && lds_need(t) > (size_t)kGramSmallLds);
+        if (n_big > 0 && n_big * 20 <= o.n_tiles) {
+            for (int t = 0; t < o.n_tiles; ++t)
+                if (o.tile_ncam[t] > 0 && lds_need(t) > (size_t)kGramSmallLds) {
+                    for (int q = 0; q < 64; ++q) o.slot_cidx[64 * t + q] = 255;
+                    o.tile_ncam[t] = 0; o.tile_gt_off[t] = -1;        // (its table cells stay allocated, unused)
+                }
+        }
+        o.n_gt_cells = (int)o.gt_cell.size();
+    }
     // camera-major positions of the lanes that write a camera-side partial: every valid lane of an irregular tile,
     // the first track (lanes < L) of a regular one.  Within a camera: slot order.
     auto writes = [&](int s2) { const int L = o.tile_stride[s2 / 64]; return o.slot_cam[s2] >= 0 && (L == 0 || (s2 % 64) < L); };

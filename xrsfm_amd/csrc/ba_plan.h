@@ -19,7 +19,10 @@ struct CholPlan {
     int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring
     int n_hubs = 0, band = 0;
     bool use_levels = false;
-    size_t pairs_shm = 0;            // dynamic LDS of k_schur_pairs: staged operand of the largest regular tile
+    // k_schur_pairs is launched once per LDS class: items whose staged operand fits 10 KB (16 workgroups per CU) and the rest
+    size_t pairs_shm = 0, pairs_shm_big = 0;
+    std::vector<int> pairs_items;    // item indices: Gram tiles of the small class | Gram tiles of the big class | other items
+    int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
     std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, one_k, tiles_nz;
     std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
     std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_trsm, lv_rptr, lv_rj, lv_bptr, lv_bi;     // level schedule
@@ -37,8 +40,11 @@ struct CholPlan {
 
 typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
 
-// Pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a.  `keyed` lists the pairs
-// that WRITE a partial block: every pair of an irregular tile, the pairs of the first track of a regular tile.
+// Pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a.  `keyed` lists everything that
+// WRITES a partial block, as (block key, index into pair_dst):
+//   * a Gram tile (ba_pack.h) writes one partial per camera pair that some track of the tile sees together; its index is
+//     n_obs_pairs + the cell of the tile's C x C table;
+//   * every other tile writes one partial per observation pair; its index is the pair index spp[s] + dd - 1.
 inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& keyed) {
     const int ns = k.n_slots;
     spp.assign(ns + 1, 0);
@@ -52,16 +58,28 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
         }
         for (int s = 0; s < ns; ++s) spp[s + 1] = spp[s] + rest[s];
     }
+    const int n_obs_pairs = spp[ns];
     keyed.clear();
-    keyed.reserve(spp[ns]);
+    keyed.reserve((size_t)n_obs_pairs / 2 + 16);
     for (int s = 0; s < ns; ++s) {
         const int np = spp[s + 1] - spp[s];
-        const int L = k.tile_stride[s / 64];
+        const bool gram = k.tile_ncam[s / 64] > 0;
         for (int dd = 1; dd <= np; ++dd) {
             const unsigned long long cb = (unsigned)k.slot_cam[s + dd], ca = (unsigned)k.slot_cam[s];
             if (cb <= ca) return XRSFM_BA_EINVAL;   // two observations of one track in the same frame
-            if (L == 0 || (s % 64) < L) keyed.push_back({(cb << 32) | ca, spp[s] + dd - 1});
+            if (!gram) keyed.push_back({(cb << 32) | ca, spp[s] + dd - 1});
         }
+    }
+    int cams[64];
+    for (int t = 0; t < k.n_tiles; ++t) {
+        const int C = k.tile_ncam[t];
+        if (C <= 0) continue;
+        for (int q = 0; q < 64 && k.slot_cam[64 * t + q] >= 0; ++q) cams[k.slot_cidx[64 * t + q]] = k.slot_cam[64 * t + q];
+        const unsigned char* cell = k.gt_cell.data() + k.tile_gt_off[t];
+        for (int a = 0; a < C; ++a)
+            for (int b = a + 1; b < C; ++b)
+                if (cell[a * C + b])
+                    keyed.push_back({((unsigned long long)(unsigned)cams[b] << 32) | (unsigned)cams[a], n_obs_pairs + k.tile_gt_off[t] + a * C + b});
     }
     std::sort(keyed.begin(), keyed.end());
     return 0;
@@ -101,7 +119,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P = CholPlan();
     P.spp = spp;
     P.n = 6 * Nc;
-    P.n_pairs = spp[ns];
+    P.n_pairs = spp[ns] + k.n_gt_cells;      // pair_dst: observation pairs | cells of the Gram tiles' tables
     P.n_writes = (int)keyed.size();
     std::vector<unsigned long long> blk_keys;
     if (pattern) blk_keys = *pattern;
@@ -296,14 +314,27 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.use_levels = (2 * n_levels <= T);
     P.one_k.resize(T);
     for (int t = 0; t < T; ++t) P.one_k[t] = t;
-    for (int t = 0; t < k.n_tiles; ++t) {
-        const int L = k.tile_stride[t];
-        if (L <= 0) continue;
-        int nvalid = 0;
-        for (int q = 0; q < 64; ++q) nvalid += k.slot_cam[64 * t + q] >= 0;
-        const int T2 = nvalid / L, Cp = ((3 * T2 + 3) & ~3) + 2;
-        P.pairs_shm = std::max(P.pairs_shm, (size_t)(6 * L) * Cp * sizeof(double) + (size_t)L * L * sizeof(int));
-        P.pairs_shm = std::max(P.pairs_shm, (size_t)64 * 15 * sizeof(double));      // reduction buffer of the diagonal terms (kRedLd)
+    {
+        const size_t base = (size_t)64 * 15 * sizeof(double);      // reduction buffer of the diagonal terms (kRedLd)
+        const size_t small_cap = kGramSmallLds;
+        const int n_items = (int)k.items.size() / 2;
+        std::vector<int> big, other;
+        P.pairs_shm = base; P.pairs_shm_big = base;
+        for (int it = 0; it < n_items; ++it) {
+            const int t = k.items[2 * it];
+            if (k.items[2 * it + 1] != 1 || k.tile_ncam[t] <= 0) { other.push_back(it); continue; }   // per-pair path, long tracks
+            const int C = k.tile_ncam[t];
+            int ntrk = 0;
+            for (int q = 0; q < 64 && k.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || k.slot_pt[64 * t + q] != k.slot_pt[64 * t + q - 1]);
+            const int Cp = ((3 * ntrk + 3) & ~3) + 2;
+            const size_t need = std::max(base, (size_t)(6 * C) * Cp * sizeof(double) + (size_t)C * C * sizeof(int));
+            if (need <= small_cap) { P.pairs_items.push_back(it); P.pairs_shm = std::max(P.pairs_shm, need); }
+            else { big.push_back(it); P.pairs_shm_big = std::max(P.pairs_shm_big, need); }
+        }
+        P.n_pairs_small = (int)P.pairs_items.size();
+        P.n_pairs_big = (int)big.size(); P.n_pairs_other = (int)other.size();
+        P.pairs_items.insert(P.pairs_items.end(), big.begin(), big.end());
+        P.pairs_items.insert(P.pairs_items.end(), other.begin(), other.end());
     }
     return 0;
 }

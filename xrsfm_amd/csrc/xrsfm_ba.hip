@@ -90,7 +90,9 @@ struct CholHost {
     int *slot_pair_ptr = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr;
     double *scat2 = nullptr, *Sblk = nullptr;
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
-    size_t pairs_shm = 0;                         // dynamic LDS of k_schur_pairs: staged operands of the largest regular tile
+    size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
+    int* pairs_items = nullptr; int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
+    hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // the non-Gram items run concurrently
     // right-looking schedule (dense patterns): one panel after the other
     int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
     std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
@@ -440,7 +442,7 @@ int chol_setup(xrsfm_ba_context* c) {
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
     if (6 * Nc > kCholMaxN && (!P.use_levels || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
-    h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.cam_off_host = P.cam_off;
+    h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off;
@@ -458,6 +460,7 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_upload(c, &h.sp_rt, P.sp_rt)); TRYC(dev_upload(c, &h.sp_rp, P.sp_rp));
     TRYC(dev_upload(c, &h.tf_ptr, P.tf_ptr)); TRYC(dev_upload(c, &h.tf_ent, P.tf_ent));
     TRYC(dev_upload(c, &h.zero2, std::vector<int>(2, 0)));
+    TRYC(dev_upload(c, &h.pairs_items, P.pairs_items));
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
     TRYC(dev_upload(c, &d_cam_off, P.cam_off)); TRYC(dev_upload(c, &d_one_k, P.one_k)); TRYC(dev_upload(c, &d_tile_rows, P.tile_rows));
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
@@ -478,7 +481,13 @@ int chol_setup(xrsfm_ba_context* c) {
     (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
     (void)hipFuncSetAttribute((const void*)k_ll_update_part, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)k_schur_pairs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.pairs_shm);
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h.pairs_shm, h.pairs_shm_big));
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.pairs_shm);
+    if (h.n_pairs_other > 0 && !h.aux) {
+        if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
+        if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                      hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) { (void)hipStreamDestroy(h.aux); h.aux = nullptr; }
+    }
     h.ready = true;
     return 0;
 }
@@ -487,7 +496,27 @@ int chol_setup(xrsfm_ba_context* c) {
 int chol_assemble(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
-    if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k_schur_pairs, dim3(d.n_items), dim3(kWave), h.pairs_shm, d, h.slot_pair_ptr, h.pair_dst, h.scat2);
+    const int n_obs_pairs = h.n_pairs - c->pk.n_gt_cells;
+    {   // one pass over the items = up to three launches (Gram tiles per LDS class; everything else, concurrently on a second
+        // stream: it is usually tiny and would otherwise add its full latency); the profile counts the pass
+        Timed t_(c, K_SCHUR_PAIRS);
+        const bool fork = h.n_pairs_other > 0 && h.aux;
+        if (fork) {
+            HIPCHK(hipEventRecord(h.ev_fork, c->stream));
+            HIPCHK(hipStreamWaitEvent(h.aux, h.ev_fork, 0));
+            hipLaunchKernelGGL(k_schur_pairs<false>, dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, h.aux, d, h.pairs_items + h.n_pairs_small + h.n_pairs_big,
+                               h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+            HIPCHK(hipEventRecord(h.ev_join, h.aux));
+        } else if (h.n_pairs_other > 0) {
+            hipLaunchKernelGGL(k_schur_pairs<false>, dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, c->stream, d, h.pairs_items + h.n_pairs_small + h.n_pairs_big,
+                               h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+        }
+        if (h.n_pairs_small > 0)
+            hipLaunchKernelGGL(k_schur_pairs<true>, dim3(h.n_pairs_small), dim3(kWave), h.pairs_shm, c->stream, d, h.pairs_items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+        if (h.n_pairs_big > 0)
+            hipLaunchKernelGGL(k_schur_pairs<true>, dim3(h.n_pairs_big), dim3(kWave), h.pairs_shm_big, c->stream, d, h.pairs_items + h.n_pairs_small, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+        if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
+    }
     if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
@@ -615,6 +644,7 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    if (c->chol.aux) { (void)hipStreamSynchronize(c->chol.aux); (void)hipStreamDestroy(c->chol.aux); (void)hipEventDestroy(c->chol.ev_fork); (void)hipEventDestroy(c->chol.ev_join); }
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
@@ -678,6 +708,9 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     d.items = tmp_it;
     TRY(dev_upload(c, &tmp_i, k.tile_stride)); d.tile_stride = tmp_i;
     TRY(dev_upload(c, &tmp_i, k.tile_maxlen)); d.tile_maxlen = tmp_i;
+    TRY(dev_upload(c, &tmp_i, k.tile_ncam)); d.tile_ncam = tmp_i;
+    TRY(dev_upload(c, &tmp_i, k.tile_gt_off)); d.tile_gt_off = tmp_i;
+    { unsigned char* tmp_b = nullptr; TRY(dev_upload(c, &tmp_b, k.slot_cidx)); d.slot_cidx = tmp_b; }
     TRY(dev_upload(c, &tmp_c, cams)); d.cam = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam_cand = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); c->cam0 = tmp_c;

@@ -79,8 +79,10 @@ def _project_simple_radial(q, t, P, intr):
 def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
                  mode: str = "sequential", k_dist: float = 0.0, noise: float = 0.5,
                  outlier_frac: float = 0.02, perturb=(0.01, 0.05, 0.10),
-                 min_tri_angle_deg: float = 2.0) -> dict:
-    """Return a dict of flat arrays (keys = fields of ``xrsfm_ba_problem``) + ground truth."""
+                 min_tri_angle_deg: float = 2.0, dropout: float = 0.0) -> dict:
+    """Return a dict of flat arrays (keys = fields of ``xrsfm_ba_problem``) + ground truth.
+    ``dropout`` > 0 removes each observation with that probability (at least two per point stay): ragged tracks with many
+    distinct camera tuples, like a real reconstruction with missed detections."""
     assert n_cams >= k_obs >= 1
     rng = np.random.Generator(np.random.PCG64(seed))
     intr = (KITTI_INTR[0], KITTI_INTR[1], KITTI_INTR[2], k_dist)
@@ -163,6 +165,12 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     # observations, frame-major order
     obs_pt = np.repeat(np.arange(n_points), k_obs)
     obs_cam = cams_of.reshape(-1)
+    if dropout > 0.0 and k_obs > 2:
+        keep = rng.random((n_points, k_obs)) >= dropout
+        short = keep.sum(1) < 2
+        keep[short, 0] = True; keep[short, k_obs - 1] = True      # the widest baseline of the window
+        keep = keep.reshape(-1)
+        obs_pt, obs_cam = obs_pt[keep], obs_cam[keep]
     order = np.lexsort((obs_pt, obs_cam))
     obs_pt = obs_pt[order].astype(np.int32); obs_cam = obs_cam[order].astype(np.int32)
     uv, _ = _project_simple_radial(q_gt[obs_cam], t_gt[obs_cam], P_gt[obs_pt], intr)
@@ -202,5 +210,7 @@ CONFIGS = {
     # a dense reduced camera matrix, no regular tiles
     # a long sequential trajectory: 30 000 camera unknowns, still on the exact (band-ordered) Cholesky path
     "X": dict(n_cams=5000, n_points=1_000_000, k_obs=4, seed=6),
+    # ragged tracks (windows of 8 frames, 35 % missed detections): ~15 000 distinct camera tuples, few regular tiles
+    "R": dict(n_cams=1000, n_points=400_000, k_obs=8, seed=7, dropout=0.35),
     "U": dict(n_cams=500, n_points=100_000, k_obs=5, seed=5, mode="unordered"),
 }
