@@ -105,7 +105,8 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 pairs_V(F, E, hc, V);
                 pairs_diag(F, V, hc, d.gp + 3 * (size_t)s.pt, o28);
             }
-            const int cp = d.slot_campos[s.slot];
+            const int cp = d.slot_campos_g[s.slot];
+            const int Cg = GRAM ? d.tile_ncam[it.first_tile] : 0;
             if (L > 0) {
                 // Regular tile: sum the 28 values over the tracks through the wave's LDS (the region the operand V is staged
                 // in afterwards): every lane deposits its values, then one lane per (camera, value) adds the T entries in
@@ -125,6 +126,43 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                         for (int t = 0; t < T; ++t) sum += src[t * L * kRedLd];
                         const int cpr = __shfl(cp, r, kWave);                // lanes < L are the writers of the tile
                         d.scat[28 * (size_t)cpr + 14 * h + k] = sum;
+                    }
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            } else if (Cg > 0) {
+                // Gram tile with ragged tracks: the same through LDS, per DISTINCT camera of the tile: the lane that owns
+                // (camera c, value k) adds the entries of the lanes whose observation is in camera c, in lane order; the
+                // first of them holds the camera's entry in the scatter buffer.
+                const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
+                double* red = smem;
+                const int nq = 14 * Cg;
+                unsigned long long m0 = 0, m1 = 0, m2 = 0;                  // lane masks of the cameras of q = lane, lane+64, lane+128
+                for (int cc = 0; cc < Cg; ++cc) {
+                    const unsigned long long m = __ballot(cidx == cc);
+                    if (lane / 14 == cc) m0 = m;
+                    if ((lane + 64) / 14 == cc) m1 = m;
+                    if ((lane + 128) / 14 == cc) m2 = m;
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int k = 0; k < 14; ++k) red[lane * kRedLd + k] = o28[14 * h + k];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int rd = 0; rd < 3; ++rd) {
+                        const int q = lane + 64 * rd;
+                        unsigned long long m = rd == 0 ? m0 : (rd == 1 ? m1 : m2);
+                        const bool on = q < nq;
+                        const int k = q % 14;
+                        const int first = on ? __ffsll((long long)m) - 1 : 0;
+                        const int cpr = __shfl(cp, first, kWave);
+                        if (on) {
+                            double sum = 0.0;
+                            while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * kRedLd + k]; m &= m - 1; }
+                            d.scat[28 * (size_t)cpr + 14 * h + k] = sum;
+                        }
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
@@ -233,7 +271,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             load_FE(d, sa, d.slot_cam[sa], pt, Fa, Ea);
             pairs_V(Fa, Ea, hc, Va);
             pairs_diag(Fa, Va, hc, d.gp + 3 * (size_t)pt, o28);
-            double* out = d.scat + 28 * (size_t)d.slot_campos[sa];
+            double* out = d.scat + 28 * (size_t)d.slot_campos_g[sa];
             for (int k = 0; k < 28; ++k) out[k] = o28[k];
         }
         const int pbase = slot_pair_ptr[sa];

@@ -55,6 +55,8 @@ struct Dev {
     const int* tile_ncam;     // [n_tiles] C > 0: Gram tile with C distinct cameras (ba_pack.h)
     const int* tile_gt_off;   // [n_tiles] offset of its C x C destination table behind the observation pairs in pair_dst
     const unsigned char* slot_cidx;   // [n_slots] index of the slot's camera among the tile's distinct cameras
+    const int* slot_campos_g; // [n_slots] like slot_campos, for the S assembly (one writer per distinct camera of a Gram tile)
+    const int* cam_ptr_g;     // [n_cams+1]
     // cameras
     CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
     double* cam_act;    // [Nc] 1.0 if any rank observes the camera (cameras without observations are not in the program)

@@ -25,6 +25,10 @@ struct Packed {
     std::vector<int> tile_maxlen;    // [n_tiles] longest track in the tile (<= 64)
     std::vector<int> tile_stride;    // [n_tiles] L > 0: every track of the tile has the same L cameras ("regular" tile)
     int n_cam_entries = 0;
+    // The same for the S assembly (k_schur_pairs -> k_chol_segsum): a Gram tile sums the diagonal-block / rhs terms of every
+    // camera over its tracks first, so only the first lane of each distinct camera writes an entry.
+    std::vector<int> cam_ptr_g, slot_campos_g;
+    int n_cam_entries_g = 0;
     // "Gram tiles" (S assembly): a single tile whose tracks see at most kGramMaxCams distinct cameras.  Its camera-pair blocks
     // come out of ONE Gram product V V^T, V = [6 x distinct camera] x [3 x track] (zero where a track does not see a camera),
     // already summed over the tracks; a regular tile is the dense special case.
@@ -262,6 +266,27 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     o.slot_campos.assign(o.n_slots, -1);
     for (int s2 = 0; s2 < o.n_slots; ++s2)
         if (writes(s2)) o.slot_campos[s2] = cf[o.slot_cam[s2]]++;
+    {
+        std::vector<char> wg(o.n_slots, 0);
+        for (int t = 0; t < o.n_tiles; ++t) {
+            const int C = o.tile_ncam[t];
+            if (C <= 0) { for (int q = 0; q < 64; ++q) wg[64 * t + q] = writes(64 * t + q); continue; }
+            bool seen[kGramMaxCams] = {false};
+            for (int q = 0; q < 64 && o.slot_cam[64 * t + q] >= 0; ++q) {
+                const int ci = o.slot_cidx[64 * t + q];
+                if (!seen[ci]) { seen[ci] = true; wg[64 * t + q] = 1; }
+            }
+        }
+        o.cam_ptr_g.assign(Nc + 1, 0);
+        for (int s2 = 0; s2 < o.n_slots; ++s2)
+            if (wg[s2]) o.cam_ptr_g[o.slot_cam[s2] + 1]++;
+        for (int c = 0; c < Nc; ++c) o.cam_ptr_g[c + 1] += o.cam_ptr_g[c];
+        o.n_cam_entries_g = o.cam_ptr_g[Nc];
+        std::vector<int> cg(o.cam_ptr_g.begin(), o.cam_ptr_g.end() - 1);
+        o.slot_campos_g.assign(o.n_slots, -1);
+        for (int s2 = 0; s2 < o.n_slots; ++s2)
+            if (wg[s2]) o.slot_campos_g[s2] = cg[o.slot_cam[s2]]++;
+    }
     std::vector<char> cam_seen(Nc, 0);
     for (int s2 = 0; s2 < o.n_slots; ++s2)
         if (o.slot_cam[s2] >= 0) cam_seen[o.slot_cam[s2]] = 1;

@@ -517,7 +517,7 @@ int chol_assemble(xrsfm_ba_context* c) {
             hipLaunchKernelGGL(k_schur_pairs<true>, dim3(h.n_pairs_big), dim3(kWave), h.pairs_shm_big, c->stream, d, h.pairs_items + h.n_pairs_small, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
         if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
-    if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
+    if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
     if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc);
@@ -711,6 +711,8 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_upload(c, &tmp_i, k.tile_ncam)); d.tile_ncam = tmp_i;
     TRY(dev_upload(c, &tmp_i, k.tile_gt_off)); d.tile_gt_off = tmp_i;
     { unsigned char* tmp_b = nullptr; TRY(dev_upload(c, &tmp_b, k.slot_cidx)); d.slot_cidx = tmp_b; }
+    TRY(dev_upload(c, &tmp_i, k.slot_campos_g)); d.slot_campos_g = tmp_i;
+    TRY(dev_upload(c, &tmp_i, k.cam_ptr_g)); d.cam_ptr_g = tmp_i;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); d.cam_cand = tmp_c;
     TRY(dev_upload(c, &tmp_c, cams)); c->cam0 = tmp_c;
