@@ -168,12 +168,17 @@ def test_edge_cases(lib):
                                                      (80, 12, 70, "unordered"), (40, 800, 6, "unordered"),
                                                      # band / ring patterns -> nested-dissection order + level schedule
                                                      (60, 700, 2, "sequential"), (130, 1500, 4, "sequential"),
-                                                     (257, 2500, 3, "sequential")])
+                                                     (257, 2500, 3, "sequential"),
+                                                     # ragged tracks (missed detections): non-dense Gram tiles
+                                                     (40, 1200, 8, "ragged"), (90, 2500, 12, "ragged")])
 def test_cholesky_reduced_system(lib, n_cams, n_pts, k_obs, mode):
     """Explicit reduced camera matrix S and the tile Cholesky solve against the oracle's dense Schur complement."""
     import scipy.linalg as sla
     from xrsfm_amd import capi
-    arr = H.make(n_cams, n_pts, k_obs, seed=106, min_tri_angle_deg=0.5, mode=mode)
+    if mode == "ragged":
+        arr = H.make(n_cams, n_pts, k_obs, seed=106, min_tri_angle_deg=0.5, dropout=0.35)
+    else:
+        arr = H.make(n_cams, n_pts, k_obs, seed=106, min_tri_angle_deg=0.5, mode=mode)
     pr = H.to_oracle(arr)
     ctx = capi.Context(H.to_product(arr))
     ctx.debug_linearize(5.99, True)
@@ -544,3 +549,28 @@ def test_auto_solver_beyond_the_dense_limit(lib):
     assert s_u.linear_solver_used == capi.SOLVER_PCG and s_u.final_cost < s_u.initial_cost
     with pytest.raises(Exception, match="ETOOBIG"):
         capi.solve(H.to_product(arr_u), capi.default_options(max_iterations=1, linear_solver=capi.SOLVER_CHOLESKY))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", [1, 0], ids=["cholesky", "pcg"])
+def test_ragged_tracks_match_oracle(lib, solver):
+    """Windows of 8 frames with 35 % missed detections: many distinct camera tuples, tiles whose tracks see different camera
+    subsets (non-dense Gram tiles with zero-filled cells, per-camera sums over scattered lanes).  Reduced matrix, solution of the
+    reduced system and the full solve against the oracle."""
+    from xrsfm_amd import capi
+    arr = H.make(40, 1200, 8, seed=430, dropout=0.35)
+    lens = np.bincount(arr["obs_pt"])
+    assert lens.min() >= 2 and len(set(lens.tolist())) >= 5
+    if solver == 1:
+        pr = H.to_oracle(arr)
+        ctx = capi.Context(H.to_product(arr))
+        ctx.debug_linearize(use_scaling=True)
+        y, S = ctx.debug_cholesky_solve(1e4, want_S=True)
+        cost, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+        ctx.close()
+        assert np.isfinite(S).all() and np.abs(S - S.T).max() <= 1e-9 * np.abs(S).max()
+    pr, s_ref, prod, s = _solve_both(dict(arr), dict(max_iterations=12, linear_solver=solver))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
