@@ -33,12 +33,20 @@ def main():
     shutil.copy(os.path.join(src, "pmc_traffic_L.json"), os.path.join(dst, "pmc_traffic_L.json"))
     with open(os.path.join(dst, f"{tag}_bench_lines.md"), "w") as f:
         f.write(f"# Round {tag[1:]} — bench.py lines (MI355X, 1 GPU, host with {nproc} cores), `python bench.py --config C --steps 5 --warmup 2`\n")
-        for cfg, note in (("L", "default workload"), ("S", ""), ("K", "KITTI-00-sized sequential problem")):
+        for cfg, note in (("L", "default workload"), ("S", ""), ("K", "KITTI-00-sized sequential problem"),
+                          ("X", "5000 cameras: 30 000 camera unknowns on the exact Cholesky path"),
+                          ("R", "ragged tracks: windows of 8 frames, 35 % missed detections"),
+                          ("U", "random visibility, dense reduced camera matrix; no CPU leg")):
+            if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
+                continue
             f.write(f"\n## config {cfg}" + (f" ({note})" if note else "") + "\n```\n" + rd(f"bench_{cfg}.json").strip() + "\n```\n")
             d = json.loads(rd(f"bench_{cfg}.json"))
             b = d.get("cpu_baseline") or {}
-            f.write(f"\n{d['ms_per_step']:.2f} ms per solve, {d['value']:.3e} {d['unit']}; CPU port {b.get('cores')} threads: "
-                    f"{b.get('value', 0):.3e} ({b.get('gpu_vs_cpu', 0):.0f}x)")
+            f.write(f"\n{d['ms_per_step']:.2f} ms per solve ({d['lm_iterations_per_step']:.0f} LM iterations), {d['value']:.3e} {d['unit']}")
+            if not b:
+                f.write(".\n")
+                continue
+            f.write(f"; CPU port {b.get('cores')} threads: {b.get('value', 0):.3e} ({b.get('gpu_vs_cpu', 0):.0f}x)")
             if "more_threads" in b:
                 m = b["more_threads"]
                 f.write(f", {m['cores']} threads: {m['value']:.3e} ({m['gpu_vs_cpu']:.0f}x)")

@@ -20,8 +20,9 @@ grep "^{\"metric\"" $OUT/stats_bench.log | tail -1 > $OUT/stats_bench_line.json
 rm -rf $OUT/stats $OUT/fetch $OUT/write
 # 4. bench lines with the CPU leg
 cd $ROOT
-for cfg in L S K; do
+for cfg in L S K X R; do
   python bench.py --config $cfg --steps 5 --warmup 2 2> $OUT/bench_$cfg.err | tail -1 > $OUT/bench_$cfg.json
 done
+python bench.py --config U --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_U.err | tail -1 > $OUT/bench_U.json
 nproc > $OUT/nproc.txt
 ls -la $OUT

@@ -281,11 +281,50 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
                 xn2 += Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
             if (is_long && lane == 0 && tl == 0) long_pt = s.pt;
         }
-        {   // camera-side terms: one partial per camera for a regular tile, one per observation otherwise
-            const int stride = d.tile_stride[it.first_tile + tl];
-            if (stride > 0) strided_reduce<12>(cs, stride, lane);
-            const int cp = d.slot_campos[s.slot];
-            if (cp >= 0) {
+        {   // camera-side terms: one partial per camera of the tile for a regular tile (wave pre-reduction) and for a Gram tile
+            // with ragged tracks (sum per distinct camera through LDS, like k_schur_pairs), one per observation otherwise
+            const int tile = it.first_tile + tl;
+            const int stride = d.tile_stride[tile];
+            const int Cg = LONG ? 0 : d.tile_ncam[tile];
+            const int cp = d.slot_campos_g[s.slot];
+            if (stride > 0) {
+                strided_reduce<12>(cs, stride, lane);
+                if (cp >= 0) {
+                    double2* out = reinterpret_cast<double2*>(d.scat + 12 * (size_t)cp);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
+                }
+            } else if (Cg > 0) {
+                extern __shared__ __attribute__((aligned(16))) double lin_smem[];
+                double* red = lin_smem + (threadIdx.x >> 6) * (kWave * 13);          // this wave's [64][13]
+                const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
+                unsigned long long m0 = 0, m1 = 0;                                   // lane masks of the cameras of q = lane, lane + 64
+                for (int cc = 0; cc < Cg; ++cc) {
+                    const unsigned long long m = __ballot(cidx == cc);
+                    if (lane / 12 == cc) m0 = m;
+                    if ((lane + 64) / 12 == cc) m1 = m;
+                }
+#pragma unroll
+                for (int k = 0; k < 12; ++k) red[lane * 13 + k] = cs[k];
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int rd = 0; rd < 2; ++rd) {
+                    const int q = lane + 64 * rd;
+                    unsigned long long m = rd == 0 ? m0 : m1;
+                    const bool on = q < 12 * Cg;
+                    const int first = on ? __ffsll((long long)m) - 1 : 0;
+                    const int cpr = __shfl(cp, first, kWave);
+                    if (on) {
+                        const int k = q % 12;
+                        double sum = 0.0;
+                        while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * 13 + k]; m &= m - 1; }
+                        d.scat[12 * (size_t)cpr + k] = sum;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+            } else if (cp >= 0) {
                 double2* out = reinterpret_cast<double2*>(d.scat + 12 * (size_t)cp);
 #pragma unroll
                 for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
