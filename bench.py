@@ -231,7 +231,9 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
         if world == 1 and os.path.exists(pmc):      # separate rocprofv3 --pmc passes (tools/pmc_summary.py), bytes per launch
-            traffic = json.load(open(pmc)).get(dom)
+            table = json.load(open(pmc))          # template instantiations of one kernel (k_schur_pairs<true|false>) make up one pass
+            hits = [v for k, v in table.items() if k == dom or k.startswith(dom + "<")]
+            traffic = sum(hits) if hits else None
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "algorithmic_bytes_per_launch": alg}
