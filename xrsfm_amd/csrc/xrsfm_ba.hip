@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/xrsfm_ba.h"
@@ -229,6 +230,42 @@ int dev_upload(xrsfm_ba_context* c, T** p, const std::vector<T>& v) {
     if (!v.empty() && hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return XRSFM_BA_ENODEV;
     return 0;
 }
+
+// Many small host -> device arrays per call (an LBA-sized solve uploads ~45 of them at ~10 us each): arrays below 1 MB are
+// gathered into one staging buffer, one device block and ONE copy; the big ones keep their own copy.
+struct BatchUpload {
+    struct Req { void** dst; const void* src; size_t bytes, off; };
+    std::vector<Req> reqs;
+    size_t total = 0;
+    xrsfm_ba_context* c;
+    int err = 0;
+    explicit BatchUpload(xrsfm_ba_context* ctx) : c(ctx) {}
+    template <typename T> void add(T** dst, const std::vector<T>& v) { add_raw(reinterpret_cast<void**>(dst), v.data(), v.size() * sizeof(T)); }
+    void add_raw(void** dst, const void* src, size_t bytes) {
+        if (err) return;
+        if (bytes >= ((size_t)1 << 20)) {
+            unsigned char* q = nullptr;
+            if ((err = dev_alloc(c, &q, bytes))) return;
+            if (hipMemcpy(q, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { err = XRSFM_BA_ENODEV; return; }
+            *dst = q;
+            return;
+        }
+        reqs.push_back({dst, src, bytes, total});
+        total += ((bytes > 0 ? bytes : 1) + 255) & ~(size_t)255;
+    }
+    int flush() {
+        if (err) return err;
+        if (reqs.empty()) return 0;
+        unsigned char* base = nullptr;
+        if ((err = dev_alloc(c, &base, total))) return err;
+        std::vector<unsigned char> stage(total);
+        for (const Req& r : reqs) if (r.bytes) memcpy(stage.data() + r.off, r.src, r.bytes);
+        if (hipMemcpy(base, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) return err = XRSFM_BA_ENODEV;
+        for (const Req& r : reqs) *r.dst = base + r.off;
+        reqs.clear(); total = 0;
+        return 0;
+    }
+};
 
 inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
 
@@ -448,21 +485,24 @@ int chol_setup(xrsfm_ba_context* c) {
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off;
     int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
-    TRYC(dev_upload(c, &h.slot_pair_ptr, P.spp)); TRYC(dev_upload(c, &h.pair_dst, P.pair_dst));
-    TRYC(dev_upload(c, &h.blk_ptr, P.blk_ptr)); TRYC(dev_upload(c, &h.blk_rc, P.blk_rc));
-    TRYC(dev_upload(c, &h.tiles_nz, P.tiles_nz)); TRYC(dev_upload(c, &h.rows_flat, P.rows_flat));
-    TRYC(dev_upload(c, &h.pairs_flat, P.pairs_flat)); TRYC(dev_upload(c, &h.cols_flat, P.cols_flat));
-    TRYC(dev_upload(c, &h.lv_k, P.lv_k)); TRYC(dev_upload(c, &h.lv_tgt, P.lv_tgt)); TRYC(dev_upload(c, &h.lv_cptr, P.lv_cptr));
-    TRYC(dev_upload(c, &h.lv_cj, P.lv_cj)); TRYC(dev_upload(c, &h.lv_trsm, P.lv_trsm));
-    TRYC(dev_upload(c, &h.lv_rptr, P.lv_rptr)); TRYC(dev_upload(c, &h.lv_rj, P.lv_rj));
-    TRYC(dev_upload(c, &h.lv_bptr, P.lv_bptr)); TRYC(dev_upload(c, &h.lv_bi, P.lv_bi));
-    TRYC(dev_upload(c, &h.sp_tgt, P.sp_tgt)); TRYC(dev_upload(c, &h.sp_q, P.sp_q));
-    TRYC(dev_upload(c, &h.sp_rt, P.sp_rt)); TRYC(dev_upload(c, &h.sp_rp, P.sp_rp));
-    TRYC(dev_upload(c, &h.tf_ptr, P.tf_ptr)); TRYC(dev_upload(c, &h.tf_ent, P.tf_ent));
-    TRYC(dev_upload(c, &h.zero2, std::vector<int>(2, 0)));
-    TRYC(dev_upload(c, &h.pairs_items, P.pairs_items));
+    BatchUpload up(c);
+    up.add(&h.slot_pair_ptr, P.spp); up.add(&h.pair_dst, P.pair_dst);
+    up.add(&h.blk_ptr, P.blk_ptr); up.add(&h.blk_rc, P.blk_rc);
+    up.add(&h.tiles_nz, P.tiles_nz); up.add(&h.rows_flat, P.rows_flat);
+    up.add(&h.pairs_flat, P.pairs_flat); up.add(&h.cols_flat, P.cols_flat);
+    up.add(&h.lv_k, P.lv_k); up.add(&h.lv_tgt, P.lv_tgt); up.add(&h.lv_cptr, P.lv_cptr);
+    up.add(&h.lv_cj, P.lv_cj); up.add(&h.lv_trsm, P.lv_trsm);
+    up.add(&h.lv_rptr, P.lv_rptr); up.add(&h.lv_rj, P.lv_rj);
+    up.add(&h.lv_bptr, P.lv_bptr); up.add(&h.lv_bi, P.lv_bi);
+    up.add(&h.sp_tgt, P.sp_tgt); up.add(&h.sp_q, P.sp_q);
+    up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp);
+    up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
+    const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
+    up.add(&h.zero2, two_zeros);
+    up.add(&h.pairs_items, P.pairs_items);
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
-    TRYC(dev_upload(c, &d_cam_off, P.cam_off)); TRYC(dev_upload(c, &d_one_k, P.one_k)); TRYC(dev_upload(c, &d_tile_rows, P.tile_rows));
+    up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
+    TRYC(up.flush());
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
         double* both = nullptr;
@@ -697,33 +737,22 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     std::vector<double> cam_act(k.n_cams);
     for (int i = 0; i < k.n_cams; ++i) cam_act[i] = (k.cam_ptr[i + 1] > k.cam_ptr[i]) ? 1.0 : 0.0;
 #define TRY(x) do { e = (x); if (e) { xrsfm_ba_destroy(c); return e; } } while (0)
-    int* tmp_i; double* tmp_d; unsigned char* tmp_u; Item* tmp_it; CamRec* tmp_c;
-    TRY(dev_upload(c, &tmp_i, k.slot_cam)); d.slot_cam = tmp_i;
-    TRY(dev_upload(c, &tmp_i, k.slot_pt)); d.slot_pt = tmp_i;
-    TRY(dev_upload(c, &tmp_i, k.slot_campos)); d.slot_campos = tmp_i;
-    TRY(dev_upload(c, &tmp_d, k.slot_u)); d.slot_u = tmp_d;
-    TRY(dev_upload(c, &tmp_d, k.slot_v)); d.slot_v = tmp_d;
-    TRY(dev_alloc(c, &tmp_it, k.items.size() / 2));
-    if (!k.items.empty() && hipMemcpy(tmp_it, k.items.data(), k.items.size() * sizeof(int), hipMemcpyHostToDevice) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
-    d.items = tmp_it;
-    TRY(dev_upload(c, &tmp_i, k.tile_stride)); d.tile_stride = tmp_i;
-    TRY(dev_upload(c, &tmp_i, k.tile_maxlen)); d.tile_maxlen = tmp_i;
-    TRY(dev_upload(c, &tmp_i, k.tile_ncam)); d.tile_ncam = tmp_i;
-    TRY(dev_upload(c, &tmp_i, k.tile_gt_off)); d.tile_gt_off = tmp_i;
-    { unsigned char* tmp_b = nullptr; TRY(dev_upload(c, &tmp_b, k.slot_cidx)); d.slot_cidx = tmp_b; }
-    TRY(dev_upload(c, &tmp_i, k.slot_campos_g)); d.slot_campos_g = tmp_i;
-    TRY(dev_upload(c, &tmp_i, k.cam_ptr_g)); d.cam_ptr_g = tmp_i;
-    TRY(dev_upload(c, &tmp_c, cams)); d.cam = tmp_c;
-    TRY(dev_upload(c, &tmp_c, cams)); d.cam_cand = tmp_c;
-    TRY(dev_upload(c, &tmp_c, cams)); c->cam0 = tmp_c;
-    TRY(dev_upload(c, &tmp_i, model)); d.cam_model = tmp_i;
-    TRY(dev_upload(c, &tmp_u, cconst)); d.cam_const = tmp_u;
-    TRY(dev_upload(c, &tmp_i, k.cam_ptr)); d.cam_ptr = tmp_i;
-    TRY(dev_upload(c, &tmp_d, cam_act)); d.cam_act = tmp_d;
-    TRY(dev_upload(c, &tmp_d, P)); d.P = tmp_d;
-    TRY(dev_upload(c, &tmp_d, P)); d.P_cand = tmp_d;
-    TRY(dev_upload(c, &tmp_d, P)); c->P0 = tmp_d;
-    TRY(dev_upload(c, &tmp_u, k.pt_const)); d.pt_const = tmp_u;
+    {
+        // (const members of Dev are set through a cast: the arrays are written exactly once, here)
+        BatchUpload up(c);
+        auto P_ = [](auto& member) { return const_cast<std::remove_const_t<std::remove_pointer_t<std::remove_reference_t<decltype(member)>>>**>(&member); };
+        up.add(P_(d.slot_cam), k.slot_cam); up.add(P_(d.slot_pt), k.slot_pt); up.add(P_(d.slot_campos), k.slot_campos);
+        up.add(P_(d.slot_u), k.slot_u); up.add(P_(d.slot_v), k.slot_v);
+        up.add_raw(reinterpret_cast<void**>(const_cast<Item**>(&d.items)), k.items.data(), k.items.size() * sizeof(int));
+        up.add(P_(d.tile_stride), k.tile_stride); up.add(P_(d.tile_maxlen), k.tile_maxlen);
+        up.add(P_(d.tile_ncam), k.tile_ncam); up.add(P_(d.tile_gt_off), k.tile_gt_off); up.add(P_(d.slot_cidx), k.slot_cidx);
+        up.add(P_(d.slot_campos_g), k.slot_campos_g); up.add(P_(d.cam_ptr_g), k.cam_ptr_g);
+        up.add(P_(d.cam), cams); up.add(P_(d.cam_cand), cams); up.add(&c->cam0, cams);
+        up.add(P_(d.cam_model), model); up.add(P_(d.cam_const), cconst); up.add(P_(d.cam_ptr), k.cam_ptr); up.add(P_(d.cam_act), cam_act);
+        up.add(P_(d.P), P); up.add(P_(d.P_cand), P); up.add(&c->P0, P);
+        up.add(P_(d.pt_const), k.pt_const);
+        TRY(up.flush());
+    }
     const size_t ns = (size_t)k.n_slots, nc = (size_t)k.n_cams, np = (size_t)k.n_pts;
     TRY(dev_alloc(c, &d.scale_c, nc * 6)); TRY(dev_alloc(c, &d.scale_p, np * 3));
     TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Jp, ns * 6)); TRY(dev_alloc(c, &d.camrec, nc));
