@@ -516,13 +516,22 @@ int chol_setup(xrsfm_ba_context* c) {
 #undef TRYC
     HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * (size_t)P.n_pad * P.n_pad, c->stream));
     const int shm = 2 * kNB * kLdT * (int)sizeof(double);
-    (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)k_ll_update_part, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-    (void)hipFuncSetAttribute((const void*)k_schur_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max(h.pairs_shm, h.pairs_shm_big));
-    (void)hipFuncSetAttribute((const void*)k_schur_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h.pairs_shm);
+    {   // dynamic-LDS limits: once per device and process (each call costs a few microseconds, an LBA-sized solve has few to spare)
+        static std::mutex mu;
+        static std::vector<char> done_for(64, 0);
+        std::lock_guard<std::mutex> g(mu);
+        if (c->device < 64 && !done_for[c->device]) {
+            const int pairs_max = kGramMaxLds + kGramMaxCams * kGramMaxCams * (int)sizeof(int);
+            (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+            (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+            (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+            (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+            (void)hipFuncSetAttribute((const void*)k_ll_update_part, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            done_for[c->device] = 1;
+        }
+    }
     if (h.n_pairs_other > 0 && !h.aux) {
         if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
