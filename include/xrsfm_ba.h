@@ -248,6 +248,14 @@ int xrsfm_ba_debug_schur_product(xrsfm_ba_context *ctx, double radius, const dou
  * entries at most (upper bound of the slot count). */
 int xrsfm_ba_debug_pack(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *slot_obs);
 
+/* The S-assembly side of the packing (no GPU needed): Gram tiles and the item classes of k_schur_pairs.
+ * stats[0] Gram tiles, [1] cells of their C x C destination tables, [2] camera-major entries of the S assembly (one per
+ * distinct camera of a Gram tile), [3] largest C, [4]/[5]/[6] items in the small-LDS Gram class / big-LDS Gram class /
+ * per-pair + long class, [7] partial blocks written per pass.  tile_ncam (may be NULL): [tiles]; slot_cidx (may be NULL):
+ * [slots], 255 outside Gram tiles; slot_campos_g (may be NULL): [slots], -1 for non-writers. */
+int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *tile_ncam, uint8_t *slot_cidx,
+                             int32_t *slot_campos_g);
+
 /* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
  * (0 natural, 1 nested dissection of a band/ring), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
  * [6] level schedule used (else right-looking), [7] structurally non-zero tiles after fill.  cam_offset (may be NULL):

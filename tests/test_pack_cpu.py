@@ -73,3 +73,57 @@ def test_packing_edge_cases(lib):
     # points without observations are not active
     arr["points"] = np.concatenate([arr["points"], np.zeros((3, 3))]); arr["point_const"] = np.zeros(43, np.uint8)
     assert capi.debug_pack(H.to_product(arr))["active_points"] == 40
+
+
+@pytest.mark.parametrize("kind", ["regular", "ragged", "wide"])
+def test_gram_tiles_and_item_classes(kind):
+    """S-assembly side of the packing (ba_pack.h / ba_plan.h): Gram tiles, their camera indices, the per-camera writers and the
+    item classes of k_schur_pairs."""
+    from xrsfm_amd import capi
+    if kind == "regular":
+        arr = H.make(60, 3000, 4, seed=11)                       # 50 tracks per tuple: groups start on tile boundaries
+    elif kind == "ragged":
+        arr = H.make(60, 3000, 8, seed=12, dropout=0.35)
+    else:
+        arr = H.make(40, 60, 30, seed=13, mode="unordered")      # 30-camera tracks: more than 10 distinct cameras per tile
+    g = capi.debug_pack_gram(H.to_product(arr))
+    so, ncam, cidx, cpg = g["slot_obs"], g["tile_ncam"], g["slot_cidx"], g["slot_campos_g"]
+    cam = np.where(so >= 0, arr["obs_cam"][np.clip(so, 0, None)], -1)
+    pt = np.where(so >= 0, arr["obs_pt"][np.clip(so, 0, None)], -1)
+    n_tiles = ncam.shape[0]
+    assert g["items_small"] + g["items_big"] + g["items_other"] == g["items"]
+    assert g["items_small"] + g["items_big"] == g["gram_tiles"] == int((ncam > 0).sum())
+    expect_entries, expect_writes = 0, 0
+    for t in range(n_tiles):
+        sl = slice(64 * t, 64 * t + 64)
+        c, p_, ci, cp = cam[sl], pt[sl], cidx[sl], cpg[sl]
+        valid = c >= 0
+        if ncam[t] > 0:
+            distinct = np.unique(c[valid])
+            assert ncam[t] == len(distinct) <= 10 and len(distinct) >= 2
+            assert np.array_equal(distinct[ci[valid]], c[valid])                  # index into the ascending camera list
+            # exactly one writer per distinct camera: its first lane
+            for k, cc in enumerate(distinct):
+                lanes = np.nonzero(valid & (c == cc))[0]
+                assert cp[lanes[0]] >= 0 and (cp[lanes[1:]] < 0).all()
+            expect_entries += len(distinct)
+            pairs = set()
+            for j in np.unique(p_[valid]):
+                cs_ = np.sort(c[valid & (p_ == j)])
+                pairs.update((a, b) for i, a in enumerate(cs_) for b in cs_[i + 1:])
+            expect_writes += len(pairs)                                           # one partial block per co-visible pair
+        else:
+            assert (ci[valid] == 255).all() if valid.any() else True
+            expect_entries += int((cp >= 0).sum())
+            for j in np.unique(p_[valid]):
+                n = int((valid & (p_ == j)).sum())
+                expect_writes += n * (n - 1) // 2 if g["long_items"] == 0 else 0
+    assert g["cam_entries_g"] == expect_entries
+    if g["long_items"] == 0:
+        assert g["block_writes"] == expect_writes
+    if kind == "regular":
+        assert g["items_other"] <= 0.05 * g["items"] and g["items_big"] == 0     # one launch class for sequential data
+    if kind == "ragged":
+        assert g["gram_tiles"] >= 0.9 * n_tiles
+    if kind == "wide":
+        assert g["gram_tiles"] == 0 and g["items_other"] == g["items"]

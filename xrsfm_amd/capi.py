@@ -78,7 +78,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -133,6 +133,8 @@ def load(path: str | None = None):
     lib.xrsfm_ba_refine_pose.argtypes = [C.POINTER(COptions), C.c_int32, _c_double_p, C.c_int32, _c_double_p, _c_double_p, _c_uint8_p,
                                          _c_double_p, _c_double_p, C.POINTER(CSummary)]
     lib.xrsfm_ba_refine_pose.restype = C.c_int
+    lib.xrsfm_ba_debug_pack_gram.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p, _c_uint8_p, _c_int32_p]
+    lib.xrsfm_ba_debug_pack_gram.restype = C.c_int
     lib.xrsfm_ba_debug_chol_plan.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
     lib.xrsfm_ba_debug_chol_plan.restype = C.c_int
     lib.xrsfm_ba_debug_pack.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
@@ -413,3 +415,18 @@ def pose_graph_solve(rot_q, pos, scale, edges, weight_o=0.0, scale_costs=(), pos
     s = CPgSummary()
     check(load().xrsfm_pg_solve(C.byref(o), C.byref(p), C.byref(s)), "xrsfm_pg_solve")
     return pos, scale, s
+
+
+def debug_pack_gram(problem: ProblemArrays) -> dict:
+    """Gram tiles and S-assembly item classes of the host-side packing (works without a GPU)."""
+    st = debug_pack(problem)
+    stats = np.zeros(8, np.int32)
+    ncam = np.zeros(max(st["tiles"], 1), np.int32); cidx = np.zeros(max(st["slots"], 1), np.uint8); cpg = np.zeros(max(st["slots"], 1), np.int32)
+    cs = problem.c_struct()
+    check(load().xrsfm_ba_debug_pack_gram(C.byref(cs), stats.ctypes.data_as(_c_int32_p), ncam.ctypes.data_as(_c_int32_p),
+                                          cidx.ctypes.data_as(_c_uint8_p), cpg.ctypes.data_as(_c_int32_p)), "xrsfm_ba_debug_pack_gram")
+    keys = ("gram_tiles", "table_cells", "cam_entries_g", "max_cams", "items_small", "items_big", "items_other", "block_writes")
+    out = dict(zip(keys, (int(v) for v in stats)))
+    out.update(tile_ncam=ncam[:st["tiles"]], slot_cidx=cidx[:st["slots"]], slot_campos_g=cpg[:st["slots"]], slot_obs=st["slot_obs"],
+               items=st["items"], long_items=st["long_items"])
+    return out

@@ -1251,6 +1251,26 @@ int xrsfm_ba_debug_pack(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* sl
     return 0;
 }
 
+int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* tile_ncam, uint8_t* slot_cidx, int32_t* slot_campos_g) {
+    if (!p || !stats) return XRSFM_BA_EINVAL;
+    Packed k;
+    int e = pack_problem(*p, k);
+    if (e) return e;
+    std::vector<int> spp;
+    PairKeys keyed;
+    if ((e = chol_local_keys(k, spp, keyed))) return e;
+    CholPlan P;
+    if ((e = chol_plan_build(k, spp, keyed, nullptr, P))) return e;
+    int n_gram = 0, cmax = 0;
+    for (int t = 0; t < k.n_tiles; ++t) { n_gram += k.tile_ncam[t] > 0; cmax = std::max(cmax, k.tile_ncam[t]); }
+    stats[0] = n_gram; stats[1] = k.n_gt_cells; stats[2] = k.n_cam_entries_g; stats[3] = cmax;
+    stats[4] = P.n_pairs_small; stats[5] = P.n_pairs_big; stats[6] = P.n_pairs_other; stats[7] = P.n_writes;
+    if (tile_ncam) for (int t = 0; t < k.n_tiles; ++t) tile_ncam[t] = k.tile_ncam[t];
+    if (slot_cidx) for (int s2 = 0; s2 < k.n_slots; ++s2) slot_cidx[s2] = k.slot_cidx[s2];
+    if (slot_campos_g) for (int s2 = 0; s2 < k.n_slots; ++s2) slot_campos_g[s2] = k.slot_campos_g[s2];
+    return 0;
+}
+
 int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* cam_offset) {
     if (!p || !stats) return XRSFM_BA_EINVAL;
     Packed k;
