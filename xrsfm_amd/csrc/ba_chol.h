@@ -76,6 +76,52 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
     o28[27] = 0.0;
 }
 
+// G = V V^T for an operand of NI 16-row tiles staged in LDS (row stride Cp doubles, K = C4 columns): per K-step of 4 every
+// lane reads ONE value per row tile — the same register is the A operand of the products in its tile row and the B operand of
+// those in its tile column (identical layouts) — and all NI(NI+1)/2 accumulators advance: independent MFMA chains instead of
+// one dependent chain per tile pair, a third of the LDS reads.  Then the blocks (camera rb > camera ra) go to their
+// destinations (dtab: [C][C], -1 = the pair never occurs in the tile).
+template <int NI>
+__device__ __forceinline__ void gram_product(const double* __restrict__ Vst, int R, int Cp, int C4, int C, const int* __restrict__ dtab,
+                                             double* __restrict__ scat2, int lane) {
+    static_assert(NI >= 1 && NI <= 4, "a Gram tile has at most 10 cameras = 60 operand rows (ba_pack.h: kGramMaxCams)");
+    const int li = lane & 15, lk = lane >> 4;
+    v4d acc[NI * (NI + 1) / 2];
+#pragma unroll
+    for (int p = 0; p < NI * (NI + 1) / 2; ++p) acc[p] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* rowp[NI];
+#pragma unroll
+    for (int I = 0; I < NI; ++I) rowp[I] = Vst + min(16 * I + li, R - 1) * Cp + lk;
+    for (int k0 = 0; k0 < C4; k0 += 4) {
+        double a[NI];
+#pragma unroll
+        for (int I = 0; I < NI; ++I) a[I] = rowp[I][k0];
+        int p = 0;
+#pragma unroll
+        for (int I = 0; I < NI; ++I)
+#pragma unroll
+            for (int J = 0; J <= I; ++J) { acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[p], 0, 0, 0); ++p; }
+    }
+    int p = 0;
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            const int col = 16 * J + li;
+            const int ra = col / 6, j = col - 6 * ra;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 16 * I + lk + 4 * g;
+                const int rb = row / 6, i = row - 6 * rb;
+                if (row < R && col < R && rb > ra) {
+                    const int dst = dtab[ra * C + rb];
+                    if (dst >= 0) scat2[36 * (size_t)dst + 6 * i + j] = acc[p][g];
+                }
+            }
+            ++p;
+        }
+}
+
 // GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
 // needs do not shape its allocation: 118 VGPRs, no spills); GRAM = false: per-pair tiles and long tracks.  The two
 // instantiations write disjoint outputs and run concurrently on two streams.
@@ -208,26 +254,12 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             }
             __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand and dtab are in LDS
             __builtin_amdgcn_wave_barrier();
-            const int li = lane & 15, lk = lane >> 4;
-            const int nI = Rp >> 4;
-            for (int I = 0; I < nI; ++I)
-                for (int J = 0; J <= I; ++J) {
-                    v4d acc = {0.0, 0.0, 0.0, 0.0};
-                    const double* ap = Vst + min(16 * I + li, R - 1) * Cp + lk;
-                    const double* bp = Vst + min(16 * J + li, R - 1) * Cp + lk;
-                    for (int k0 = 0; k0 < C4; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ap[k0], bp[k0], acc, 0, 0, 0);
-                    const int col = 16 * J + li;
-                    const int ra = col / 6, j = col - 6 * ra;
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = 16 * I + lk + 4 * g;
-                        const int rb = row / 6, i = row - 6 * rb;
-                        if (row < R && col < R && rb > ra) {
-                            const int dst = dtab[ra * C + rb];
-                            if (dst >= 0) scat2[36 * (size_t)dst + 6 * i + j] = acc[g];
-                        }
-                    }
-                }
+            switch (Rp >> 4) {                             // 16-row operand tiles: all tile pairs of the Gram matrix at once
+                case 1: gram_product<1>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
+                case 2: gram_product<2>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
+                case 3: gram_product<3>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
+                default: gram_product<4>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
+            }
             return;
         }
         if (GRAM) return;           // (not reached: keeps the per-pair code out of the Gram instantiation)
