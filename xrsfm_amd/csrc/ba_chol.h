@@ -12,6 +12,7 @@
 //    forward / backward substitution one panel per launch.
 #pragma once
 #include "ba_kernels.h"
+#include "ba_pack.h"
 
 namespace xba {
 
@@ -76,14 +77,15 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
     o28[27] = 0.0;
 }
 
-// G = V V^T for an operand of NI 16-row tiles staged in LDS (row stride Cp doubles, K = C4 columns): per K-step of 4 every
-// lane reads ONE value per row tile — the same register is the A operand of the products in its tile row and the B operand of
-// those in its tile column (identical layouts) — and all NI(NI+1)/2 accumulators advance: independent MFMA chains instead of
-// one dependent chain per tile pair, a third of the LDS reads.  Then the blocks (camera rb > camera ra) go to their
-// destinations (dtab: [C][C], -1 = the pair never occurs in the tile).
+// G = V V^T for a Gram tile whose operand has NI 16-row tiles (row stride Cp doubles).  The tracks are staged in `passes`
+// rounds of Th tracks (two rounds when one would not fit the small LDS class: the accumulators simply carry over); per
+// K-step of 4 every lane reads ONE value per row tile — the same register is the A operand of the products in its tile row
+// and the B operand of those in its tile column (identical layouts) — and all NI(NI+1)/2 accumulators advance.  Then the
+// blocks (camera rb > camera ra) go to their destinations (dtab: [C][C], -1 = the pair never occurs in the tile).
 template <int NI>
-__device__ __forceinline__ void gram_product(const double* __restrict__ Vst, int R, int Cp, int C4, int C, const int* __restrict__ dtab,
-                                             double* __restrict__ scat2, int lane) {
+__device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int Cp, int C, const int* __restrict__ dtab,
+                                          double* __restrict__ scat2, int lane, const double (&V)[18], bool valid, int t, int cidx,
+                                          int T, int Th, int passes, bool dense) {
     static_assert(NI >= 1 && NI <= 4, "a Gram tile has at most 10 cameras = 60 operand rows (ba_pack.h: kGramMaxCams)");
     const int li = lane & 15, lk = lane >> 4;
     v4d acc[NI * (NI + 1) / 2];
@@ -92,15 +94,40 @@ __device__ __forceinline__ void gram_product(const double* __restrict__ Vst, int
     const double* rowp[NI];
 #pragma unroll
     for (int I = 0; I < NI; ++I) rowp[I] = Vst + min(16 * I + li, R - 1) * Cp + lk;
-    for (int k0 = 0; k0 < C4; k0 += 4) {
-        double a[NI];
+    for (int h = 0; h < passes; ++h) {
+        const int t0 = h * Th, tn = min(Th, T - t0);           // tracks t0 .. t0+tn-1 in this round
+        const int C4 = (3 * tn + 3) & ~3;
+        if (dense && passes == 1) {
+            // dense (regular) tile: only the K padding columns 3T..Cp-1 need zeros (rows beyond R are never staged: reads are
+            // clamped, results discarded)
+            const int padc = Cp - 3 * tn;
+            for (int e = lane; e < R * padc; e += kWave) {
+                const int row = e / padc, cc = 3 * tn + (e - row * padc);
+                Vst[row * Cp + cc] = 0.0;
+            }
+        } else {
+            for (int e = lane; e < R * Cp; e += kWave) Vst[e] = 0.0;           // LDS operations of one wave complete in order
+        }
+        if (valid && t >= t0 && t < t0 + tn) {
 #pragma unroll
-        for (int I = 0; I < NI; ++I) a[I] = rowp[I][k0];
-        int p = 0;
+            for (int i = 0; i < 6; ++i)
 #pragma unroll
-        for (int I = 0; I < NI; ++I)
+                for (int m = 0; m < 3; ++m) Vst[(6 * cidx + i) * Cp + 3 * (t - t0) + m] = V[3 * i + m];
+        }
+        __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand (and dtab) are in LDS
+        __builtin_amdgcn_wave_barrier();
+        for (int k0 = 0; k0 < C4; k0 += 4) {
+            double a[NI];
 #pragma unroll
-            for (int J = 0; J <= I; ++J) { acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[p], 0, 0, 0); ++p; }
+            for (int I = 0; I < NI; ++I) a[I] = rowp[I][k0];
+            int p = 0;
+#pragma unroll
+            for (int I = 0; I < NI; ++I)
+#pragma unroll
+                for (int J = 0; J <= I; ++J) { acc[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[I], a[J], acc[p], 0, 0, 0); ++p; }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // the reads above are done before the next round overwrites the operand
+        __builtin_amdgcn_wave_barrier();
     }
     int p = 0;
 #pragma unroll
@@ -228,37 +255,22 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             const int nvalid = __popcll(__ballot(s.valid));
             const int t = __popcll(headmask & ((2ull << lane) - 1ull)) - 1;        // rank of the lane's track in the tile
             const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : 0;
-            const int R = 6 * C, Rp = (R + 15) & ~15, C4 = (3 * T + 3) & ~3, Cp = C4 + 2;
+            int passes = 1;
+            (void)gram_lds_need(C, T, &passes);                             // one staging round, or two with half the tracks each
+            const int Th = (T + passes - 1) / passes;
+            const int R = 6 * C, Rp = (R + 15) & ~15, Cp = ((3 * Th + 3) & ~3) + 2;
             double* Vst = smem;                                             // only the R rows that hold data are staged
             int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [C][C] destination of block (cb > ca) at [ca][cb], -1 none
             {
                 const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[it.first_tile];
                 for (int e = lane; e < C * C; e += kWave) dtab[e] = src[e];
             }
-            if (nvalid == T * C) {
-                // dense (regular) tile: only the K padding columns 3T..Cp-1 need zeros (rows beyond R are never staged: reads
-                // are clamped, results discarded)
-                const int padc = Cp - 3 * T;
-                for (int e = lane; e < R * padc; e += kWave) {
-                    const int row = e / padc, cc = 3 * T + (e - row * padc);
-                    Vst[row * Cp + cc] = 0.0;
-                }
-            } else {
-                for (int e = lane; e < R * Cp; e += kWave) Vst[e] = 0.0;       // LDS operations of one wave complete in order
-            }
-            if (s.valid) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) Vst[(6 * cidx + i) * Cp + 3 * t + m] = V[3 * i + m];
-            }
-            __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand and dtab are in LDS
-            __builtin_amdgcn_wave_barrier();
-            switch (Rp >> 4) {                             // 16-row operand tiles: all tile pairs of the Gram matrix at once
-                case 1: gram_product<1>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
-                case 2: gram_product<2>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
-                case 3: gram_product<3>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
-                default: gram_product<4>(Vst, R, Cp, C4, C, dtab, scat2, lane); break;
+            const bool dense = nvalid == T * C;
+            switch (Rp >> 4) {                             // 16-row operand tiles
+                case 1: gram_tile<1>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
+                case 2: gram_tile<2>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
+                case 3: gram_tile<3>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
+                default: gram_tile<4>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
             }
             return;
         }

@@ -15,6 +15,20 @@ constexpr int kGramMaxCams = 10;         // 60 operand rows: 4 MFMA row tiles
 constexpr int kGramMaxLds = 20 * 1024;   // staged operand of one tile (bytes); larger tiles use the per-pair path
 constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly launches: 160 KB / 16 workgroups
 
+// LDS bytes of a Gram tile with C cameras and T tracks: operand [6C][3T'+pad] + the C x C destination table, where the tracks
+// are staged in ONE pass (T' = T) if that fits the small class and otherwise in TWO passes of T' = ceil(T/2) tracks with the
+// accumulators kept across the passes.  The kernel (k_schur_pairs) evaluates the same rule.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+inline int gram_lds_need(int C, int T, int* passes) {
+    const int one = 6 * C * ((((3 * T + 3) & ~3)) + 2) * 8 + C * C * 4;
+    if (one <= kGramSmallLds) { *passes = 1; return one; }
+    const int Th = (T + 1) / 2;
+    *passes = 2;
+    return 6 * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + C * C * 4;
+}
+
 struct Packed {
     int n_cams = 0, n_pts = 0, n_obs = 0, n_tiles = 0, n_slots = 0;
     std::vector<int> pt_orig;        // packed point -> caller point index
@@ -224,8 +238,8 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
             if (nc == 0) continue;
             std::sort(cams, cams + nc);
             const int C = (int)(std::unique(cams, cams + nc) - cams);
-            const int Cp = ((3 * ntrk + 3) & ~3) + 2;
-            if (C < 2 || C > kGramMaxCams || (size_t)(6 * C) * Cp * sizeof(double) > (size_t)kGramMaxLds) continue;
+            int passes = 1;
+            if (C < 2 || C > kGramMaxCams || gram_lds_need(C, ntrk, &passes) > kGramMaxLds) continue;
             o.tile_ncam[t] = C;
             o.tile_gt_off[t] = (int)o.gt_cell.size();
             o.gt_cell.resize(o.gt_cell.size() + (size_t)C * C, 0);
@@ -239,9 +253,9 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         // The S-assembly kernel runs once per LDS class (<= 10 KB: 16 workgroups per CU; larger).  A handful of large tiles
         // is not worth a second launch (its duration is one tile's latency, ~15 us): they take the per-pair path instead.
         auto lds_need = [&](int t) {
-            int ntrk = 0;
+            int ntrk = 0, passes = 1;
             for (int q = 0; q < 64 && o.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || o.slot_pt[64 * t + q] != o.slot_pt[64 * t + q - 1]);
-            return (size_t)(6 * o.tile_ncam[t]) * (((3 * ntrk + 3) & ~3) + 2) * sizeof(double) + (size_t)o.tile_ncam[t] * o.tile_ncam[t] * sizeof(int);
+            return (size_t)gram_lds_need(o.tile_ncam[t], ntrk, &passes);
         };
         int n_big = 0;
         for (int t = 0; t < o.n_tiles; ++t) n_big += (o.tile_ncam[t] > 0 && lds_need(t) > (size_t)kGramSmallLds);

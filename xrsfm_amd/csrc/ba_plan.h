@@ -326,8 +326,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             const int C = k.tile_ncam[t];
             int ntrk = 0;
             for (int q = 0; q < 64 && k.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || k.slot_pt[64 * t + q] != k.slot_pt[64 * t + q - 1]);
-            const int Cp = ((3 * ntrk + 3) & ~3) + 2;
-            const size_t need = std::max(base, (size_t)(6 * C) * Cp * sizeof(double) + (size_t)C * C * sizeof(int));
+            int passes = 1;
+            const size_t need = std::max(base, (size_t)gram_lds_need(C, ntrk, &passes));
             if (need <= small_cap) { P.pairs_items.push_back(it); P.pairs_shm = std::max(P.pairs_shm, need); }
             else { big.push_back(it); P.pairs_shm_big = std::max(P.pairs_shm_big, need); }
         }
