@@ -141,8 +141,8 @@ def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="L", choices=["S", "L", "K", "U", "X", "R"])
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
