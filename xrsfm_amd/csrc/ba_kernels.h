@@ -27,6 +27,7 @@ struct PcgStatus {
     double pq;
     int it;
     int done;
+    unsigned arrived;   // workgroups of k_pcg_p that have read the status (the last one writes the new one)
 };
 
 // scalar slots (device buffer `scal`)
@@ -82,6 +83,7 @@ struct Dev {
     double* part;       // per-item partial sums, 4 * n_items
     double* campart;    // per-camera partials, 2 * n_cams
     double* ptpart;     // per-workgroup partials of point kernels, cdiv(n_pts, 256)
+    double* pcgpart;    // [3][n_cams] per-camera partial dot products of the PCG iteration
     double* scal;       // S_COUNT scalars
     PcgStatus* st;
 };
@@ -615,15 +617,19 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
     return s;  // same value in every thread
 }
 
-__device__ __forceinline__ void sym6_mul(const double* m, const double* x, double* y) {
-    // m: upper triangle row-major (21)
-    double A[6][6];
-    int idx = 0;
-    for (int a = 0; a < 6; ++a)
-        for (int b = a; b < 6; ++b) { A[a][b] = m[idx]; A[b][a] = m[idx]; ++idx; }
+__device__ __forceinline__ void sym6_mul(const double* __restrict__ m, const double* x, double* y) {
+    // m: upper triangle row-major (21); fully unrolled, the packed index folds to a constant (no private array)
+    double mm[21];
+#pragma unroll
+    for (int k = 0; k < 21; ++k) mm[k] = m[k];
+#pragma unroll
     for (int a = 0; a < 6; ++a) {
         double s = 0.0;
-        for (int b = 0; b < 6; ++b) s += A[a][b] * x[b];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const int lo = a < b ? a : b, hi = a < b ? b : a;
+            s += mm[6 * lo - lo * (lo - 1) / 2 + (hi - lo)] * x[b];
+        }
         y[a] = s;
     }
 }
@@ -647,7 +653,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(Dev d) {
     rz = block_sum<kPcgThreads>(rz, lds);
     bb = block_sum<kPcgThreads>(bb, lds);
     if (threadIdx.x == 0) {
-        d.st->rz = rz; d.st->rr = bb; d.st->bb = bb; d.st->pq = 0.0; d.st->it = 0;
+        d.st->rz = rz; d.st->rr = bb; d.st->bb = bb; d.st->pq = 0.0; d.st->it = 0; d.st->arrived = 0u;
         d.st->done = (bb == 0.0) ? 1 : 0;
     }
 }
@@ -743,46 +749,82 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
     }
 }
 
-// One PCG iteration's vector work on the (small) camera vectors; single workgroup.
-// On entry pq holds sum_i F^T z (all-reduced over ranks); D_c^2 p is added here.
-__global__ __launch_bounds__(kPcgThreads) void k_pcg_update(Dev d, double tol, int max_it) {
+// One PCG iteration's vector work on the camera vectors, three short multi-workgroup launches (thread = camera).  The dot
+// products are deterministic: per-camera partials, and EVERY workgroup of the next launch adds the partial array in the same
+// fixed order (a few thousand values from L2) instead of waiting for a single-workgroup reduction kernel.
+constexpr int kPcgBlock = 256;
+__device__ __forceinline__ double reduce_partials(const double* __restrict__ a, int n, double* lds) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += kPcgBlock) s += a[i];
+    return block_sum<kPcgBlock>(s, lds);
+}
+
+// (1) q = S p (all-reduced sum over the observations) + D_c^2 p;  partial p.q per camera
+__global__ __launch_bounds__(kPcgBlock) void k_pcg_q(Dev d, double* __restrict__ part) {
     if (d.st->done) return;
-    __shared__ double lds[kPcgThreads / kWave];
-    const double rz = d.st->rz, bb = d.st->bb;
-    const int it0 = d.st->it;
+    const int c = blockIdx.x * kPcgBlock + threadIdx.x;
+    if (c >= d.n_cams) return;
     double pq = 0.0;
-    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads)
-        for (int k = 0; k < 6; ++k) {
-            const size_t i = 6 * (size_t)c + k;
-            const double qv = d.pq[i] + d.Dc2[i] * d.pp[i];
-            d.pq[i] = qv;
-            pq += d.pp[i] * qv;
-        }
-    pq = block_sum<kPcgThreads>(pq, lds);
-    const double alpha = rz / pq;
-    double rz_new = 0.0, rr = 0.0;
-    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
-        double r[6], z[6];
-        for (int k = 0; k < 6; ++k) {
-            const size_t i = 6 * (size_t)c + k;
-            d.px[i] += alpha * d.pp[i];
-            r[k] = d.pr[i] - alpha * d.pq[i];
-            d.pr[i] = r[k];
-        }
-        sym6_mul(d.Minv + 21 * (size_t)c, r, z);
-        for (int k = 0; k < 6; ++k) { d.pz[6 * (size_t)c + k] = z[k]; rz_new += r[k] * z[k]; rr += r[k] * r[k]; }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const size_t i = 6 * (size_t)c + k;
+        const double pv = d.pp[i];
+        const double qv = d.pq[i] + d.Dc2[i] * pv;
+        d.pq[i] = qv;
+        pq += pv * qv;
     }
-    rz_new = block_sum<kPcgThreads>(rz_new, lds);
-    rr = block_sum<kPcgThreads>(rr, lds);
+    part[c] = pq;
+}
+
+// (2) alpha = rz / p.q;  x += alpha p, r -= alpha q, z = M^-1 r;  partial r.z and r.r per camera
+__global__ __launch_bounds__(kPcgBlock) void k_pcg_xr(Dev d, double* __restrict__ part) {
+    if (d.st->done) return;
+    __shared__ double lds[kPcgBlock / kWave];
+    const double pq = reduce_partials(part, d.n_cams, lds);
+    const double alpha = d.st->rz / pq;
+    const int c = blockIdx.x * kPcgBlock + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.st->pq = pq;
+    if (c >= d.n_cams) return;
+    double r[6], z[6], rz = 0.0, rr = 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const size_t i = 6 * (size_t)c + k;
+        d.px[i] += alpha * d.pp[i];
+        r[k] = d.pr[i] - alpha * d.pq[i];
+        d.pr[i] = r[k];
+    }
+    sym6_mul(d.Minv + 21 * (size_t)c, r, z);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { d.pz[6 * (size_t)c + k] = z[k]; rz += r[k] * z[k]; rr += r[k] * r[k]; }
+    part[(size_t)d.n_cams + c] = rz;
+    part[2 * (size_t)d.n_cams + c] = rr;
+}
+
+// (3) beta = rz_new / rz;  p = z + beta p;  status
+__global__ __launch_bounds__(kPcgBlock) void k_pcg_p(Dev d, const double* __restrict__ part, double tol, int max_it) {
+    if (d.st->done) return;
+    __shared__ double lds[kPcgBlock / kWave];
+    const double rz_new = reduce_partials(part + d.n_cams, d.n_cams, lds);
+    const double rr = reduce_partials(part + 2 * (size_t)d.n_cams, d.n_cams, lds);
+    const double rz = d.st->rz, bb = d.st->bb, pq = d.st->pq;
+    const int it0 = d.st->it;
     const double beta = rz_new / rz;
-    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads)
+    const int c = blockIdx.x * kPcgBlock + threadIdx.x;
+    if (c < d.n_cams) {
+#pragma unroll
         for (int k = 0; k < 6; ++k) {
             const size_t i = 6 * (size_t)c + k;
             d.pp[i] = d.pz[i] + beta * d.pp[i];
         }
+    }
+    // the status is written by the LAST workgroup to get here, after every workgroup has read the old one
+    __shared__ bool last;
+    __threadfence();
     __syncthreads();
-    if (threadIdx.x == 0) {
-        d.st->rz = rz_new; d.st->rr = rr; d.st->pq = pq; d.st->it = it0 + 1;
+    if (threadIdx.x == 0) last = (atomicAdd(&d.st->arrived, 1u) + 1u == gridDim.x);
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        d.st->rz = rz_new; d.st->rr = rr; d.st->it = it0 + 1; d.st->arrived = 0u;
         d.st->done = (rr <= tol * tol * bb || it0 + 1 >= max_it || !(pq > 0.0)) ? 1 : 0;
     }
 }

@@ -435,7 +435,13 @@ int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary
         for (int i = 0; i < chunk; ++i) {
             int e = schur_product(c, d.pp, d.pq, launched);
             if (e) return e;
-            { Timed t_(c, K_PCG_VEC, launched); hipLaunchKernelGGL(k_pcg_update, dim3(1), dim3(kPcgThreads), 0, c->stream, d, opt.pcg_tolerance, opt.pcg_max_iterations); }
+            if (d.n_cams > 0) {
+                Timed t_(c, K_PCG_VEC, launched);
+                const dim3 grid(cdiv(d.n_cams, kPcgBlock));
+                hipLaunchKernelGGL(k_pcg_q, grid, dim3(kPcgBlock), 0, c->stream, d, d.pcgpart);
+                hipLaunchKernelGGL(k_pcg_xr, grid, dim3(kPcgBlock), 0, c->stream, d, d.pcgpart);
+                hipLaunchKernelGGL(k_pcg_p, grid, dim3(kPcgBlock), 0, c->stream, d, (const double*)d.pcgpart, opt.pcg_tolerance, opt.pcg_max_iterations);
+            }
             ++launched;
         }
     }
@@ -775,6 +781,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     TRY(dev_alloc(c, &d.part, (size_t)d.n_items * 4));
     TRY(dev_alloc(c, &d.campart, nc * 2));
     TRY(dev_alloc(c, &d.ptpart, np / kBlock + 2));
+    TRY(dev_alloc(c, &d.pcgpart, nc * 3));
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));
     TRY(dev_alloc(c, &d.st, (size_t)1));
 #undef TRY

@@ -212,5 +212,7 @@ CONFIGS = {
     "X": dict(n_cams=5000, n_points=1_000_000, k_obs=4, seed=6),
     # ragged tracks (windows of 8 frames, 35 % missed detections): ~15 000 distinct camera tuples, few regular tiles
     "R": dict(n_cams=1000, n_points=400_000, k_obs=8, seed=7, dropout=0.35),
+    # the same beyond the dense limit (18 000 camera unknowns, unordered): implicit-Schur PCG path
+    "V": dict(n_cams=3000, n_points=300_000, k_obs=5, seed=8, mode="unordered"),
     "U": dict(n_cams=500, n_points=100_000, k_obs=5, seed=5, mode="unordered"),
 }
