@@ -43,10 +43,10 @@ def _worker(rank, world, port, arr, solver, opt_kw, out_prefix):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", [1, 0], ids=["cholesky", "pcg"])
-@pytest.mark.parametrize("mode,world", [("sequential", 2), ("unordered", 2), ("sequential", 3)])
+@pytest.mark.parametrize("mode,world", [("sequential", 2), ("unordered", 2), ("sequential", 3), ("ragged", 2)])
 def test_ranks_equal_one_rank(lib, tmp_path, solver, mode, world):
     from xrsfm_amd import capi
-    arr = H.make(24, 1500, 4, seed=140, mode=mode)
+    arr = H.make(24, 1500, 8, seed=140, dropout=0.35) if mode == "ragged" else H.make(24, 1500, 4, seed=140, mode=mode)
     opt_kw = dict(max_iterations=8)
     ref = H.to_product(arr)
     s1 = capi.solve(ref, capi.default_options(linear_solver=solver, **opt_kw))
@@ -63,5 +63,8 @@ def test_ranks_equal_one_rank(lib, tmp_path, solver, mode, world):
     for r in range(1, world):
         assert np.array_equal(z[0]["q"], z[r]["q"]) and np.array_equal(z[0]["t"], z[r]["t"])
     n_p = arr["points"].shape[0]
+    # (ragged tracks leave points seen by two neighbouring frames only: their depth amplifies the 1e-9 differences of the
+    # cameras by five orders of magnitude, at no difference in cost)
+    ptol = 1e-2 if mode == "ragged" else 1e-5
     for r in range(world):
-        assert np.abs(z[r]["P"] - ref.points[np.arange(n_p) % world == r]).max() < 1e-5
+        assert np.abs(z[r]["P"] - ref.points[np.arange(n_p) % world == r]).max() < ptol
