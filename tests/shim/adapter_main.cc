@@ -1,6 +1,7 @@
 // Test driver for the adapter: builds a xrsfm::Map (shim types) from a flat problem dump, calls BASolver, dumps the Map.
-// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba|refine|posegraph> [frame_id | loop.bin]
+// usage: adapter_main <in.bin> <out.bin> <mode: gba|gba_fast|structure|kgba|lba|refine|posegraph|keyframes|refframe> [frame_id | loop.bin]
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -41,6 +42,7 @@ int main(int argc, char **argv) {
     map.init_id1 = 0; map.init_id2 = 1;
     xrsfm::BASolver solver;
     int refine_status = 0;
+    bool extra = false;
     const std::string mode = argv[3];
     if (mode == "gba") solver.GBA(map);
     else if (mode == "gba_fast") solver.GBA(map, false);
@@ -92,12 +94,45 @@ int main(int argc, char **argv) {
         }
         solver.ScalePoseGraphUnorder(li, map, use_key);
     }
+    else if (mode == "keyframes" || mode == "refframe") {
+        // KeyFrameSelection / UpdateByRefFrame (the adapter's optional map_ops.cc in the _mapops binary): every frame starts as a
+        // key frame, covisibility = frames sharing a track, frame argv[4] is forced (loop-matched)
+        for (auto &tr : map.tracks_)
+            for (auto &o1 : tr.observations_)
+                for (auto &o2 : tr.observations_)
+                    if (o1.first != o2.first) {
+                        auto &v = map.frameid2covisible_frameids_[o1.first];
+                        if (std::find(v.begin(), v.end(), o2.first) == v.end()) v.push_back(o2.first);
+                    }
+        for (auto &fr : map.frames_) fr.is_keyframe = true;
+        xrsfm::KeyFrameSelection(map, {argc > 4 ? atoi(argv[4]) : 0}, true);
+        if (mode == "refframe") {
+            // move every key frame by one rigid motion of the world (Tcw' = Tcw * G): the others must follow exactly
+            const double g_q[4] = {0.0, std::sin(0.05), 0.0, std::cos(0.05)}, g_t[3] = {0.3, -0.1, 0.2};
+            for (auto &fr : map.frames_) {
+                if (!fr.is_keyframe) continue;
+                double *q = fr.Tcw.q.coeffs().data(), *t = fr.Tcw.t.data();
+                const double ax = q[0], ay = q[1], az = q[2], aw = q[3];
+                // t' = R(q) g_t + t ; q' = q * g_q
+                const double ux = 2 * (ay * g_t[2] - az * g_t[1]), uy = 2 * (az * g_t[0] - ax * g_t[2]), uz = 2 * (ax * g_t[1] - ay * g_t[0]);
+                t[0] += g_t[0] + aw * ux + (ay * uz - az * uy); t[1] += g_t[1] + aw * uy + (az * ux - ax * uz); t[2] += g_t[2] + aw * uz + (ax * uy - ay * ux);
+                q[0] = aw * g_q[0] + ax * g_q[3] + ay * g_q[2] - az * g_q[1]; q[1] = aw * g_q[1] - ax * g_q[2] + ay * g_q[3] + az * g_q[0];
+                q[2] = aw * g_q[2] + ax * g_q[1] - ay * g_q[0] + az * g_q[3]; q[3] = aw * g_q[3] - ax * g_q[0] - ay * g_q[1] - az * g_q[2];
+            }
+            xrsfm::UpdateByRefFrame(map);
+        }
+        extra = true;
+    }
     else return 2;
     FILE *o = fopen(argv[2], "wb");
     int32_t st = mode == "refine" ? refine_status : solver.last_status();
     fwrite(&st, 4, 1, o);
     for (auto &fr : map.frames_) { fwrite(fr.Tcw.q.coeffs().data(), 8, 4, o); fwrite(fr.Tcw.t.data(), 8, 3, o); }
     for (auto &tr : map.tracks_) fwrite(tr.point3d_.data(), 8, 3, o);
+    if (extra) {
+        for (auto &fr : map.frames_) { int32_t v[2] = {fr.is_keyframe ? 1 : 0, fr.ref_id}; fwrite(v, 4, 2, o); }
+        for (auto &tr : map.tracks_) { int32_t v = tr.is_keypoint ? 1 : 0; fwrite(&v, 4, 1, o); }
+    }
     fclose(o);
     return 0;
 }

@@ -61,6 +61,7 @@ class Track {
     bool outlier = false;
     int ref_id = -1;
     double depth = -1;
+    bool is_keypoint = false;
 };
 
 class Frame {

@@ -2,6 +2,7 @@
 #include <cmath>
 #include "base/map.h"
 #include "geometry/colmap/base/triangulation.h"
+#ifndef SHIM_REAL_MAP_OPS      // (the second harness binary links compat/base/map_ops.cc instead of these stand-ins)
 namespace xrsfm {
 void KeyFrameSelection(Map &map, std::vector<int> forced, const bool) {
     for (auto &f : map.frames_) {
@@ -12,6 +13,7 @@ void KeyFrameSelection(Map &map, std::vector<int> forced, const bool) {
 }
 void UpdateByRefFrame(Map &) {}
 } // namespace xrsfm
+#endif
 namespace colmap {
 std::vector<double> CalculateTriangulationAngles(const xrsfm::vector3 &c1, const xrsfm::vector3 &c2,
                                                  const std::vector<xrsfm::vector3> &pts) {

@@ -259,3 +259,101 @@ def test_adapter_pose_graph_keyframe_mode(exe, tmp_path):
     assert status == 0, err
     assert "loop_cor: 1 num_edge: 2" in out
     assert np.abs(q - arr["cam_q"]).max() < 1e-9 and np.abs(t - arr["cam_t"]).max() < 1e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# KeyFrameSelection / UpdateByRefFrame of the adapter's optional compat/base/map_ops.cc (host code: no GPU)
+EXE_MAPOPS = os.path.join(SHIM, "_build", "adapter_main_mapops")
+
+
+def _key_frame_selection_python(arr, forced, sequential=True):
+    """Independent restatement of src/base/map.cc:428-607 on the flat arrays (every frame registered and initially key)."""
+    nc, npts = arr["cam_q"].shape[0], arr["points"].shape[0]
+    obs_of = [[] for _ in range(npts)]
+    tracks_of = [[] for _ in range(nc)]
+    for c, j in zip(arr["obs_cam"], arr["obs_pt"]):
+        obs_of[int(j)].append(int(c)); tracks_of[int(c)].append(int(j))
+    cov = [sorted({c2 for j in tracks_of[c] for c2 in obs_of[j] if c2 != c}) for c in range(nc)]
+    key = [True] * nc
+    for f in range(nc):
+        if f in (0, 1):
+            continue
+        n3d = len(tracks_of[f])
+        red = sum(1 for j in tracks_of[f] if sum(1 for c2 in obs_of[j] if c2 != f and key[c2]) >= 3)
+        if red < 200 or red < 0.6 * n3d or not cov[f]:
+            continue
+        if sequential:
+            kn = [c for c in cov[f] if key[c]]
+            min_connect = None
+            for a, b in zip(kn[:-1], kn[1:]):
+                if a < f < b:
+                    shared = sum(1 for j in tracks_of[a] if b in obs_of[j])
+                    min_connect = shared if min_connect is None else min(min_connect, shared)
+            if min_connect is not None and min_connect < 200:
+                continue
+        key[f] = False
+    ref = [-1] * nc
+    for f in forced:
+        key[f] = True
+    for f in range(nc):
+        if key[f]:
+            continue
+        shared = {}
+        for j in tracks_of[f]:
+            for c2 in obs_of[j]:
+                if c2 != f and key[c2]:
+                    shared[c2] = shared.get(c2, 0) + 1
+        if shared:
+            best = max(shared.values())
+            ref[f] = min(c for c, n in shared.items() if n == best)
+        else:
+            for i in range(1, nc):
+                if f + i < nc and key[f + i]:
+                    ref[f] = f + i; break
+                if f - i > 0 and key[f - i]:
+                    ref[f] = f - i; break
+    keypoint = [sum(1 for c in obs_of[j] if key[c]) >= 2 for j in range(npts)]
+    return np.array(key), np.array(ref), np.array(keypoint)
+
+
+def _run_mapops(arr, tmp_path, mode, forced):
+    subprocess.run(["make", "-C", SHIM], check=True, capture_output=True)
+    inp, out = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _dump(arr, inp)
+    p = subprocess.run([EXE_MAPOPS, inp, out, mode, str(forced)], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    raw = open(out, "rb").read()
+    nc, npt = arr["cam_q"].shape[0], arr["points"].shape[0]
+    cams = np.frombuffer(raw, dtype="f8", count=7 * nc, offset=4).reshape(nc, 7)
+    off = 4 + 56 * nc + 24 * npt
+    kr = np.frombuffer(raw, dtype="i4", count=2 * nc, offset=off).reshape(nc, 2)
+    kp = np.frombuffer(raw, dtype="i4", count=npt, offset=off + 8 * nc)
+    return cams[:, :4].copy(), cams[:, 4:].copy(), kr[:, 0].astype(bool), kr[:, 1].copy(), kp.astype(bool), p.stdout
+
+
+def test_key_frame_selection_matches_restatement(lib, tmp_path):
+    arr = H.make(16, 6000, 6, seed=160)          # ~2000 tracks per frame, six frames each: plenty of redundancy
+    q, t, key, ref, kp, out = _run_mapops(arr, tmp_path, "keyframes", 7)
+    key2, ref2, kp2 = _key_frame_selection_python(arr, [7])
+    assert np.array_equal(key, key2) and np.array_equal(ref[~key], ref2[~key2]) and np.array_equal(kp, kp2)
+    assert key[0] and key[1] and key[7] and (~key).sum() >= 3          # the initial pair and the loop frame stay, some frames go
+    assert "!!! init remove:" in out and "|7" in out
+    assert all(key[r] for r in ref[~key])                              # references are key frames
+
+
+def test_update_by_ref_frame_keeps_relative_poses(lib, tmp_path):
+    """All key frames are moved by one rigid motion; UpdateByRefFrame must carry every other frame along: the pose of a frame
+    relative to its reference key frame is unchanged (map.cc:642-663)."""
+    arr = H.make(16, 6000, 6, seed=160)
+    q, t, key, ref, kp, out = _run_mapops(arr, tmp_path, "refframe", 7)
+    assert (~key).sum() >= 3
+    for f in np.nonzero(~key)[0]:
+        r = ref[f]
+        def rel(qf, tf, qr, tr):          # T_f * T_r^-1
+            qi, ti = _pose_inv(qr, tr)
+            return _qmul(qf, qi), _quat_rot(qf, ti) + tf
+        q0, t0 = rel(arr["cam_q"][f], arr["cam_t"][f], arr["cam_q"][r], arr["cam_t"][r])
+        q1, t1 = rel(q[f], t[f], q[r], t[r])
+        assert np.abs(q0 - q1).max() < 1e-12 and np.abs(t0 - t1).max() < 1e-10
+    # the key frames themselves carry the motion that was applied (they moved), the others followed (they moved too)
+    assert np.abs(t - arr["cam_t"]).min(axis=1).max() > 0 and np.abs(t[~key] - arr["cam_t"][~key]).max() > 1e-3

@@ -8,7 +8,8 @@
 //                                LBA gauge fallbacks (:551-584)
 //   solver options               :70-77 with :586-589 (LBA), :626-634 (GBA), :667-670 (KGBA)
 //   printed summary              PrintSolverSummary :14-68, "LBA:" line :537-549, "kf: a/b" :676
-//   KGBA pre/post                KeyFrameSelection / UpdateByRefFrame stay in the reference (src/base/map.cc:428-663)
+//   KGBA pre/post                KeyFrameSelection / UpdateByRefFrame stay in the reference (src/base/map.cc:428-663); builds
+//                                without src/base link the restatement in ../base/map_ops.cc instead
 //   pose graph                   ScalePoseGraphUnorder :147-328 with AddCovisibilityEdge :79-115, AddLoopEdge :117-145
 #include "ba_solver.h"
 
