@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <numeric>
+#include <thread>
 #include <vector>
 
 #include "../../include/xrsfm_ba.h"
@@ -27,6 +28,18 @@ inline int gram_lds_need(int C, int T, int* passes) {
     const int Th = (T + 1) / 2;
     *passes = 2;
     return 6 * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + C * C * 4;
+}
+
+// Host-side helper: run fn(begin, end) over [0, n) on up to 8 threads (large problems only; the packing of config L is ~100 ms
+// of single-thread work otherwise).  The pieces are disjoint, so the result does not depend on the thread count.
+template <typename F>
+inline void pack_parallel_for(long long n, F&& fn, long long min_n = 200000) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(8u, hw);
+    if (nt == 1) { fn(0LL, n); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    for (auto& x : th) x.join();
 }
 
 struct Packed {
@@ -81,8 +94,10 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     std::vector<int> fill(ptr.begin(), ptr.end() - 1), csr(No);
     for (int i = 0; i < No; ++i) csr[fill[p.obs_pt[i]]++] = i;
     // observations of every track ordered by camera
-    for (int j = 0; j < Np; ++j)
-        std::stable_sort(csr.begin() + ptr[j], csr.begin() + ptr[j + 1], [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+    pack_parallel_for(Np, [&](long long j0, long long j1) {
+        for (long long j = j0; j < j1; ++j)
+            std::stable_sort(csr.begin() + ptr[j], csr.begin() + ptr[j + 1], [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+    });
     // active points: short tracks sorted by their camera tuple (tracks seeing the same cameras become neighbours:
     // locality of the camera gathers, and whole tiles that share one tuple can be pre-reduced in the wave),
     // long tracks (> 64 obs) at the end
@@ -108,16 +123,18 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         std::vector<KI> ki(order.size());
         const int kbits = (Nc + 1 < (1 << 15)) ? 15 : 20, kcams = (kbits == 15) ? 4 : 3;
         const bool wide = Nc + 1 >= (1 << 20);         // camera ids do not fit the key: plain comparator sort
-        for (size_t n = 0; n < order.size(); ++n) {
-            const int j = order[n];
-            const int len = cnt[j + 1];
-            unsigned long long key = (len > 64) ? (1ull << 63) : 0ull;
-            for (int q = 0; q < kcams; ++q) {
-                const unsigned long long c = (q < len) ? (unsigned long long)p.obs_cam[csr[ptr[j] + q]] + 1ull : 0ull;
-                key |= c << (kbits * (kcams - 1 - q));
+        pack_parallel_for((long long)order.size(), [&](long long n0, long long n1) {
+            for (long long n = n0; n < n1; ++n) {
+                const int j = order[n];
+                const int len = cnt[j + 1];
+                unsigned long long key = (len > 64) ? (1ull << 63) : 0ull;
+                for (int q = 0; q < kcams; ++q) {
+                    const unsigned long long c = (q < len) ? (unsigned long long)p.obs_cam[csr[ptr[j] + q]] + 1ull : 0ull;
+                    key |= c << (kbits * (kcams - 1 - q));
+                }
+                ki[n] = {key, j};
             }
-            ki[n] = {key, j};
-        }
+        });
         auto full_less = [&](int a, int b) {
             const bool la = cnt[a + 1] > 64, lb = cnt[b + 1] > 64;
             if (la != lb) return lb;
@@ -126,7 +143,23 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         if (wide) {
             std::stable_sort(order.begin(), order.end(), full_less);
         } else {
-            std::sort(ki.begin(), ki.end(), [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; });
+            const auto ki_less = [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; };
+            if (ki.size() < 400000) {
+                std::sort(ki.begin(), ki.end(), ki_less);
+            } else {                                    // 8 sorted runs in parallel, then three rounds of pairwise merges (a total order: unique result)
+                const size_t nk = ki.size();
+                size_t cut[9];
+                for (int q = 0; q <= 8; ++q) cut[q] = nk * q / 8;
+                pack_parallel_for(8 * 200000LL, [&](long long a, long long b) {
+                    for (long long q = a / 200000; q < b / 200000; ++q) std::sort(ki.begin() + cut[q], ki.begin() + cut[q + 1], ki_less);
+                });
+                for (int width = 1; width < 8; width *= 2) {
+                    std::vector<std::thread> th;
+                    for (int q = 0; q + width < 8; q += 2 * width)
+                        th.emplace_back([&, q, width] { std::inplace_merge(ki.begin() + cut[q], ki.begin() + cut[q + width], ki.begin() + cut[std::min(q + 2 * width, 8)], ki_less); });
+                    for (auto& x : th) x.join();
+                }
+            }
             for (size_t n = 0; n < ki.size(); ++n) order[n] = ki[n].idx;
             for (size_t b = 0; b < ki.size();) {       // equal leading cameras: finish with the full comparison (stable)
                 size_t e = b + 1;
@@ -154,12 +187,19 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     // A group of tracks with one camera tuple that fills at least a tile by itself starts on a tile boundary: its tiles are
     // then all regular (one dense Gram product each, small LDS footprint) instead of the first one mixing two tuples.
     std::vector<char> big_group_start(o.n_pts, 0);
-    for (int b = 0; b < o.n_pts;) {
-        int e = b + 1;
-        while (e < o.n_pts && !tuple_less(order[b], order[e]) && !tuple_less(order[e], order[b])) ++e;
-        const int len = cnt[order[b] + 1];
-        if (len <= 64 && (long long)(e - b) * len >= 64) big_group_start[b] = 1;
-        b = e;
+    {
+        // same[n]: track n has the same tuple as track n-1 (sorted order: one direction of the comparison suffices)
+        std::vector<char> same(o.n_pts, 0);
+        pack_parallel_for(o.n_pts, [&](long long n0, long long n1) {
+            for (long long n = std::max<long long>(n0, 1); n < n1; ++n) same[n] = !tuple_less(order[n - 1], order[n]);
+        });
+        for (int b = 0; b < o.n_pts;) {
+            int e = b + 1;
+            while (e < o.n_pts && same[e]) ++e;
+            const int len = cnt[order[b] + 1];
+            if (len <= 64 && (long long)(e - b) * len >= 64) big_group_start[b] = 1;
+            b = e;
+        }
     }
     int cur_tile_start = -1;  // tile index of the open short tile, -1 if none
     for (int pj = 0; pj < o.n_pts; ++pj) {
@@ -186,8 +226,10 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     o.n_slots = (int)o.slot_cam.size();
     o.n_tiles = o.n_slots / 64;
     o.slot_u.assign(o.n_slots, 0.0); o.slot_v.assign(o.n_slots, 0.0);
-    for (int s = 0; s < o.n_slots; ++s)
-        if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
+    pack_parallel_for(o.n_slots, [&](long long s0, long long s1) {
+        for (long long s = s0; s < s1; ++s)
+            if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
+    });
     o.tile_maxlen.assign(o.n_tiles, 1);
     for (int t = 0; t < o.n_tiles; ++t) {
         int run = 0, best = 1;
@@ -226,30 +268,45 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         std::vector<char> single(o.n_tiles, 0);
         for (size_t it = 0; it + 1 < o.items.size(); it += 2)
             if (o.items[it + 1] == 1) single[o.items[it]] = 1;
-        int cams[64];
-        for (int t = 0; t < o.n_tiles; ++t) {
-            if (!single[t]) continue;
-            const int b0 = 64 * t;
-            int nc = 0, ntrk = 0;
-            for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q) {
-                cams[nc++] = o.slot_cam[b0 + q];
-                ntrk += (q == 0 || o.slot_pt[b0 + q] != o.slot_pt[b0 + q - 1]);
+        std::vector<int> tile_cams((size_t)o.n_tiles * kGramMaxCams, -1);       // ascending distinct cameras of the Gram tiles
+        pack_parallel_for(o.n_tiles, [&](long long t0, long long t1) {
+            int cams[64];
+            for (long long t = t0; t < t1; ++t) {
+                if (!single[t]) continue;
+                const long long b0 = 64 * t;
+                int nc = 0, ntrk = 0;
+                for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q) {
+                    cams[nc++] = o.slot_cam[b0 + q];
+                    ntrk += (q == 0 || o.slot_pt[b0 + q] != o.slot_pt[b0 + q - 1]);
+                }
+                if (nc == 0) continue;
+                std::sort(cams, cams + nc);
+                const int C = (int)(std::unique(cams, cams + nc) - cams);
+                int passes = 1;
+                if (C < 2 || C > kGramMaxCams || gram_lds_need(C, ntrk, &passes) > kGramMaxLds) continue;
+                o.tile_ncam[t] = C;
+                for (int q = 0; q < C; ++q) tile_cams[(size_t)t * kGramMaxCams + q] = cams[q];
+                for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)
+                    o.slot_cidx[b0 + q] = (unsigned char)(std::lower_bound(cams, cams + C, o.slot_cam[b0 + q]) - cams);
             }
-            if (nc == 0) continue;
-            std::sort(cams, cams + nc);
-            const int C = (int)(std::unique(cams, cams + nc) - cams);
-            int passes = 1;
-            if (C < 2 || C > kGramMaxCams || gram_lds_need(C, ntrk, &passes) > kGramMaxLds) continue;
-            o.tile_ncam[t] = C;
-            o.tile_gt_off[t] = (int)o.gt_cell.size();
-            o.gt_cell.resize(o.gt_cell.size() + (size_t)C * C, 0);
-            unsigned char* cell = o.gt_cell.data() + o.tile_gt_off[t];
-            for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)
-                o.slot_cidx[b0 + q] = (unsigned char)(std::lower_bound(cams, cams + C, o.slot_cam[b0 + q]) - cams);
-            for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)         // pairs inside a track (cameras ascend in a track)
-                for (int q2 = q + 1; q2 < 64 && o.slot_cam[b0 + q2] >= 0 && o.slot_pt[b0 + q2] == o.slot_pt[b0 + q]; ++q2)
-                    cell[o.slot_cidx[b0 + q] * C + o.slot_cidx[b0 + q2]] = 1;
+        }, 4000);
+        {
+            size_t off = 0;
+            for (int t = 0; t < o.n_tiles; ++t)
+                if (o.tile_ncam[t] > 0) { o.tile_gt_off[t] = (int)off; off += (size_t)o.tile_ncam[t] * o.tile_ncam[t]; }
+            o.gt_cell.assign(off, 0);
         }
+        pack_parallel_for(o.n_tiles, [&](long long t0, long long t1) {
+            for (long long t = t0; t < t1; ++t) {
+                const int C = o.tile_ncam[t];
+                if (C <= 0) continue;
+                const long long b0 = 64 * t;
+                unsigned char* cell = o.gt_cell.data() + o.tile_gt_off[t];
+                for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)         // pairs inside a track (cameras ascend in a track)
+                    for (int q2 = q + 1; q2 < 64 && o.slot_cam[b0 + q2] >= 0 && o.slot_pt[b0 + q2] == o.slot_pt[b0 + q]; ++q2)
+                        cell[o.slot_cidx[b0 + q] * C + o.slot_cidx[b0 + q2]] = 1;
+            }
+        }, 4000);
         // The S-assembly kernel runs once per LDS class (<= 10 KB: 16 workgroups per CU; larger).  A handful of large tiles
         // is not worth a second launch (its duration is one tile's latency, ~15 us): they take the per-pair path instead.
         auto lds_need = [&](int t) {
