@@ -7,6 +7,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include "geometry/track_filter.h"
 #include "optimization/ba_solver.h"
 
 template <typename T> static std::vector<T> rd(FILE *f, size_t n) { std::vector<T> v(n); if (n && fread(v.data(), sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); } return v; }
@@ -42,7 +43,8 @@ int main(int argc, char **argv) {
     map.init_id1 = 0; map.init_id2 = 1;
     xrsfm::BASolver solver;
     int refine_status = 0;
-    bool extra = false;
+    bool extra = false, filter_dump = false;
+    int filter_ret = 0;
     const std::string mode = argv[3];
     if (mode == "gba") solver.GBA(map);
     else if (mode == "gba_fast") solver.GBA(map, false);
@@ -123,12 +125,30 @@ int main(int argc, char **argv) {
         }
         extra = true;
     }
+    else if (mode == "filter") {
+        // FilterPoints3dGPU(map, max_re = argv[4], deg = argv[5]); appended to the dump: per track {outlier, #observations, error, angle},
+        // per frame the number of DeleteNumCorHavePoint3D calls and of features still attached to a track
+        const int one_frame = argc > 6 ? atoi(argv[6]) : -1;
+        filter_ret = one_frame < 0 ? xrsfm::FilterPoints3dGPU(map, atof(argv[4]), atof(argv[5]))
+                                   : xrsfm::FilterPointsFrameGPU(map, one_frame, atof(argv[4]), atof(argv[5]));
+        filter_dump = true;
+    }
     else return 2;
     FILE *o = fopen(argv[2], "wb");
-    int32_t st = mode == "refine" ? refine_status : solver.last_status();
+    int32_t st = mode == "refine" ? refine_status : (mode == "filter" ? filter_ret : solver.last_status());
     fwrite(&st, 4, 1, o);
     for (auto &fr : map.frames_) { fwrite(fr.Tcw.q.coeffs().data(), 8, 4, o); fwrite(fr.Tcw.t.data(), 8, 3, o); }
     for (auto &tr : map.tracks_) fwrite(tr.point3d_.data(), 8, 3, o);
+    if (filter_dump) {
+        for (auto &tr : map.tracks_) { double v[4] = {tr.outlier ? 1.0 : 0.0, (double)tr.observations_.size(), tr.error, tr.angle_}; fwrite(v, 8, 4, o); }
+        map.shim_deleted_corr_.resize(map.frames_.size(), 0);
+        for (size_t i = 0; i < map.frames_.size(); ++i) {
+            int32_t attached = 0;
+            for (int id : map.frames_[i].track_ids_) attached += id != -1;
+            int32_t v[2] = {map.shim_deleted_corr_[i], attached};
+            fwrite(v, 4, 2, o);
+        }
+    }
     if (extra) {
         for (auto &fr : map.frames_) { int32_t v[2] = {fr.is_keyframe ? 1 : 0, fr.ref_id}; fwrite(v, 4, 2, o); }
         for (auto &tr : map.tracks_) { int32_t v = tr.is_keypoint ? 1 : 0; fwrite(&v, 4, 1, o); }

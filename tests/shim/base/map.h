@@ -62,6 +62,7 @@ class Track {
     int ref_id = -1;
     double depth = -1;
     bool is_keypoint = false;
+    double error = 0;
 };
 
 class Frame {
@@ -94,6 +95,12 @@ class Map {
     inline const class Camera &Camera(int camera_id) const { return camera_map_.at(camera_id); }
     inline class Camera &Camera(int camera_id) { return camera_map_.at(camera_id); }
     std::unordered_map<int, std::vector<int>> frameid2covisible_frameids_;
+    // shim: the reference walks the correspondence graph here; the harness only counts the calls per frame
+    std::vector<int> shim_deleted_corr_;
+    inline void DeleteNumCorHavePoint3D(int frame_id, int /*p2d_id*/) {
+        if (shim_deleted_corr_.size() < frames_.size()) shim_deleted_corr_.resize(frames_.size(), 0);
+        shim_deleted_corr_[frame_id]++;
+    }
     // shim: undistorted pinhole normalisation with the camera's first parameters (f, cx, cy); the reference inverts the
     // full distortion model (camera_model.hpp ImageToNormalized)
     inline vector2 GetNormalizedPoint(const int frame_id, const int p2d_id) {

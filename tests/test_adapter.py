@@ -133,6 +133,63 @@ def test_adapter_refine_pose_equals_c_abi(exe, tmp_path):
     assert abs(float(m.group(2)) - np.sqrt(s.final_cost / s.num_residuals)) < 1e-4 * max(1.0, float(m.group(2)))
 
 
+def _filter_expected(arr, track_ids, max_re, deg):
+    """Map state the reference's FilterPoint3d loop leaves behind, from the oracle's masks."""
+    import math
+    from oracle import ba_oracle as bo
+    sel = np.isin(arr["obs_pt"], track_ids)
+    remap = -np.ones(arr["points"].shape[0], np.int64); remap[track_ids] = np.arange(len(track_ids))
+    sub = dict(arr, points=arr["points"][track_ids], obs_cam=arr["obs_cam"][sel], obs_pt=remap[arr["obs_pt"][sel]].astype(np.int32),
+               obs_uv=arr["obs_uv"][sel])
+    ref = bo.filter_tracks(H.to_oracle(sub), max_re, math.radians(deg))
+    n_tr, n_fr = arr["points"].shape[0], arr["cam_q"].shape[0]
+    outlier = np.zeros(n_tr); n_obs = np.bincount(arr["obs_pt"], minlength=n_tr).astype(float)
+    error = np.zeros(n_tr); angle = np.full(n_tr, np.nan)
+    unlinked = np.zeros(n_fr, np.int64)
+    oc, op = sub["obs_cam"], sub["obs_pt"]
+    for k, j in enumerate(track_ids):
+        mine = op == k
+        if ref["track_outlier"][k] == 1:
+            outlier[j] = 1; np.add.at(unlinked, oc[mine], 1); continue
+        gone = mine & (ref["obs_delete"] == 1)
+        n_obs[j] -= gone.sum(); np.add.at(unlinked, oc[gone], 1)
+        error[j] = ref["track_error"][k]; angle[j] = ref["track_angle"][k]
+        if ref["track_outlier"][k] == 2:
+            outlier[j] = 1; np.add.at(unlinked, oc[mine & ~gone], 1)
+    attached = np.bincount(arr["obs_cam"], minlength=n_fr) - unlinked
+    return ref, outlier, n_obs, error, angle, unlinked, attached
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("one_frame", [-1, 5])
+def test_adapter_track_filter_leaves_reference_map_state(exe, tmp_path, one_frame):
+    """FilterPoints3dGPU / FilterPointsFrameGPU (compat/geometry/track_filter.h; replace the bodies of track_processor.cc:321-349):
+    outlier flags, surviving observations, Track::error / angle_, detached features, correspondence updates and the printed
+    counters equal what FilterPoint3d (:280-319) does, per the oracle restatement."""
+    arr = H.make(12, 900, 4, seed=150, outlier_frac=0.08, min_tri_angle_deg=0.2)
+    arr = H.with_models(arr, seed=8)
+    arr["points"][::50] += np.array([0.0, 0.0, -70.0])
+    arr["points"][7::60] *= 40.0
+    max_re, deg = 4.0, 1.5
+    n_tr, n_fr = arr["points"].shape[0], arr["cam_q"].shape[0]
+    track_ids = np.arange(n_tr) if one_frame < 0 else np.unique(arr["obs_pt"][arr["obs_cam"] == one_frame])
+    ref, outlier, n_obs, error, angle, unlinked, attached = _filter_expected(arr, track_ids, max_re, deg)
+    status, q, t, P, out, err = _run(exe, arr, tmp_path, "filter", max_re, deg, one_frame)
+    assert status == int(ref["num_filtered"].sum()) and status > 50, err
+    assert f"Outlier num1: {ref['num_filtered'][0]} Outlier num2: {ref['num_filtered'][1]}" in out
+    assert np.array_equal(q, arr["cam_q"]) and np.array_equal(P, arr["points"])
+    raw = open(tmp_path / "out.bin", "rb").read()
+    off = 4 + 56 * n_fr + 24 * n_tr
+    tr = np.frombuffer(raw, dtype="f8", count=4 * n_tr, offset=off).reshape(n_tr, 4)
+    fr = np.frombuffer(raw, dtype="i4", count=2 * n_fr, offset=off + 32 * n_tr).reshape(n_fr, 2)
+    assert np.array_equal(tr[:, 0], outlier) and {0.0, 1.0} == set(np.unique(outlier))
+    assert np.array_equal(tr[:, 1], n_obs)
+    touched = np.isin(np.arange(n_tr), track_ids) & ~np.isnan(angle)
+    assert np.abs(tr[touched, 2] - error[touched]).max() < 1e-9 and np.abs(tr[touched, 3] - angle[touched]).max() < 1e-12
+    assert np.array_equal(tr[~touched, 2], np.zeros(int((~touched).sum()))) and np.all(tr[~touched, 3] == -1.0)   # defaults kept
+    assert np.array_equal(fr[:, 0], unlinked) and np.array_equal(fr[:, 1], attached)
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # ScalePoseGraphUnorder (host code: these run without a GPU)
 def _quat_rot(q, v):
