@@ -210,6 +210,38 @@ typedef struct xrsfm_pg_summary {
 void xrsfm_pg_default_options(xrsfm_pg_options *opt);
 int xrsfm_pg_solve(const xrsfm_pg_options *opt, xrsfm_pg_problem *problem, xrsfm_pg_summary *summary);
 
+/* ---- Metric-scale refinement against AprilTag corners: the two ceres::Solve calls of tag_refine
+ * (/root/reference/src/tag/tag_extract.hpp:193-265).  HOST code like the pose graph.  Detection
+ * (apriltag/OpenCV) and the RANSAC triangulation of the corners (CreatePoint3dRAW, tag_extract.hpp:176-192) stay with the
+ * caller; this entry point takes the normalised observations and the triangulated corners.
+ *   stage 1 (tag_extract.hpp:197-234): per tag 4 x TagCost(get_tag(tag_length)[i], 1.0) on (tag_q, tag_t, scale) with the
+ *            corners constant, QuatParam on tag_q, scale >= scale_lower; max_num_iterations 500, other options default
+ *   stage 2 (tag_extract.hpp:236-265): the corners become variable and carry one ProjectionCost per observing frame; every
+ *            track point carries one ProjectionCost per observation; all frame poses stay constant
+ * The caller then divides frame translations and points by the returned scale (tag_extract.hpp:267-275). */
+typedef struct xrsfm_tag_problem {
+    int32_t n_frames;
+    const double *frame_q;      /* [n_frames][4] x,y,z,w  Tcw, constant */
+    const double *frame_t;      /* [n_frames][3] */
+    int32_t n_tags;
+    double tag_length;
+    double *tag_corners;        /* [n_tags][4][3] in: triangulated world corners (pt_world_vec); out (stage 2): refined */
+    double *tag_q, *tag_t;      /* [n_tags][4], [n_tags][3]  T_w_tag in/out (the reference starts at identity / zero) */
+    double scale;               /* in/out (the reference starts at 1.0) */
+    double scale_lower;         /* 0.2 (tag_extract.hpp:227) */
+    int32_t n_tag_obs;          /* (tag, frame) pairs */
+    const int32_t *tag_obs_tag, *tag_obs_frame;
+    const double *tag_obs_xy;   /* [n_tag_obs][4][2] normalised image coordinates of the four corners */
+    int32_t n_points, n_obs;    /* tracks of the map (used by stage 2 only; n_obs may be 0) */
+    double *points;             /* [n_points][3] in/out */
+    const int32_t *obs_frame, *obs_pt;
+    const double *obs_xy;       /* [n_obs][2] normalised image coordinates (Frame::points_normalized) */
+} xrsfm_tag_problem;
+
+void xrsfm_tag_default_options(xrsfm_pg_options *opt);   /* 500 iterations, radius 1e4, tolerances 1e-6 / 1e-8 / 1e-10 */
+/* stages = 1: only the first solve; 2: both, like the reference.  summaries[stages]. termination codes as xrsfm_pg_summary. */
+int xrsfm_tag_refine(const xrsfm_pg_options *opt, xrsfm_tag_problem *problem, int32_t stages, xrsfm_pg_summary *summaries);
+
 /* Post-BA track filter on the same flat arrays (Point3dProcessor::FilterPoints3d,
  * /root/reference/src/geometry/track_processor.cc:280-332, called after every KGBA at incremental_mapper.cc:83-85).
  * The problem here is the whole map: every registered frame and every observation of every non-outlier track.

@@ -72,6 +72,7 @@ class Frame {
     bool registered = false;
     bool is_keyframe = false;
     std::vector<vector2> points;
+    std::vector<vector2> points_normalized;
     std::vector<int> track_ids_;
     Pose Tcw, tcw_old;
     int ref_id = -1;
@@ -90,6 +91,8 @@ class Map {
     std::vector<Track> tracks_;
     std::vector<Frame> frames_;
     std::map<int, class Camera> camera_map_;
+    std::map<int, Frame> frame_map_;
+    std::map<int, Track> track_map_;
     int init_id1 = -1;
     int init_id2 = -1;
     inline const class Camera &Camera(int camera_id) const { return camera_map_.at(camera_id); }

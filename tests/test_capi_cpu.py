@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_header_symbols_are_exported(lib):
     from xrsfm_amd import capi
     hdr = open(os.path.join(ROOT, "include", "xrsfm_ba.h")).read()
-    declared = set(re.findall(r"\b(xrsfm_(?:ba|pg)_[a-z_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(xrsfm_(?:ba|pg|tag)_[a-z_]+)\s*\(", hdr))
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
@@ -24,13 +24,13 @@ def test_struct_layouts_match_header(lib):
     """ctypes mirrors vs the C structs: sizes via a compile probe with gcc."""
     import ctypes, subprocess, tempfile
     from xrsfm_amd import capi
-    src = '#include <stdio.h>\n#include "xrsfm_ba.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(xrsfm_ba_problem), sizeof(xrsfm_ba_options), sizeof(xrsfm_ba_summary), sizeof(xrsfm_pg_problem), sizeof(xrsfm_pg_options), sizeof(xrsfm_pg_summary));return 0;}\n'
+    src = '#include <stdio.h>\n#include "xrsfm_ba.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(xrsfm_ba_problem), sizeof(xrsfm_ba_options), sizeof(xrsfm_ba_summary), sizeof(xrsfm_pg_problem), sizeof(xrsfm_pg_options), sizeof(xrsfm_pg_summary), sizeof(xrsfm_tag_problem));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         open(os.path.join(d, "p.c"), "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(d, "p.c"), "-o", os.path.join(d, "p")], check=True)
         out = subprocess.run([os.path.join(d, "p")], capture_output=True, text=True, check=True).stdout.split()
     assert [int(x) for x in out] == [ctypes.sizeof(c) for c in (capi.CProblem, capi.COptions, capi.CSummary, capi.CPgProblem, capi.CPgOptions,
-                                                               capi.CPgSummary)]
+                                                               capi.CPgSummary, capi.CTagProblem)]
 
 
 def test_default_options_are_the_reference_gba_settings(lib):

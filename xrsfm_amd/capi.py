@@ -45,6 +45,14 @@ class CPgSummary(C.Structure):
                 ("n_unsuccessful", C.c_int32), ("termination", C.c_int32)]
 
 
+class CTagProblem(C.Structure):
+    _fields_ = [("n_frames", C.c_int32), ("frame_q", _c_double_p), ("frame_t", _c_double_p), ("n_tags", C.c_int32),
+                ("tag_length", C.c_double), ("tag_corners", _c_double_p), ("tag_q", _c_double_p), ("tag_t", _c_double_p),
+                ("scale", C.c_double), ("scale_lower", C.c_double), ("n_tag_obs", C.c_int32), ("tag_obs_tag", _c_int32_p),
+                ("tag_obs_frame", _c_int32_p), ("tag_obs_xy", _c_double_p), ("n_points", C.c_int32), ("n_obs", C.c_int32),
+                ("points", _c_double_p), ("obs_frame", _c_int32_p), ("obs_pt", _c_int32_p), ("obs_xy", _c_double_p)]
+
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_uint64, C.c_int)
 
 
@@ -79,6 +87,7 @@ EXPORTS = [
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
+    "xrsfm_tag_default_options", "xrsfm_tag_refine",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -126,6 +135,10 @@ def load(path: str | None = None):
     lib.xrsfm_pg_default_options.restype = None
     lib.xrsfm_pg_solve.argtypes = [C.POINTER(CPgOptions), C.POINTER(CPgProblem), C.POINTER(CPgSummary)]
     lib.xrsfm_pg_solve.restype = C.c_int
+    lib.xrsfm_tag_default_options.argtypes = [C.POINTER(CPgOptions)]
+    lib.xrsfm_tag_default_options.restype = None
+    lib.xrsfm_tag_refine.argtypes = [C.POINTER(CPgOptions), C.POINTER(CTagProblem), C.c_int32, C.POINTER(CPgSummary)]
+    lib.xrsfm_tag_refine.restype = C.c_int
     lib.xrsfm_ba_debug_comm_hook.argtypes = [C.c_void_p, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p]
     lib.xrsfm_ba_debug_comm_hook.restype = C.c_int
     lib.xrsfm_ba_refine_pose_options.argtypes = [C.POINTER(COptions)]
@@ -415,6 +428,45 @@ def pose_graph_solve(rot_q, pos, scale, edges, weight_o=0.0, scale_costs=(), pos
     s = CPgSummary()
     check(load().xrsfm_pg_solve(C.byref(o), C.byref(p), C.byref(s)), "xrsfm_pg_solve")
     return pos, scale, s
+
+
+def tag_refine(frame_q, frame_t, tag_corners, tag_obs_tag, tag_obs_frame, tag_obs_xy, tag_length, points=None, obs_frame=None,
+               obs_pt=None, obs_xy=None, stages=2, tag_q=None, tag_t=None, scale=1.0, scale_lower=0.2, **opt_overrides):
+    """xrsfm_tag_refine (host code): the two solves of tag_refine (tag_extract.hpp:193-265).
+    Returns dict(scale, tag_q, tag_t, tag_corners, points, summaries); inputs are not modified."""
+    keep = []
+
+    def f64(a, copy=False):
+        a = np.array(a, float, copy=True) if copy else np.ascontiguousarray(a, float)
+        keep.append(a); return a
+
+    def i32(a):
+        a = np.ascontiguousarray(a, np.int32); keep.append(a); return a
+
+    frame_q, frame_t = f64(frame_q), f64(frame_t)
+    corners = f64(tag_corners, copy=True).reshape(-1, 4, 3)
+    n_tags = corners.shape[0]
+    tq = f64(np.tile([0.0, 0.0, 0.0, 1.0], (n_tags, 1)) if tag_q is None else tag_q, copy=True)
+    tt = f64(np.zeros((n_tags, 3)) if tag_t is None else tag_t, copy=True)
+    p = CTagProblem()
+    p.n_frames, p.frame_q, p.frame_t = frame_q.shape[0], _dp(frame_q), _dp(frame_t)
+    p.n_tags, p.tag_length, p.tag_corners, p.tag_q, p.tag_t = n_tags, float(tag_length), _dp(corners), _dp(tq), _dp(tt)
+    p.scale, p.scale_lower = float(scale), float(scale_lower)
+    ot, of, oxy = i32(tag_obs_tag), i32(tag_obs_frame), f64(tag_obs_xy)
+    p.n_tag_obs, p.tag_obs_tag, p.tag_obs_frame, p.tag_obs_xy = ot.shape[0], ot.ctypes.data_as(_c_int32_p), of.ctypes.data_as(_c_int32_p), _dp(oxy)
+    pts = None
+    if points is not None:
+        pts = f64(points, copy=True)
+        a, b, c = i32(obs_frame), i32(obs_pt), f64(obs_xy)
+        p.n_points, p.n_obs, p.points = pts.shape[0], a.shape[0], _dp(pts)
+        p.obs_frame, p.obs_pt, p.obs_xy = a.ctypes.data_as(_c_int32_p), b.ctypes.data_as(_c_int32_p), _dp(c)
+    o = CPgOptions()
+    load().xrsfm_tag_default_options(C.byref(o))
+    for k, v in opt_overrides.items():
+        setattr(o, k, v)
+    sums = (CPgSummary * 2)()
+    check(load().xrsfm_tag_refine(C.byref(o), C.byref(p), int(stages), sums), "xrsfm_tag_refine")
+    return dict(scale=p.scale, tag_q=tq, tag_t=tt, tag_corners=corners, points=pts, summaries=[sums[i] for i in range(stages)])
 
 
 def debug_pack_gram(problem: ProblemArrays) -> dict:

@@ -28,6 +28,7 @@
 #include "ba_pack.h"
 #include "ba_plan.h"
 #include "pose_graph.h"
+#include "tag_refine.h"
 
 using namespace xba;
 
@@ -1037,6 +1038,32 @@ int xrsfm_pg_solve(const xrsfm_pg_options* opt, xrsfm_pg_problem* p, xrsfm_pg_su
     if (opt) o = *opt; else xrsfm_pg_default_options(&o);
     xpg::Solver solver(*p);
     return solver.run(o, summary);
+}
+
+// ---------------------------------------------------------------- tag refinement (host code)
+void xrsfm_tag_default_options(xrsfm_pg_options* o) {
+    if (!o) return;
+    o->max_iterations = 500;            // tag_extract.hpp:231
+    o->function_tolerance = 1e-6; o->parameter_tolerance = 1e-8; o->gradient_tolerance = 1e-10;
+    o->initial_radius = 1e4; o->verbose = 0;
+}
+
+int xrsfm_tag_refine(const xrsfm_pg_options* opt, xrsfm_tag_problem* p, int32_t stages, xrsfm_pg_summary* summaries) {
+    if (!p || !summaries || stages < 1 || stages > 2) return XRSFM_BA_EINVAL;
+    if (p->n_frames < 0 || p->n_tags < 0 || p->n_tag_obs < 0 || p->n_points < 0 || p->n_obs < 0) return XRSFM_BA_EINVAL;
+    if (p->n_frames > 0 && (!p->frame_q || !p->frame_t)) return XRSFM_BA_EINVAL;
+    if (p->n_tags > 0 && (!p->tag_corners || !p->tag_q || !p->tag_t)) return XRSFM_BA_EINVAL;
+    if (p->n_tag_obs > 0 && (!p->tag_obs_tag || !p->tag_obs_frame || !p->tag_obs_xy)) return XRSFM_BA_EINVAL;
+    if (p->n_points > 0 && !p->points) return XRSFM_BA_EINVAL;
+    if (p->n_obs > 0 && (!p->obs_frame || !p->obs_pt || !p->obs_xy)) return XRSFM_BA_EINVAL;
+    if (!(p->tag_length > 0.0) || !std::isfinite(p->scale)) return XRSFM_BA_EINVAL;
+    for (int i = 0; i < p->n_tag_obs; ++i)
+        if (p->tag_obs_tag[i] < 0 || p->tag_obs_tag[i] >= p->n_tags || p->tag_obs_frame[i] < 0 || p->tag_obs_frame[i] >= p->n_frames) return XRSFM_BA_EINVAL;
+    for (int i = 0; i < p->n_obs; ++i)
+        if (p->obs_pt[i] < 0 || p->obs_pt[i] >= p->n_points || p->obs_frame[i] < 0 || p->obs_frame[i] >= p->n_frames) return XRSFM_BA_EINVAL;
+    xrsfm_pg_options o;
+    if (opt) o = *opt; else xrsfm_tag_default_options(&o);
+    return xtag::refine(o, *p, stages, summaries);
 }
 
 // ---------------------------------------------------------------- pose-only refinement
