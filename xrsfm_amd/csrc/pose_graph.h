@@ -10,7 +10,7 @@
 //   solver                 ba_solver.cc:258-266: DOGLEG, initial radius 1e16, max 100 iterations, Ceres default tolerances
 // Ceres itself is not available: the trust-region logic below follows the published traditional-dogleg strategy
 // (Gauss-Newton step with a 1e-8 relative regulariser, Cauchy point, radius update 0.5x / max(r, 3|step|)) with Ceres'
-// handling of bounds (projection inside Plus + backtracking along the projected step).  PARITY UNPINNED against real Ceres;
+// handling of bounds (projection inside Plus + the projected Armijo search of line_search.h on every step).  PARITY UNPINNED against real Ceres;
 // tests compare the minimum with an independent bounded least-squares solver (scipy) on the same residuals.
 #pragma once
 #include <algorithm>
@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/xrsfm_ba.h"
+#include "line_search.h"
 
 namespace xpg {
 
@@ -320,33 +321,42 @@ struct Solver {
             for (int i = 0; i < nv; ++i) { dl_norm += dl[i] * dl[i]; step[i] = dl[i] / diag[i]; }
             dl_norm = std::sqrt(dl_norm);
             sum->iterations = it + 1;
-            // bounds: backtrack along the projected step until the cost does not increase (Ceres: projected Armijo search)
-            double t = 1.0;
-            double cost_c = 0.0;
-            for (int ls = 0; ls < (constrained ? 20 : 1); ++ls) {
-                std::vector<double> st(nv);
-                for (int i = 0; i < nv; ++i) st[i] = t * step[i];
-                plus(pos.data(), sc.data(), st.data(), pos_c.data(), sc_c.data());
-                cost_c = g.eval(pos_c.data(), sc_c.data(), r_c.data());
-                if (!constrained || cost_c <= cost || ls == 19) break;
-                t *= 0.5;
-            }
-            if (t != 1.0) for (int i = 0; i < nv; ++i) step[i] *= t;
-            // model cost change -(J d)^T (r + J d / 2)
+            // model cost change -(J d)^T (r + J d / 2) of the trust-region step (Ceres keeps it when the line search shortens d)
             std::fill(Jd.begin(), Jd.end(), 0.0);
             for_rows(pos.data(), sc.data(), [&](int ri, const Row& row) { for (int x = 0; x < row.n; ++x) Jd[ri] += row.val[x] * step[row.idx[x]]; });
             double model = 0.0;
             for (size_t i = 0; i < Jd.size(); ++i) model -= Jd[i] * (r[i] + 0.5 * Jd[i]);
-            double xnorm = 0.0, snorm = 0.0;
-            for (int i = 0; i < p.n_frames; ++i) if (g.vp[i] >= 0) for (int k = 0; k < 3; ++k) { xnorm += pos[3 * i + k] * pos[3 * i + k]; const double d = pos_c[3 * i + k] - pos[3 * i + k]; snorm += d * d; }
-            for (int i = 0; i < p.n_scales; ++i) if (g.vs[i] >= 0) { xnorm += sc[i] * sc[i]; const double d = sc_c[i] - sc[i]; snorm += d * d; }
-            xnorm = std::sqrt(xnorm); snorm = std::sqrt(snorm);
             if (!(model > 0.0) || !std::isfinite(model)) {           // invalid step
                 sum->n_unsuccessful++;
                 radius *= 0.5; reuse = true;
                 if (radius < 1e-32) return finish(4, cost);
                 continue;
             }
+            // bounds: projected Armijo search along the step before it is evaluated (TrustRegionMinimizer::DoLineSearch)
+            double cost_c = 0.0;
+            if (constrained) {
+                double slope0 = 0.0, dmax = 0.0;
+                for (int i = 0; i < nv; ++i) { slope0 += grad[i] * step[i]; dmax = std::max(dmax, std::fabs(step[i])); }
+                std::vector<double> st(nv), gt(nv);
+                auto eval = [&](double a, xls::Sample& sm) {
+                    for (int i = 0; i < nv; ++i) st[i] = a * step[i];
+                    plus(pos.data(), sc.data(), st.data(), pos_c.data(), sc_c.data());
+                    sm.x = a; sm.f = g.eval(pos_c.data(), sc_c.data(), r_c.data()); sm.has_g = true;
+                    std::fill(gt.begin(), gt.end(), 0.0);
+                    for_rows(pos_c.data(), sc_c.data(), [&](int ri, const Row& row) { for (int x = 0; x < row.n; ++x) gt[row.idx[x]] += row.val[x] * r_c[ri]; });
+                    sm.g = 0.0;
+                    for (int i = 0; i < nv; ++i) sm.g += gt[i] * step[i];
+                    return std::isfinite(sm.f);
+                };
+                const double t = xls::armijo_search(eval, cost, slope0, dmax);
+                if (t != 1.0) for (int i = 0; i < nv; ++i) step[i] *= t;
+            }
+            plus(pos.data(), sc.data(), step.data(), pos_c.data(), sc_c.data());
+            cost_c = g.eval(pos_c.data(), sc_c.data(), r_c.data());
+            double xnorm = 0.0, snorm = 0.0;
+            for (int i = 0; i < p.n_frames; ++i) if (g.vp[i] >= 0) for (int k = 0; k < 3; ++k) { xnorm += pos[3 * i + k] * pos[3 * i + k]; const double d = pos_c[3 * i + k] - pos[3 * i + k]; snorm += d * d; }
+            for (int i = 0; i < p.n_scales; ++i) if (g.vs[i] >= 0) { xnorm += sc[i] * sc[i]; const double d = sc_c[i] - sc[i]; snorm += d * d; }
+            xnorm = std::sqrt(xnorm); snorm = std::sqrt(snorm);
             if (snorm <= o.parameter_tolerance * (xnorm + o.parameter_tolerance)) return finish(2, cost);
             const double change = cost - cost_c;
             if (std::fabs(change) <= o.function_tolerance * cost) return finish(3, cost);

@@ -26,6 +26,7 @@
 #include <cstdint>
 
 #include "../../include/xrsfm_ba.h"
+#include "line_search.h"
 
 namespace xtag {
 
@@ -52,58 +53,6 @@ inline void quat_plus(const double* q, const double* th, double* o) {
                          q[3] * d[3] - q[0] * d[0] - q[1] * d[1] - q[2] * d[2]};
     const double m = std::sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2] + r[3] * r[3]);
     for (int k = 0; k < 4; ++k) o[k] = r[k] / m;
-}
-
-// Minimum over [lo, hi] of the polynomial that interpolates the given values / slopes (Ceres: MinimizeInterpolatingPolynomial).
-struct Sample { double x, f, g; bool has_g; };
-inline double minimize_interpolant(const Sample* s, int n, double lo, double hi) {
-    int m = 0;
-    for (int i = 0; i < n; ++i) m += s[i].has_g ? 2 : 1;
-    double A[6][7];
-    int row = 0;
-    for (int i = 0; i < n; ++i) {          // coefficient k multiplies x^k
-        double pw = 1.0;
-        for (int k = 0; k < m; ++k) { A[row][k] = pw; pw *= s[i].x; }
-        A[row][m] = s[i].f; ++row;
-        if (s[i].has_g) {
-            pw = 1.0;
-            A[row][0] = 0.0;
-            for (int k = 1; k < m; ++k) { A[row][k] = k * pw; pw *= s[i].x; }
-            A[row][m] = s[i].g; ++row;
-        }
-    }
-    for (int c = 0; c < m; ++c) {          // Gauss-Jordan with partial pivoting
-        int piv = c;
-        for (int r = c + 1; r < m; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
-        if (A[piv][c] == 0.0) return 0.5 * (lo + hi);
-        if (piv != c) for (int k = 0; k <= m; ++k) std::swap(A[piv][k], A[c][k]);
-        for (int r = 0; r < m; ++r) if (r != c) {
-            const double f = A[r][c] / A[c][c];
-            for (int k = c; k <= m; ++k) A[r][k] -= f * A[c][k];
-        }
-    }
-    double coef[6];
-    for (int k = 0; k < m; ++k) coef[k] = A[k][m] / A[k][k];
-    auto val = [&](double x) { double v = 0.0; for (int k = m - 1; k >= 0; --k) v = v * x + coef[k]; return v; };
-    auto der = [&](double x) { double v = 0.0; for (int k = m - 1; k >= 1; --k) v = v * x + k * coef[k]; return v; };
-    double best_x = lo, best = val(lo);
-    if (val(hi) < best) { best = val(hi); best_x = hi; }
-    const int kCells = 256;                // stationary points inside the bracket: sign changes of the derivative, bisected
-    double xa = lo, da = der(lo);
-    for (int i = 1; i <= kCells; ++i) {
-        const double xb = lo + (hi - lo) * i / kCells, db = der(xb);
-        if ((da < 0.0 && db >= 0.0) || (da > 0.0 && db <= 0.0)) {
-            double l = xa, r = xb, dl = da;
-            for (int it = 0; it < 80; ++it) {
-                const double mid = 0.5 * (l + r), dm = der(mid);
-                if ((dl < 0.0) == (dm < 0.0)) { l = mid; dl = dm; } else r = mid;
-            }
-            const double x = 0.5 * (l + r), v = val(x);
-            if (v < best) { best = v; best_x = x; }
-        }
-        xa = xb; da = db;
-    }
-    return best_x;
 }
 
 // 3x3 symmetric positive definite solve (lower: a00 a10 a11 a20 a21 a22); false when not positive definite
@@ -400,7 +349,7 @@ struct Solver {
         double slope0 = 0.0, dmax = 0.0;
         for (size_t i = 0; i < delta.size(); ++i) { slope0 += g0[i] * delta[i]; dmax = std::max(dmax, std::fabs(delta[i])); }
         std::vector<double> d(delta.size());
-        auto eval = [&](double a, Sample& s) {
+        auto eval = [&](double a, xls::Sample& s) {
             for (size_t i = 0; i < d.size(); ++i) d[i] = a * delta[i];
             plus(x, d.data(), tmp);
             s.x = a; s.f = evaluate(tmp, true); s.has_g = true;
@@ -408,25 +357,7 @@ struct Solver {
             for (size_t i = 0; i < d.size(); ++i) s.g += grad[i] * delta[i];
             return std::isfinite(s.f);
         };
-        const Sample start = {0.0, cost, slope0, true};
-        Sample prev = {0, 0, 0, false}, cur;
-        bool prev_valid = false;
-        bool cur_valid = eval(1.0, cur);
-        int iters = 0;
-        while (!cur_valid || cur.f > cost + 1e-4 * slope0 * cur.x) {
-            if (++iters >= 20) return 1.0;                       // search failed: the step is left as it is
-            double a;
-            const double lo = 1e-3 * cur.x, hi = 0.6 * cur.x;
-            if (!cur_valid) a = std::min(std::max(0.5 * cur.x, lo), hi);
-            else {
-                Sample ss[3] = {start, cur, prev};
-                a = minimize_interpolant(ss, prev_valid ? 3 : 2, lo, hi);
-            }
-            if (a * dmax < 1e-9) return 1.0;
-            prev = cur; prev_valid = cur_valid;
-            cur_valid = eval(a, cur);
-        }
-        return cur.x;
+        return xls::armijo_search(eval, cost, slope0, dmax);
     }
 
     int run(const xrsfm_pg_options& o, State& x, xrsfm_pg_summary* sum) {
