@@ -9,10 +9,16 @@ region; xrsfm_ba_reset restores the state between steps).  value = LM
 iterations (successful + unsuccessful, as the reference counts them,
 ba_solver.cc:22-25) x (cams + points) / second, whole job.
 
-N > 1: one process per GPU (torch.distributed.run), the tracks of the SAME
-problem are sharded by point over the ranks ("strong" scaling, BASELINE.json
-config 4), cameras replicated, per-camera sums all-reduced with RCCL inside the
-library (xrsfm_ba_comm_init).
+N > 1: one process per GPU (torch.distributed.run); the tracks are sharded by
+point over the ranks, cameras replicated, per-camera sums and the reduced camera
+blocks all-reduced with RCCL inside the library (xrsfm_ba_comm_init).
+  --scaling weak (default): the point set grows with N (N x 500k points over the
+      same 1000 cameras at config L), so every rank keeps a config-sized shard --
+      the regime the sharding is for (maps that outgrow one GPU);
+  --scaling strong: the SAME problem is split over the ranks (BASELINE.json
+      config 4 read literally).  One solve of L is 8.8 ms on one GPU and a third
+      of each LM iteration is the replicated exact factorisation of the reduced
+      camera system, so this cannot speed up much.
 
 The JSON line carries `roofline` (dominant HBM-streaming kernel, algorithmic
 bytes of SURVEY.md section 8d / DESIGN.md section 5, duration from HIP events
@@ -50,6 +56,14 @@ def shard_problem(arr: dict, rank: int, world: int) -> dict:
     out["obs_cam"] = np.ascontiguousarray(arr["obs_cam"][keep_obs])
     out["obs_pt"] = np.ascontiguousarray(new_idx[arr["obs_pt"][keep_obs]].astype(np.int32))
     out["obs_uv"] = np.ascontiguousarray(arr["obs_uv"][keep_obs])
+    return out
+
+
+def weak_scaled_config(cfg: dict, world: int) -> dict:
+    """Weak scaling: `world` times the points of the configuration over the same cameras (camera poses do not depend on the
+    point count: the generator draws them first), so that the j % world shard of every rank has the configuration's size."""
+    out = dict(cfg)
+    out["n_points"] = cfg["n_points"] * world
     return out
 
 
@@ -146,6 +160,8 @@ def main():
     ap.add_argument("--config", default="L", choices=["S", "L", "K", "U", "X", "R", "V"])
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = N x the points of the config over the same cameras; strong = the config split N ways")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
@@ -165,7 +181,8 @@ def main():
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    cfg = synth.CONFIGS[args.config]
+    cfg = dict(synth.CONFIGS[args.config])
+    cfg = weak_scaled_config(cfg, world) if args.scaling == "weak" else cfg
     full = synth.make_problem(**cfg)
     arr = {k: full[k] for k in capi.ProblemArrays.FIELDS}
     n_cams, n_points, n_obs = arr["cam_q"].shape[0], arr["points"].shape[0], arr["obs_cam"].shape[0]
@@ -244,10 +261,11 @@ def main():
             "metric": "BA iterations/sec x (cams+points)", "value": iters * (n_cams + n_points) / dt,
             "unit": "cam-pts*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic BAL-style {args.config}: {n_cams} cams / {n_points} points / {n_obs} obs, "
                                    f"GBA accurate (ba_solver.cc:626-629), seed {cfg['seed']}",
-                       "parallelism": f"points sharded x{world}, cameras replicated" if world > 1 else "single GPU",
+                       "parallelism": (f"points sharded x{world} ({prob.n_points} points / {prob.n_obs} obs on rank 0), cameras replicated, "
+                                       f"3 RCCL all-reduces per LM iteration") if world > 1 else "single GPU",
                        "linear_solver": "cholesky (explicit reduced camera matrix, exact)" if last.linear_solver_used == 1
                        else f"implicit-Schur PCG tol {opt.pcg_tolerance:g}"},
             "lm_iterations_per_step": iters / args.steps, "pcg_iterations_per_step": pcg / args.steps,

@@ -77,3 +77,22 @@ def test_point_sharding_and_allreduce_reproduce_single_rank(tmp_path):
     assert H.rel_err(z["hcc"], np.einsum("nii->ni", lin.Hcc)) < 1e-12 and H.rel_err(z["gc"], lin.gc) < 1e-12
     assert H.rel_err(z["rb"], -bo._scatter_add(n_c, pr.obs_cam, np.einsum("nij,nj->ni", WH, lin.gp[pr.obs_pt]))) < 1e-12
     assert H.rel_err(z["sx"], bo._scatter_add(n_c, pr.obs_cam, np.einsum("nki,nk->ni", lin.Fs, zz))) < 1e-12
+
+
+def test_weak_scaled_workload_keeps_cameras_and_shard_size():
+    """bench.py --scaling weak: N x the points over the SAME cameras (ground truth and initial state of every camera do not
+    depend on N... the generator draws the cameras first), every rank's j % N shard has the configuration's size."""
+    from bench import shard_problem, weak_scaled_config
+    from xrsfm_amd import synth
+    cfg = dict(n_cams=40, n_points=3000, k_obs=4, seed=9)
+    one = synth.make_problem(**cfg)
+    four = synth.make_problem(**weak_scaled_config(cfg, 4))
+    assert four["points"].shape[0] == 4 * one["points"].shape[0] and four["obs_cam"].shape[0] == 4 * one["obs_cam"].shape[0]
+    assert np.array_equal(four["gt_q"], one["gt_q"]) and np.array_equal(four["gt_t"], one["gt_t"])
+    parts = [shard_problem({k: four[k] for k in ("cam_q", "cam_t", "cam_const", "cam_intr", "intr_model", "intr_params", "points",
+                                                 "point_const", "obs_cam", "obs_pt", "obs_uv")}, r, 4) for r in range(4)]
+    assert [p["points"].shape[0] for p in parts] == [3000] * 4
+    assert all(abs(p["obs_cam"].shape[0] - one["obs_cam"].shape[0]) == 0 for p in parts)
+    assert all(np.array_equal(p["cam_q"], four["cam_q"]) for p in parts)
+    # every camera keeps observations in every shard (the per-camera sums of all ranks are meaningful)
+    assert all(np.unique(p["obs_cam"]).size == 40 for p in parts)

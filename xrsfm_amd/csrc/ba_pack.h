@@ -3,7 +3,10 @@
 // problem.AddResidualBlock loop (/root/reference/src/optimization/ba_solver.cc:336-349).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <numeric>
 #include <thread>
 #include <vector>
@@ -81,6 +84,15 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         if (m < 0 || m > 4) return XRSFM_BA_EINVAL;
     }
     const int No = p.n_obs, Np = p.n_points, Nc = p.n_cams;
+    // XRSFM_BA_PACK_TIMING=1: phase times of the host-side packing on stderr (developer aid)
+    const bool timing = std::getenv("XRSFM_BA_PACK_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto mark = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[pack] %-28s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(t - t_prev).count());
+        t_prev = t;
+    };
     std::vector<int> cnt(Np + 1, 0), mincam(Np, INT32_MAX);
     for (int i = 0; i < No; ++i) {
         const int c = p.obs_cam[i], j = p.obs_pt[i];
@@ -93,11 +105,13 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     for (int j = 0; j < Np; ++j) ptr[j + 1] = ptr[j] + cnt[j + 1];
     std::vector<int> fill(ptr.begin(), ptr.end() - 1), csr(No);
     for (int i = 0; i < No; ++i) csr[fill[p.obs_pt[i]]++] = i;
+    mark("csr by point");
     // observations of every track ordered by camera
     pack_parallel_for(Np, [&](long long j0, long long j1) {
         for (long long j = j0; j < j1; ++j)
             std::stable_sort(csr.begin() + ptr[j], csr.begin() + ptr[j + 1], [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
     });
+    mark("per-track camera sort");
     // active points: short tracks sorted by their camera tuple (tracks seeing the same cameras become neighbours:
     // locality of the camera gathers, and whole tiles that share one tuple can be pre-reduced in the wave),
     // long tracks (> 64 obs) at the end
@@ -173,6 +187,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
             }
         }
     }
+    mark("tuple sort");
     o.n_cams = Nc; o.n_pts = (int)order.size(); o.n_obs = No;
     o.pt_orig = order;
     o.pt_const.assign(o.n_pts, 0);
@@ -201,6 +216,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
             b = e;
         }
     }
+    mark("group starts");
     int cur_tile_start = -1;  // tile index of the open short tile, -1 if none
     for (int pj = 0; pj < o.n_pts; ++pj) {
         const int j = order[pj];
@@ -230,6 +246,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         for (long long s = s0; s < s1; ++s)
             if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
     });
+    mark("slots + uv");
     o.tile_maxlen.assign(o.n_tiles, 1);
     for (int t = 0; t < o.n_tiles; ++t) {
         int run = 0, best = 1;
@@ -261,6 +278,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     for (size_t it = 0; it + 1 < o.items.size(); it += 2)          // long items are never regular
         if (o.items[it + 1] > 1)
             for (int t = o.items[it]; t < o.items[it] + o.items[it + 1]; ++t) o.tile_stride[t] = 0;
+    mark("maxlen + regular tiles");
     // Gram tiles
     o.tile_ncam.assign(o.n_tiles, 0); o.tile_gt_off.assign(o.n_tiles, -1);
     o.slot_cidx.assign(o.n_slots, 255); o.gt_cell.clear();
@@ -325,6 +343,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         }
         o.n_gt_cells = (int)o.gt_cell.size();
     }
+    mark("gram tiles");
     // camera-major positions of the lanes that write a camera-side partial: every valid lane of an irregular tile,
     // the first track (lanes < L) of a regular one.  Within a camera: slot order.
     auto writes = [&](int s2) { const int L = o.tile_stride[s2 / 64]; return o.slot_cam[s2] >= 0 && (L == 0 || (s2 % 64) < L); };
@@ -358,6 +377,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         for (int s2 = 0; s2 < o.n_slots; ++s2)
             if (wg[s2]) o.slot_campos_g[s2] = cg[o.slot_cam[s2]]++;
     }
+    mark("camera-major maps");
     std::vector<char> cam_seen(Nc, 0);
     for (int s2 = 0; s2 < o.n_slots; ++s2)
         if (o.slot_cam[s2] >= 0) cam_seen[o.slot_cam[s2]] = 1;
@@ -371,6 +391,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     }
     for (int pj = 0; pj < o.n_pts; ++pj)
         if (!o.pt_const[pj]) o.n_var_p++;
+    mark("counts");
     return XRSFM_BA_OK;
 }
 
