@@ -8,7 +8,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <memory>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../include/xrsfm_ba.h"
@@ -45,11 +47,55 @@ inline void pack_parallel_for(long long n, F&& fn, long long min_n = 200000) {
     for (auto& x : th) x.join();
 }
 
+// XRSFM_BA_PACK_TIMING=1: phase times of the host-side set-up (packing, Cholesky plan) on stderr (developer aid)
+struct PhaseTimer {
+    const char* tag;
+    bool on;
+    std::chrono::steady_clock::time_point prev;
+    explicit PhaseTimer(const char* t) : tag(t), on(std::getenv("XRSFM_BA_PACK_TIMING") != nullptr), prev(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[%s] %-28s %7.2f ms\n", tag, what, 1e3 * std::chrono::duration<double>(t - prev).count());
+        prev = t;
+    }
+};
+
+// Vector whose resize() leaves new elements uninitialised: the large per-slot arrays are written exactly once, in parallel,
+// so the pages are first touched by the threads that fill them instead of being zeroed by one thread beforehand.
+template <typename T>
+struct RawAlloc : std::allocator<T> {
+    template <typename U> struct rebind { using other = RawAlloc<U>; };
+    RawAlloc() = default;
+    template <typename U> RawAlloc(const RawAlloc<U>&) {}
+    template <typename U> void construct(U* q) noexcept { ::new ((void*)q) U; }
+    template <typename U, typename A0, typename... A> void construct(U* q, A0&& a0, A&&... a) { ::new ((void*)q) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+};
+template <typename T> using RawVec = std::vector<T, RawAlloc<T>>;
+
+// Fixed partition of [0, n) into up to 8 pieces whose boundaries are multiples of `align` (one piece for small n), and a runner
+// that hands every piece its index: for two-pass algorithms (count, then place) that need the same partition twice.
+inline std::vector<long long> pack_cuts(long long n, long long min_n, long long align) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(8u, hw);
+    std::vector<long long> cut(nt + 1);
+    for (int t = 0; t <= nt; ++t) cut[t] = (t == nt) ? n : (n * t / nt) / align * align;
+    return cut;
+}
+template <typename F>
+inline void pack_parallel_chunks(const std::vector<long long>& cut, F&& fn) {
+    const int nc = (int)cut.size() - 1;
+    if (nc == 1) { fn(0, cut[0], cut[1]); return; }
+    std::vector<std::thread> th;
+    for (int t = 0; t < nc; ++t) th.emplace_back([&, t] { fn(t, cut[t], cut[t + 1]); });
+    for (auto& x : th) x.join();
+}
+
 struct Packed {
     int n_cams = 0, n_pts = 0, n_obs = 0, n_tiles = 0, n_slots = 0;
     std::vector<int> pt_orig;        // packed point -> caller point index
-    std::vector<int> slot_cam, slot_pt, slot_campos, slot_obs;  // slot_obs: caller obs index (-1 pad)
-    std::vector<double> slot_u, slot_v;
+    RawVec<int> slot_cam, slot_pt, slot_obs, slot_campos;   // slot_obs: caller obs index (-1 pad)
+    RawVec<double> slot_u, slot_v;
     std::vector<int> items;          // pairs {first_tile, n_tiles}
     std::vector<int> cam_ptr;        // [n_cams+1] into the camera-major scatter buffer (entries, not observations)
     std::vector<int> tile_maxlen;    // [n_tiles] longest track in the tile (<= 64)
@@ -57,7 +103,8 @@ struct Packed {
     int n_cam_entries = 0;
     // The same for the S assembly (k_schur_pairs -> k_chol_segsum): a Gram tile sums the diagonal-block / rhs terms of every
     // camera over its tracks first, so only the first lane of each distinct camera writes an entry.
-    std::vector<int> cam_ptr_g, slot_campos_g;
+    std::vector<int> cam_ptr_g;
+    RawVec<int> slot_campos_g;
     int n_cam_entries_g = 0;
     // "Gram tiles" (S assembly): a single tile whose tracks see at most kGramMaxCams distinct cameras.  Its camera-pair blocks
     // come out of ONE Gram product V V^T, V = [6 x distinct camera] x [3 x track] (zero where a track does not see a camera),
@@ -84,21 +131,13 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         if (m < 0 || m > 4) return XRSFM_BA_EINVAL;
     }
     const int No = p.n_obs, Np = p.n_points, Nc = p.n_cams;
-    // XRSFM_BA_PACK_TIMING=1: phase times of the host-side packing on stderr (developer aid)
-    const bool timing = std::getenv("XRSFM_BA_PACK_TIMING") != nullptr;
-    auto t_prev = std::chrono::steady_clock::now();
-    auto mark = [&](const char* what) {
-        if (!timing) return;
-        const auto t = std::chrono::steady_clock::now();
-        fprintf(stderr, "[pack] %-28s %7.2f ms\n", what, 1e3 * std::chrono::duration<double>(t - t_prev).count());
-        t_prev = t;
-    };
-    std::vector<int> cnt(Np + 1, 0), mincam(Np, INT32_MAX);
+    PhaseTimer timer("pack");
+    auto mark = [&](const char* what) { timer.mark(what); };
+    std::vector<int> cnt(Np + 1, 0);
     for (int i = 0; i < No; ++i) {
         const int c = p.obs_cam[i], j = p.obs_pt[i];
         if (c < 0 || c >= Nc || j < 0 || j >= Np) return XRSFM_BA_EINVAL;
         cnt[j + 1]++;
-        mincam[j] = std::min(mincam[j], c);
     }
     // CSR by caller point
     std::vector<int> ptr(Np + 1, 0);
@@ -108,8 +147,20 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     mark("csr by point");
     // observations of every track ordered by camera
     pack_parallel_for(Np, [&](long long j0, long long j1) {
-        for (long long j = j0; j < j1; ++j)
-            std::stable_sort(csr.begin() + ptr[j], csr.begin() + ptr[j + 1], [&](int a, int b) { return p.obs_cam[a] < p.obs_cam[b]; });
+        for (long long j = j0; j < j1; ++j) {
+            int* b = csr.data() + ptr[j];
+            const int len = ptr[j + 1] - ptr[j];
+            if (len <= 32) {                        // stable insertion sort: frame-major input is already in order
+                for (int x = 1; x < len; ++x) {
+                    const int v = b[x], cv = p.obs_cam[v];
+                    int y = x - 1;
+                    while (y >= 0 && p.obs_cam[b[y]] > cv) { b[y + 1] = b[y]; --y; }
+                    b[y + 1] = v;
+                }
+            } else {
+                std::stable_sort(b, b + len, [&](int a, int c) { return p.obs_cam[a] < p.obs_cam[c]; });
+            }
+        }
     });
     mark("per-track camera sort");
     // active points: short tracks sorted by their camera tuple (tracks seeing the same cameras become neighbours:
@@ -128,6 +179,8 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         }
         return la < lb;
     };
+    std::vector<unsigned long long> sort_keys;      // keys of `order` after the sort (empty: comparator sort)
+    int key_cams = 0;
     {
         // The comparator walks two tuples through three indirections per element; sorting 64-bit keys built from the
         // first cameras (4 x 15 bits, or 3 x 20 bits for more than 32k cameras; +1 so that a shorter tuple sorts before its
@@ -157,24 +210,31 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         if (wide) {
             std::stable_sort(order.begin(), order.end(), full_less);
         } else {
-            const auto ki_less = [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; };
-            if (ki.size() < 400000) {
-                std::sort(ki.begin(), ki.end(), ki_less);
-            } else {                                    // 8 sorted runs in parallel, then three rounds of pairwise merges (a total order: unique result)
-                const size_t nk = ki.size();
-                size_t cut[9];
-                for (int q = 0; q <= 8; ++q) cut[q] = nk * q / 8;
-                pack_parallel_for(8 * 200000LL, [&](long long a, long long b) {
-                    for (long long q = a / 200000; q < b / 200000; ++q) std::sort(ki.begin() + cut[q], ki.begin() + cut[q + 1], ki_less);
-                });
-                for (int width = 1; width < 8; width *= 2) {
-                    std::vector<std::thread> th;
-                    for (int q = 0; q + width < 8; q += 2 * width)
-                        th.emplace_back([&, q, width] { std::inplace_merge(ki.begin() + cut[q], ki.begin() + cut[q + width], ki.begin() + cut[std::min(q + 2 * width, 8)], ki_less); });
-                    for (auto& x : th) x.join();
-                }
+            // (key, idx) order.  Large inputs: ki is in ascending idx order, so a stable LSD radix sort over the key fields
+            // yields it; one pass per camera field (kbits wide) and a last one for the long-track flag
+            if (ki.size() < 100000) {                    // small calls (LBA): the bucket arrays would cost more than the sort
+                std::sort(ki.begin(), ki.end(), [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; });
+            } else {
+                std::vector<KI> tmp(ki.size());
+                std::vector<unsigned> hist;
+                auto pass = [&](int shift, int bits) {
+                    const size_t nb = (size_t)1 << bits;
+                    const unsigned long long mask = nb - 1;
+                    hist.assign(nb + 1, 0u);
+                    for (const KI& e : ki) hist[((e.key >> shift) & mask) + 1]++;
+                    bool one_bucket = false;
+                    for (size_t b = 0; b < nb && !one_bucket; ++b) one_bucket = hist[b + 1] == ki.size();
+                    if (one_bucket) return;                              // every key has the same digit: nothing to do
+                    for (size_t b = 0; b < nb; ++b) hist[b + 1] += hist[b];
+                    for (const KI& e : ki) tmp[hist[(e.key >> shift) & mask]++] = e;
+                    ki.swap(tmp);
+                };
+                for (int q = kcams - 1; q >= 0; --q) pass(kbits * (kcams - 1 - q), kbits);
+                pass(63, 1);
             }
             for (size_t n = 0; n < ki.size(); ++n) order[n] = ki[n].idx;
+            sort_keys.resize(ki.size()); key_cams = kcams;
+            for (size_t n = 0; n < ki.size(); ++n) sort_keys[n] = ki[n].key;
             for (size_t b = 0; b < ki.size();) {       // equal leading cameras: finish with the full comparison (stable)
                 size_t e = b + 1;
                 while (e < ki.size() && ki[e].key == ki[b].key) ++e;
@@ -191,14 +251,8 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     o.n_cams = Nc; o.n_pts = (int)order.size(); o.n_obs = No;
     o.pt_orig = order;
     o.pt_const.assign(o.n_pts, 0);
-    o.items.clear(); o.slot_cam.clear(); o.slot_pt.clear(); o.slot_obs.clear();
-    {
-        const size_t cap = (size_t)No + (size_t)No / 8 + 4096;      // slots incl. tile padding (grows if a pathological input needs more)
-        o.slot_cam.reserve(cap); o.slot_pt.reserve(cap); o.slot_obs.reserve(cap); o.items.reserve(2 * (cap / 64 + 1));
-    }
-    auto pad_tile = [&]() {
-        while (o.slot_cam.size() % 64) { o.slot_cam.push_back(-1); o.slot_pt.push_back(-1); o.slot_obs.push_back(-1); }
-    };
+    o.items.clear();
+    o.items.reserve(2 * ((size_t)No / 48 + 16));
     // A group of tracks with one camera tuple that fills at least a tile by itself starts on a tile boundary: its tiles are
     // then all regular (one dense Gram product each, small LDS footprint) instead of the first one mixing two tuples.
     std::vector<char> big_group_start(o.n_pts, 0);
@@ -206,7 +260,12 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         // same[n]: track n has the same tuple as track n-1 (sorted order: one direction of the comparison suffices)
         std::vector<char> same(o.n_pts, 0);
         pack_parallel_for(o.n_pts, [&](long long n0, long long n1) {
-            for (long long n = std::max<long long>(n0, 1); n < n1; ++n) same[n] = !tuple_less(order[n - 1], order[n]);
+            for (long long n = std::max<long long>(n0, 1); n < n1; ++n) {
+                const int a = order[n - 1], b = order[n];
+                // tuples no longer than the key are equal exactly when their keys are (the key holds every camera + 1)
+                if (!sort_keys.empty() && cnt[a + 1] <= key_cams && cnt[b + 1] <= key_cams) same[n] = sort_keys[n - 1] == sort_keys[n];
+                else same[n] = !tuple_less(a, b);
+            }
         });
         for (int b = 0; b < o.n_pts;) {
             int e = b + 1;
@@ -217,64 +276,86 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         }
     }
     mark("group starts");
-    int cur_tile_start = -1;  // tile index of the open short tile, -1 if none
-    for (int pj = 0; pj < o.n_pts; ++pj) {
-        const int j = order[pj];
-        const int len = cnt[j + 1];
-        o.pt_const[pj] = (p.point_const && p.point_const[j]) ? 1 : 0;
-        const int* obs_b = csr.data() + ptr[j];
-        if (len <= 64) {
-            const int used = (int)(o.slot_cam.size() % 64);
-            if (cur_tile_start < 0 || used + len > 64 || used == 0 || big_group_start[pj]) {
-                pad_tile();
-                cur_tile_start = (int)(o.slot_cam.size() / 64);
-                o.items.push_back(cur_tile_start); o.items.push_back(1);
+    // Placement first (one cheap pass over the tracks: where every track starts, which tiles open), then the slots are
+    // filled in parallel.
+    std::vector<long long> trk_start(o.n_pts);
+    {
+        long long pos = 0;            // slots laid out so far (incl. padding)
+        int cur_tile_start = -1;      // tile index of the open short tile, -1 if none
+        auto pad = [&]() { pos = (pos + 63) & ~63LL; };
+        for (int pj = 0; pj < o.n_pts; ++pj) {
+            const int len = cnt[order[pj] + 1];
+            if (len <= 64) {
+                const int used = (int)(pos % 64);
+                if (cur_tile_start < 0 || used + len > 64 || used == 0 || big_group_start[pj]) {
+                    pad();
+                    cur_tile_start = (int)(pos / 64);
+                    o.items.push_back(cur_tile_start); o.items.push_back(1);
+                }
+            } else {
+                pad();
+                cur_tile_start = -1;
+                o.items.push_back((int)(pos / 64)); o.items.push_back((len + 63) / 64);
             }
-        } else {
-            pad_tile();
-            cur_tile_start = -1;
-            o.items.push_back((int)(o.slot_cam.size() / 64)); o.items.push_back((len + 63) / 64);
+            trk_start[pj] = pos;
+            pos += len;
+            if (len > 64) pad();
         }
-        for (int q = 0; q < len; ++q) { const int i = obs_b[q]; o.slot_cam.push_back(p.obs_cam[i]); o.slot_pt.push_back(pj); o.slot_obs.push_back(i); }
-        if (len > 64) pad_tile();
+        pad();
+        if (pos > INT32_MAX) return XRSFM_BA_EINVAL;
+        o.n_slots = (int)pos;
     }
-    pad_tile();
-    o.n_slots = (int)o.slot_cam.size();
     o.n_tiles = o.n_slots / 64;
-    o.slot_u.assign(o.n_slots, 0.0); o.slot_v.assign(o.n_slots, 0.0);
-    pack_parallel_for(o.n_slots, [&](long long s0, long long s1) {
-        for (long long s = s0; s < s1; ++s)
-            if (o.slot_obs[s] >= 0) { o.slot_u[s] = p.obs_uv[2 * (size_t)o.slot_obs[s]]; o.slot_v[s] = p.obs_uv[2 * (size_t)o.slot_obs[s] + 1]; }
-    });
+    o.slot_cam.resize(o.n_slots); o.slot_pt.resize(o.n_slots); o.slot_obs.resize(o.n_slots);
+    o.slot_u.resize(o.n_slots); o.slot_v.resize(o.n_slots);
+    mark("placement + alloc");
+    pack_parallel_for(o.n_pts, [&](long long p0, long long p1) {
+        for (long long pj = p0; pj < p1; ++pj) {
+            const int j = order[pj];
+            const int len = cnt[j + 1];
+            o.pt_const[pj] = (p.point_const && p.point_const[j]) ? 1 : 0;
+            const int* obs_b = csr.data() + ptr[j];
+            const long long s0 = trk_start[pj];
+            for (int q = 0; q < len; ++q) {
+                const int i = obs_b[q];
+                o.slot_cam[s0 + q] = p.obs_cam[i]; o.slot_pt[s0 + q] = (int)pj; o.slot_obs[s0 + q] = i;
+                o.slot_u[s0 + q] = p.obs_uv[2 * (size_t)i]; o.slot_v[s0 + q] = p.obs_uv[2 * (size_t)i + 1];
+            }
+            // padding up to the next track (or the end): owned by this track's thread as well
+            const long long s1 = (pj + 1 < o.n_pts) ? trk_start[pj + 1] : (long long)o.n_slots;
+            for (long long s2 = s0 + len; s2 < s1; ++s2) { o.slot_cam[s2] = -1; o.slot_pt[s2] = -1; o.slot_obs[s2] = -1; o.slot_u[s2] = 0.0; o.slot_v[s2] = 0.0; }
+        }
+    }, 50000);
+    if (o.n_pts == 0 && o.n_slots > 0) return XRSFM_BA_EINVAL;       // (no tracks means no slots)
     mark("slots + uv");
+    // per tile: longest track run; regular tiles = >= 2 tracks, all with the same camera tuple of length L <= 32
     o.tile_maxlen.assign(o.n_tiles, 1);
-    for (int t = 0; t < o.n_tiles; ++t) {
-        int run = 0, best = 1;
-        for (int q = 0; q < 64; ++q) {
-            const int s2 = 64 * t + q;
-            if (o.slot_cam[s2] < 0) break;
-            run = (q > 0 && o.slot_pt[s2] == o.slot_pt[s2 - 1]) ? run + 1 : 1;
-            best = std::max(best, run);
-        }
-        o.tile_maxlen[t] = best;
-    }
-    // regular tiles: >= 2 tracks, all with the same camera tuple of length L <= 32
     o.tile_stride.assign(o.n_tiles, 0);
-    for (int t = 0; t < o.n_tiles; ++t) {
-        const int b0 = 64 * t;
-        if (o.slot_cam[b0] < 0) continue;
-        int L = 1;
-        while (L < 64 && o.slot_cam[b0 + L] >= 0 && o.slot_pt[b0 + L] == o.slot_pt[b0]) ++L;
-        if (L > 32 || L >= 64) continue;
-        bool regular = true;
-        int nvalid = L;
-        for (int s2 = b0 + L; s2 < b0 + 64 && o.slot_cam[s2] >= 0; ++s2, ++nvalid) {
-            const int r = (s2 - b0) % L;
-            if (o.slot_cam[s2] != o.slot_cam[b0 + r]) { regular = false; break; }
-            if (r > 0 ? o.slot_pt[s2] != o.slot_pt[s2 - 1] : o.slot_pt[s2] == o.slot_pt[s2 - 1]) { regular = false; break; }
+    pack_parallel_for(o.n_tiles, [&](long long t0, long long t1) {
+        for (long long t = t0; t < t1; ++t) {
+            const long long b0 = 64 * t;
+            int run = 0, best = 1;
+            for (int q = 0; q < 64; ++q) {
+                const long long s2 = b0 + q;
+                if (o.slot_cam[s2] < 0) break;
+                run = (q > 0 && o.slot_pt[s2] == o.slot_pt[s2 - 1]) ? run + 1 : 1;
+                best = std::max(best, run);
+            }
+            o.tile_maxlen[t] = best;
+            if (o.slot_cam[b0] < 0) continue;
+            int L = 1;
+            while (L < 64 && o.slot_cam[b0 + L] >= 0 && o.slot_pt[b0 + L] == o.slot_pt[b0]) ++L;
+            if (L > 32 || L >= 64) continue;
+            bool regular = true;
+            int nvalid = L;
+            for (long long s2 = b0 + L; s2 < b0 + 64 && o.slot_cam[s2] >= 0; ++s2, ++nvalid) {
+                const int r = (int)((s2 - b0) % L);
+                if (o.slot_cam[s2] != o.slot_cam[b0 + r]) { regular = false; break; }
+                if (r > 0 ? o.slot_pt[s2] != o.slot_pt[s2 - 1] : o.slot_pt[s2] == o.slot_pt[s2 - 1]) { regular = false; break; }
+            }
+            if (regular && nvalid % L == 0 && nvalid >= 2 * L) o.tile_stride[t] = L;
         }
-        if (regular && nvalid % L == 0 && nvalid >= 2 * L) o.tile_stride[t] = L;
-    }
+    }, 4000);
     for (size_t it = 0; it + 1 < o.items.size(); it += 2)          // long items are never regular
         if (o.items[it + 1] > 1)
             for (int t = o.items[it]; t < o.items[it] + o.items[it + 1]; ++t) o.tile_stride[t] = 0;
@@ -308,6 +389,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
                     o.slot_cidx[b0 + q] = (unsigned char)(std::lower_bound(cams, cams + C, o.slot_cam[b0 + q]) - cams);
             }
         }, 4000);
+        mark("  gram: cameras of tiles");
         {
             size_t off = 0;
             for (int t = 0; t < o.n_tiles; ++t)
@@ -325,6 +407,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
                         cell[o.slot_cidx[b0 + q] * C + o.slot_cidx[b0 + q2]] = 1;
             }
         }, 4000);
+        mark("  gram: cells");
         // The S-assembly kernel runs once per LDS class (<= 10 KB: 16 workgroups per CU; larger).  A handful of large tiles
         // is not worth a second launch (its duration is one tile's latency, ~15 us): they take the per-pair path instead.
         auto lds_need = [&](int t) {
@@ -346,37 +429,48 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     mark("gram tiles");
     // camera-major positions of the lanes that write a camera-side partial: every valid lane of an irregular tile,
     // the first track (lanes < L) of a regular one.  Within a camera: slot order.
-    auto writes = [&](int s2) { const int L = o.tile_stride[s2 / 64]; return o.slot_cam[s2] >= 0 && (L == 0 || (s2 % 64) < L); };
-    o.cam_ptr.assign(Nc + 1, 0);
-    for (int s2 = 0; s2 < o.n_slots; ++s2)
-        if (writes(s2)) o.cam_ptr[o.slot_cam[s2] + 1]++;
-    for (int c = 0; c < Nc; ++c) o.cam_ptr[c + 1] += o.cam_ptr[c];
-    o.n_cam_entries = o.cam_ptr[Nc];
-    std::vector<int> cf(o.cam_ptr.begin(), o.cam_ptr.end() - 1);
-    o.slot_campos.assign(o.n_slots, -1);
-    for (int s2 = 0; s2 < o.n_slots; ++s2)
-        if (writes(s2)) o.slot_campos[s2] = cf[o.slot_cam[s2]]++;
-    {
-        std::vector<char> wg(o.n_slots, 0);
-        for (int t = 0; t < o.n_tiles; ++t) {
-            const int C = o.tile_ncam[t];
-            if (C <= 0) { for (int q = 0; q < 64; ++q) wg[64 * t + q] = writes(64 * t + q); continue; }
+    // Stable counting sort by camera, in parallel: every piece of the slot range counts its flagged slots per camera, a serial
+    // pass over cameras x pieces turns the counts into start positions, then every piece numbers its own slots.
+    RawVec<char> w_all(o.n_slots), w_gram(o.n_slots);
+    pack_parallel_for(o.n_tiles, [&](long long t0, long long t1) {
+        for (long long t = t0; t < t1; ++t) {
+            const int L = o.tile_stride[t], C = o.tile_ncam[t];
             bool seen[kGramMaxCams] = {false};
-            for (int q = 0; q < 64 && o.slot_cam[64 * t + q] >= 0; ++q) {
-                const int ci = o.slot_cidx[64 * t + q];
-                if (!seen[ci]) { seen[ci] = true; wg[64 * t + q] = 1; }
+            for (int q = 0; q < 64; ++q) {
+                const long long s2 = 64 * t + q;
+                const char w = o.slot_cam[s2] >= 0 && (L == 0 || q < L);
+                w_all[s2] = w;
+                if (C <= 0) { w_gram[s2] = w; continue; }
+                char g = 0;
+                if (o.slot_cam[s2] >= 0) { const int ci = o.slot_cidx[s2]; if (!seen[ci]) { seen[ci] = true; g = 1; } }
+                w_gram[s2] = g;
             }
         }
-        o.cam_ptr_g.assign(Nc + 1, 0);
-        for (int s2 = 0; s2 < o.n_slots; ++s2)
-            if (wg[s2]) o.cam_ptr_g[o.slot_cam[s2] + 1]++;
-        for (int c = 0; c < Nc; ++c) o.cam_ptr_g[c + 1] += o.cam_ptr_g[c];
-        o.n_cam_entries_g = o.cam_ptr_g[Nc];
-        std::vector<int> cg(o.cam_ptr_g.begin(), o.cam_ptr_g.end() - 1);
-        o.slot_campos_g.assign(o.n_slots, -1);
-        for (int s2 = 0; s2 < o.n_slots; ++s2)
-            if (wg[s2]) o.slot_campos_g[s2] = cg[o.slot_cam[s2]]++;
-    }
+    }, 4000);
+    auto camera_major = [&](const RawVec<char>& flag, std::vector<int>& cam_ptr, RawVec<int>& campos) {
+        const std::vector<long long> cut = pack_cuts(o.n_slots, 400000, 64);
+        const int nch = (int)cut.size() - 1;
+        std::vector<std::vector<int>> local(nch);
+        pack_parallel_chunks(cut, [&](int t, long long s0, long long s1) {
+            local[t].assign(Nc, 0);
+            for (long long s2 = s0; s2 < s1; ++s2) if (flag[s2]) local[t][o.slot_cam[s2]]++;
+        });
+        cam_ptr.assign(Nc + 1, 0);
+        int run = 0;
+        for (int c = 0; c < Nc; ++c) {
+            cam_ptr[c] = run;
+            for (int t = 0; t < nch; ++t) { const int v = local[t][c]; local[t][c] = run; run += v; }
+        }
+        cam_ptr[Nc] = run;
+        campos.resize(o.n_slots);
+        pack_parallel_chunks(cut, [&](int t, long long s0, long long s1) {
+            for (long long s2 = s0; s2 < s1; ++s2) campos[s2] = flag[s2] ? local[t][o.slot_cam[s2]]++ : -1;
+        });
+    };
+    camera_major(w_all, o.cam_ptr, o.slot_campos);
+    o.n_cam_entries = o.cam_ptr[Nc];
+    camera_major(w_gram, o.cam_ptr_g, o.slot_campos_g);
+    o.n_cam_entries_g = o.cam_ptr_g[Nc];
     mark("camera-major maps");
     std::vector<char> cam_seen(Nc, 0);
     for (int s2 = 0; s2 < o.n_slots; ++s2)

@@ -47,41 +47,76 @@ typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b <
 //   * every other tile writes one partial per observation pair; its index is the pair index spp[s] + dd - 1.
 inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& keyed) {
     const int ns = k.n_slots;
-    spp.assign(ns + 1, 0);
-    {
+    // Two parallel passes over fixed pieces of the slot range (a track may continue into the next piece: long items):
+    //   A  spp[s + 1] <- number of later slots of the same track (= pairs that start at s), piece totals
+    //   B  prefix sums in place, validation, and the keys of the per-pair path
+    const std::vector<long long> cut = pack_cuts(ns, 400000, 64);
+    const int nch = (int)cut.size() - 1;
+    spp.resize((size_t)ns + 1);
+    spp[0] = 0;
+    std::vector<long long> total(nch, 0);
+    pack_parallel_chunks(cut, [&](int t, long long s0, long long s1) {
         int run = 0;
-        std::vector<int> rest(ns, 0);
-        for (int s = ns - 1; s >= 0; --s) {
-            if (k.slot_cam[s] < 0) { run = 0; rest[s] = 0; continue; }
-            run = (s + 1 < ns && k.slot_cam[s + 1] >= 0 && k.slot_pt[s + 1] == k.slot_pt[s]) ? run + 1 : 0;
-            rest[s] = run;
+        if (s1 < ns && k.slot_cam[s1] >= 0)
+            for (long long s = s1 + 1; s < ns && k.slot_cam[s] >= 0 && k.slot_pt[s] == k.slot_pt[s1]; ++s) ++run;
+        long long sum = 0;
+        for (long long s = s1 - 1; s >= s0; --s) {
+            if (k.slot_cam[s] < 0) run = 0;
+            else run = (s + 1 < ns && k.slot_cam[s + 1] >= 0 && k.slot_pt[s + 1] == k.slot_pt[s]) ? run + 1 : 0;
+            spp[s + 1] = run;
+            sum += run;
         }
-        for (int s = 0; s < ns; ++s) spp[s + 1] = spp[s] + rest[s];
-    }
-    const int n_obs_pairs = spp[ns];
+        total[t] = sum;
+    });
+    std::vector<long long> base(nch + 1, 0);
+    for (int t = 0; t < nch; ++t) base[t + 1] = base[t] + total[t];
+    if (base[nch] > INT32_MAX) return XRSFM_BA_EINVAL;
+    const int n_obs_pairs = (int)base[nch];
+    std::vector<PairKeys> local(nch);
+    std::vector<char> bad(nch, 0);
+    pack_parallel_chunks(cut, [&](int t, long long s0, long long s1) {
+        int acc = (int)base[t];
+        PairKeys& out = local[t];
+        for (long long s = s0; s < s1; ++s) {
+            const int start = acc, np = spp[s + 1];
+            acc += np;
+            spp[s + 1] = acc;
+            if (np == 0) continue;
+            const bool gram = k.tile_ncam[s / 64] > 0;
+            const unsigned long long ca = (unsigned)k.slot_cam[s];
+            for (int dd = 1; dd <= np; ++dd) {
+                const unsigned long long cb = (unsigned)k.slot_cam[s + dd];
+                if (cb <= ca) { bad[t] = 1; return; }   // two observations of one track in the same frame
+                if (!gram) out.push_back({(cb << 32) | ca, start + dd - 1});
+            }
+        }
+    });
+    for (int t = 0; t < nch; ++t) if (bad[t]) return XRSFM_BA_EINVAL;
+    // Gram tiles: one key per co-visible camera pair of the tile
+    const std::vector<long long> tcut = pack_cuts(k.n_tiles, 8000, 1);
+    std::vector<PairKeys> glocal(tcut.size() - 1);
+    pack_parallel_chunks(tcut, [&](int t, long long t0, long long t1) {
+        int cams[64];
+        PairKeys& out = glocal[t];
+        for (long long tile = t0; tile < t1; ++tile) {
+            const int C = k.tile_ncam[tile];
+            if (C <= 0) continue;
+            for (int q = 0; q < 64 && k.slot_cam[64 * tile + q] >= 0; ++q) cams[k.slot_cidx[64 * tile + q]] = k.slot_cam[64 * tile + q];
+            const unsigned char* cell = k.gt_cell.data() + k.tile_gt_off[tile];
+            for (int a = 0; a < C; ++a)
+                for (int b = a + 1; b < C; ++b)
+                    if (cell[a * C + b])
+                        out.push_back({((unsigned long long)(unsigned)cams[b] << 32) | (unsigned)cams[a], n_obs_pairs + k.tile_gt_off[tile] + a * C + b});
+        }
+    });
+    size_t nk = 0;
+    for (const auto& v : local) nk += v.size();
+    for (const auto& v : glocal) nk += v.size();
     keyed.clear();
-    keyed.reserve((size_t)n_obs_pairs / 2 + 16);
-    for (int s = 0; s < ns; ++s) {
-        const int np = spp[s + 1] - spp[s];
-        const bool gram = k.tile_ncam[s / 64] > 0;
-        for (int dd = 1; dd <= np; ++dd) {
-            const unsigned long long cb = (unsigned)k.slot_cam[s + dd], ca = (unsigned)k.slot_cam[s];
-            if (cb <= ca) return XRSFM_BA_EINVAL;   // two observations of one track in the same frame
-            if (!gram) keyed.push_back({(cb << 32) | ca, spp[s] + dd - 1});
-        }
-    }
-    int cams[64];
-    for (int t = 0; t < k.n_tiles; ++t) {
-        const int C = k.tile_ncam[t];
-        if (C <= 0) continue;
-        for (int q = 0; q < 64 && k.slot_cam[64 * t + q] >= 0; ++q) cams[k.slot_cidx[64 * t + q]] = k.slot_cam[64 * t + q];
-        const unsigned char* cell = k.gt_cell.data() + k.tile_gt_off[t];
-        for (int a = 0; a < C; ++a)
-            for (int b = a + 1; b < C; ++b)
-                if (cell[a * C + b])
-                    keyed.push_back({((unsigned long long)(unsigned)cams[b] << 32) | (unsigned)cams[a], n_obs_pairs + k.tile_gt_off[t] + a * C + b});
-    }
-    std::sort(keyed.begin(), keyed.end());
+    keyed.reserve(nk);
+    for (const auto& v : local) keyed.insert(keyed.end(), v.begin(), v.end());
+    for (const auto& v : glocal) keyed.insert(keyed.end(), v.begin(), v.end());
+    std::sort(keyed.begin(), keyed.end());           // (key, index) pairs are distinct: the order does not depend on the pieces
     return 0;
 }
 

@@ -241,7 +241,7 @@ struct BatchUpload {
     xrsfm_ba_context* c;
     int err = 0;
     explicit BatchUpload(xrsfm_ba_context* ctx) : c(ctx) {}
-    template <typename T> void add(T** dst, const std::vector<T>& v) { add_raw(reinterpret_cast<void**>(dst), v.data(), v.size() * sizeof(T)); }
+    template <typename T, typename A> void add(T** dst, const std::vector<T, A>& v) { add_raw(reinterpret_cast<void**>(dst), v.data(), v.size() * sizeof(T)); }
     void add_raw(void** dst, const void* src, size_t bytes) {
         if (err) return;
         if (bytes >= ((size_t)1 << 20)) {
@@ -458,8 +458,10 @@ int chol_setup(xrsfm_ba_context* c) {
     const int Nc = k.n_cams;
     std::vector<int> spp;
     PairKeys keyed;
+    PhaseTimer timer("chol setup");
     int e = chol_local_keys(k, spp, keyed);
     if (e) return e;
+    timer.mark("pair keys");
     // multi-GPU: every rank must hold the same blocks in the same order so that the block values can be all-reduced:
     // union of the ranks' camera pairs by an all-reduce(max) of an N_c x N_c occupancy map (once per problem)
     if (c->n_ranks > 1 && !c->have_pattern) {
@@ -482,6 +484,7 @@ int chol_setup(xrsfm_ba_context* c) {
     }
     CholPlan P;
     if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P))) return e;
+    timer.mark("plan");
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
     if (6 * Nc > kCholMaxN && (!P.use_levels || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
@@ -510,6 +513,7 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
     up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
     TRYC(up.flush());
+    timer.mark("uploads");
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
         double* both = nullptr;
@@ -544,6 +548,7 @@ int chol_setup(xrsfm_ba_context* c) {
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) { (void)hipStreamDestroy(h.aux); h.aux = nullptr; }
     }
+    timer.mark("allocations + attributes");
     h.ready = true;
     return 0;
 }
@@ -719,8 +724,10 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     if (device < 0 || device >= ndev) return XRSFM_BA_EINVAL;
     xrsfm_ba_context* c = new xrsfm_ba_context();
     c->device = device;
+    PhaseTimer timer("create");
     int e = pack_problem(*p, c->pk);
     if (e) { delete c; return e; }
+    timer.mark("pack_problem");
     {
         HostBundle hb;
         if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
@@ -752,6 +759,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
         for (int a = 0; a < 3; ++a) P[3 * (size_t)j + a] = p->points[3 * (size_t)k.pt_orig[j] + a];
     std::vector<double> cam_act(k.n_cams);
     for (int i = 0; i < k.n_cams; ++i) cam_act[i] = (k.cam_ptr[i + 1] > k.cam_ptr[i]) ? 1.0 : 0.0;
+    timer.mark("stream + host staging");
 #define TRY(x) do { e = (x); if (e) { xrsfm_ba_destroy(c); return e; } } while (0)
     {
         // (const members of Dev are set through a cast: the arrays are written exactly once, here)
@@ -769,6 +777,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
         up.add(P_(d.pt_const), k.pt_const);
         TRY(up.flush());
     }
+    timer.mark("uploads");
     const size_t ns = (size_t)k.n_slots, nc = (size_t)k.n_cams, np = (size_t)k.n_pts;
     TRY(dev_alloc(c, &d.scale_c, nc * 6)); TRY(dev_alloc(c, &d.scale_p, np * 3));
     TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Jp, ns * 6)); TRY(dev_alloc(c, &d.camrec, nc));
@@ -789,6 +798,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     // (the scatter buffers need no clearing: every entry is written before it is read)
     if (hipMemsetAsync(d.scal, 0, sizeof(double) * S_COUNT, c->stream) != hipSuccess || hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
+    timer.mark("work buffers");
     *out = c;
     return XRSFM_BA_OK;
 }
