@@ -35,12 +35,12 @@ inline int gram_lds_need(int C, int T, int* passes) {
     return 6 * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + C * C * 4;
 }
 
-// Host-side helper: run fn(begin, end) over [0, n) on up to 8 threads (large problems only; the packing of config L is ~100 ms
+// Host-side helper: run fn(begin, end) over [0, n) on up to 8 threads (16 for the largest loops) (large problems only; the packing of config L is ~100 ms
 // of single-thread work otherwise).  The pieces are disjoint, so the result does not depend on the thread count.
 template <typename F>
 inline void pack_parallel_for(long long n, F&& fn, long long min_n = 200000) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(8u, hw);
+    const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(n >= 5 * min_n ? 16u : 8u, hw);
     if (nt == 1) { fn(0LL, n); return; }
     std::vector<std::thread> th;
     for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });

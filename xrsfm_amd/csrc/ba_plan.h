@@ -116,7 +116,24 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
     keyed.reserve(nk);
     for (const auto& v : local) keyed.insert(keyed.end(), v.begin(), v.end());
     for (const auto& v : glocal) keyed.insert(keyed.end(), v.begin(), v.end());
-    std::sort(keyed.begin(), keyed.end());           // (key, index) pairs are distinct: the order does not depend on the pieces
+    // (key, index) order.  The entries were appended in ascending index order (pairs by slot, then the Gram cells by tile), so a
+    // stable LSD radix sort over the two camera fields of the key gives it; small lists take std::sort.
+    if (keyed.size() < 50000) { std::sort(keyed.begin(), keyed.end()); return 0; }
+    int cam_bits = 1;
+    while (cam_bits < 32 && (1ll << cam_bits) < (long long)k.n_cams) ++cam_bits;
+    PairKeys tmp(keyed.size());
+    std::vector<unsigned> hist;
+    auto pass = [&](int shift, int bits) {
+        const size_t nb = (size_t)1 << bits;
+        const unsigned long long mask = nb - 1;
+        hist.assign(nb + 1, 0u);
+        for (const auto& e : keyed) hist[((e.first >> shift) & mask) + 1]++;
+        for (size_t b = 0; b < nb; ++b) hist[b + 1] += hist[b];
+        for (const auto& e : keyed) tmp[hist[(e.first >> shift) & mask]++] = e;
+        keyed.swap(tmp);
+    };
+    for (int field = 0; field < 2; ++field)
+        for (int done = 0; done < cam_bits; done += 16) pass(32 * field + done, std::min(16, cam_bits - done));
     return 0;
 }
 
