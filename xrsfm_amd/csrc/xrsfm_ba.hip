@@ -754,9 +754,11 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
         model[i] = p->intr_model[ii];
         cconst[i] = p->cam_const ? p->cam_const[i] : 0;
     }
-    std::vector<double> P(3 * (size_t)k.n_pts);
-    for (int j = 0; j < k.n_pts; ++j)
-        for (int a = 0; a < 3; ++a) P[3 * (size_t)j + a] = p->points[3 * (size_t)k.pt_orig[j] + a];
+    RawVec<double> P(3 * (size_t)k.n_pts);
+    pack_parallel_for(k.n_pts, [&](long long j0, long long j1) {
+        for (long long j = j0; j < j1; ++j)
+            for (int a = 0; a < 3; ++a) P[3 * (size_t)j + a] = p->points[3 * (size_t)k.pt_orig[j] + a];
+    });
     std::vector<double> cam_act(k.n_cams);
     for (int i = 0; i < k.n_cams; ++i) cam_act[i] = (k.cam_ptr[i + 1] > k.cam_ptr[i]) ? 1.0 : 0.0;
     timer.mark("stream + host staging");
@@ -865,10 +867,12 @@ int xrsfm_ba_download(xrsfm_ba_context* c, double* cam_q, double* cam_t, double*
         }
     }
     if (points) {
-        std::vector<double> P(3 * (size_t)k.n_pts);
+        RawVec<double> P(3 * (size_t)k.n_pts);       // (uninitialised: overwritten by the copy)
         if (k.n_pts) HIPCHK(hipMemcpy(P.data(), c->d.P, sizeof(double) * P.size(), hipMemcpyDeviceToHost));
-        for (int j = 0; j < k.n_pts; ++j)
-            for (int a = 0; a < 3; ++a) points[3 * (size_t)k.pt_orig[j] + a] = P[3 * (size_t)j + a];
+        pack_parallel_for(k.n_pts, [&](long long j0, long long j1) {      // back to the caller's point order
+            for (long long j = j0; j < j1; ++j)
+                for (int a = 0; a < 3; ++a) points[3 * (size_t)k.pt_orig[j] + a] = P[3 * (size_t)j + a];
+        });
     }
     return 0;
 }
