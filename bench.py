@@ -13,8 +13,9 @@ N > 1: one process per GPU (torch.distributed.run); the tracks are sharded by
 point over the ranks, cameras replicated, per-camera sums and the reduced camera
 blocks all-reduced with RCCL inside the library (xrsfm_ba_comm_init).
   --scaling weak (default): the point set grows with N (N x 500k points over the
-      same 1000 cameras at config L), so every rank keeps a config-sized shard --
-      the regime the sharding is for (maps that outgrow one GPU);
+      same 1000 cameras at config L; every rank generates and holds one
+      config-sized shard) -- the regime the sharding is for (maps that outgrow
+      one GPU);
   --scaling strong: the SAME problem is split over the ranks (BASELINE.json
       config 4 read literally).  One solve of L is 8.8 ms on one GPU and a third
       of each LM iteration is the replicated exact factorisation of the reduced
@@ -59,12 +60,12 @@ def shard_problem(arr: dict, rank: int, world: int) -> dict:
     return out
 
 
-def weak_scaled_config(cfg: dict, world: int) -> dict:
-    """Weak scaling: `world` times the points of the configuration over the same cameras (camera poses do not depend on the
-    point count: the generator draws them first), so that the j % world shard of every rank has the configuration's size."""
-    out = dict(cfg)
-    out["n_points"] = cfg["n_points"] * world
-    return out
+def weak_scaled_shard(cfg: dict, rank: int, world: int) -> dict:
+    """Weak scaling: the problem of `world` ranks is the union of `world` configuration-sized point shards over the same
+    cameras (synth.make_problem(point_seed=rank): cameras from the seed alone, points from a stream per shard), so every rank
+    generates only its own shard.  world == 1 is the configuration itself (the historical single-stream problem)."""
+    from xrsfm_amd import synth
+    return synth.make_problem(**cfg) if world == 1 else synth.make_problem(**cfg, point_seed=rank)
 
 
 def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, nnzb: int = 0):
@@ -182,11 +183,20 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     cfg = dict(synth.CONFIGS[args.config])
-    cfg = weak_scaled_config(cfg, world) if args.scaling == "weak" else cfg
-    full = synth.make_problem(**cfg)
-    arr = {k: full[k] for k in capi.ProblemArrays.FIELDS}
-    n_cams, n_points, n_obs = arr["cam_q"].shape[0], arr["points"].shape[0], arr["obs_cam"].shape[0]
-    local = shard_problem(arr, rank, world)
+    if args.scaling == "weak":
+        full = weak_scaled_shard(cfg, rank, world)
+        arr = {k: full[k] for k in capi.ProblemArrays.FIELDS}
+        local = arr
+        n_cams = arr["cam_q"].shape[0]
+        sizes = torch.tensor([arr["points"].shape[0], arr["obs_cam"].shape[0]], dtype=torch.int64, device="cuda")
+        if world > 1:
+            dist.all_reduce(sizes)
+        n_points, n_obs = int(sizes[0].item()), int(sizes[1].item())      # of the whole job
+    else:
+        full = synth.make_problem(**cfg)
+        arr = {k: full[k] for k in capi.ProblemArrays.FIELDS}
+        n_cams, n_points, n_obs = arr["cam_q"].shape[0], arr["points"].shape[0], arr["obs_cam"].shape[0]
+        local = shard_problem(arr, rank, world)
     prob = capi.ProblemArrays(**{k: np.array(v, copy=True) for k, v in local.items()})
     ctx = capi.Context(prob, device=local_rank)
     if world > 1 or os.environ.get("XRSFM_BA_FORCE_COMM") == "1":     # the env var exercises the RCCL path on one GPU

@@ -30,7 +30,7 @@ def _worker(rank, world, port, arr, solver, opt_kw, out_prefix):
         t = torch.from_numpy(buf)
         dist.all_reduce(t, op=dist.ReduceOp.SUM if op == 0 else dist.ReduceOp.MAX)
 
-    local = shard_problem(arr, rank, world)
+    local = arr[rank] if isinstance(arr, list) else shard_problem(arr, rank, world)      # list: one ready-made shard per rank
     ctx = capi.Context(H.to_product(local))
     ctx.comm_hook(world, rank, allreduce)
     s = ctx.run(capi.default_options(linear_solver=solver, **opt_kw))
@@ -68,3 +68,34 @@ def test_ranks_equal_one_rank(lib, tmp_path, solver, mode, world):
     ptol = 1e-2 if mode == "ragged" else 1e-5
     for r in range(world):
         assert np.abs(z[r]["P"] - ref.points[np.arange(n_p) % world == r]).max() < ptol
+
+
+@pytest.mark.gpu
+def test_weak_scaling_shards_equal_their_union(lib, tmp_path):
+    """bench.py --scaling weak: every rank holds its own generated shard (synth.make_problem(point_seed=rank)).  Two such ranks
+    must take the LM decisions of, and end with the cameras of, the single-rank solve of the union problem."""
+    from xrsfm_amd import capi, synth
+    cfg = dict(n_cams=24, n_points=1200, k_obs=4, seed=141)
+    fields = capi.ProblemArrays.FIELDS
+    shards = [{k: v for k, v in synth.make_problem(**cfg, point_seed=r).items() if k in fields} for r in range(2)]
+    union = dict(shards[0])
+    union["points"] = np.vstack([sh["points"] for sh in shards])
+    union["point_const"] = np.concatenate([sh["point_const"] for sh in shards])
+    union["obs_cam"] = np.concatenate([sh["obs_cam"] for sh in shards])
+    union["obs_pt"] = np.concatenate([shards[0]["obs_pt"], shards[1]["obs_pt"] + shards[0]["points"].shape[0]]).astype(np.int32)
+    union["obs_uv"] = np.vstack([sh["obs_uv"] for sh in shards])
+    opt_kw = dict(max_iterations=8)
+    ref = H.to_product(union)
+    s1 = capi.solve(ref, capi.default_options(linear_solver=1, **opt_kw))
+    prefix = str(tmp_path / "weak")
+    mp.spawn(_worker, args=(2, _free_port(), shards, 1, opt_kw, prefix), nprocs=2, join=True)
+    z = [np.load(f"{prefix}{r}.npz") for r in range(2)]
+    n_res = 2 * union["obs_cam"].shape[0]
+    n0 = shards[0]["points"].shape[0]
+    for r in range(2):
+        assert tuple(z[r]["stat"]) == (s1.n_successful, s1.n_unsuccessful, s1.termination_reason)
+        assert abs(z[r]["cost"][0] - s1.initial_cost) <= 1e-12 * s1.initial_cost
+        assert abs(np.sqrt(z[r]["cost"][1] / n_res) - np.sqrt(s1.final_cost / n_res)) < 1e-6
+        assert np.abs(z[r]["q"] - ref.cam_q).max() < 1e-5 and np.abs(z[r]["t"] - ref.cam_t).max() < 1e-5
+        assert np.abs(z[r]["P"] - ref.points[r * n0:(r + 1) * n0]).max() < 1e-5
+    assert np.array_equal(z[0]["q"], z[1]["q"]) and np.array_equal(z[0]["t"], z[1]["t"])

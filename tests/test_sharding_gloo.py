@@ -79,20 +79,31 @@ def test_point_sharding_and_allreduce_reproduce_single_rank(tmp_path):
     assert H.rel_err(z["sx"], bo._scatter_add(n_c, pr.obs_cam, np.einsum("nki,nk->ni", lin.Fs, zz))) < 1e-12
 
 
-def test_weak_scaled_workload_keeps_cameras_and_shard_size():
-    """bench.py --scaling weak: N x the points over the SAME cameras (ground truth and initial state of every camera do not
-    depend on N... the generator draws the cameras first), every rank's j % N shard has the configuration's size."""
-    from bench import shard_problem, weak_scaled_config
+def test_weak_scaled_shards_share_cameras_and_differ_in_points():
+    """bench.py --scaling weak: rank r generates synth.make_problem(point_seed=r): the cameras (ground truth and perturbed
+    initial state) depend on the seed alone, the points / observations come from a stream per shard; world == 1 is the
+    historical single-stream problem."""
+    from bench import weak_scaled_shard
     from xrsfm_amd import synth
     cfg = dict(n_cams=40, n_points=3000, k_obs=4, seed=9)
-    one = synth.make_problem(**cfg)
-    four = synth.make_problem(**weak_scaled_config(cfg, 4))
-    assert four["points"].shape[0] == 4 * one["points"].shape[0] and four["obs_cam"].shape[0] == 4 * one["obs_cam"].shape[0]
-    assert np.array_equal(four["gt_q"], one["gt_q"]) and np.array_equal(four["gt_t"], one["gt_t"])
-    parts = [shard_problem({k: four[k] for k in ("cam_q", "cam_t", "cam_const", "cam_intr", "intr_model", "intr_params", "points",
-                                                 "point_const", "obs_cam", "obs_pt", "obs_uv")}, r, 4) for r in range(4)]
-    assert [p["points"].shape[0] for p in parts] == [3000] * 4
-    assert all(abs(p["obs_cam"].shape[0] - one["obs_cam"].shape[0]) == 0 for p in parts)
-    assert all(np.array_equal(p["cam_q"], four["cam_q"]) for p in parts)
-    # every camera keeps observations in every shard (the per-camera sums of all ranks are meaningful)
-    assert all(np.unique(p["obs_cam"]).size == 40 for p in parts)
+    one = weak_scaled_shard(cfg, 0, 1)
+    ref = synth.make_problem(**cfg)
+    assert all(np.array_equal(one[k], ref[k]) for k in ref)
+    shards = [weak_scaled_shard(cfg, r, 4) for r in range(4)]
+    for sh in shards:
+        assert sh["points"].shape == (3000, 3) and sh["obs_cam"].shape[0] == ref["obs_cam"].shape[0]
+        assert np.array_equal(sh["gt_q"], ref["gt_q"]) and np.array_equal(sh["gt_t"], ref["gt_t"])          # same scene cameras
+        assert np.array_equal(sh["cam_q"], shards[0]["cam_q"]) and np.array_equal(sh["cam_t"], shards[0]["cam_t"])
+        assert np.array_equal(sh["cam_const"], ref["cam_const"])
+        assert np.unique(sh["obs_cam"]).size == 40             # every camera has observations in every shard
+    assert not np.array_equal(shards[0]["points"], shards[1]["points"])
+    assert not np.array_equal(shards[0]["gt_points"], ref["gt_points"])
+    # the union is a consistent BA problem: the ground truth reprojects onto every shard's observations up to the noise
+    from oracle import ba_oracle as bo
+    for sh in shards[:2]:
+        arr = {k: sh[k] for k in ("cam_q", "cam_t", "cam_const", "cam_intr", "intr_model", "intr_params", "points", "point_const",
+                                   "obs_cam", "obs_pt", "obs_uv")}
+        pr = H.to_oracle(dict(arr, cam_q=sh["gt_q"], cam_t=sh["gt_t"], points=sh["gt_points"]))
+        cost = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points, want_jac=False)
+        rmse = np.sqrt(2 * cost / (2 * sh["obs_cam"].shape[0]))
+        assert rmse < 2.0, rmse            # 0.5 px noise + 2 % outliers under the Huber loss

@@ -79,12 +79,17 @@ def _project_simple_radial(q, t, P, intr):
 def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
                  mode: str = "sequential", k_dist: float = 0.0, noise: float = 0.5,
                  outlier_frac: float = 0.02, perturb=(0.01, 0.05, 0.10),
-                 min_tri_angle_deg: float = 2.0, dropout: float = 0.0) -> dict:
+                 min_tri_angle_deg: float = 2.0, dropout: float = 0.0, point_seed: int | None = None) -> dict:
     """Return a dict of flat arrays (keys = fields of ``xrsfm_ba_problem``) + ground truth.
     ``dropout`` > 0 removes each observation with that probability (at least two per point stay): ragged tracks with many
-    distinct camera tuples, like a real reconstruction with missed detections."""
+    distinct camera tuples, like a real reconstruction with missed detections.
+    ``point_seed``: None = one random stream for everything (the historical problems).  An integer makes the cameras
+    (ground truth AND perturbed initial state) a function of ``seed`` alone and draws the points, observations and their
+    noise from a stream of their own: calls that differ only in ``point_seed`` are disjoint point shards of one larger
+    problem over the same cameras (bench.py --scaling weak, one shard per rank)."""
     assert n_cams >= k_obs >= 1
     rng = np.random.Generator(np.random.PCG64(seed))
+    rng_cam0 = rng if point_seed is None else np.random.Generator(np.random.PCG64([seed, 999983]))
     intr = (KITTI_INTR[0], KITTI_INTR[1], KITTI_INTR[2], k_dist)
     # Closed loop with a constant inter-camera spacing of 2*pi*40/100 = 2.51 units (the spacing of
     # BASELINE.json config 2: 100 cameras on a radius-40 ring; a KITTI-like per-frame baseline), so the
@@ -115,6 +120,8 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     Rq = _rot_from_quat(q_gt)
     t_gt = -np.einsum("nij,nj->ni", Rq, centre)
 
+    if point_seed is not None:
+        rng = np.random.Generator(np.random.PCG64([seed, 1000003 + int(point_seed)]))
     # points: base camera c0, placed in the frustum of camera c0 + k_obs/2, seen by k_obs cameras
     P_gt = np.empty((n_points, 3))
     cams_of = np.empty((n_points, k_obs), dtype=np.int64)
@@ -182,8 +189,8 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     # perturbed initial state; frames 0/1 keep their translation (gauge)
     s_rot, s_t, s_p = perturb
     # rotation and camera CENTRE are perturbed (t = -R c follows); the gauge frames 0/1 stay exact
-    drot = rng.normal(0, s_rot, (n_cams, 3)); drot[0:2] = 0.0
-    dcen = rng.normal(0, s_t, (n_cams, 3)); dcen[0:2] = 0.0
+    drot = rng_cam0.normal(0, s_rot, (n_cams, 3)); drot[0:2] = 0.0
+    dcen = rng_cam0.normal(0, s_t, (n_cams, 3)); dcen[0:2] = 0.0
     q0 = _quat_plus(q_gt, drot)
     t0 = -np.einsum("nij,nj->ni", _rot_from_quat(q0), centre + dcen)
     t0[0:2] = t_gt[0:2]; q0[0:2] = q_gt[0:2]
