@@ -228,7 +228,11 @@ def test_profile_entries(lib):
     ctx = capi.Context(H.to_product(arr))
     s = ctx.run(capi.default_options(profile=1))
     prof = ctx.profile()
-    assert prof["k_linearize"][1] == s.n_successful + 2      # two linearisations at iteration 0, one per accepted step
+    # two linearisations at iteration 0; then every attempted step is followed either by a linearisation at the candidate
+    # (its cost is the candidate cost) or, after a rejected step, by a cost-only pass plus a linearisation if it is accepted
+    n_lin, n_cost = prof["k_linearize"][1], prof["k_cost"][1]
+    assert 2 + s.n_successful <= n_lin <= 2 + s.lm_steps_attempted
+    assert n_cost <= s.n_unsuccessful and (n_lin - 2) + n_cost >= s.lm_steps_attempted
     assert prof["k_potrf"][1] > 0 and s.dom_kernel_ms > 0
     ctx.close()
 

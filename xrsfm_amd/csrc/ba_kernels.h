@@ -32,7 +32,7 @@ struct PcgStatus {
 
 // scalar slots (device buffer `scal`)
 enum Scal {
-    S_COST = 0, S_XNORM2_PTS, S_COST_CAND, S_MODEL, S_STEP2_PTS, S_STEP2_CAMS, S_XNORM2_CAMS,
+    S_COST = 0, S_XNORM2_PTS, S_MODEL, S_STEP2_PTS, S_COST_CAND, S_STEP2_CAMS, S_XNORM2_CAMS,     // [0,4) and [2,5) each travel in one all-reduce
     S_GRADMAX_PTS, S_GRADMAX_CAMS, S_COUNT = 16
 };
 

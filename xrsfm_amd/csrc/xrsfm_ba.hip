@@ -136,6 +136,9 @@ struct xrsfm_ba_context {
     std::vector<Rec> recs;
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
     bool linearized = false;
+    // Second set of linearisation buffers: every LM step linearises at the CANDIDATE point right after the back-substitution
+    // (its cost is the candidate cost the step test needs, so no separate cost pass exists); an accepted step swaps the sets.
+    struct LinBuf { double* rt = nullptr; double* Jp = nullptr; CamLin* camrec = nullptr; double* Hpp = nullptr; double* gp = nullptr; double* camlin = nullptr; } alt;
     std::vector<unsigned long long> pattern_keys;   // union of the ranks' off-diagonal camera pairs ((row << 32) | col), sorted
     bool have_pattern = false;
     CholHost chol;
@@ -349,48 +352,51 @@ int fetch_scalars(xrsfm_ba_context* c) {
     return 0;
 }
 
-// Linearise at the current state (scale arrays as they are).  Leaves S_COST, S_XNORM2_PTS in d.scal
-// and camlin / Hpp / gp filled.
-int linearize(xrsfm_ba_context* c, double huber_a) {
-    Dev& d = c->d;
+// Linearise at the state `d` views (the context's own Dev, or the candidate view of finish_step).  Leaves S_COST, S_XNORM2_PTS in
+// the scalar block and camlin / Hpp / gp / rt / Jp of that view filled.  with_step: the partial sums the preceding
+// back-substitution left (model decrease, squared step norms, |x_cams|^2) are reduced by the same launch and, with several
+// ranks, travel in the same all-reduce: layout behind the camera block = [cost, |x_pts|^2, model, |step_pts|^2, rank slots].
+int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step) {
+    const Dev& own = c->d;
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_lin, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), kWavesPerBlock * kWave * 13 * sizeof(double), d, huber_a);
     if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camlin, (const PcgStatus*)nullptr);
     {
-        // the two scalar partial sums land behind the camera block so that ONE all-reduce covers both
         double* tail = d.camlin + (size_t)d.n_cams * 12;
+        const bool multi = c->multi();
         ReduceJobs j{};
-        j.in[0] = d.part; j.n[0] = d.n_items; j.out[0] = tail; j.op[0] = 0;
-        j.in[1] = d.part + d.n_items; j.n[1] = d.n_items; j.out[1] = tail + 1; j.op[1] = 0;
+        int nj = 0;
+        auto job = [&](const double* in, int n, double* out, int op) { j.in[nj] = in; j.n[nj] = n; j.out[nj] = out; j.op[nj] = op; ++nj; };
+        job(d.part, d.n_items, multi ? tail : d.scal + S_COST, 0);
+        job(d.part + d.n_items, d.n_items, multi ? tail + 1 : d.scal + S_XNORM2_PTS, 0);
         // max-norm of the point gradient: points are rank-local, so with several ranks every rank writes its maximum to its own
         // slot behind the sums (the other slots are 0): the SUM all-reduce then hands every rank all the maxima
-        j.in[2] = d.part + 2 * (size_t)d.n_items; j.n[2] = d.n_items; j.op[2] = 1;
-        j.out[2] = c->multi() ? tail + 2 + c->rank : d.scal + S_GRADMAX_PTS;
-        if (!c->multi()) {     // single rank: the sums go straight to the scalar block as well
-            j.in[3] = j.in[0]; j.n[3] = j.n[0]; j.out[3] = d.scal + S_COST; j.op[3] = 0;
-            j.in[4] = j.in[1]; j.n[4] = j.n[1]; j.out[4] = d.scal + S_XNORM2_PTS; j.op[4] = 0;
-        } else {
-            HIPCHK(hipMemsetAsync(tail + 2, 0, sizeof(double) * (size_t)c->n_ranks, c->stream));
+        job(d.part + 2 * (size_t)d.n_items, d.n_items, multi ? tail + 4 + c->rank : d.scal + S_GRADMAX_PTS, 1);
+        if (with_step) {
+            job(own.part + 2 * (size_t)own.n_items, own.n_items, multi ? tail + 2 : d.scal + S_MODEL, 0);
+            job(own.part + 3 * (size_t)own.n_items, own.n_items, multi ? tail + 3 : d.scal + S_STEP2_PTS, 0);
+            job(own.campart, own.n_cams, d.scal + S_STEP2_CAMS, 0);
+            job(own.campart + own.n_cams, own.n_cams, d.scal + S_XNORM2_CAMS, 0);
         }
-        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(c->multi() ? 3 : 5), dim3(kPcgThreads), 0, j);
-        if (c->multi()) {
-            int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 2 + (size_t)c->n_ranks, kNcclSum);
+        if (multi) HIPCHK(hipMemsetAsync(tail + 2, 0, sizeof(double) * (2 + (size_t)c->n_ranks), c->stream));
+        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(nj), dim3(kPcgThreads), 0, j);
+        if (multi) {
+            int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 4 + (size_t)c->n_ranks, kNcclSum);
             if (e) return e;
-            HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST, S_XNORM2_PTS adjacent
+            HIPCHK(hipMemcpyAsync(d.scal + S_COST, tail, 4 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));   // S_COST .. S_STEP2_PTS adjacent
         }
     }
     return 0;
 }
 
-// after linearize(), which leaves the point part in S_GRADMAX_PTS (one rank) or in the per-rank slots behind camlin
-int gradient_max_enqueue(xrsfm_ba_context* c) {
-    Dev& d = c->d;
-    const double* rank_max = c->multi() ? d.camlin + (size_t)d.n_cams * 12 + 2 : nullptr;
+// after linearize() of the same view, which leaves the point part in S_GRADMAX_PTS (one rank) or in the per-rank slots behind camlin
+int gradient_max_enqueue(xrsfm_ba_context* c, const Dev& d) {
+    const double* rank_max = c->multi() ? d.camlin + (size_t)d.n_cams * 12 + 4 : nullptr;
     LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, d.scal + S_GRADMAX_CAMS, rank_max, c->n_ranks, d.scal + S_GRADMAX_PTS);
     return 0;
 }
 int gradient_max(xrsfm_ba_context* c, double* out) {
-    int e = gradient_max_enqueue(c);
+    int e = gradient_max_enqueue(c, c->d);
     if (e) return e;
     e = fetch_scalars(c);
     if (e) return e;
@@ -632,10 +638,39 @@ int chol_factor_solve(xrsfm_ba_context* c) {
 }
 
 // back-substitute, build the candidate state, evaluate its cost; scalars end up in h_scal
-int finish_step(xrsfm_ba_context* c, double huber_a) {
+// The candidate view of the problem: state = the candidate cameras / points, linearisation buffers = the alternate set,
+// partial sums in the upper half of `part` (the back-substitution's partials in the lower half are still to be reduced).
+Dev candidate_view(const xrsfm_ba_context* c) {
+    Dev v = c->d;
+    std::swap(v.cam, v.cam_cand); std::swap(v.P, v.P_cand);
+    v.rt = c->alt.rt; v.Jp = c->alt.Jp; v.camrec = c->alt.camrec; v.Hpp = c->alt.Hpp; v.gp = c->alt.gp; v.camlin = c->alt.camlin;
+    v.part = c->d.part + 4 * (size_t)c->d.n_items;
+    return v;
+}
+void accept_candidate(xrsfm_ba_context* c) {
+    Dev& d = c->d;
+    std::swap(d.cam, d.cam_cand); std::swap(d.P, d.P_cand);
+    std::swap(d.rt, c->alt.rt); std::swap(d.Jp, c->alt.Jp); std::swap(d.camrec, c->alt.camrec);
+    std::swap(d.Hpp, c->alt.Hpp); std::swap(d.gp, c->alt.gp); std::swap(d.camlin, c->alt.camlin);
+}
+
+// Back-substitution -> candidate state, then either
+//   speculate: linearisation AT the candidate (its cost is the candidate cost; if the step is accepted the next iteration
+//              starts from it and nothing else has to run), or
+//   otherwise: a cost-only pass over the candidate (the linearisation follows only if the step is accepted).
+// The caller speculates while steps are being accepted: a rejected step wastes the difference between the two passes.
+// One hand-off of all scalars to the host either way.
+int finish_step(xrsfm_ba_context* c, double huber_a, bool speculate) {
     Dev& d = c->d;
     if (d.n_items > 0) LAUNCH(c, K_BACKSUB, k_backsub, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d);
     if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
+    if (speculate) {
+        const Dev cand = candidate_view(c);
+        int e = linearize(c, huber_a, cand, true);
+        if (e) return e;
+        if ((e = gradient_max_enqueue(c, cand))) return e;
+        return fetch_scalars(c);
+    }
     if (d.n_items > 0) LAUNCH(c, K_COST, k_cost, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, huber_a);
     {
         ReduceJobs j{};
@@ -645,7 +680,7 @@ int finish_step(xrsfm_ba_context* c, double huber_a) {
         for (int q = 0; q < 5; ++q) { j.in[q] = ins[q]; j.n[q] = ns[q]; j.out[q] = outs[q]; j.op[q] = 0; }
         LAUNCH(c, K_SMALL, k_reduce_multi, dim3(5), dim3(kPcgThreads), 0, j);
     }
-    int e = allreduce(c, d.scal + S_COST_CAND, 3, kNcclSum);   // COST_CAND, MODEL, STEP2_PTS adjacent
+    int e = allreduce(c, d.scal + S_MODEL, 3, kNcclSum);   // MODEL, STEP2_PTS, COST_CAND adjacent
     if (e) return e;
     return fetch_scalars(c);
 }
@@ -661,12 +696,12 @@ int init_scaling_and_linearize(xrsfm_ba_context* c, double huber_a, bool use_sca
     int e;
     LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_cams * 6, kBlock) + 1), dim3(kBlock), 0, d.scale_c, 1.0, (size_t)d.n_cams * 6);
     LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, d.scale_p, 1.0, (size_t)d.n_pts * 3);
-    if ((e = linearize(c, huber_a))) return e;
+    if ((e = linearize(c, huber_a, d, false))) return e;
     if (use_scaling) {
         // point norms are local to the rank that owns the track; camera norms were all-reduced in linearize()
         const long long n = std::max((long long)d.n_cams * 6, (long long)d.n_pts * 3);
         LAUNCH(c, K_SMALL, k_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, d);
-        if ((e = linearize(c, huber_a))) return e;
+        if ((e = linearize(c, huber_a, d, false))) return e;
     }
     c->linearized = true;
     return 0;
@@ -783,14 +818,15 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     const size_t ns = (size_t)k.n_slots, nc = (size_t)k.n_cams, np = (size_t)k.n_pts;
     TRY(dev_alloc(c, &d.scale_c, nc * 6)); TRY(dev_alloc(c, &d.scale_p, np * 3));
     TRY(dev_alloc(c, &d.rt, ns * 2)); TRY(dev_alloc(c, &d.Jp, ns * 6)); TRY(dev_alloc(c, &d.camrec, nc));
-    TRY(dev_alloc(c, &d.Hpp, np * 6)); TRY(dev_alloc(c, &d.gp, np * 3)); TRY(dev_alloc(c, &d.Hinv, np * 6)); TRY(dev_alloc(c, &d.Hc, np * 6));
-    TRY(dev_alloc(c, &d.camlin, nc * 12 + 2 + kMaxRanks)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
+    TRY(dev_alloc(c, &c->alt.rt, ns * 2)); TRY(dev_alloc(c, &c->alt.Jp, ns * 6)); TRY(dev_alloc(c, &c->alt.camrec, nc));
+    TRY(dev_alloc(c, &d.Hpp, np * 6)); TRY(dev_alloc(c, &d.gp, np * 3)); TRY(dev_alloc(c, &c->alt.Hpp, np * 6)); TRY(dev_alloc(c, &c->alt.gp, np * 3)); TRY(dev_alloc(c, &d.Hinv, np * 6)); TRY(dev_alloc(c, &d.Hc, np * 6));
+    TRY(dev_alloc(c, &d.camlin, nc * 12 + 4 + kMaxRanks)); TRY(dev_alloc(c, &c->alt.camlin, nc * 12 + 4 + kMaxRanks)); TRY(dev_alloc(c, &d.Dc2, nc * 6)); TRY(dev_alloc(c, &d.camS, nc * 28));
     TRY(dev_alloc(c, &d.Minv, nc * 21)); TRY(dev_alloc(c, &d.b, nc * 6));
     TRY(dev_alloc(c, &d.px, nc * 6 + kNB)); TRY(dev_alloc(c, &d.pr, nc * 6)); TRY(dev_alloc(c, &d.pz, nc * 6));
     TRY(dev_alloc(c, &d.pp, nc * 6)); TRY(dev_alloc(c, &d.pq, nc * 6));
     TRY(dev_alloc(c, &d.yp, np * 3));
     TRY(dev_alloc(c, &d.scat, (size_t)(k.n_obs > 0 ? k.n_obs : 1) * 28));
-    TRY(dev_alloc(c, &d.part, (size_t)d.n_items * 4));
+    TRY(dev_alloc(c, &d.part, (size_t)d.n_items * 7));      // [0,4n): own view (linearise 0..3n, back-substitution 2n..4n); [4n,7n): candidate view
     TRY(dev_alloc(c, &d.campart, nc * 2));
     TRY(dev_alloc(c, &d.ptpart, np / kBlock + 2));
     TRY(dev_alloc(c, &d.pcgpart, nc * 3));
@@ -928,25 +964,19 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
     if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
     int it = 0, invalid = 0;
     const double max_radius = 1e16, min_radius = 1e-32, min_rel_decrease = 1e-3;
-    // After an accepted step the new linearisation is only ENQUEUED: its cost, |x|^2 and gradient max-norm stay in the device
-    // scalar block and reach the host together with the scalars of the next step (one host round trip per LM iteration
-    // instead of two).  The gradient-tolerance exit is then detected one solve late; that solve is discarded and not counted.
-    bool pending = false;
-    auto take_pending = [&]() {
-        cost = 0.5 * c->h_scal[S_COST];
-        xnorm2_pts = c->h_scal[S_XNORM2_PTS];
-        gmax = std::fmax(c->h_scal[S_GRADMAX_PTS], c->h_scal[S_GRADMAX_CAMS]);
-        pending = false;
-    };
+    // While steps are being accepted, finish_step() linearises at the candidate straight away: one host round trip per LM
+    // iteration hands over the model decrease and step norms of the step AND the cost, |x|^2 and gradient max-norm at the
+    // candidate.  After a rejected step (they come in runs while the radius collapses) only the cost of the candidate is
+    // evaluated, and the linearisation follows once a step is accepted again; once a solve has seen a rejection, two accepted
+    // steps in a row are needed before the next one is linearised ahead again (near convergence accepted and rejected steps
+    // alternate, and a wasted linearisation costs more than a saved cost pass).
+    // XRSFM_BA_SPECULATE = 0 (never) / 1 (whenever the last step was accepted) overrides the rule: measurement aid
+    const char* spec_env = std::getenv("XRSFM_BA_SPECULATE");
+    const int spec_mode = spec_env ? std::atoi(spec_env) : 2;
+    bool speculate = spec_mode != 0;
+    int accepted_run = 0;
     while (true) {
-        if (it >= opt.max_iterations) {
-            if (pending) {
-                if ((e = fetch_scalars(c))) return e;
-                take_pending();
-                if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
-            }
-            return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
-        }
+        if (it >= opt.max_iterations) return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
         ++it;
         sum->lm_steps_attempted++;
         if ((e = prepare_step(c, radius, solver == XRSFM_BA_SOLVER_CHOLESKY))) return e;
@@ -956,14 +986,7 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
             if ((e = chol_assemble(c))) return e;
             if ((e = chol_factor_solve(c))) return e;
         }
-        if ((e = finish_step(c, opt.huber_a))) return e;
-        if (pending) {
-            take_pending();
-            if (gmax <= opt.gradient_tolerance) {     // the solve above started from a converged point: discard it
-                --it; sum->lm_steps_attempted--;
-                return finish(XRSFM_BA_CONVERGENCE, 1, cost);
-            }
-        }
+        if ((e = finish_step(c, opt.huber_a, speculate))) return e;
         const double* s = c->h_scal;
         const double model_change = s[S_MODEL];
         const double xnorm = std::sqrt(xnorm2_pts + s[S_XNORM2_CAMS]);
@@ -976,7 +999,7 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
             continue;
         }
         invalid = 0;
-        const double cost_cand = 0.5 * s[S_COST_CAND];
+        const double cost_cand = 0.5 * (speculate ? s[S_COST] : s[S_COST_CAND]);    // (S_COST: of the linearisation at the candidate)
         const double step_norm = std::sqrt(s[S_STEP2_PTS] + s[S_STEP2_CAMS]);
         if (step_norm <= opt.parameter_tolerance * (xnorm + opt.parameter_tolerance))
             return finish(XRSFM_BA_CONVERGENCE, 2, cost);
@@ -984,23 +1007,28 @@ int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_sum
         if (std::fabs(cost_change) <= opt.function_tolerance * cost) return finish(XRSFM_BA_CONVERGENCE, 3, cost);
         const double rel = cost_change / model_change;
         if (rel > min_rel_decrease) {
-            std::swap(d.cam, d.cam_cand);
-            std::swap(d.P, d.P_cand);
-            if ((e = linearize(c, opt.huber_a))) return e;
-            radius = std::fmin(max_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
-            decrease = 2.0;
-            sum->n_successful++;
-            if (opt.verbose || c->profiling) {     // the progress line needs the numbers now; profiling drains its event pool at every fetch
+            if (speculate) {
+                accept_candidate(c);
+                cost = cost_cand;
+                xnorm2_pts = s[S_XNORM2_PTS];
+                gmax = std::fmax(s[S_GRADMAX_PTS], s[S_GRADMAX_CAMS]);
+            } else {
+                std::swap(d.cam, d.cam_cand);
+                std::swap(d.P, d.P_cand);
+                if ((e = linearize(c, opt.huber_a, d, false))) return e;
                 if ((e = gradient_max(c, &gmax))) return e;
                 cost = 0.5 * c->h_scal[S_COST];
                 xnorm2_pts = c->h_scal[S_XNORM2_PTS];
-                print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
-                if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
-            } else {
-                if ((e = gradient_max_enqueue(c))) return e;
-                pending = true;
             }
+            ++accepted_run;
+            speculate = spec_mode == 2 ? (sum->n_unsuccessful == 0 || accepted_run >= 2) : spec_mode == 1;
+            radius = std::fmin(max_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
+            decrease = 2.0;
+            sum->n_successful++;
+            print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
+            if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
         } else {
+            speculate = false; accepted_run = 0;
             radius /= decrease; decrease *= 2.0;
             sum->n_unsuccessful++;
             print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
