@@ -275,7 +275,7 @@ def main():
             "config": {"workload": f"synthetic BAL-style {args.config}: {n_cams} cams / {n_points} points / {n_obs} obs, "
                                    f"GBA accurate (ba_solver.cc:626-629), seed {cfg['seed']}",
                        "parallelism": (f"points sharded x{world} ({prob.n_points} points / {prob.n_obs} obs on rank 0), cameras replicated, "
-                                       f"3 RCCL all-reduces per LM iteration") if world > 1 else "single GPU",
+                                       f"2 RCCL all-reduces per accepted LM step") if world > 1 else "single GPU",
                        "linear_solver": "cholesky (explicit reduced camera matrix, exact)" if last.linear_solver_used == 1
                        else f"implicit-Schur PCG tol {opt.pcg_tolerance:g}"},
             "lm_iterations_per_step": iters / args.steps, "pcg_iterations_per_step": pcg / args.steps,
