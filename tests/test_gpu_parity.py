@@ -367,6 +367,20 @@ def test_filter_tracks_matches_reference_rules(lib, variant):
     assert np.abs(got["track_angle"][keep] - ref["track_angle"][keep]).max() < 1e-12
 
 
+def test_filter_tracks_reproduces_golden(lib):
+    """tests/golden/track_filter.npz (make_golden_extra.py): masks and counters bit-exact, error / angle to 1e-9 / 1e-12."""
+    import os
+    from xrsfm_amd import capi
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "track_filter.npz"))
+    arr = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    got = capi.filter_tracks(H.to_product(arr), float(z["max_re"]), float(z["min_angle"]))
+    for k in ("obs_delete", "track_outlier", "num_filtered"):
+        assert np.array_equal(got[k], z["out_" + k]), k
+    keep = z["out_track_outlier"] != 1
+    assert np.abs(got["track_error"][keep] - z["out_track_error"][keep]).max() < 1e-9
+    assert np.abs(got["track_angle"][keep] - z["out_track_angle"][keep]).max() < 1e-12
+
+
 def test_headline_config_properties(lib):
     """BASELINE.json config 4 (1k cams / 500k points / 2M obs), the bench workload: termination, cost decrease, the
     reported cost is the cost of the returned state, bit-reproducibility, and RMSE parity with the C restatement."""

@@ -9,7 +9,9 @@ import pytest
 from oracle import ba_cpu, ba_oracle as bo
 from tests import helpers as H
 
-GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
+OTHER = {"track_filter.npz", "tag_refine.npz"}          # fixtures of the "next" rows (make_golden_extra.py), tested below
+GOLD = sorted(p for p in glob.glob(os.path.join(GOLD_DIR, "*.npz")) if os.path.basename(p) not in OTHER)
 
 
 def _load(path):
@@ -79,3 +81,36 @@ def test_lm_properties():
     assert all(b <= a for a, b in zip(costs, costs[1:]))
     s2 = bo.solve(pr, bo.Options())
     assert s2.n_successful <= 1
+
+
+def test_track_filter_oracle_reproduces_golden():
+    z = np.load(os.path.join(GOLD_DIR, "track_filter.npz"))
+    arr = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+    ref = bo.filter_tracks(H.to_oracle(arr), float(z["max_re"]), float(z["min_angle"]))
+    for k in ("obs_delete", "track_outlier", "num_filtered"):
+        assert np.array_equal(ref[k], z["out_" + k]), k
+    assert np.allclose(ref["track_error"], z["out_track_error"], rtol=0, atol=1e-12)
+    assert np.allclose(ref["track_angle"], z["out_track_angle"], rtol=0, atol=1e-14)
+    assert set(np.unique(z["out_track_outlier"])) == {0, 1, 2}
+
+
+def test_tag_refine_oracle_and_product_reproduce_golden(lib):
+    """tag_refine.npz: inputs + the scipy oracle's minima of both stages.  The oracle must reproduce them; the product
+    (xrsfm_tag_refine, host code: runs without a GPU) reaches them with tight tolerances."""
+    from oracle import tag_oracle as to
+    from scipy.spatial.transform import Rotation
+    from xrsfm_amd import capi
+    z = np.load(os.path.join(GOLD_DIR, "tag_refine.npz"))
+    tag_obs = (z["tag_obs_tag"], z["tag_obs_frame"], z["tag_obs_xy"])
+    obs = (z["obs_frame"], z["obs_pt"], z["obs_xy"])
+    q1, t1, s1, c1 = to.solve_stage1(z["corners"], float(z["tag_length"]))
+    assert abs(s1 - float(z["stage1_scale"])) < 1e-9 and abs(c1 - float(z["stage1_cost"])) <= 1e-9 * c1
+    tight = dict(function_tolerance=1e-15, parameter_tolerance=1e-14, gradient_tolerance=1e-13)
+    out = capi.tag_refine(z["frame_q"], z["frame_t"], z["corners"], *tag_obs, float(z["tag_length"]), points=z["points"],
+                          obs_frame=obs[0], obs_pt=obs[1], obs_xy=obs[2], stages=2, **tight)
+    s_1, s_2 = out["summaries"]
+    assert abs(s_1.final_cost - float(z["stage1_cost"])) <= 1e-9 * s_1.final_cost
+    assert abs(s_2.final_cost - float(z["stage2_cost"])) <= 1e-6 * s_2.final_cost
+    assert abs(out["scale"] - float(z["stage2_scale"])) < 1e-5 * out["scale"]
+    assert np.max((Rotation.from_quat(out["tag_q"]).inv() * Rotation.from_quat(z["stage2_q"])).magnitude()) < 1e-4
+    assert np.abs(out["tag_corners"] - z["stage2_corners"]).max() < 1e-4 and np.abs(out["points"] - z["stage2_points"]).max() < 1e-4
