@@ -239,7 +239,8 @@ def test_profile_entries(lib):
 
 def _golden():
     import glob, os
-    return sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    other = {"track_filter.npz", "tag_refine.npz"}       # fixtures of the "next" rows: their own tests
+    return sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")) if os.path.basename(p) not in other)
 
 
 @pytest.mark.parametrize("path", _golden(), ids=[p.split("/")[-1][:-4] for p in _golden()])
