@@ -88,3 +88,24 @@ def test_empty_problem_plan():
     arr["obs_uv"] = arr["obs_uv"][:0]
     plan = capi.debug_chol_plan(H.to_product(arr))
     assert plan["blocks"] == 0 and plan["tiles"] >= 1
+
+
+def test_large_unordered_problem_is_refused_before_the_symbolic_factorisation(lib):
+    """20 000 cameras with random visibility: the natural-order tile pattern fills in completely, and the symbolic
+    factorisation of 1875 x 1875 tiles would need ~10^9 list entries.  The plan must stop with XRSFM_BA_ETOOBIG right after
+    the ordering decision (xrsfm_ba_run then takes the PCG path), in well under a second of plan time."""
+    import time
+    from xrsfm_amd import capi
+    rng = np.random.default_rng(3)
+    n_c, n_p = 20000, 60000
+    ks = rng.integers(2, 6, n_p)
+    obs_pt = np.repeat(np.arange(n_p, dtype=np.int32), ks)
+    obs_cam = np.concatenate([rng.choice(n_c, size=k, replace=False) for k in ks]).astype(np.int32)
+    arr = dict(cam_q=np.tile([0, 0, 0, 1.0], (n_c, 1)), cam_t=np.zeros((n_c, 3)), cam_const=np.zeros(n_c, np.uint8),
+               cam_intr=np.zeros(n_c, np.int32), intr_model=np.array([2], np.int32), intr_params=np.array([[700.0, 600, 200, 0, 0, 0, 0, 0]]),
+               points=rng.normal(size=(n_p, 3)), point_const=np.zeros(n_p, np.uint8), obs_cam=obs_cam, obs_pt=obs_pt,
+               obs_uv=rng.normal(size=(len(obs_cam), 2)))
+    t0 = time.perf_counter()
+    with pytest.raises(RuntimeError, match="-6"):
+        capi.debug_chol_plan(capi.ProblemArrays(**arr))
+    assert time.perf_counter() - t0 < 20.0

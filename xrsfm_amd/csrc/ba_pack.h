@@ -7,6 +7,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <numeric>
 #include <memory>
 #include <thread>
@@ -43,8 +44,10 @@ inline void pack_parallel_for(long long n, F&& fn, long long min_n = 200000) {
     const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(n >= 5 * min_n ? 16u : 8u, hw);
     if (nt == 1) { fn(0LL, n); return; }
     std::vector<std::thread> th;
-    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+    std::vector<std::exception_ptr> err(nt);      // an exception in a worker (std::bad_alloc) is rethrown by the caller's thread
+    for (int t = 0; t < nt; ++t) th.emplace_back([&, t] { try { fn(n * t / nt, n * (t + 1) / nt); } catch (...) { err[t] = std::current_exception(); } });
     for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 // XRSFM_BA_PACK_TIMING=1: phase times of the host-side set-up (packing, Cholesky plan) on stderr (developer aid)
@@ -87,8 +90,10 @@ inline void pack_parallel_chunks(const std::vector<long long>& cut, F&& fn) {
     const int nc = (int)cut.size() - 1;
     if (nc == 1) { fn(0, cut[0], cut[1]); return; }
     std::vector<std::thread> th;
-    for (int t = 0; t < nc; ++t) th.emplace_back([&, t] { fn(t, cut[t], cut[t + 1]); });
+    std::vector<std::exception_ptr> err(nc);
+    for (int t = 0; t < nc; ++t) th.emplace_back([&, t] { try { fn(t, cut[t], cut[t + 1]); } catch (...) { err[t] = std::current_exception(); } });
     for (auto& x : th) x.join();
+    for (auto& e : err) if (e) std::rethrow_exception(e);
 }
 
 struct Packed {

@@ -165,8 +165,12 @@ inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<
 }  // namespace plan_detail
 
 // `pattern`: union of all ranks' camera pairs (sorted, unique) or nullptr for the local pairs.
+// Limits (checked BEFORE the symbolic factorisation, whose work and memory grow with the cube of the tile count when the
+// pattern fills in): more than `max_dense_unknowns` camera unknowns are only planned when the band / ring ordering applies,
+// and then only while the n_pad^2 doubles of the tile storage stay within `max_tile_bytes`; XRSFM_BA_ETOOBIG otherwise.
 inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const PairKeys& keyed,
-                           const std::vector<unsigned long long>* pattern, CholPlan& P) {
+                           const std::vector<unsigned long long>* pattern, CholPlan& P,
+                           long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX) {
     const int Nc = k.n_cams, ns = k.n_slots;
     P = CholPlan();
     P.spp = spp;
@@ -258,6 +262,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     }
     if (T == 0) { T = 1; P.tile_rows.push_back(0); }
     P.T = T; P.n_pad = T * kPlanTile;
+    if (6LL * Nc > max_dense_unknowns &&
+        (P.ordering != 1 || (unsigned long long)P.n_pad * (unsigned long long)P.n_pad * sizeof(double) > max_tile_bytes)) return XRSFM_BA_ETOOBIG;
 
     // ---- tile pattern + symbolic factorisation
     std::vector<char> nz((size_t)T * T, 0);

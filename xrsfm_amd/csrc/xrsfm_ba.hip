@@ -489,7 +489,7 @@ int chol_setup(xrsfm_ba_context* c) {
         c->have_pattern = true;
     }
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P))) return e;
+    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
     timer.mark("plan");
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
@@ -710,6 +710,15 @@ int init_scaling_and_linearize(xrsfm_ba_context* c, double huber_a, bool use_sca
 }  // namespace
 
 // ---------------------------------------------------------------- C-ABI
+// No C++ exception may cross the C boundary: host allocations that fail (std::bad_alloc from the packing, the plans or the
+// host solvers) become XRSFM_BA_ENOMEM, anything else XRSFM_BA_FAILURE.
+template <typename F>
+static int no_throw(F&& f) {
+    try { return f(); }
+    catch (const std::bad_alloc&) { return XRSFM_BA_ENOMEM; }
+    catch (...) { return XRSFM_BA_FAILURE; }
+}
+
 extern "C" {
 
 void xrsfm_ba_default_options(xrsfm_ba_options* o) {
@@ -748,6 +757,8 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     delete c;
 }
 
+static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out);
+
 int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** out) {
     if (!p || !out) return XRSFM_BA_EINVAL;
     *out = nullptr;
@@ -757,7 +768,14 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
         return XRSFM_BA_ENODEV;
     }
     if (device < 0 || device >= ndev) return XRSFM_BA_EINVAL;
-    xrsfm_ba_context* c = new xrsfm_ba_context();
+    xrsfm_ba_context* c = new (std::nothrow) xrsfm_ba_context();
+    if (!c) return XRSFM_BA_ENOMEM;
+    try { return create_body(p, device, c, out); }          // (the body releases c itself on the errors it returns)
+    catch (const std::bad_alloc&) { xrsfm_ba_destroy(c); *out = nullptr; return XRSFM_BA_ENOMEM; }
+    catch (...) { xrsfm_ba_destroy(c); *out = nullptr; return XRSFM_BA_FAILURE; }
+}
+
+static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out) {
     c->device = device;
     PhaseTimer timer("create");
     int e = pack_problem(*p, c->pk);
@@ -913,7 +931,7 @@ int xrsfm_ba_download(xrsfm_ba_context* c, double* cam_q, double* cam_t, double*
     return 0;
 }
 
-int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_summary* sum) {
+static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_summary* sum) {
     if (!c || !optp || !sum) return XRSFM_BA_EINVAL;
     const xrsfm_ba_options opt = *optp;
     HIPCHK(hipSetDevice(c->device));
@@ -1063,7 +1081,7 @@ void xrsfm_pg_default_options(xrsfm_pg_options* o) {
     o->initial_radius = 1e16; o->verbose = 0;
 }
 
-int xrsfm_pg_solve(const xrsfm_pg_options* opt, xrsfm_pg_problem* p, xrsfm_pg_summary* summary) {
+static int pg_solve_impl(const xrsfm_pg_options* opt, xrsfm_pg_problem* p, xrsfm_pg_summary* summary) {
     if (!p || !summary) return XRSFM_BA_EINVAL;
     if (p->n_frames < 0 || p->n_scales < p->n_frames || p->n_edges < 0 || p->n_scale_costs < 0) return XRSFM_BA_EINVAL;
     if (p->n_frames > 0 && (!p->rot_q || !p->pos)) return XRSFM_BA_EINVAL;
@@ -1090,7 +1108,7 @@ void xrsfm_tag_default_options(xrsfm_pg_options* o) {
     o->initial_radius = 1e4; o->verbose = 0;
 }
 
-int xrsfm_tag_refine(const xrsfm_pg_options* opt, xrsfm_tag_problem* p, int32_t stages, xrsfm_pg_summary* summaries) {
+static int tag_refine_impl(const xrsfm_pg_options* opt, xrsfm_tag_problem* p, int32_t stages, xrsfm_pg_summary* summaries) {
     if (!p || !summaries || stages < 1 || stages > 2) return XRSFM_BA_EINVAL;
     if (p->n_frames < 0 || p->n_tags < 0 || p->n_tag_obs < 0 || p->n_points < 0 || p->n_obs < 0) return XRSFM_BA_EINVAL;
     if (p->n_frames > 0 && (!p->frame_q || !p->frame_t)) return XRSFM_BA_EINVAL;
@@ -1336,7 +1354,7 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     PairKeys keyed;
     if ((e = chol_local_keys(k, spp, keyed))) return e;
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, nullptr, P))) return e;
+    if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
     int n_gram = 0, cmax = 0;
     for (int t = 0; t < k.n_tiles; ++t) { n_gram += k.tile_ncam[t] > 0; cmax = std::max(cmax, k.tile_ncam[t]); }
     stats[0] = n_gram; stats[1] = k.n_gt_cells; stats[2] = k.n_cam_entries_g; stats[3] = cmax;
@@ -1356,7 +1374,7 @@ int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     PairKeys keyed;
     if ((e = chol_local_keys(k, spp, keyed))) return e;
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, nullptr, P))) return e;
+    if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
     stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
     stats[6] = P.use_levels ? 1 : 0; stats[7] = P.n_tiles_nz;
     if (cam_offset) for (int i = 0; i < k.n_cams; ++i) cam_offset[i] = P.cam_off[i];
@@ -1410,3 +1428,8 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------- exception barrier of the entry points that allocate on the host
+int xrsfm_ba_run(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_summary* sum) { return no_throw([&] { return ba_run_impl(c, optp, sum); }); }
+int xrsfm_pg_solve(const xrsfm_pg_options* opt, xrsfm_pg_problem* p, xrsfm_pg_summary* summary) { return no_throw([&] { return pg_solve_impl(opt, p, summary); }); }
+int xrsfm_tag_refine(const xrsfm_pg_options* opt, xrsfm_tag_problem* p, int32_t stages, xrsfm_pg_summary* summaries) { return no_throw([&] { return tag_refine_impl(opt, p, stages, summaries); }); }
