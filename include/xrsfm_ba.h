@@ -165,7 +165,10 @@ int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm
  *   points3d [n][3], uv [n][2], inlier_mask [n] (NULL = all inliers; only non-zero entries enter, like pnp.cc:43-45)
  *   q[4] (x,y,z,w), t[3]    in: the RANSAC pose; out: the refined pose
  * summary->initial_cost / final_cost with num_residuals give the two "[px]" values the reference prints (pnp.cc:63-70).
- * Runs the same device LM path as xrsfm_ba_solve (a one-camera problem whose Schur complement is the 6x6 normal matrix). */
+ * One persistent workgroup runs the whole LM loop on the device (xrsfm_amd/csrc/ba_refine.h: normal equations by block reduction,
+ * 6x6 damped solve and trust-region bookkeeping on one lane, candidate linearised in the pass that yields its cost): one
+ * upload, one launch, one read-back, ~0.12 ms per call.  Same arithmetic and loop semantics as xrsfm_ba_solve on the
+ * one-camera problem, which stays available as the cross-check (environment variable XRSFM_BA_REFINE_ENGINE=1). */
 void xrsfm_ba_refine_pose_options(xrsfm_ba_options *opt);
 int xrsfm_ba_refine_pose(const xrsfm_ba_options *opt, int32_t model, const double *intr_params, int32_t n,
                          const double *points3d, const double *uv, const uint8_t *inlier_mask, double *q, double *t,

@@ -510,6 +510,28 @@ def test_refine_pose_matches_oracle(lib, model):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("model", [0, 1, 2, 3, 4])
+def test_refine_pose_persistent_kernel_equals_engine(lib, model):
+    """The one-workgroup LM kernel (ba_refine.h, the default) against the same problem through the general engine
+    (XRSFM_BA_REFINE_ENGINE=1): same step counts and exits, costs to 1e-10, pose to 1e-9 (summation orders differ)."""
+    import os
+    from xrsfm_amd import capi
+    arr = H.make_pose_problem(500, seed=700 + model, model=model, outlier_frac=0.15)
+    args = (model, arr["intr_params"][0], arr["points"], arr["obs_uv"], arr["cam_q"][0], arr["cam_t"][0])
+    q1, t1, s1 = capi.refine_pose(*args)
+    os.environ["XRSFM_BA_REFINE_ENGINE"] = "1"
+    try:
+        q2, t2, s2 = capi.refine_pose(*args)
+    finally:
+        del os.environ["XRSFM_BA_REFINE_ENGINE"]
+    assert (s1.n_successful, s1.n_unsuccessful, s1.termination, s1.termination_reason, s1.lm_steps_attempted) == \
+           (s2.n_successful, s2.n_unsuccessful, s2.termination, s2.termination_reason, s2.lm_steps_attempted)
+    assert abs(s1.initial_cost - s2.initial_cost) <= 1e-12 * s2.initial_cost and abs(s1.final_cost - s2.final_cost) <= 1e-10 * s2.final_cost
+    assert np.abs(q1 - q2).max() < 1e-9 and np.abs(t1 - t2).max() < 1e-9
+    assert (s1.num_residuals, s1.num_effective_params, s1.linear_solver_used) == (s2.num_residuals, s2.num_effective_params, s2.linear_solver_used)
+
+
+@pytest.mark.gpu
 def test_refine_pose_edge_cases(lib):
     from xrsfm_amd import capi
     arr = H.make_pose_problem(40, seed=9, model=2)
