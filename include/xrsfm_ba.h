@@ -173,6 +173,13 @@ void xrsfm_ba_refine_pose_options(xrsfm_ba_options *opt);
 int xrsfm_ba_refine_pose(const xrsfm_ba_options *opt, int32_t model, const double *intr_params, int32_t n,
                          const double *points3d, const double *uv, const uint8_t *inlier_mask, double *q, double *t,
                          xrsfm_ba_summary *summary);
+/* The same for several frames in one upload / launch / read-back (one workgroup per frame): e.g. the candidate next frames of
+ * incremental_mapper.cc:41-46 or the frames of a loop correction.  Frame f owns the correspondences corr_ptr[f] ..
+ * corr_ptr[f+1] of the concatenated arrays (corr_ptr[0] = 0); models [n_frames], intr_params [n_frames][8], q [n_frames][4],
+ * t [n_frames][3], summaries [n_frames].  Every frame gets exactly the result of its own xrsfm_ba_refine_pose call. */
+int xrsfm_ba_refine_poses(const xrsfm_ba_options *opt, int32_t n_frames, const int32_t *models, const double *intr_params,
+                          const int32_t *corr_ptr, const double *points3d, const double *uv, const uint8_t *inlier_mask,
+                          double *q, double *t, xrsfm_ba_summary *summaries);
 
 /* ---- Scaled pose graph of BASolver::ScalePoseGraphUnorder (/root/reference/src/optimization/ba_solver.cc:147-328; SURVEY 8f
  * row f4).  HOST code (O(frames) unknowns; no GPU needed or used): it completes the BASolver interface without Ceres.

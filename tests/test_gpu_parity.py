@@ -532,6 +532,27 @@ def test_refine_pose_persistent_kernel_equals_engine(lib, model):
 
 
 @pytest.mark.gpu
+def test_refine_poses_batch_equals_single_calls(lib):
+    """xrsfm_ba_refine_poses: several frames in one launch (one workgroup each) = the single-frame calls, bit for bit; frames of
+    different sizes and camera models, one with an inlier mask, one without correspondences."""
+    from xrsfm_amd import capi
+    probs = [H.make_pose_problem(n, seed=800 + i, model=m) for i, (n, m) in enumerate([(300, 2), (40, 4), (1500, 0), (7, 3), (200, 1)])]
+    masks = [None, None, (np.arange(1500) % 5 != 0).astype(np.uint8), None, np.zeros(200, np.uint8)]
+    frames = [(p["points"], p["obs_uv"], mk) for p, mk in zip(probs, masks)]
+    models = [int(p["intr_model"][0]) for p in probs]
+    intr = [p["intr_params"][0] for p in probs]
+    q0 = np.array([p["cam_q"][0] for p in probs]); t0 = np.array([p["cam_t"][0] for p in probs])
+    qb, tb, sb = capi.refine_poses(models, intr, frames, q0, t0)
+    for f, p in enumerate(probs):
+        q1, t1, s1 = capi.refine_pose(models[f], intr[f], p["points"], p["obs_uv"], q0[f], t0[f], inlier_mask=masks[f])
+        assert np.array_equal(qb[f], q1) and np.array_equal(tb[f], t1)
+        assert (sb[f].initial_cost, sb[f].final_cost, sb[f].n_successful, sb[f].n_unsuccessful, sb[f].termination_reason, sb[f].num_residuals) == \
+               (s1.initial_cost, s1.final_cost, s1.n_successful, s1.n_unsuccessful, s1.termination_reason, s1.num_residuals)
+    assert sb[4].num_residuals == 0 and np.array_equal(qb[4], q0[4])
+    assert sb[0].final_cost < sb[0].initial_cost
+
+
+@pytest.mark.gpu
 def test_refine_pose_edge_cases(lib):
     from xrsfm_amd import capi
     arr = H.make_pose_problem(40, seed=9, model=2)

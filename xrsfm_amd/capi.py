@@ -87,7 +87,7 @@ EXPORTS = [
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
-    "xrsfm_tag_default_options", "xrsfm_tag_refine",
+    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -133,6 +133,9 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
     lib.xrsfm_pg_default_options.argtypes = [C.POINTER(CPgOptions)]
     lib.xrsfm_pg_default_options.restype = None
+    lib.xrsfm_ba_refine_poses.argtypes = [C.POINTER(COptions), C.c_int32, _c_int32_p, _c_double_p, _c_int32_p, _c_double_p, _c_double_p,
+                                          _c_uint8_p, _c_double_p, _c_double_p, C.POINTER(CSummary)]
+    lib.xrsfm_ba_refine_poses.restype = C.c_int
     lib.xrsfm_pg_solve.argtypes = [C.POINTER(CPgOptions), C.POINTER(CPgProblem), C.POINTER(CPgSummary)]
     lib.xrsfm_pg_solve.restype = C.c_int
     lib.xrsfm_tag_default_options.argtypes = [C.POINTER(CPgOptions)]
@@ -388,6 +391,33 @@ def refine_pose(model: int, intr_params, points3d, uv, q, t, inlier_mask=None, o
                                       mask.ctypes.data_as(_c_uint8_p) if mask is not None else None, _dp(q), _dp(t), C.byref(s)),
           "xrsfm_ba_refine_pose")
     return q, t, s
+
+
+def refine_poses(models, intr_params, frames, q, t, options=None):
+    """xrsfm_ba_refine_poses: `frames` is a list of (points3d [n,3], uv [n,2], inlier_mask or None) per frame; models
+    [n_frames], intr_params [n_frames][<=8], q [n_frames][4], t [n_frames][3].  Returns (q, t, [summary per frame])."""
+    nf = len(frames)
+    prm = np.zeros((nf, 8))
+    for f in range(nf):
+        v = np.asarray(intr_params[f], float)[:8]; prm[f, :len(v)] = v
+    corr_ptr = np.zeros(nf + 1, np.int32)
+    for f in range(nf):
+        corr_ptr[f + 1] = corr_ptr[f] + np.asarray(frames[f][0]).reshape(-1, 3).shape[0]
+    P = np.ascontiguousarray(np.vstack([np.asarray(fr[0], float).reshape(-1, 3) for fr in frames]) if nf else np.zeros((0, 3)))
+    UV = np.ascontiguousarray(np.vstack([np.asarray(fr[1], float).reshape(-1, 2) for fr in frames]) if nf else np.zeros((0, 2)))
+    any_mask = any(fr[2] is not None for fr in frames)
+    mask = None
+    if any_mask:
+        mask = np.ascontiguousarray(np.concatenate([np.ones(np.asarray(fr[0]).reshape(-1, 3).shape[0], np.uint8) if fr[2] is None
+                                                    else np.asarray(fr[2], np.uint8) for fr in frames]))
+    q = np.array(q, float).reshape(nf, 4).copy(); t = np.array(t, float).reshape(nf, 3).copy()
+    mdl = np.ascontiguousarray(models, np.int32)
+    sums = (CSummary * max(nf, 1))()
+    check(load().xrsfm_ba_refine_poses(C.byref(options) if options is not None else None, nf, mdl.ctypes.data_as(_c_int32_p), _dp(prm),
+                                       corr_ptr.ctypes.data_as(_c_int32_p), _dp(P), _dp(UV),
+                                       mask.ctypes.data_as(_c_uint8_p) if mask is not None else None, _dp(q), _dp(t), sums),
+          "xrsfm_ba_refine_poses")
+    return q, t, [sums[f] for f in range(nf)]
 
 
 def pose_graph_solve(rot_q, pos, scale, edges, weight_o=0.0, scale_costs=(), pos_const=None, scale_const=None, scale_lower=None,

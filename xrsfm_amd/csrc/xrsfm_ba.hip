@@ -1144,6 +1144,84 @@ void xrsfm_ba_refine_pose_options(xrsfm_ba_options* o) {
 static int refine_pose_engine(const xrsfm_ba_options& o, int32_t model, const double* intr_params, int32_t n, const double* points3d,
                               const double* uv, const uint8_t* inlier_mask, double* q, double* t, xrsfm_ba_summary* summary);
 
+// n_frames jobs in one upload / launch (grid.x = frames) / read-back.  corr_ptr[f]..corr_ptr[f+1] are frame f's correspondences.
+static int refine_poses_kernel(const xrsfm_ba_options& o, int32_t n_frames, const int32_t* models, const double* intr_params,
+                               const int32_t* corr_ptr, const double* points3d, const double* uv, const uint8_t* inlier_mask,
+                               double* q, double* t, xrsfm_ba_summary* summaries) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "[xrsfm_ba] no HIP device visible: the BA path has no CPU fallback\n");
+        return XRSFM_BA_ENODEV;
+    }
+    const int device = 0;
+    HIPCHK(hipSetDevice(device));
+    std::vector<int> m(n_frames, 0), first(n_frames + 1, 0);
+    for (int f = 0; f < n_frames; ++f) {
+        for (int i = corr_ptr[f]; i < corr_ptr[f + 1]; ++i) m[f] += (!inlier_mask || inlier_mask[i]) ? 1 : 0;
+        first[f + 1] = first[f] + m[f];
+    }
+    const size_t M = (size_t)first[n_frames];
+    // one staging block: jobs | points | observations | results
+    static_assert(sizeof(RefineJob) % 8 == 0 && sizeof(RefineResult) % 8 == 0, "staging layout");
+    const size_t off_P = (sizeof(RefineJob) * (size_t)n_frames + 255) & ~(size_t)255, off_uv = off_P + sizeof(double) * 3 * M;
+    const size_t off_res = (off_uv + sizeof(double) * 2 * M + 255) & ~(size_t)255;
+    const size_t total = off_res + sizeof(RefineResult) * (size_t)n_frames;
+    size_t cls = 0;
+    unsigned char* dev = static_cast<unsigned char*>(g_cache.get(device, total, &cls));
+    if (!dev) return XRSFM_BA_ENOMEM;
+    HostBundle hb;
+    if (!g_bundles.get(device, &hb)) { g_cache.put(device, dev, cls); return XRSFM_BA_ENODEV; }
+    std::vector<unsigned char> stage(off_res);
+    double* hP = reinterpret_cast<double*>(stage.data() + off_P);
+    double* hU = reinterpret_cast<double*>(stage.data() + off_uv);
+    for (int f = 0; f < n_frames; ++f) {
+        RefineJob job{};
+        job.n = m[f]; job.model = models[f];
+        job.P = reinterpret_cast<const double*>(dev + off_P) + 3 * (size_t)first[f];
+        job.uv = reinterpret_cast<const double*>(dev + off_uv) + 2 * (size_t)first[f];
+        for (int k = 0; k < 8; ++k) job.intr[k] = intr_params[8 * (size_t)f + k];
+        for (int k = 0; k < 4; ++k) job.q[k] = q[4 * (size_t)f + k];
+        for (int k = 0; k < 3; ++k) job.t[k] = t[3 * (size_t)f + k];
+        memcpy(stage.data() + sizeof(RefineJob) * (size_t)f, &job, sizeof(job));
+        size_t w = (size_t)first[f];
+        for (int i = corr_ptr[f]; i < corr_ptr[f + 1]; ++i) {
+            if (inlier_mask && !inlier_mask[i]) continue;      // only the inliers enter, like pnp.cc:43-45
+            for (int k = 0; k < 3; ++k) hP[3 * w + k] = points3d[3 * (size_t)i + k];
+            hU[2 * w] = uv[2 * (size_t)i]; hU[2 * w + 1] = uv[2 * (size_t)i + 1];
+            ++w;
+        }
+    }
+    RefineOpt ro{o.max_iterations, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance, o.initial_radius, o.huber_a};
+    std::vector<RefineResult> res(n_frames);
+    int e = XRSFM_BA_OK;
+    if (hipMemcpyAsync(dev, stage.data(), off_res, hipMemcpyHostToDevice, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    if (!e) {
+        hipLaunchKernelGGL(k_refine_pose, dim3(n_frames), dim3(kBlock), 0, hb.stream, reinterpret_cast<const RefineJob*>(dev), ro,
+                           reinterpret_cast<RefineResult*>(dev + off_res));
+        if (hipGetLastError() != hipSuccess) e = XRSFM_BA_ENODEV;
+    }
+    if (!e && hipMemcpyAsync(res.data(), dev + off_res, sizeof(RefineResult) * (size_t)n_frames, hipMemcpyDeviceToHost, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    if (hipStreamSynchronize(hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    g_bundles.put(device, hb);
+    g_cache.put(device, dev, cls);
+    if (e) return e;
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    for (int f = 0; f < n_frames; ++f) {
+        xrsfm_ba_summary* sm = summaries + f;
+        memset(sm, 0, sizeof(*sm));
+        for (int k = 0; k < 4; ++k) q[4 * (size_t)f + k] = res[f].q[k];
+        for (int k = 0; k < 3; ++k) t[3 * (size_t)f + k] = res[f].t[k];
+        sm->initial_cost = res[f].initial_cost; sm->final_cost = res[f].final_cost;
+        sm->num_residuals = 2 * m[f]; sm->num_effective_params = 6;
+        sm->n_successful = res[f].n_successful; sm->n_unsuccessful = res[f].n_unsuccessful;
+        sm->termination = res[f].termination; sm->termination_reason = res[f].reason;
+        sm->lm_steps_attempted = res[f].attempted; sm->linear_solver_used = XRSFM_BA_SOLVER_CHOLESKY;
+        sm->total_time_s = secs;
+    }
+    return XRSFM_BA_OK;
+}
+
 int xrsfm_ba_refine_pose(const xrsfm_ba_options* opt, int32_t model, const double* intr_params, int32_t n, const double* points3d,
                          const double* uv, const uint8_t* inlier_mask, double* q, double* t, xrsfm_ba_summary* summary) {
     if (!intr_params || !q || !t || !summary || n < 0 || model < 0 || model > 4) return XRSFM_BA_EINVAL;
@@ -1151,67 +1229,22 @@ int xrsfm_ba_refine_pose(const xrsfm_ba_options* opt, int32_t model, const doubl
     xrsfm_ba_options o;
     if (opt) o = *opt; else xrsfm_ba_refine_pose_options(&o);
     if (std::getenv("XRSFM_BA_REFINE_ENGINE")) return no_throw([&] { return refine_pose_engine(o, model, intr_params, n, points3d, uv, inlier_mask, q, t, summary); });
-    return no_throw([&]() -> int {
-        const auto t_begin = std::chrono::steady_clock::now();
-        int ndev = 0;
-        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
-            fprintf(stderr, "[xrsfm_ba] no HIP device visible: the BA path has no CPU fallback\n");
-            return XRSFM_BA_ENODEV;
-        }
-        const int device = 0;
-        HIPCHK(hipSetDevice(device));
-        int m = 0;
-        for (int i = 0; i < n; ++i) m += (!inlier_mask || inlier_mask[i]) ? 1 : 0;
-        // one staging block: job | points | observations | result
-        const size_t off_P = 256, off_uv = off_P + sizeof(double) * 3 * (size_t)m, off_res = (off_uv + sizeof(double) * 2 * (size_t)m + 255) & ~(size_t)255;
-        const size_t total = off_res + 256;
-        static_assert(sizeof(RefineJob) <= 256 && sizeof(RefineResult) <= 256, "staging layout");
-        size_t cls = 0;
-        unsigned char* dev = static_cast<unsigned char*>(g_cache.get(device, total, &cls));
-        if (!dev) return XRSFM_BA_ENOMEM;
-        HostBundle hb;
-        if (!g_bundles.get(device, &hb)) { g_cache.put(device, dev, cls); return XRSFM_BA_ENODEV; }
-        std::vector<unsigned char> stage(off_res);
-        RefineJob job{};
-        job.n = m; job.model = model;
-        job.P = reinterpret_cast<const double*>(dev + off_P); job.uv = reinterpret_cast<const double*>(dev + off_uv);
-        for (int k = 0; k < 8; ++k) job.intr[k] = intr_params[k];
-        for (int k = 0; k < 4; ++k) job.q[k] = q[k];
-        for (int k = 0; k < 3; ++k) job.t[k] = t[k];
-        memcpy(stage.data(), &job, sizeof(job));
-        double* hP = reinterpret_cast<double*>(stage.data() + off_P);
-        double* hU = reinterpret_cast<double*>(stage.data() + off_uv);
-        for (int i = 0, w = 0; i < n; ++i) {
-            if (inlier_mask && !inlier_mask[i]) continue;      // only the inliers enter, like pnp.cc:43-45
-            for (int k = 0; k < 3; ++k) hP[3 * (size_t)w + k] = points3d[3 * (size_t)i + k];
-            hU[2 * (size_t)w] = uv[2 * (size_t)i]; hU[2 * (size_t)w + 1] = uv[2 * (size_t)i + 1];
-            ++w;
-        }
-        RefineOpt ro{o.max_iterations, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance, o.initial_radius, o.huber_a};
-        RefineResult res{};
-        int e = XRSFM_BA_OK;
-        if (hipMemcpyAsync(dev, stage.data(), off_res, hipMemcpyHostToDevice, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (!e) {
-            hipLaunchKernelGGL(k_refine_pose, dim3(1), dim3(kBlock), 0, hb.stream, reinterpret_cast<const RefineJob*>(dev), ro,
-                               reinterpret_cast<RefineResult*>(dev + off_res));
-            if (hipGetLastError() != hipSuccess) e = XRSFM_BA_ENODEV;
-        }
-        if (!e && hipMemcpyAsync(&res, dev + off_res, sizeof(res), hipMemcpyDeviceToHost, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (hipStreamSynchronize(hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
-        g_bundles.put(device, hb);
-        g_cache.put(device, dev, cls);
-        if (e) return e;
-        memset(summary, 0, sizeof(*summary));
-        for (int k = 0; k < 4; ++k) q[k] = res.q[k];
-        for (int k = 0; k < 3; ++k) t[k] = res.t[k];
-        summary->initial_cost = res.initial_cost; summary->final_cost = res.final_cost;
-        summary->num_residuals = 2 * m; summary->num_effective_params = 6;
-        summary->n_successful = res.n_successful; summary->n_unsuccessful = res.n_unsuccessful;
-        summary->termination = res.termination; summary->termination_reason = res.reason;
-        summary->lm_steps_attempted = res.attempted; summary->linear_solver_used = XRSFM_BA_SOLVER_CHOLESKY;
-        summary->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-        return XRSFM_BA_OK;
-    });
+    const int32_t corr_ptr[2] = {0, n};
+    return no_throw([&] { return refine_poses_kernel(o, 1, &model, intr_params, corr_ptr, points3d, uv, inlier_mask, q, t, summary); });
+}
+
+int xrsfm_ba_refine_poses(const xrsfm_ba_options* opt, int32_t n_frames, const int32_t* models, const double* intr_params,
+                          const int32_t* corr_ptr, const double* points3d, const double* uv, const uint8_t* inlier_mask,
+                          double* q, double* t, xrsfm_ba_summary* summaries) {
+    if (n_frames < 0 || (n_frames > 0 && (!models || !intr_params || !corr_ptr || !q || !t || !summaries))) return XRSFM_BA_EINVAL;
+    if (n_frames == 0) return XRSFM_BA_OK;
+    if (corr_ptr[0] != 0) return XRSFM_BA_EINVAL;
+    for (int f = 0; f < n_frames; ++f)
+        if (models[f] < 0 || models[f] > 4 || corr_ptr[f + 1] < corr_ptr[f]) return XRSFM_BA_EINVAL;
+    if (corr_ptr[n_frames] > 0 && (!points3d || !uv)) return XRSFM_BA_EINVAL;
+    xrsfm_ba_options o;
+    if (opt) o = *opt; else xrsfm_ba_refine_pose_options(&o);
+    return no_throw([&] { return refine_poses_kernel(o, n_frames, models, intr_params, corr_ptr, points3d, uv, inlier_mask, q, t, summaries); });
 }
 
 static int refine_pose_engine(const xrsfm_ba_options& o, int32_t model, const double* intr_params, int32_t n, const double* points3d,
