@@ -214,7 +214,7 @@ typedef struct xrsfm_pg_options {
 typedef struct xrsfm_pg_summary {
     double initial_cost, final_cost;
     int32_t iterations, n_successful, n_unsuccessful;
-    int32_t termination;        /* 1 gradient, 2 parameter, 3 function tolerance, 4 radius, 5 max iterations, 6 linear solver failure */
+    int32_t termination;        /* 1 gradient, 2 parameter, 3 function tolerance, 4 radius, 5 max iterations, 6 failure (linear solver, non-finite input) */
 } xrsfm_pg_summary;
 
 void xrsfm_pg_default_options(xrsfm_pg_options *opt);

@@ -190,3 +190,20 @@ def test_compat_refine_map_with_tags_equals_c_abi(capi, tmp_path):
     assert np.array_equal(ft, sc["frame_t"] / scale)
     assert extra[0] == 8.0 / scale and extra[1] == 3.0 / scale
     assert p.stdout.count("xrsfm_ba Report:") == 2 and "tag refine stage 2" in p.stdout
+
+
+def test_degenerate_inputs_do_not_crash(capi):
+    sc = make_scene(seed=21, n_tags=1, n_points=10)
+    # no tags: stage 1 has nothing to do, stage 2 refines the track points, the scale stays 1
+    out = capi.tag_refine(sc["frame_q"], sc["frame_t"], np.zeros((0, 4, 3)), np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros((0, 4, 2)), 0.1,
+                          points=sc["points"], obs_frame=sc["obs"][0], obs_pt=sc["obs"][1], obs_xy=sc["obs"][2], stages=2)
+    assert out["scale"] == 1.0 and out["summaries"][0].iterations == 0 and out["summaries"][1].final_cost < out["summaries"][1].initial_cost
+    # a point nobody observes keeps its value
+    pts = np.vstack([sc["points"], [[100.0, 0, 0]]])
+    out = capi.tag_refine(sc["frame_q"], sc["frame_t"], sc["corners"], *sc["tag_obs"], sc["tag_length"], points=pts,
+                          obs_frame=sc["obs"][0], obs_pt=sc["obs"][1], obs_xy=sc["obs"][2], stages=2)
+    assert np.array_equal(out["points"][-1], [100.0, 0, 0])
+    # non-finite input: reported as a failure (termination 6), nothing changes
+    bad = sc["corners"].copy(); bad[0, 0, 0] = np.nan
+    out = capi.tag_refine(sc["frame_q"], sc["frame_t"], bad, *sc["tag_obs"], sc["tag_length"], stages=1)
+    assert out["summaries"][0].termination == 6 and out["scale"] == 1.0

@@ -250,6 +250,7 @@ struct Solver {
             sum->final_cost = c; sum->termination = term;
             return XRSFM_BA_OK;
         };
+        if (!std::isfinite(cost)) return finish(6, cost);        // non-finite input: nothing to minimise (Ceres: FAILURE)
         if (nv == 0) return finish(1, cost);
         for (int it = 0;; ++it) {
             if (!reuse) {

@@ -367,6 +367,7 @@ struct Solver {
         double cost = evaluate(x, true);
         sum->initial_cost = cost; sum->iterations = 0; sum->n_successful = 0; sum->n_unsuccessful = 0;
         auto finish = [&](int term, double c) { sum->final_cost = c; sum->termination = term; return XRSFM_BA_OK; };
+        if (!std::isfinite(cost)) return finish(6, cost);        // non-finite input: nothing to minimise (Ceres: FAILURE)
         std::vector<double> S(n);
         for (int i = 0; i < n; ++i) S[i] = 1.0 / (1.0 + std::sqrt(diag(i)));
         double gmax = projected_gradient_max(x, tmp);
