@@ -1,0 +1,83 @@
+"""bench.py's N > 1 control flow on CPU: two gloo ranks run bench.main() with the device layer replaced by stand-ins
+(torch.cuda calls, the NCCL process group and xrsfm_amd.capi.Context).  What is under test is the launcher contract: rank /
+world handling, per-rank shard generation (weak) or sharding (strong), the size all-reduce, the unique-id broadcast, the
+barrier + MAX-over-ranks timing and the single JSON line of rank 0.  The numerics are the GPU tests' business."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+DRIVER = r'''
+import os, sys, types
+sys.path.insert(0, {root!r})
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.is_available = lambda: True
+torch.cuda.set_device = lambda d: None
+torch.cuda.synchronize = lambda *a: None
+_tensor, _zeros = torch.tensor, torch.zeros
+torch.tensor = lambda *a, **k: _tensor(*a, **{{x: y for x, y in k.items() if x != "device"}})
+torch.zeros = lambda *a, **k: _zeros(*a, **{{x: y for x, y in k.items() if x != "device"}})
+_init = dist.init_process_group
+dist.init_process_group = lambda backend=None, device_id=None, **k: _init(backend="gloo", **k)
+from xrsfm_amd import capi, synth
+synth.CONFIGS["S"] = dict(n_cams=12, n_points=300, k_obs=4, seed=2)          # keep the generated problems tiny
+LOG = []
+class FakeSummary:
+    n_successful, n_unsuccessful, pcg_iterations, linear_solver_used, termination_reason = 5, 1, 0, 1, 3
+    initial_cost, final_cost = 10.0, 1.0
+class FakeContext:
+    def __init__(self, prob, device=0): self.prob = prob; LOG.append(("ctx", device, prob.n_points, prob.n_obs))
+    def comm_init(self, world, rank, uid): LOG.append(("comm", world, rank, len(uid), sum(uid)))
+    def reset(self): pass
+    def run(self, opt=None): return FakeSummary()
+    def download(self): return self.prob.cam_q, self.prob.cam_t, self.prob.points
+    def profile(self): return {{"k_schur_pairs": (1.4, 14), "k_linearize": (1.2, 15)}}
+    def close(self): pass
+capi.device_count = lambda: 1
+capi.Context = FakeContext
+capi.comm_unique_id = lambda: bytes(range(128))
+import bench
+sys.argv = ["bench.py"] + {argv!r}
+bench.main()
+print("LOG", LOG)
+'''
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_two_rank_launch_contract(tmp_path, scaling):
+    port = _free_port()
+    argv = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--config", "S", "--no-cpu", "--scaling", scaling]
+    script = tmp_path / "driver.py"
+    script.write_text(DRIVER.format(root=ROOT, argv=argv))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    lines1 = [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and len(lines1) == 0                      # ONE JSON line, from rank 0
+    j = json.loads(lines0[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 2 and j["warmup"] == 1 and j["scaling"] == scaling and j["higher_is_better"] is True
+    assert j["unit"] == "cam-pts*iter/s" and j["dtype"] == "f64" and j["data"] == "synthetic" and j["vs_baseline"] is None
+    n_points_total = 600 if scaling == "weak" else 300                # weak: every rank holds a config-sized shard
+    assert f"/ {n_points_total} points /" in j["config"]["workload"] and "sharded x2" in j["config"]["parallelism"]
+    assert abs(j["value"] - 12 * (12 + n_points_total) / (j["ms_per_step"] * 2e-3)) <= 1e-6 * j["value"]     # 2 steps x 6 LM iterations
+    assert j["roofline"]["kernel"] == "k_schur_pairs" and j["cpu_baseline"] is None
+    # every rank: its own device, its own shard, the same communicator id
+    logs = [eval([l for l in o.splitlines() if l.startswith("LOG")][0][4:]) for o, _ in outs]
+    per_rank_points = 300 if scaling == "weak" else 150
+    for rank, log in enumerate(logs):
+        assert log[0][:3] == ("ctx", rank, per_rank_points)
+        assert log[1] == ("comm", 2, rank, 128, sum(range(128)))
