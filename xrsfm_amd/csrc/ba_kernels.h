@@ -518,7 +518,6 @@ __global__ __launch_bounds__(kBlock) void k_schur_prep(Dev d) {
     for (int k = 0; k < 28; ++k) o[k] = 0.0;
     if (cam >= 0) {
         const int pt = d.slot_pt[slot];
-        const size_t ns = (size_t)d.n_slots;
         double F[12], E[6];
         load_FE(d, slot, cam, d.slot_pt[slot], F, E);
         const double* Hi = d.Hinv + 6 * (size_t)pt;
@@ -667,7 +666,6 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
     const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (item >= d.n_items) return;
     const Item it = d.items[item];
-    const size_t ns = (size_t)d.n_slots;
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         double F[12], E[6], v0 = 0.0, v1 = 0.0;
