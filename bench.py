@@ -158,7 +158,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="L", choices=["S", "L", "K", "U", "X", "R", "V"])
+    ap.add_argument("--config", default="L", choices=["S", "L", "K", "U", "X", "R", "V", "D"])
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],

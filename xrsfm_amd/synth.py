@@ -222,4 +222,7 @@ CONFIGS = {
     # the same beyond the dense limit (18 000 camera unknowns, unordered): implicit-Schur PCG path
     "V": dict(n_cams=3000, n_points=300_000, k_obs=5, seed=8, mode="unordered"),
     "U": dict(n_cams=500, n_points=100_000, k_obs=5, seed=5, mode="unordered"),
+    # the dense limit of the exact path: 12 000 camera unknowns, unordered -> right-looking tile Cholesky of a full S
+    # (the configuration the MFMA utilisation of the reduced solve is quoted on)
+    "D": dict(n_cams=2000, n_points=200_000, k_obs=5, seed=9, mode="unordered"),
 }
