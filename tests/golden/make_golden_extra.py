@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Golden fixtures of the "next" rows: post-BA track filter (f1) and tag refinement (f4).
+"""Golden fixtures of the "next" rows: post-BA track filter (f1), scaled pose graph and tag refinement (f4).
 
 Run from the repo root:  python tests/golden/make_golden_extra.py
 Inputs come from the seeded generators of the tests, expected outputs from the oracles (oracle/ba_oracle.py
@@ -15,8 +15,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import ba_oracle as bo  # noqa: E402
+from oracle import pg_oracle as po  # noqa: E402
 from oracle import tag_oracle as to  # noqa: E402
 from tests import helpers as H  # noqa: E402
+from tests.test_pose_graph_cpu import _loop_problem  # noqa: E402
 from tests.test_tag_refine_cpu import make_scene  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -50,6 +52,20 @@ def tag_refine():
     print("tag_refine", s1, c1, s2, c2)
 
 
+def pose_graph():
+    prob, _ = _loop_problem(n=30, seed=3, scale_obs=1.03)
+    pos, sc, cost, cost0 = po.solve(prob["rot_q"], prob["pos"], prob["scale"], prob["edges"], prob["weight_o"], prob["scale_costs"],
+                                    prob["pos_const"], prob["scale_const"], prob["scale_lower"])
+    e = prob["edges"]
+    np.savez_compressed(
+        os.path.join(OUT, "pose_graph.npz"), rot_q=prob["rot_q"], pos=prob["pos"], scale=prob["scale"], weight_o=prob["weight_o"],
+        edge_a=e["a"], edge_b=e["b"], edge_sa=e["sa"], edge_sb=e["sb"], edge_q_mea=e["q_mea"], edge_p_mea=e["p_mea"],
+        scale_costs=np.array(prob["scale_costs"], float), pos_const=prob["pos_const"], scale_const=prob["scale_const"],
+        scale_lower=prob["scale_lower"], out_pos=pos, out_scale=sc, out_cost=cost, init_cost=cost0)
+    print("pose_graph", cost0, cost)
+
+
 if __name__ == "__main__":
     track_filter()
     tag_refine()
+    pose_graph()

@@ -10,7 +10,7 @@ from oracle import ba_cpu, ba_oracle as bo
 from tests import helpers as H
 
 GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
-OTHER = {"track_filter.npz", "tag_refine.npz"}          # fixtures of the "next" rows (make_golden_extra.py), tested below
+OTHER = {"track_filter.npz", "tag_refine.npz", "pose_graph.npz"}          # fixtures of the "next" rows (make_golden_extra.py), tested below
 GOLD = sorted(p for p in glob.glob(os.path.join(GOLD_DIR, "*.npz")) if os.path.basename(p) not in OTHER)
 
 
@@ -114,3 +114,25 @@ def test_tag_refine_oracle_and_product_reproduce_golden(lib):
     assert abs(out["scale"] - float(z["stage2_scale"])) < 1e-5 * out["scale"]
     assert np.max((Rotation.from_quat(out["tag_q"]).inv() * Rotation.from_quat(z["stage2_q"])).magnitude()) < 1e-4
     assert np.abs(out["tag_corners"] - z["stage2_corners"]).max() < 1e-4 and np.abs(out["points"] - z["stage2_points"]).max() < 1e-4
+
+
+def test_pose_graph_oracle_and_product_reproduce_golden(lib):
+    """pose_graph.npz: a drifted loop with covisibility, loop and scale edges + the bounded least-squares minimum of the oracle.
+    The oracle must reproduce it; the product (xrsfm_pg_solve, host code) ends at the same minimum within what its function
+    tolerance (1e-6 per step, Ceres' default) allows, and reaches it with tight tolerances."""
+    from oracle import pg_oracle as po
+    from xrsfm_amd import capi
+    z = np.load(os.path.join(GOLD_DIR, "pose_graph.npz"))
+    edges = dict(a=z["edge_a"], b=z["edge_b"], sa=z["edge_sa"], sb=z["edge_sb"], q_mea=z["edge_q_mea"], p_mea=z["edge_p_mea"])
+    sc_costs = [(int(a), int(b), float(c)) for a, b, c in z["scale_costs"]]
+    kw = dict(weight_o=float(z["weight_o"]), scale_costs=sc_costs, pos_const=z["pos_const"], scale_const=z["scale_const"], scale_lower=z["scale_lower"])
+    p_ref, s_ref, cost_ref, cost0 = po.solve(z["rot_q"], z["pos"], z["scale"], edges, **kw)
+    assert abs(cost_ref - float(z["out_cost"])) <= 1e-9 * cost_ref and abs(cost0 - float(z["init_cost"])) <= 1e-12 * cost0
+    assert np.abs(p_ref - z["out_pos"]).max() < 1e-6 and np.abs(s_ref - z["out_scale"]).max() < 1e-6
+    pos, sc, s = capi.pose_graph_solve(z["rot_q"], z["pos"], z["scale"], edges, **kw)
+    assert abs(s.initial_cost - float(z["init_cost"])) <= 1e-9 * s.initial_cost
+    assert abs(s.final_cost - float(z["out_cost"])) <= 2e-3 * s.final_cost
+    pos, sc, s = capi.pose_graph_solve(z["rot_q"], z["pos"], z["scale"], edges, function_tolerance=1e-14, parameter_tolerance=1e-13,
+                                       gradient_tolerance=1e-12, max_iterations=500, **kw)
+    assert abs(s.final_cost - float(z["out_cost"])) <= 1e-6 * s.final_cost
+    assert np.abs(pos - z["out_pos"]).max() < 1e-3 and np.abs(sc - z["out_scale"]).max() < 1e-3
