@@ -138,17 +138,46 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     const int No = p.n_obs, Np = p.n_points, Nc = p.n_cams;
     PhaseTimer timer("pack");
     auto mark = [&](const char* what) { timer.mark(what); };
-    std::vector<int> cnt(Np + 1, 0);
-    for (int i = 0; i < No; ++i) {
-        const int c = p.obs_cam[i], j = p.obs_pt[i];
-        if (c < 0 || c >= Nc || j < 0 || j >= Np) return XRSFM_BA_EINVAL;
-        cnt[j + 1]++;
+    // CSR by caller point (observation indices of every track, in input order): a stable counting sort.  Large inputs in
+    // parallel: every piece of the observation list counts per point, a pass over points x pieces turns the counts into the
+    // pieces' start positions inside each track, every piece places its observations.
+    std::vector<int> cnt(Np + 1, 0), ptr(Np + 1, 0);
+    RawVec<int> csr(No);
+    const std::vector<long long> ocut = pack_cuts(No, 1000000, 1);
+    const int och = (int)ocut.size() - 1;
+    if (och > 1 && (size_t)och * (size_t)Np <= ((size_t)64 << 20)) {
+        std::vector<std::vector<int>> lc(och);
+        std::vector<char> bad(och, 0);
+        pack_parallel_chunks(ocut, [&](int t, long long i0, long long i1) {
+            lc[t].assign(Np, 0);
+            for (long long i = i0; i < i1; ++i) {
+                const int c = p.obs_cam[i], j = p.obs_pt[i];
+                if (c < 0 || c >= Nc || j < 0 || j >= Np) { bad[t] = 1; return; }
+                lc[t][j]++;
+            }
+        });
+        for (int t = 0; t < och; ++t) if (bad[t]) return XRSFM_BA_EINVAL;
+        pack_parallel_for(Np, [&](long long j0, long long j1) {
+            for (long long j = j0; j < j1; ++j) {
+                int run = 0;
+                for (int t = 0; t < och; ++t) { const int v = lc[t][j]; lc[t][j] = run; run += v; }
+                cnt[j + 1] = run;
+            }
+        }, 100000);
+        for (int j = 0; j < Np; ++j) ptr[j + 1] = ptr[j] + cnt[j + 1];
+        pack_parallel_chunks(ocut, [&](int t, long long i0, long long i1) {
+            for (long long i = i0; i < i1; ++i) { const int j = p.obs_pt[i]; csr[ptr[j] + lc[t][j]++] = (int)i; }
+        });
+    } else {
+        for (int i = 0; i < No; ++i) {
+            const int c = p.obs_cam[i], j = p.obs_pt[i];
+            if (c < 0 || c >= Nc || j < 0 || j >= Np) return XRSFM_BA_EINVAL;
+            cnt[j + 1]++;
+        }
+        for (int j = 0; j < Np; ++j) ptr[j + 1] = ptr[j] + cnt[j + 1];
+        std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+        for (int i = 0; i < No; ++i) csr[fill[p.obs_pt[i]]++] = i;
     }
-    // CSR by caller point
-    std::vector<int> ptr(Np + 1, 0);
-    for (int j = 0; j < Np; ++j) ptr[j + 1] = ptr[j] + cnt[j + 1];
-    std::vector<int> fill(ptr.begin(), ptr.end() - 1), csr(No);
-    for (int i = 0; i < No; ++i) csr[fill[p.obs_pt[i]]++] = i;
     mark("csr by point");
     // observations of every track ordered by camera
     pack_parallel_for(Np, [&](long long j0, long long j1) {
@@ -220,26 +249,43 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
             if (ki.size() < 100000) {                    // small calls (LBA): the bucket arrays would cost more than the sort
                 std::sort(ki.begin(), ki.end(), [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; });
             } else {
+                // parallel stable LSD radix sort: every piece of the input counts its digits, a pass over digits x pieces turns
+                // the counts into start positions, every piece scatters its elements in input order.  Digits of at most 11
+                // bits (bucket tables stay in L1/L2), and only the bits a camera id + 1 can occupy in each field.
                 std::vector<KI> tmp(ki.size());
-                std::vector<unsigned> hist;
+                const std::vector<long long> cut = pack_cuts((long long)ki.size(), 100000, 1);
+                const int nch = (int)cut.size() - 1;
+                std::vector<std::vector<unsigned>> hist(nch);
                 auto pass = [&](int shift, int bits) {
                     const size_t nb = (size_t)1 << bits;
                     const unsigned long long mask = nb - 1;
-                    hist.assign(nb + 1, 0u);
-                    for (const KI& e : ki) hist[((e.key >> shift) & mask) + 1]++;
+                    pack_parallel_chunks(cut, [&](int t, long long n0, long long n1) {
+                        hist[t].assign(nb, 0u);
+                        for (long long n = n0; n < n1; ++n) hist[t][(ki[n].key >> shift) & mask]++;
+                    });
+                    unsigned run = 0;
                     bool one_bucket = false;
-                    for (size_t b = 0; b < nb && !one_bucket; ++b) one_bucket = hist[b + 1] == ki.size();
-                    if (one_bucket) return;                              // every key has the same digit: nothing to do
-                    for (size_t b = 0; b < nb; ++b) hist[b + 1] += hist[b];
-                    for (const KI& e : ki) tmp[hist[(e.key >> shift) & mask]++] = e;
+                    for (size_t b2 = 0; b2 < nb; ++b2) {
+                        unsigned in_bucket = 0;
+                        for (int t = 0; t < nch; ++t) { const unsigned v = hist[t][b2]; hist[t][b2] = run; run += v; in_bucket += v; }
+                        one_bucket |= in_bucket == ki.size();
+                    }
+                    if (one_bucket) return;                              // every key has the same digit: nothing to move
+                    pack_parallel_chunks(cut, [&](int t, long long n0, long long n1) {
+                        for (long long n = n0; n < n1; ++n) tmp[hist[t][(ki[n].key >> shift) & mask]++] = ki[n];
+                    });
                     ki.swap(tmp);
                 };
-                for (int q = kcams - 1; q >= 0; --q) pass(kbits * (kcams - 1 - q), kbits);
+                int fbits = 1;                                           // bits of a field value (camera id + 1 <= Nc)
+                while (fbits < kbits && (1ll << fbits) <= (long long)Nc) ++fbits;
+                for (int q = kcams - 1; q >= 0; --q)
+                    for (int done = 0; done < fbits; done += 11) pass(kbits * (kcams - 1 - q) + done, std::min(11, fbits - done));
                 pass(63, 1);
             }
-            for (size_t n = 0; n < ki.size(); ++n) order[n] = ki[n].idx;
             sort_keys.resize(ki.size()); key_cams = kcams;
-            for (size_t n = 0; n < ki.size(); ++n) sort_keys[n] = ki[n].key;
+            pack_parallel_for((long long)ki.size(), [&](long long n0, long long n1) {
+                for (long long n = n0; n < n1; ++n) { order[n] = ki[n].idx; sort_keys[n] = ki[n].key; }
+            });
             for (size_t b = 0; b < ki.size();) {       // equal leading cameras: finish with the full comparison (stable)
                 size_t e = b + 1;
                 while (e < ki.size() && ki[e].key == ki[b].key) ++e;
