@@ -18,6 +18,7 @@ namespace xba {
 
 constexpr int kNB = 64;          // tile size (ba_plan.h: kPlanTile)
 constexpr int kLdT = 66;         // LDS row stride (doubles): conflict-free ds_read_b64 for MFMA operands
+constexpr int kCamsPerTileDev = 10;   // cameras per 64-row tile (ba_plan.h: kCamsPerTile)
 
 struct CholDev {
     int n, n_pad, T;
@@ -432,26 +433,12 @@ __device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f6
 //   with 16x16x16 products on the FP64 matrix cores.  3 barriers per block column.
 //   With rptr/rj (level schedule) the forward substitution of the panel is folded in:
 //   y_k = Linv_k (rhs_k - sum_{j in row(k)} L_kj y_j); every L_kj and y_j belongs to a lower level.
-__global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict__ klist, const int* __restrict__ rptr,
-                                               const int* __restrict__ rj) {
-    const int k = klist[blockIdx.x];
-    const int nb = (c.tile_rows[k] + 15) >> 4;       // 16-row blocks that are not pure identity padding
-    __shared__ double A[kNB][kLdT];
-    __shared__ double Li[kNB][kLdT];
-    __shared__ double Tb[3][16][17];
+// The factorisation proper, on a tile that is already in LDS: A (lower triangle valid, upper zero) becomes L, Li becomes
+// L^-1 (Li must hold the identity on the padding rows >= 16 nb and zeros elsewhere).  Called by all 256 threads of the
+// workgroup after a barrier; ends with a barrier.
+__device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT], double (*Tb)[16][17], int nb) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
-    double* base = c.S + (size_t)(k * kNB) * c.n_pad + k * kNB;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {           // 2048 double2 of the tile, 8 per thread; the upper triangle is masked to 0
-        const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
-        const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * c.n_pad + col);
-        A[r][col] = (col <= r) ? v.x : 0.0;
-        A[r][col + 1] = (col + 1 <= r) ? v.y : 0.0;
-        Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
-        Li[r][col + 1] = (r == col + 1 && r >= 16 * nb) ? 1.0 : 0.0;
-    }
-    __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         const int b0 = 16 * kb;
         if (wave == 0) {
@@ -543,6 +530,28 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
         }
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict__ klist, const int* __restrict__ rptr,
+                                               const int* __restrict__ rj) {
+    const int k = klist[blockIdx.x];
+    const int nb = (c.tile_rows[k] + 15) >> 4;       // 16-row blocks that are not pure identity padding
+    __shared__ double A[kNB][kLdT];
+    __shared__ double Li[kNB][kLdT];
+    __shared__ double Tb[3][16][17];
+    const int t = threadIdx.x;
+    double* base = c.S + (size_t)(k * kNB) * c.n_pad + k * kNB;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {           // 2048 double2 of the tile, 8 per thread; the upper triangle is masked to 0
+        const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
+        const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * c.n_pad + col);
+        A[r][col] = (col <= r) ? v.x : 0.0;
+        A[r][col + 1] = (col + 1 <= r) ? v.y : 0.0;
+        Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
+        Li[r][col + 1] = (r == col + 1 && r >= 16 * nb) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    potrf_lds(A, Li, Tb, nb);
     double* lo = c.Linv + (size_t)k * kNB * kNB;
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
@@ -959,6 +968,190 @@ __global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict
     tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, acc, tmp, true, nullptr);
     __syncthreads();
     if (threadIdx.x < kNB) c.x[k * kNB + threadIdx.x] = tmp[threadIdx.x];
+}
+
+// ------------------------------------------------------------ fused level kernels
+// One launch per elimination-tree level (on a split level after k_ll_update_part + k_ll_update_reduce, which leave the
+// updated tiles and right-hand side in place: the lists are then empty).  One workgroup per structurally non-zero
+// tile (i,k) of the level's columns k:
+//   1. the update of the pivot tile, A_kk - sum_j L_kj L_kj^T, formed by EVERY workgroup of column k in the same order
+//      (bit-identical), and — off-diagonal workgroups — of its own tile, A_ik - sum_j L_ij L_kj^T: products on the FP64 matrix
+//      cores with the next operands prefetched.  (Summing a split level's partial tiles here as well was measured: 16-32
+//      dependent L2 round trips per workgroup, 31 us per level; the 16-workgroups-per-tile reduction launch is faster.)
+//   2. L_kk = chol, Linv_k (potrf_lds), again by every workgroup of the column: no tile of a level waits for another
+//      workgroup, so a level costs one launch instead of update -> potrf -> trsm (three dependent launches, the pivot
+//      factorisation of 12-17 us on the critical path either way);
+//   3. diagonal workgroup: stores L_kk, Linv_k and the forward substitution y_k = Linv_k (rhs_k - sum_j L_kj y_j);
+//      off-diagonal workgroup: L_ik = (A_ik - ...) Linv_k^T.
+// Ceres solves the same system with a supernodal sparse Cholesky (ba_solver.cc:74); this is the exact solve, restated.
+__global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
+                                                   const int* __restrict__ dj) {
+    __shared__ double A[kNB][kLdT];
+    __shared__ double Li[kNB][kLdT];
+    __shared__ double Tb[3][16][17];
+    __shared__ double yv[kNB], fv[kNB];
+    const int b = blockIdx.x;
+    const int i = tiles[2 * b], k = tiles[2 * b + 1];
+    const bool diag = (i == k);
+    const int nb = (c.tile_rows[k] + 15) >> 4;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+    const int o = t >> 2, part = t & 3;
+    const size_t ld = (size_t)c.n_pad;
+    const double* Skk = c.S + (size_t)(k * kNB) * ld + k * kNB;
+    double* Sik = c.S + (size_t)(i * kNB) * ld + k * kNB;
+    // the assembled tiles, in the accumulator layout of tile_abt_mfma (requested now, used after the update phase)
+    v4d skk[2][2], sik[2][2], akk[2][2], aik[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 16 * m + lk + 4 * g, col = c0 + 16 * n2 + li;
+                skk[m][n2][g] = Skk[(size_t)r * ld + col];
+                sik[m][n2][g] = diag ? 0.0 : Sik[(size_t)r * ld + col];
+                akk[m][n2][g] = 0.0; aik[m][n2][g] = 0.0;
+            }
+    double fsum = 0.0;              // (diagonal workgroup) this thread's share of sum_j L_kj y_j, row o
+    if (t < kNB) fv[t] = 0.0;
+    {
+        double* As = &A[0][0]; double* Bs = &Li[0][0];
+        const int qa = dptr[b], qb = dptr[b + 1];
+        double2 ra[8], rb[8];
+        if (qa < qb) {
+            const int jj = dj[qa]; const bool own = jj >= 0; const int j = own ? jj : ~jj;
+            load_tile_regs(rb, c.S + (size_t)(k * kNB) * ld + j * kNB, ld);
+            if (!diag && own) load_tile_regs(ra, c.S + (size_t)(i * kNB) * ld + j * kNB, ld);
+        }
+        for (int q = qa; q < qb; ++q) {
+            const int jj = dj[q]; const bool own = jj >= 0; const int j = own ? jj : ~jj;
+            __syncthreads();                       // the previous products no longer read LDS
+            store_tile_lds(Bs, rb);
+            if (!diag && own) store_tile_lds(As, ra);
+            if (diag && t < kNB) yv[t] = c.y[j * kNB + t];
+            __syncthreads();
+            if (q + 1 < qb) {                      // next contribution: loads in flight during the MFMAs below
+                const int jn = dj[q + 1]; const bool ownn = jn >= 0; const int j2 = ownn ? jn : ~jn;
+                load_tile_regs(rb, c.S + (size_t)(k * kNB) * ld + j2 * kNB, ld);
+                if (!diag && ownn) load_tile_regs(ra, c.S + (size_t)(i * kNB) * ld + j2 * kNB, ld);
+            }
+            if (diag) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) fsum += Bs[o * kLdT + part * 16 + m] * yv[part * 16 + m];
+            }
+            tile_abt_mfma(Bs, Bs, akk);
+            if (!diag && own) tile_abt_mfma(As, Bs, aik);
+        }
+        __syncthreads();
+        if (diag) {
+            fsum += __shfl_xor(fsum, 1, kWave);
+            fsum += __shfl_xor(fsum, 2, kWave);
+            if (part == 0) fv[o] = fsum;
+        }
+    }
+    // the pivot tile: lower triangle of A_kk - update, identity on the padding rows of Linv
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int r = r0 + 16 * m + lk + 4 * g, col = c0 + 16 * n2 + li;
+                A[r][col] = (col <= r) ? skk[m][n2][g] - akk[m][n2][g] : 0.0;
+                Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
+            }
+    __syncthreads();
+    potrf_lds(A, Li, Tb, nb);
+    if (diag) {
+        // Only Linv_k is stored: nothing reads the factor of a pivot tile again (updates, substitutions and the backward
+        // pass use the off-diagonal tiles and Linv), and S(k,k) must keep its assembled value while other workgroups of the
+        // column may still be reading it.
+        double* lo = c.Linv + (size_t)k * kNB * kNB;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
+            reinterpret_cast<double2*>(lo)[e] = make_double2((col <= r) ? Li[r][col] : 0.0, (col + 1 <= r) ? Li[r][col + 1] : 0.0);
+        }
+        if (t < kNB) yv[t] = c.rhs[k * kNB + t] - fv[t];
+        __syncthreads();
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) sacc += Li[o][part * 16 + m] * yv[part * 16 + m];
+        sacc += __shfl_xor(sacc, 1, kWave);
+        sacc += __shfl_xor(sacc, 2, kWave);
+        if (part == 0) c.y[k * kNB + o] = sacc;
+        return;
+    }
+    // off-diagonal tile: X = (A_ik - update) -> LDS (the factor L_kk is no longer needed here), L_ik = X Linv_k^T
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) A[r0 + 16 * m + lk + 4 * g][c0 + 16 * n2 + li] = sik[m][n2][g] - aik[m][n2][g];
+    __syncthreads();
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    tile_abt_mfma(&A[0][0], &Li[0][0], acc);
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) Sik[(size_t)(r0 + 16 * m + lk + 4 * g) * ld + c0 + 16 * n2 + li] = acc[m][n2][g];
+}
+
+// Backward substitution, one level per launch: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i).  Every term of the sum
+// is requested at once (the column list is staged in LDS first); the solution is also written in camera order.  (Turning it
+// into the candidate cameras here as well — quaternion plus on one lane per camera — put 4 us on the critical path of each
+// of the five levels; that work now rides in trailing workgroups of k_backsub.)
+__global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict__ klist, const int* __restrict__ cptr,
+                                                const int* __restrict__ ci, const int* __restrict__ tile_cam, double* __restrict__ px) {
+    __shared__ double acc[kNB];
+    __shared__ int ids[64];
+    const int k = klist[blockIdx.x];
+    const int t = threadIdx.x, o = t >> 2, part = t & 3;
+    const int q0 = cptr[blockIdx.x], q1 = cptr[blockIdx.x + 1];
+    // what does not depend on the other tiles is requested first: this thread's 16 entries of Linv_k^T and y_k
+    const double* Lk = c.Linv + (size_t)k * kNB * kNB;
+    double lk[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) lk[m] = Lk[(part * 16 + m) * kNB + o];
+    const double yk = c.y[k * kNB + o];
+    double s = 0.0;
+    for (int qb = q0; qb < q1; qb += 64) {
+        const int n = min(64, q1 - qb);
+        __syncthreads();
+        if (t < n) ids[t] = ci[qb + t];
+        __syncthreads();
+#pragma unroll 4
+        for (int e = 0; e < n; ++e) {
+            const int i = ids[e];
+            const double* M = c.S + (size_t)(i * kNB + part * 16) * c.n_pad + k * kNB + o;
+            const double* xv = c.x + i * kNB + part * 16;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) s += M[(size_t)m * c.n_pad] * xv[m];
+        }
+    }
+    s += __shfl_xor(s, 1, kWave);
+    s += __shfl_xor(s, 2, kWave);
+    if (part == 0) acc[o] = yk - s;
+    __syncthreads();
+    double s2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s2 += lk[m] * acc[part * 16 + m];
+    s2 += __shfl_xor(s2, 1, kWave);
+    s2 += __shfl_xor(s2, 2, kWave);
+    if (part == 0) {
+        c.x[k * kNB + o] = s2;
+        const int cam = (o < 6 * kCamsPerTileDev) ? tile_cam[k * kCamsPerTileDev + o / 6] : -1;
+        if (cam >= 0) px[6 * (size_t)cam + o % 6] = s2;          // the solution in camera order (what k_sol_gather did)
+    }
 }
 
 __global__ void k_zero_vec(double* p, int n) {

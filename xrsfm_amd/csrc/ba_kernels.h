@@ -203,17 +203,20 @@ __device__ __forceinline__ void load_FE(const Dev& d, int slot, int cam, int pt,
 }
 
 // Per-camera linearisation record (run before every linearisation: cameras, scales and masks as they are now).
-__global__ void k_cam_lin(Dev d) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= d.n_cams) return;
+__device__ __forceinline__ void cam_lin_one(const Dev& d, int c, const double q[4], CamLin* __restrict__ out) {
     CamLin r;
-    const double q[4] = {d.cam[c].q[0], d.cam[c].q[1], d.cam[c].q[2], d.cam[c].q[3]};
     quat_to_mat(q, r.M);
     const unsigned cc = d.cam_const[c];
     const double* sc = d.scale_c + 6 * (size_t)c;
     for (int k = 0; k < 3; ++k) { r.sq[k] = (cc & 1u) ? 0.0 : sc[k]; r.st[k] = (cc & 2u) ? 0.0 : sc[3 + k]; }
     r.pad = 0.0;
-    d.camrec[c] = r;
+    out[c] = r;
+}
+__global__ void k_cam_lin(Dev d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n_cams) return;
+    const double q[4] = {d.cam[c].q[0], d.cam[c].q[1], d.cam[c].q[2], d.cam[c].q[3]};
+    cam_lin_one(d, c, q, d.camrec);
 }
 
 // ---------------------------------------------------------------- linearise
@@ -406,8 +409,10 @@ __global__ __launch_bounds__(kBlock) void k_cost(Dev d, double huber_a) {
 // One workgroup per camera; scat holds K doubles per observation in camera-major
 // order.  Thread (g,k) accumulates component k over observations g, g+G, ...;
 // the G partials are then added in fixed order.
-template <int K>
-__device__ __forceinline__ void segsum_body(const double* __restrict__ scat, const int* __restrict__ ptr, double* __restrict__ out, int c) {
+// WT: the result is stored write-through (agent-scope store), for a consumer in the same launch (k_lin_tail).
+template <int K, bool WT = false>
+__device__ __forceinline__ void segsum_body(const double* __restrict__ scat, const int* __restrict__ ptr, double* __restrict__ out, int c,
+                                            double* lds_out = nullptr) {
     constexpr int G = kBlock / K;
     __shared__ double lds[G * K];
     const int t = threadIdx.x;
@@ -417,7 +422,13 @@ __device__ __forceinline__ void segsum_body(const double* __restrict__ scat, con
         double acc = 0.0;
         const double* base = scat + (size_t)beg * K + t;
         const int n = end - beg;
-        for (int o = g; o < n; o += G) { acc += *base; base += (size_t)G * K; }
+        int o = g;
+        for (; o + 3 * G < n; o += 4 * G) {          // four loads in flight, added in list order
+            const double v0 = base[0], v1 = base[(size_t)G * K], v2 = base[(size_t)2 * G * K], v3 = base[(size_t)3 * G * K];
+            acc += v0; acc += v1; acc += v2; acc += v3;
+            base += (size_t)4 * G * K;
+        }
+        for (; o < n; o += G) { acc += *base; base += (size_t)G * K; }
         lds[t] = acc;
     }
     __syncthreads();
@@ -425,7 +436,9 @@ __device__ __forceinline__ void segsum_body(const double* __restrict__ scat, con
         double s = 0.0;
 #pragma unroll 4
         for (int g = 0; g < G; ++g) s += lds[g * K + t];
-        out[(size_t)c * K + t] = s;
+        if (WT) __hip_atomic_store(out + (size_t)c * K + t, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else out[(size_t)c * K + t] = s;
+        if (lds_out) lds_out[t] = s;
     }
 }
 
@@ -828,8 +841,41 @@ __global__ __launch_bounds__(kPcgBlock) void k_pcg_p(Dev d, const double* __rest
 }
 
 // ---------------------------------------------------------------- back-substitution + update
+// Candidate cameras: Plus(x, -y*scale); |dx|^2 and |x|^2 per camera (ambient, variable blocks only).
+// y: the camera's 6 entries of the (scaled) solution.  camrec_cand (optional): the candidate's linearisation record is
+// written as well (the level-scheduled backward substitution produces the candidate cameras tile by tile, ba_chol.h).
+__device__ __forceinline__ void cam_update_one(const Dev& d, int c, const double* y, CamLin* __restrict__ camrec_cand) {
+    const CamRec cur = d.cam[c];
+    CamRec nxt = cur;
+    const unsigned cc = d.cam_const[c];
+    const bool active = d.cam_act[c] > 0.0;
+    const double* sc = d.scale_c + 6 * (size_t)c;
+    double step2 = 0.0, xn2 = 0.0;
+    if (active && !(cc & 1u)) {
+        const double dl[3] = {-y[0] * sc[0], -y[1] * sc[1], -y[2] * sc[2]};
+        quat_plus(cur.q, dl, nxt.q);
+        for (int k = 0; k < 4; ++k) { const double df = nxt.q[k] - cur.q[k]; step2 += df * df; xn2 += cur.q[k] * cur.q[k]; }
+    }
+    if (active && !(cc & 2u)) {
+        for (int k = 0; k < 3; ++k) {
+            nxt.t[k] = cur.t[k] + (-y[3 + k] * sc[3 + k]);
+            const double df = nxt.t[k] - cur.t[k]; step2 += df * df; xn2 += cur.t[k] * cur.t[k];
+        }
+    }
+    d.cam_cand[c] = nxt;
+    d.campart[c] = step2;
+    d.campart[d.n_cams + c] = xn2;
+    if (camrec_cand) cam_lin_one(d, c, nxt.q, camrec_cand);
+}
+
 // y_p = Hinv (g_p - sum E^T F y_c); model cost change; candidate points.
-__global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
+// Workgroups >= n_item_blocks: candidate cameras from the camera part of the solution (thread = camera; cam_update_one).
+__global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
+    if ((int)blockIdx.x >= n_item_blocks) {
+        const int c = (blockIdx.x - n_item_blocks) * kBlock + threadIdx.x;
+        if (c < d.n_cams) cam_update_one(d, c, d.px + 6 * (size_t)c, camrec_cand);
+        return;
+    }
     const int lane = threadIdx.x & (kWave - 1);
     const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (item >= d.n_items) return;
@@ -950,55 +996,36 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d) {
     if (lane == 0) { d.part[2 * d.n_items + item] = model; d.part[3 * d.n_items + item] = step2; }
 }
 
-// Candidate cameras: Plus(x, -y*scale); |dx|^2 and |x|^2 per camera (ambient, variable blocks only).
 __global__ void k_cam_update(Dev d) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= d.n_cams) return;
-    const CamRec cur = d.cam[c];
-    CamRec nxt = cur;
-    const unsigned cc = d.cam_const[c];
-    const bool active = d.cam_act[c] > 0.0;
-    const double* y = d.px + 6 * (size_t)c;
-    const double* sc = d.scale_c + 6 * (size_t)c;
-    double step2 = 0.0, xn2 = 0.0;
-    if (active && !(cc & 1u)) {
-        const double dl[3] = {-y[0] * sc[0], -y[1] * sc[1], -y[2] * sc[2]};
-        quat_plus(cur.q, dl, nxt.q);
-        for (int k = 0; k < 4; ++k) { const double df = nxt.q[k] - cur.q[k]; step2 += df * df; xn2 += cur.q[k] * cur.q[k]; }
-    }
-    if (active && !(cc & 2u)) {
-        for (int k = 0; k < 3; ++k) {
-            nxt.t[k] = cur.t[k] + (-y[3 + k] * sc[3 + k]);
-            const double df = nxt.t[k] - cur.t[k]; step2 += df * df; xn2 += cur.t[k] * cur.t[k];
-        }
-    }
-    d.cam_cand[c] = nxt;
-    d.campart[c] = step2;
-    d.campart[d.n_cams + c] = xn2;
+    cam_update_one(d, c, d.px + 6 * (size_t)c, nullptr);
 }
 
 // Ceres' gradient max-norm |x - Plus(x, -g)|_inf with the unscaled gradient.
 // rank_max (multi-rank only): the ranks' point-gradient maxima, folded to *out_pts here.
+__device__ __forceinline__ double cam_gradmax_one(const Dev& d, int c, const double* g) {      // g: the camera's 6 gradient entries
+    double m = 0.0;
+    const unsigned cc = d.cam_const[c];
+    const bool active = d.cam_act[c] > 0.0;
+    const double* sc = d.scale_c + 6 * (size_t)c;
+    if (active && !(cc & 1u)) {
+        const CamRec& cur = d.cam[c];
+        const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
+        const double dl[3] = {-g[0] / sc[0], -g[1] / sc[1], -g[2] / sc[2]};
+        double qn[4];
+        quat_plus(q, dl, qn);
+        for (int k = 0; k < 4; ++k) m = fmax(m, fabs(q[k] - qn[k]));
+    }
+    if (active && !(cc & 2u))
+        for (int k = 0; k < 3; ++k) m = fmax(m, fabs(g[3 + k] / sc[3 + k]));
+    return m;
+}
 __global__ __launch_bounds__(kPcgThreads) void k_gradmax_cams(Dev d, double* __restrict__ out, const double* __restrict__ rank_max,
                                                            int n_ranks, double* __restrict__ out_pts) {     // one workgroup
     __shared__ double lds[kPcgThreads / kWave];
     double m = 0.0;
-    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
-        const unsigned cc = d.cam_const[c];
-        const bool active = d.cam_act[c] > 0.0;
-        const double* g = d.camlin + 12 * (size_t)c + 6;
-        const double* sc = d.scale_c + 6 * (size_t)c;
-        if (active && !(cc & 1u)) {
-            const CamRec& cur = d.cam[c];
-            const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
-            const double dl[3] = {-g[0] / sc[0], -g[1] / sc[1], -g[2] / sc[2]};
-            double qn[4];
-            quat_plus(q, dl, qn);
-            for (int k = 0; k < 4; ++k) m = fmax(m, fabs(q[k] - qn[k]));
-        }
-        if (active && !(cc & 2u))
-            for (int k = 0; k < 3; ++k) m = fmax(m, fabs(g[3 + k] / sc[3 + k]));
-    }
+    for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) m = fmax(m, cam_gradmax_one(d, c, d.camlin + 12 * (size_t)c + 6));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_down(m, off, kWave));
     if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
@@ -1078,6 +1105,105 @@ __global__ __launch_bounds__(kPcgThreads) void k_reduce_max(const double* __rest
         double r = 0.0;
         for (int i = 0; i < kPcgThreads / kWave; ++i) r = fmax(r, lds[i]);
         *out = r;
+    }
+}
+
+// ---------------------------------------------------------------- tail of a linearisation, one launch
+// What used to be k_cam_segsum<12> -> k_reduce_multi -> k_gradmax_cams -> k_publish (four dependent launches of 4-10 us).
+// At most one workgroup per CU (kTailGrid): a release fence or a ticket per CAMERA workgroup costs more than the launches
+// it replaces (measured: 1000 workgroups, each with an L2 write-back and an arrival on one counter, 31 us).
+//   * workgroup b adds the camera-major partials of the cameras b, b + G, ... (diag H_cc, g_c) in fixed order, and
+//   * reduces ITS slice of every job's partial array to one value (two-level deterministic reduction: slice boundaries
+//     depend on the sizes alone); both results leave the CU write-through (agent-scope stores), so no release fence;
+//   * the workgroup that arrives last (every storing wave drains, one ticket per workgroup, ONE acquire by the last one — the
+//     only inter-workgroup hand-off, and its consumer does nothing another workgroup waits for) adds the per-workgroup
+//     values of every job in workgroup order, takes Ceres' gradient max-norm over the cameras and, on one rank, hands the
+//     scalar block to the host through coherent memory (what k_publish did).
+constexpr int kTailGrid = 1024;
+struct TailArgs {
+    ReduceJobs jobs; int njobs;
+    double* part2;             // [8][gridDim.x] per-workgroup values
+    unsigned* ticket;          // 9 counters, 128 bytes apart (8 shards + top), zero between launches (the last workgroup resets them)
+    int gradmax;               // 1: camera gradient max-norm -> scal[S_GRADMAX_CAMS] (one rank; with several ranks it follows the all-reduce)
+    double* host; unsigned long long seq;   // != nullptr: publish the scalar block
+};
+
+constexpr int kTailJobs = 8;       // slots of the second stage: up to 7 reduction jobs + the camera gradient max-norm
+
+__global__ __launch_bounds__(kBlock) void k_lin_tail(Dev d, TailArgs a) {
+    __shared__ double sums[12];
+    __shared__ double sc[S_COUNT];
+    __shared__ bool last;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, G = gridDim.x, b = blockIdx.x;
+    // ---- stage 1: this workgroup's cameras and its slice of every job
+    double gm = 0.0;
+    for (int c = b; c < d.n_cams; c += G) {           // (uniform per workgroup: segsum_body has barriers)
+        __syncthreads();
+        segsum_body<12, true>(d.scat, d.cam_ptr_g, d.camlin, c, sums);
+        __syncthreads();
+        if (t == 0 && a.gradmax) gm = fmax(gm, cam_gradmax_one(d, c, sums + 6));
+    }
+    if (t == 0 && a.gradmax) __hip_atomic_store(a.part2 + (size_t)(kTailJobs - 1) * G + b, gm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = wave; j < a.njobs; j += kBlock / kWave) {        // one wave per job: no workgroup barriers
+        const double* in = a.jobs.in[j];
+        const int n = a.jobs.n[j], op = a.jobs.op[j];
+        const int len = (n + G - 1) / G, lo = min(n, b * len), hi = min(n, lo + len);
+        double v = 0.0;
+        for (int i = lo + lane; i < hi; i += kWave) v = (op == 0) ? v + in[i] : fmax(v, in[i]);
+        if (op == 0) v = wave_sum(v);
+        else {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, kWave));
+        }
+        if (lane == 0) __hip_atomic_store(a.part2 + (size_t)j * G + b, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // hand-off to the last arriver (MI355X guide, inter-workgroup visibility, form R1: write-through payload, every storing
+    // wave drains its stores, then one relaxed agent-scope arrival per workgroup)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        // arrivals are sharded over 8 counters (one word takes ~88 returning atomics per microsecond: 1000 arrivals on one
+        // word cost 11 us); the last arrival of a shard arrives on the top counter
+        const int sh = b & 7, nsh = min(G, 8), n_in_shard = (G - sh + 7) >> 3;
+        bool l = false;
+        if (__hip_atomic_fetch_add(a.ticket + 32 * sh, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)n_in_shard)
+            l = (__hip_atomic_fetch_add(a.ticket + 32 * 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)nsh);
+        last = l;
+    }
+    __syncthreads();
+    if (!last) return;
+    // ---- stage 2 (one workgroup): 32 lanes per slot add the G per-workgroup values in a fixed order
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (t < S_COUNT) sc[t] = __hip_atomic_load(d.scal + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    {
+        const int j = t >> 5, l32 = t & 31;
+        const bool isgm = (j == kTailJobs - 1);
+        const bool on = isgm ? (a.gradmax != 0) : (j < a.njobs);
+        const int op = isgm ? 1 : (on ? a.jobs.op[j] : 0);
+        const double* in = a.part2 + (size_t)j * G;
+        double v = 0.0;
+        if (on) for (int i = l32; i < G; i += 32) v = (op == 0) ? v + in[i] : fmax(v, in[i]);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {
+            const double ov = __shfl_down(v, off, 32);
+            v = (op == 0) ? v + ov : fmax(v, ov);
+        }
+        if (on && l32 == 0) {
+            double* out = isgm ? d.scal + S_GRADMAX_CAMS : a.jobs.out[j];
+            *out = v;
+            const long long idx = out - d.scal;
+            if (idx >= 0 && idx < S_COUNT) sc[idx] = v;
+        }
+    }
+    __syncthreads();
+    if (t < 9) __hip_atomic_store(a.ticket + 32 * t, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a.host) {
+        if (t < S_COUNT) a.host[t] = sc[t];
+        __threadfence_system();
+        __syncthreads();
+        if (t == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(a.host + S_COUNT), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -36,6 +36,14 @@ struct CholPlan {
     // fill lists: per structurally non-zero tile (tiles_nz order) its 6x6 blocks: entry >= 0 off-diagonal block id,
     // entry < 0 the diagonal block of camera -(entry+1)
     std::vector<int> tf_ptr, tf_ent;
+    // fused level kernel (k_lv_factor, ba_chol.h): one workgroup per structurally non-zero tile (i,k) of a level's columns;
+    // it forms the update of the DIAGONAL tile (k,k) itself (every workgroup of a column repeats that sum and the
+    // factorisation of the 64x64 pivot tile bit for bit, so no tile of a level waits for another one), and of its own tile.
+    //   direct level: fz_dptr/fz_dj = the row tiles j < k of column k's diagonal; entry j if (i,j) is non-zero as well
+    //                 (it then also contributes to tile (i,k)), ~j otherwise;
+    //   split level:  empty lists (k_ll_update_part + k_ll_update_reduce have updated the tiles and the right-hand side in place).
+    std::vector<int> fz_tile, fz_dptr, fz_dj, fz_off;
+    std::vector<int> tile_cam;          // [T][kCamsPerTile] camera in slot q of tile t, -1 = none (backward kernel: candidate cameras)
 };
 
 typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
@@ -262,6 +270,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     }
     if (T == 0) { T = 1; P.tile_rows.push_back(0); }
     P.T = T; P.n_pad = T * kPlanTile;
+    P.tile_cam.assign((size_t)T * kCamsPerTile, -1);
+    for (int c = 0; c < Nc; ++c) P.tile_cam[(size_t)(P.cam_off[c] / kPlanTile) * kCamsPerTile + (P.cam_off[c] % kPlanTile) / 6] = c;
     if (6LL * Nc > max_dense_unknowns &&
         (P.ordering != 1 || (unsigned long long)P.n_pad * (unsigned long long)P.n_pad * sizeof(double) > max_tile_bytes)) return XRSFM_BA_ETOOBIG;
 
@@ -319,7 +329,11 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.lv_cptr.assign(1, 0); P.lv_rptr.assign(1, 0); P.lv_bptr.assign(1, 0);
     P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0); P.lv_trsm_off.assign(n_levels + 1, 0);
     P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
+    P.fz_off.assign(n_levels + 1, 0); P.fz_dptr.assign(1, 0);
+    struct FzEnt { int i, k; };
+    std::vector<FzEnt> fz_ents;
     for (int lv = 0; lv < n_levels; ++lv) {
+        fz_ents.clear();
         for (int kk = 0; kk < T; ++kk) {
             if (level[kk] != lv) continue;
             for (int i = kk; i < T; ++i) {
@@ -327,6 +341,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
                 std::vector<int> contrib;
                 for (int j = 0; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
+                fz_ents.push_back({i, kk});
                 if (contrib.empty()) continue;
                 P.lv_tgt.push_back(i); P.lv_tgt.push_back(kk);
                 for (int j : contrib) P.lv_cj.push_back(j);
@@ -353,6 +368,14 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             }
             P.sp_max_chunks = std::max(P.sp_max_chunks, np);
         }
+        for (const FzEnt& e : fz_ents) {        // work list of the fused level kernel
+            P.fz_tile.push_back(e.i); P.fz_tile.push_back(e.k);
+            if (!split)
+                for (int j = 0; j < e.k; ++j)
+                    if (nz[(size_t)e.k * T + j]) P.fz_dj.push_back((e.i == e.k || nz[(size_t)e.i * T + j]) ? j : ~j);
+            P.fz_dptr.push_back((int)P.fz_dj.size());
+        }
+        P.fz_off[lv + 1] = (int)P.fz_tile.size() / 2;
         P.sp_chunk_off[lv + 1] = (int)P.sp_tgt.size() / 2;
         P.sp_rt_off[lv + 1] = (int)P.sp_rt.size() / 2;
         for (int kk = 0; kk < T; ++kk) {

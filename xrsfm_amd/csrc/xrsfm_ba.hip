@@ -108,6 +108,8 @@ struct CholHost {
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off;
     double* sp_work = nullptr;
+    int *fz_tile = nullptr, *fz_dptr = nullptr, *fz_dj = nullptr, *tile_cam = nullptr;   // fused level kernel (ba_plan.h)
+    std::vector<int> fz_off;
     int* zero2 = nullptr;                                    // two zeros: an empty CSR row list
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
@@ -137,6 +139,9 @@ struct xrsfm_ba_context {
     std::vector<Rec> recs;
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
     bool linearized = false;
+    bool fused = true;              // fused level kernels / linearisation tail (XRSFM_BA_FUSED=0: the launch-per-phase schedule, A/B aid)
+    bool gradmax_done = false, published = false;    // the linearisation tail did these in its own launch
+    double* part2 = nullptr; unsigned* ticket = nullptr;      // k_lin_tail
     // Second set of linearisation buffers: every LM step linearises at the CANDIDATE point right after the back-substitution
     // (its cost is the candidate cost the step test needs, so no separate cost pass exists); an accepted step swaps the sets.
     struct LinBuf { double* rt = nullptr; double* Jp = nullptr; CamLin* camrec = nullptr; double* Hpp = nullptr; double* gp = nullptr; double* camlin = nullptr; } alt;
@@ -338,9 +343,13 @@ int fetch_scalars(xrsfm_ba_context* c) {
         if (c->profiling) profile_collect(c);
         return 0;
     }
-    const unsigned long long want = ++c->seq;
-    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->d.scal, c->h_scal_dev, want);
-    HIPCHK(hipGetLastError());
+    unsigned long long want;
+    if (c->published) { want = c->seq; c->published = false; }         // k_lin_tail hands the block over itself
+    else {
+        want = ++c->seq;
+        hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->d.scal, c->h_scal_dev, want);
+        HIPCHK(hipGetLastError());
+    }
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(c->h_scal + S_COUNT);
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want; ++spins) {
         if ((spins & 0xfffff) == 0xfffff) {                 // every ~1M polls: has the stream died?
@@ -357,11 +366,12 @@ int fetch_scalars(xrsfm_ba_context* c) {
 // the scalar block and camlin / Hpp / gp / rt / Jp of that view filled.  with_step: the partial sums the preceding
 // back-substitution left (model decrease, squared step norms, |x_cams|^2) are reduced by the same launch and, with several
 // ranks, travel in the same all-reduce: layout behind the camera block = [cost, |x_pts|^2, model, |step_pts|^2, rank slots].
-int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step) {
+enum { LIN_SKIP_CAMLIN = 1, LIN_FINAL = 2 };    // LIN_FINAL: gradient max-norm and the hand-over to the host follow this linearisation
+int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step, int flags = 0) {
     const Dev& own = c->d;
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_lin, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
+    if (d.n_cams > 0 && !(flags & LIN_SKIP_CAMLIN)) LAUNCH(c, K_SMALL, k_cam_lin, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), kWavesPerBlock * kWave * 13 * sizeof(double), d, huber_a);
-    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camlin, (const PcgStatus*)nullptr);
+    if (!c->fused && d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camlin, (const PcgStatus*)nullptr);
     {
         double* tail = d.camlin + (size_t)d.n_cams * 12;
         const bool multi = c->multi();
@@ -380,7 +390,19 @@ int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step)
             job(own.campart + own.n_cams, own.n_cams, d.scal + S_XNORM2_CAMS, 0);
         }
         if (multi) HIPCHK(hipMemsetAsync(tail + 2, 0, sizeof(double) * (2 + (size_t)c->n_ranks), c->stream));
-        LAUNCH(c, K_SMALL, k_reduce_multi, dim3(nj), dim3(kPcgThreads), 0, j);
+        if (c->fused) {
+            // one launch: per-camera sums, the reductions and — on one rank, when this is the last linearisation before the
+            // host looks — the camera gradient max-norm and the hand-over of the scalar block
+            TailArgs a{};
+            a.jobs = j; a.njobs = nj; a.part2 = c->part2; a.ticket = c->ticket;
+            const bool final_here = (flags & LIN_FINAL) && !multi;
+            a.gradmax = final_here ? 1 : 0;
+            if (final_here && !c->profiling && c->h_scal_dev) { a.host = c->h_scal_dev; a.seq = ++c->seq; c->published = true; }
+            LAUNCH(c, K_SMALL, k_lin_tail, dim3(std::min(kTailGrid, std::max(d.n_cams, 1))), dim3(kBlock), 0, d, a);
+            if (final_here) c->gradmax_done = true;
+        } else {
+            LAUNCH(c, K_SMALL, k_reduce_multi, dim3(nj), dim3(kPcgThreads), 0, j);
+        }
         if (multi) {
             int e = allreduce(c, d.camlin, (size_t)d.n_cams * 12 + 4 + (size_t)c->n_ranks, kNcclSum);
             if (e) return e;
@@ -392,6 +414,7 @@ int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step)
 
 // after linearize() of the same view, which leaves the point part in S_GRADMAX_PTS (one rank) or in the per-rank slots behind camlin
 int gradient_max_enqueue(xrsfm_ba_context* c, const Dev& d) {
+    if (c->gradmax_done) { c->gradmax_done = false; return 0; }        // k_lin_tail of the same view has done it
     const double* rank_max = c->multi() ? d.camlin + (size_t)d.n_cams * 12 + 4 : nullptr;
     LAUNCH(c, K_SMALL, k_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, d.scal + S_GRADMAX_CAMS, rank_max, c->n_ranks, d.scal + S_GRADMAX_PTS);
     return 0;
@@ -499,7 +522,7 @@ int chol_setup(xrsfm_ba_context* c) {
     h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
-    h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off;
+    h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.fz_off = P.fz_off;
     int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     BatchUpload up(c);
@@ -514,6 +537,8 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.sp_tgt, P.sp_tgt); up.add(&h.sp_q, P.sp_q);
     up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp);
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
+    up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
+    up.add(&h.tile_cam, P.tile_cam);
     const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
     up.add(&h.zero2, two_zeros);
     up.add(&h.pairs_items, P.pairs_items);
@@ -598,7 +623,28 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     const int T = h.T;
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
-    if (h.use_levels) {
+    if (h.use_levels && c->fused) {
+        // one launch per elimination-tree level (three on a split level: partial products, their fixed-order sum, then the
+        // same fused kernel with empty lists), then one per level backwards
+        for (int lv = 0; lv < h.n_levels; ++lv) {
+            const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
+            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv];
+            if (nch > 0) {
+                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), shm, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
+                       h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
+                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
+                       h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
+            }
+            const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
+            if (nf > 0)
+                LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj);
+        }
+        for (int lv = h.n_levels - 1; lv >= 0; --lv) {
+            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
+            LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, d.px);
+        }
+        return 0;
+    } else if (h.use_levels) {
         // one launch per elimination-tree level and phase
         for (int lv = 0; lv < h.n_levels; ++lv) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
@@ -663,11 +709,17 @@ void accept_candidate(xrsfm_ba_context* c) {
 // One hand-off of all scalars to the host either way.
 int finish_step(xrsfm_ba_context* c, double huber_a, bool speculate) {
     Dev& d = c->d;
-    if (d.n_items > 0) LAUNCH(c, K_BACKSUB, k_backsub, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d);
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
+    // back-substitution over the tracks; trailing workgroups turn the camera part of the solution into the candidate cameras
+    // (and, when the candidate is linearised straight away, their CamLin records) next to it
+    const bool cams_done = c->fused;
+    {
+        const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cams_done ? cdiv(d.n_cams, kBlock) : 0;
+        if (nbi + nbc > 0) LAUNCH(c, K_BACKSUB, k_backsub, dim3(nbi + nbc), dim3(kBlock), 0, d, nbi, (cams_done && speculate) ? c->alt.camrec : (CamLin*)nullptr);
+    }
+    if (d.n_cams > 0 && !cams_done) LAUNCH(c, K_SMALL, k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (speculate) {
         const Dev cand = candidate_view(c);
-        int e = linearize(c, huber_a, cand, true);
+        int e = linearize(c, huber_a, cand, true, LIN_FINAL | (cams_done ? LIN_SKIP_CAMLIN : 0));
         if (e) return e;
         if ((e = gradient_max_enqueue(c, cand))) return e;
         return fetch_scalars(c);
@@ -697,12 +749,13 @@ int init_scaling_and_linearize(xrsfm_ba_context* c, double huber_a, bool use_sca
     int e;
     LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_cams * 6, kBlock) + 1), dim3(kBlock), 0, d.scale_c, 1.0, (size_t)d.n_cams * 6);
     LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, d.scale_p, 1.0, (size_t)d.n_pts * 3);
-    if ((e = linearize(c, huber_a, d, false))) return e;
+    c->gradmax_done = false; c->published = false;
+    if ((e = linearize(c, huber_a, d, false, use_scaling ? 0 : LIN_FINAL))) return e;
     if (use_scaling) {
         // point norms are local to the rank that owns the track; camera norms were all-reduced in linearize()
         const long long n = std::max((long long)d.n_cams * 6, (long long)d.n_pts * 3);
         LAUNCH(c, K_SMALL, k_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, d);
-        if ((e = linearize(c, huber_a, d, false))) return e;
+        if ((e = linearize(c, huber_a, d, false, LIN_FINAL))) return e;
     }
     c->linearized = true;
     return 0;
@@ -851,9 +904,16 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
     TRY(dev_alloc(c, &d.pcgpart, nc * 3));
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));
     TRY(dev_alloc(c, &d.st, (size_t)1));
+    TRY(dev_alloc(c, &c->part2, (size_t)kTailJobs * kTailGrid));
+    TRY(dev_alloc(c, &c->ticket, (size_t)32 * 9));
 #undef TRY
+    {
+        const char* fz = std::getenv("XRSFM_BA_FUSED");
+        c->fused = !(fz && fz[0] == '0');
+    }
     // (the scatter buffers need no clearing: every entry is written before it is read)
     if (hipMemsetAsync(d.scal, 0, sizeof(double) * S_COUNT, c->stream) != hipSuccess || hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->ticket, 0, sizeof(unsigned) * 32 * 9, c->stream) != hipSuccess ||
         hipStreamSynchronize(c->stream) != hipSuccess) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
     timer.mark("work buffers");
     *out = c;
@@ -1034,7 +1094,7 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
             } else {
                 std::swap(d.cam, d.cam_cand);
                 std::swap(d.P, d.P_cand);
-                if ((e = linearize(c, opt.huber_a, d, false))) return e;
+                if ((e = linearize(c, opt.huber_a, d, false, LIN_FINAL))) return e;
                 if ((e = gradient_max(c, &gmax))) return e;
                 cost = 0.5 * c->h_scal[S_COST];
                 xnorm2_pts = c->h_scal[S_XNORM2_PTS];
