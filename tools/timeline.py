@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Developer aid: cycle stamps of sampled waves inside the streaming kernels (library built with -DXBA_TIMELINE into
+/tmp; the shipped library has no stamps).  usage (GPU box): python tools/timeline.py [config]"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "L"
+    lib = os.path.join(ROOT, "tools", "_tl", "libxrsfm_ba_tl.so")
+    if not os.path.exists(lib):
+        os.makedirs(os.path.dirname(lib), exist_ok=True)
+        subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DXBA_TIMELINE", "-Wno-unused-value",
+                        "-Wno-deprecated-declarations", "-o", lib, os.path.join(ROOT, "xrsfm_amd", "csrc", "xrsfm_ba.hip"), "-ldl"], check=True)
+    from xrsfm_amd import capi, synth
+    L = capi.load(lib)
+    d = synth.make_problem(**synth.CONFIGS[cfg])
+    prob = capi.ProblemArrays(**{k: d[k] for k in capi.ProblemArrays.FIELDS})
+    ctx = capi.Context(prob)
+    ctx.run(capi.default_options(max_iterations=3))
+    out = np.zeros((3, 64, 16), dtype=np.uint64)
+    L.xrsfm_ba_debug_stamps.argtypes = [C.c_void_p]
+    assert L.xrsfm_ba_debug_stamps(out.ctypes.data) == 0
+    for kern, name in enumerate(["k_schur_pairs", "k_linearize", "k_backsub"]):
+        st = out[kern].astype(np.int64)
+        ok = st[:, 0] > 0
+        if not ok.any():
+            continue
+        st = st[ok]
+        n = int((st[0] > 0).sum())
+        rel = (st[:, :n] - st[:, :1])
+        print(name, "samples", len(st), "cycles from wave start (median / p10 / p90) at each stamp (100 MHz counter? see deltas):")
+        for i in range(n):
+            col = rel[:, i]
+            print(f"  stamp {i}: {np.median(col):9.0f} {np.percentile(col, 10):9.0f} {np.percentile(col, 90):9.0f}")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         }
         __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand (and dtab) are in LDS
         __builtin_amdgcn_wave_barrier();
+        XBA_STAMP(0, 6);
         for (int k0 = 0; k0 < C4; k0 += 4) {
             double a[NI];
 #pragma unroll
@@ -130,6 +131,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         __builtin_amdgcn_s_waitcnt(0xc07f);            // the reads above are done before the next round overwrites the operand
         __builtin_amdgcn_wave_barrier();
     }
+    XBA_STAMP(0, 7);
     int p = 0;
 #pragma unroll
     for (int I = 0; I < NI; ++I)
@@ -159,8 +161,12 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                    int n_obs_pairs, double* __restrict__ scat2) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
-    const int item = item_list[blockIdx.x];          // one launch per LDS class (ba_plan.h)
-    const Item it = d.items[item];
+    XBA_STAMP(0, 0);
+    // one launch per LDS class (ba_plan.h); the Gram classes list tiles, the other class items
+    const int entry = item_list[blockIdx.x];
+    Item it;
+    if (GRAM) { it.first_tile = entry; it.n_tiles = 1; }
+    else it = d.items[entry];
     if (GRAM || it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int L = d.tile_stride[it.first_tile];
@@ -172,13 +178,17 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             double o28[28];
 #pragma unroll
             for (int k = 0; k < 28; ++k) o28[k] = 0.0;
+            XBA_STAMP(0, 1);
             if (s.valid) {
                 double F[12], E[6];
                 load_FE(d, s.slot, s.cam, s.pt, F, E);
+                XBA_STAMP(0, 2);
                 const double* hc = d.Hc + 6 * (size_t)s.pt;
                 pairs_V(F, E, hc, V);
+                XBA_STAMP(0, 3);
                 pairs_diag(F, V, hc, d.gp + 3 * (size_t)s.pt, o28);
             }
+            XBA_STAMP(0, 4);
             const int cp = d.slot_campos_g[s.slot];
             const int Cg = GRAM ? d.tile_ncam[it.first_tile] : 0;
             if (L > 0) {
@@ -247,6 +257,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 for (int k = 0; k < 14; ++k) out[k] = make_double2(o28[2 * k], o28[2 * k + 1]);
             }
         }
+        XBA_STAMP(0, 5);
         const int C = d.tile_ncam[it.first_tile];
         if (GRAM) {
             // Gram tile: rows = (distinct camera of the tile, 6), columns = (track, 3); cells of cameras a track does not see
@@ -273,6 +284,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 case 3: gram_tile<3>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
                 default: gram_tile<4>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
             }
+            XBA_STAMP(0, 8);
             return;
         }
         if (GRAM) return;           // (not reached: keeps the per-pair code out of the Gram instantiation)

@@ -88,6 +88,14 @@ struct Dev {
     PcgStatus* st;
 };
 
+// Developer aid (-DXBA_TIMELINE, tools/timeline.py): cycle stamps of sampled waves inside the streaming kernels.
+#ifdef XBA_TIMELINE
+__device__ unsigned long long g_stamps[3][64][16];
+#define XBA_STAMP(kern, i) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 64 && (threadIdx.x >> 6) == 0) g_stamps[kern][blockIdx.x / 97][i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define XBA_STAMP(kern, i) do {} while (0)
+#endif
+
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll

@@ -21,7 +21,7 @@ struct CholPlan {
     bool use_levels = false;
     // k_schur_pairs is launched once per LDS class: items whose staged operand fits 10 KB (16 workgroups per CU) and the rest
     size_t pairs_shm = 0, pairs_shm_big = 0;
-    std::vector<int> pairs_items;    // item indices: Gram tiles of the small class | Gram tiles of the big class | other items
+    std::vector<int> pairs_items;    // Gram tiles of the small class | Gram tiles of the big class (tile indices) | other items (item indices)
     int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
     std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, one_k, tiles_nz;
     std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
@@ -409,8 +409,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             for (int q = 0; q < 64 && k.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || k.slot_pt[64 * t + q] != k.slot_pt[64 * t + q - 1]);
             int passes = 1;
             const size_t need = std::max(base, (size_t)gram_lds_need(C, ntrk, &passes));
-            if (need <= small_cap) { P.pairs_items.push_back(it); P.pairs_shm = std::max(P.pairs_shm, need); }
-            else { big.push_back(it); P.pairs_shm_big = std::max(P.pairs_shm_big, need); }
+            // (Gram classes list the TILE itself: one dependent load less at the head of every workgroup)
+            if (need <= small_cap) { P.pairs_items.push_back(t); P.pairs_shm = std::max(P.pairs_shm, need); }
+            else { big.push_back(t); P.pairs_shm_big = std::max(P.pairs_shm_big, need); }
         }
         P.n_pairs_small = (int)P.pairs_items.size();
         P.n_pairs_big = (int)big.size(); P.n_pairs_other = (int)other.size();

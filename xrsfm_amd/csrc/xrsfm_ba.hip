@@ -1592,6 +1592,12 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
     return 0;
 }
 
+#ifdef XBA_TIMELINE
+int xrsfm_ba_debug_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(xba::g_stamps), sizeof(unsigned long long) * 3 * 64 * 16) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+}
+#endif
+
 }  // extern "C"
 
 // ---------------------------------------------------------------- exception barrier of the entry points that allocate on the host
