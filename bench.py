@@ -12,19 +12,23 @@ ba_solver.cc:22-25) x (cams + points) / second, whole job.
 N > 1: one process per GPU (torch.distributed.run); the tracks are sharded by
 point over the ranks, cameras replicated, per-camera sums and the reduced camera
 blocks all-reduced with RCCL inside the library (xrsfm_ba_comm_init).
-  --scaling weak (default): the point set grows with N (N x 500k points over the
-      same 1000 cameras at config L; every rank generates and holds one
-      config-sized shard) -- the regime the sharding is for (maps that outgrow
-      one GPU);
-  --scaling strong: the SAME problem is split over the ranks (BASELINE.json
-      config 4 read literally).  One solve of L is 8.8 ms on one GPU and a third
-      of each LM iteration is the replicated exact factorisation of the reduced
-      camera system, so this cannot speed up much.
+  --scaling strong (default): the SAME problem is split over the ranks:
+      BASELINE.json config 4 read literally (1k cams / 500k points / 2M obs,
+      points sharded N ways).  The exact factorisation of the reduced camera
+      system is replicated on every rank, so this is bounded by Amdahl
+      (DESIGN.md section 6 has the projection from measured kernel times);
+  --scaling weak: the point set grows with N (N x 500k points over the same
+      1000 cameras at config L; every rank generates and holds one config-sized
+      shard) -- the regime the sharding is for (maps that outgrow one GPU).
 
 The JSON line carries `roofline` (dominant HBM-streaming kernel, algorithmic
 bytes of SURVEY.md section 8d / DESIGN.md section 5, duration from HIP events
-recorded by the library on its own stream) and `cpu_baseline` (oracle/ C
-restatement timed on the host cores, rank 0, N = 1 only).
+recorded by the library on its own stream; `roofline.iteration` = the whole LM
+iteration against BASELINE.md section 4's B_iter), `cpu_baseline` (oracle/ C
+restatement timed on the host cores, rank 0, N = 1 only), `host_inclusive`
+(the one-shot xrsfm_ba_solve the BASolver adapter calls: packing + upload +
+solve + download) and `mfma_utilisation` (FP64 matrix-core rate of the dense
+reduced-camera factorisation, measured on config D in the same job).
 """
 from __future__ import annotations
 
@@ -153,17 +157,78 @@ def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
     return out, prob
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64 issues at the FP64 vector rate)
+
+
+def host_inclusive(arr: dict, opt, n_cams: int, n_points: int):
+    """The call the BASolver adapter makes (compat/optimization/ba_solver.cc: xrsfm_ba_solve = create + run + download + destroy)
+    on host buffers: Map -> SoA packing, uploads, Cholesky set-up, the solve, the read-back.  Timed twice; the second call (device
+    allocation cache warm, as in a mapper that calls BA repeatedly) is reported, the first one as `first_call_ms`."""
+    from xrsfm_amd import capi
+    out = None
+    first = None
+    for rep in range(2):
+        prob = capi.ProblemArrays(**{k: np.array(v, copy=True) for k, v in arr.items()})
+        t0 = time.perf_counter()
+        ctx = capi.Context(prob)
+        t1 = time.perf_counter()
+        s = ctx.run(opt)
+        t2 = time.perf_counter()
+        ctx.download()
+        t3 = time.perf_counter()
+        ctx.close()
+        t4 = time.perf_counter()
+        iters = s.n_successful + s.n_unsuccessful
+        out = {"create_ms": (t1 - t0) * 1e3, "run_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3, "destroy_ms": (t4 - t3) * 1e3,
+               "total_ms": (t4 - t0) * 1e3, "lm_iterations": iters, "value": iters * (n_cams + n_points) / (t4 - t0),
+               "unit": "cam-pts*iter/s",
+               "what": "one-shot solve on host buffers (pack + upload | Cholesky set-up + solve | download), second call of the process"}
+        if rep == 0:
+            first = out["total_ms"]
+    out["first_call_ms"] = first
+    return out
+
+
+def mfma_utilisation():
+    """FP64 matrix-core rate of the reduced-camera solve where it is dense: config D (2000 cameras with random visibility = 12 000
+    unknowns, full S, right-looking tile Cholesky).  flop = LM steps x n^3/3; time = HIP-event totals of the profiled solve."""
+    from xrsfm_amd import capi, synth
+    cfg = dict(synth.CONFIGS["D"])
+    d = synth.make_problem(**cfg)
+    prob = capi.ProblemArrays(**{k: np.array(d[k], copy=True) for k in capi.ProblemArrays.FIELDS})
+    ctx = capi.Context(prob)
+    opt = capi.default_options(max_iterations=4)
+    ctx.run(opt)
+    ctx.reset()
+    s = ctx.run(capi.default_options(max_iterations=4, profile=1))
+    prof = ctx.profile()
+    ctx.close()
+    n = 6 * prob.n_cams
+    steps = s.lm_steps_attempted
+    flop = steps * n ** 3 / 3.0
+    t_upd = prof.get("k_update", (0.0, 0))[0] * 1e-3
+    t_chain = t_upd + prof.get("k_potrf", (0.0, 0))[0] * 1e-3 + prof.get("k_trsm", (0.0, 0))[0] * 1e-3
+    if s.linear_solver_used != capi.SOLVER_CHOLESKY or t_upd <= 0.0:
+        return None
+    return {"config": f"D: {prob.n_cams} cams random visibility, {n} camera unknowns, dense reduced matrix", "factorisations": steps,
+            "flop": flop, "trailing_update_s": t_upd, "factorisation_chain_s": t_chain,
+            "achieved_tflops": flop / t_upd / 1e12, "achieved_tflops_chain": flop / t_chain / 1e12, "peak_tflops": FP64_MFMA_PEAK_TFLOPS,
+            "frac": flop / t_upd / 1e12 / FP64_MFMA_PEAK_TFLOPS, "frac_chain": flop / t_chain / 1e12 / FP64_MFMA_PEAK_TFLOPS,
+            "dtype": "f64", "instruction": "v_mfma_f64_16x16x4_f64"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="L", choices=["S", "L", "K", "U", "X", "R", "V", "D"])
+    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "K", "U", "X", "R", "V", "D", "L0"]))
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = N x the points of the config over the same cameras; strong = the config split N ways")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N > 1: strong = the config split N ways (BASELINE.json config 4); weak = N x the points of the config over the same cameras")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-inclusive one-shot solve and the config-D MFMA measurement")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -256,14 +321,30 @@ def main():
         alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
         ach = alg / avg_s / 1e9
         traffic = None
+        traffic_source = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
         if world == 1 and os.path.exists(pmc):      # separate rocprofv3 --pmc passes (tools/pmc_summary.py), bytes per launch
             table = json.load(open(pmc))          # template instantiations of one kernel (k_schur_pairs<true|false>) make up one pass
             hits = [v for k, v in table.items() if k == dom or k.startswith(dom + "<")]
             traffic = sum(hits) if hits else None
+            # NOT measured in this run: PMC counters need their own rocprofv3 passes (tools/make_profiles.sh)
+            traffic_source = f"profiles/pmc_traffic_{args.config}.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier run, see profiles/*_pmc_traffic.md)"
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                    "traffic": traffic, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
+                    "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "algorithmic_bytes_per_launch": alg}
+        # the whole LM iteration against BASELINE.md section 4: B_iter(0) = B_lin + B_prep + B_back, plus the explicit-S terms
+        # (the nnzb off-diagonal 6x6 blocks written once; SURVEY 8d's B_S would also count a second read of J, N_obs*144,
+        # which the fused S assembly does not do: reported separately)
+        if last.linear_solver_used == 1 and world == 1:
+            nnzb = count_offdiag_blocks(local)
+            b_iter = (prob.n_obs * (184 + 160 + 168) + prob.n_points * (24 + 72 + 144) + n_cams * (56 + 216 + 160) + nnzb * 288)
+            t_iter = dt / max(iters, 1)
+            roofline["iteration"] = {
+                "bytes": b_iter, "bytes_with_B_S_second_read_of_J": b_iter + prob.n_obs * 144, "t_iter_us": t_iter * 1e6,
+                "achieved": b_iter / t_iter / 1e9, "frac": b_iter / t_iter / 1e9 / HBM_PEAK_GBS,
+                "frac_with_B_S": (b_iter + prob.n_obs * 144) / t_iter / 1e9 / HBM_PEAK_GBS,
+                "accounting": "BASELINE.md section 4 B_iter(0) + nnzb*288 (explicit block-sparse S, exact Cholesky: K = 0); "
+                              "t_iter = timed region / LM iterations (includes the iteration-0 linearisations)"}
 
     if rank == 0:
         n_res = 2 * n_obs
@@ -273,7 +354,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"synthetic BAL-style {args.config}: {n_cams} cams / {n_points} points / {n_obs} obs, "
-                                   f"GBA accurate (ba_solver.cc:626-629), seed {cfg['seed']}",
+                                   f"GBA accurate (ba_solver.cc:626-629), seed {cfg['seed']}"
+                                   + (f"; {args.scaling} scaling: " + ("this problem split over the ranks" if args.scaling == "strong"
+                                                                      else f"{world} config-sized point shards over the same cameras") if world > 1 else ""),
                        "parallelism": (f"points sharded x{world} ({prob.n_points} points / {prob.n_obs} obs on rank 0), cameras replicated, "
                                        f"2 RCCL all-reduces per accepted LM step") if world > 1 else "single GPU",
                        "linear_solver": "cholesky (explicit reduced camera matrix, exact)" if last.linear_solver_used == 1
@@ -295,8 +378,15 @@ def main():
                 base["max_cam_param_diff"] = float(max(np.abs(cpu_prob["cam_q"] - q).max(), np.abs(cpu_prob["cam_t"] - t).max()))
                 base["max_centre_diff_gauge_aligned"] = gauge_aligned_centre_diff(cpu_prob["cam_q"], cpu_prob["cam_t"], q, t)
                 out["cpu_baseline"] = base
-        print(json.dumps(out))
     ctx.close()
+    if rank == 0:
+        if world == 1 and not args.no_extras:
+            out["host_inclusive"] = host_inclusive(arr, opt, n_cams, n_points)
+            try:
+                out["mfma_utilisation"] = mfma_utilisation() if args.config in ("L", "S") else None
+            except Exception as exc:       # the side measurement must never cost the headline line
+                out["mfma_utilisation"] = {"error": str(exc)}
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 

@@ -37,6 +37,7 @@ extern "C" {
 #define XRSFM_BA_ECOMM (-4)    /* RCCL unavailable or a collective failed         */
 #define XRSFM_BA_ESTATE (-5)   /* call order violated                            */
 #define XRSFM_BA_ETOOBIG (-6)  /* explicit reduced camera matrix requested (CHOLESKY) but it does not fit: use AUTO or PCG */
+#define XRSFM_BA_EINTERNAL (-7) /* an unexpected C++ exception was stopped at the boundary (never the termination code +2) */
 
 /* camera models: ids of /root/reference/src/base/camera_model.hpp:93-209 */
 #define XRSFM_BA_SIMPLE_PINHOLE 0 /* {f,cx,cy}             uv = 2f*xn + c (reference quirk, :102-105) */

@@ -636,3 +636,62 @@ def test_ragged_tracks_match_oracle(lib, solver):
     assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
     assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
     assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_track_observed_twice_by_one_camera(lib):
+    """A track with two observations in the same frame (the map format allows it; Ceres adds both residual blocks,
+    /root/reference/src/optimization/ba_solver.cc:336-349): AUTO must not abort — it takes the implicit-Schur path, which treats
+    every observation on its own — and matches the oracle; an explicit CHOLESKY request is refused with EINVAL."""
+    from xrsfm_amd import capi
+    arr = H.make(10, 300, 4, seed=191)
+    rng = np.random.default_rng(5)
+    dup = rng.choice(arr["obs_cam"].shape[0], 12, replace=False)
+    arr["obs_cam"] = np.concatenate([arr["obs_cam"], arr["obs_cam"][dup]]).astype(np.int32)
+    arr["obs_pt"] = np.concatenate([arr["obs_pt"], arr["obs_pt"][dup]]).astype(np.int32)
+    arr["obs_uv"] = np.concatenate([arr["obs_uv"], arr["obs_uv"][dup] + rng.normal(0, 0.7, (12, 2))])
+    pr, s_ref, prod, s = _solve_both(dict(arr), dict(max_iterations=12))
+    assert s.linear_solver_used == capi.SOLVER_PCG
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert s.num_residuals == n_res
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.solve(H.to_product(arr), capi.default_options(max_iterations=2, linear_solver=capi.SOLVER_CHOLESKY))
+    # the post-BA filter on the same data: every observation gets its own mask entry
+    out = capi.filter_tracks(H.to_product(arr), 4.0, math.radians(1.5))
+    assert out["obs_delete"].shape[0] == arr["obs_cam"].shape[0]
+
+
+@pytest.mark.gpu
+def test_failure_paths_of_the_side_entry_points(lib):
+    """xrsfm_ba_filter_tracks / xrsfm_ba_refine_pose(s) with broken input on the GPU box: a negative code, no crash, outputs
+    untouched (track_processor.cc:321-349 and pnp.cc:38-71 have void/plain-int call sites: the adapters print and carry on)."""
+    import ctypes as C
+    from xrsfm_amd import capi
+    L = capi.load()
+    arr = H.make(6, 80, 3, seed=192)
+    bad = H.to_product(arr); bad.obs_pt[3] = 10_000
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.filter_tracks(bad, 4.0, 0.02)
+    bad = H.to_product(arr); bad.cam_intr[2] = 7
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.filter_tracks(bad, 4.0, 0.02)
+    # NULL output arrays / NULL problem arrays straight through the C-ABI
+    prob = H.to_product(arr)
+    cs = prob.c_struct()
+    assert L.xrsfm_ba_filter_tracks(C.byref(cs), 4.0, 0.02, None, None, None, None, None) == -1
+    cs2 = prob.c_struct(); cs2.points = None
+    od = np.zeros(prob.n_obs, np.uint8); to = np.zeros(prob.n_points, np.uint8)
+    assert L.xrsfm_ba_filter_tracks(C.byref(cs2), 4.0, 0.02, od.ctypes.data_as(C.POINTER(C.c_uint8)), to.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                    None, None, None) == -1
+    assert not od.any() and not to.any()
+    # pose refinement: unknown camera model, missing arrays
+    pa = H.make_pose_problem(60, seed=3)
+    q = pa["cam_q"][0].copy(); t = pa["cam_t"][0].copy(); q0, t0 = q.copy(), t.copy()
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.refine_pose(9, pa["intr_params"][0], pa["points"], pa["obs_uv"], q, t)
+    assert np.array_equal(q, q0) and np.array_equal(t, t0)
+    with pytest.raises(RuntimeError, match="EINVAL"):
+        capi.refine_poses([2, 7], np.stack([pa["intr_params"][0]] * 2), [(pa["points"], pa["obs_uv"], None)] * 2, np.stack([q, q]), np.stack([t, t]))

@@ -14,8 +14,15 @@ import torch.multiprocessing as mp
 from tests import helpers as H
 
 
+_rdzv_count = [0]
+
+
 def _free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+    """Rendezvous token of one spawn: a fresh FILE (torch's file:// store) — a TCP port picked by bind(0) can be taken again
+    before the workers listen on it (seen once on the GPU box: EADDRINUSE)."""
+    import tempfile
+    _rdzv_count[0] += 1
+    return os.path.join(tempfile.gettempdir(), f"xba_rdzv_{os.getpid()}_{_rdzv_count[0]}")
 
 
 def _worker(rank, world, port, arr, solver, opt_kw, out_prefix):
@@ -23,8 +30,7 @@ def _worker(rank, world, port, arr, solver, opt_kw, out_prefix):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import shard_problem
     from xrsfm_amd import capi
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.init_process_group("gloo", init_method=f"file://{port}", rank=rank, world_size=world)
 
     def allreduce(buf, op):
         t = torch.from_numpy(buf)

@@ -93,7 +93,7 @@ EXPORTS = [
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
 
 ERRORS = {-1: "EINVAL", -2: "ENODEV (no HIP device / HIP error; there is no CPU fallback)", -3: "ENOMEM",
-          -4: "ECOMM", -5: "ESTATE", -6: "ETOOBIG"}
+          -4: "ECOMM", -5: "ESTATE", -6: "ETOOBIG", -7: "EINTERNAL (unexpected exception inside the library)"}
 
 _lib = None
 

@@ -48,6 +48,12 @@ struct CholPlan {
 
 typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
 
+// A track with two observations in the same camera (the reference guards against it, pnp.cc:84, but the map format allows it;
+// Ceres simply adds both residuals): its camera pair (a,a) is a diagonal block, which the pair-block assembly does not
+// produce.  Internal code: AUTO takes the implicit-Schur PCG path, which treats every observation on its own; an explicit
+// CHOLESKY request is refused with XRSFM_BA_EINVAL.
+constexpr int kErrDuplicateObs = -100;
+
 // Pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a.  `keyed` lists everything that
 // WRITES a partial block, as (block key, index into pair_dst):
 //   * a Gram tile (ba_pack.h) writes one partial per camera pair that some track of the tile sees together; its index is
@@ -99,7 +105,7 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
             }
         }
     });
-    for (int t = 0; t < nch; ++t) if (bad[t]) return XRSFM_BA_EINVAL;
+    for (int t = 0; t < nch; ++t) if (bad[t]) return kErrDuplicateObs;
     // Gram tiles: one key per co-visible camera pair of the tile
     const std::vector<long long> tcut = pack_cuts(k.n_tiles, 8000, 1);
     std::vector<PairKeys> glocal(tcut.size() - 1);

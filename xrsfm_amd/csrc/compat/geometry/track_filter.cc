@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdio>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "xrsfm_ba.h"
@@ -113,9 +114,12 @@ int FilterPoints3dGPU(Map &map, const double max_re, const double deg) {
 }
 
 int FilterPointsFrameGPU(Map &map, const int frame_id, const double max_re, const double deg) {
+    // every track once, in the order of its first key point: a frame that lists one track at two key points (pnp.cc:84 guards
+    // against it, the map format does not) must not enter the flat problem twice — the masks come back per track
     std::vector<int> track_ids;
+    std::unordered_set<int> seen;
     for (const int track_id : map.frames_[frame_id].track_ids_)
-        if (track_id != -1) track_ids.push_back(track_id);
+        if (track_id != -1 && seen.insert(track_id).second) track_ids.push_back(track_id);
     return filter_tracks_gpu(map, track_ids, max_re, deg);
 }
 

@@ -490,7 +490,7 @@ int chol_setup(xrsfm_ba_context* c) {
     PairKeys keyed;
     PhaseTimer timer("chol setup");
     int e = chol_local_keys(k, spp, keyed);
-    if (e) return e;
+    if (e) return e;          // (kErrDuplicateObs: translated by the callers)
     timer.mark("pair keys");
     // multi-GPU: every rank must hold the same blocks in the same order so that the block values can be all-reduced:
     // union of the ranks' camera pairs by an all-reduce(max) of an N_c x N_c occupancy map (once per problem)
@@ -765,12 +765,12 @@ int init_scaling_and_linearize(xrsfm_ba_context* c, double huber_a, bool use_sca
 
 // ---------------------------------------------------------------- C-ABI
 // No C++ exception may cross the C boundary: host allocations that fail (std::bad_alloc from the packing, the plans or the
-// host solvers) become XRSFM_BA_ENOMEM, anything else XRSFM_BA_FAILURE.
+// host solvers) become XRSFM_BA_ENOMEM, anything else XRSFM_BA_EINTERNAL (a negative code like every other error).
 template <typename F>
 static int no_throw(F&& f) {
     try { return f(); }
     catch (const std::bad_alloc&) { return XRSFM_BA_ENOMEM; }
-    catch (...) { return XRSFM_BA_FAILURE; }
+    catch (...) { return XRSFM_BA_EINTERNAL; }
 }
 
 extern "C" {
@@ -826,7 +826,7 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
     if (!c) return XRSFM_BA_ENOMEM;
     try { return create_body(p, device, c, out); }          // (the body releases c itself on the errors it returns)
     catch (const std::bad_alloc&) { xrsfm_ba_destroy(c); *out = nullptr; return XRSFM_BA_ENOMEM; }
-    catch (...) { xrsfm_ba_destroy(c); *out = nullptr; return XRSFM_BA_FAILURE; }
+    catch (...) { xrsfm_ba_destroy(c); *out = nullptr; return XRSFM_BA_EINTERNAL; }
 }
 
 static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out) {
@@ -1005,12 +1005,18 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
         // exact tile Cholesky whenever its plan is feasible (always up to kCholMaxN unknowns; larger problems when the camera
         // graph is a band / ring), implicit-Schur PCG otherwise
         e = chol_setup(c);
-        if (e == XRSFM_BA_ETOOBIG || e == XRSFM_BA_ENOMEM) solver = XRSFM_BA_SOLVER_PCG;
+        if (e == XRSFM_BA_ETOOBIG || e == XRSFM_BA_ENOMEM || e == kErrDuplicateObs) solver = XRSFM_BA_SOLVER_PCG;
         else if (e) return e;
         else solver = XRSFM_BA_SOLVER_CHOLESKY;
     }
     if (solver != XRSFM_BA_SOLVER_PCG && solver != XRSFM_BA_SOLVER_CHOLESKY) return XRSFM_BA_EINVAL;
-    if (solver == XRSFM_BA_SOLVER_CHOLESKY && (e = chol_setup(c))) return e;
+    if (solver == XRSFM_BA_SOLVER_CHOLESKY && (e = chol_setup(c))) {
+        if (e == kErrDuplicateObs) {
+            fprintf(stderr, "[xrsfm_ba] a track is observed twice by one camera: the explicit reduced camera matrix is not available, use AUTO or PCG\n");
+            return XRSFM_BA_EINVAL;
+        }
+        return e;
+    }
     sum->linear_solver_used = solver;
     c->profiling = opt.profile != 0;
     for (int i = 0; i < K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
@@ -1334,9 +1340,15 @@ static int refine_pose_engine(const xrsfm_ba_options& o, int32_t model, const do
 }
 
 // ---------------------------------------------------------------- post-BA track filter
-int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, double min_tri_angle_rad, uint8_t* obs_delete,
-                           uint8_t* track_outlier, double* track_error, double* track_angle, int32_t* num_filtered) {
+static int filter_tracks_impl(const xrsfm_ba_problem* p, double max_reproj_error, double min_tri_angle_rad, uint8_t* obs_delete,
+                              uint8_t* track_outlier, double* track_error, double* track_angle, int32_t* num_filtered) {
     if (!p || !obs_delete || !track_outlier) return XRSFM_BA_EINVAL;
+    // the same pointer checks as pack_problem (ba_pack.h)
+    if (p->n_cams < 0 || p->n_points < 0 || p->n_obs < 0 || p->n_intr < 0) return XRSFM_BA_EINVAL;
+    if (p->n_obs > 0 && (!p->obs_cam || !p->obs_pt || !p->obs_uv)) return XRSFM_BA_EINVAL;
+    if (p->n_cams > 0 && (!p->cam_q || !p->cam_t || !p->cam_intr)) return XRSFM_BA_EINVAL;
+    if (p->n_points > 0 && !p->points) return XRSFM_BA_EINVAL;
+    if (p->n_intr > 0 && (!p->intr_model || !p->intr_params)) return XRSFM_BA_EINVAL;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         fprintf(stderr, "[xrsfm_ba] no HIP device visible: the track filter has no CPU fallback\n");
@@ -1414,6 +1426,11 @@ int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, d
     }
     for (void* b : bufs) (void)hipFree(b);
     return e;
+}
+
+int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, double min_tri_angle_rad, uint8_t* obs_delete,
+                           uint8_t* track_outlier, double* track_error, double* track_angle, int32_t* num_filtered) {
+    return no_throw([&] { return filter_tracks_impl(p, max_reproj_error, min_tri_angle_rad, obs_delete, track_outlier, track_error, track_angle, num_filtered); });
 }
 
 // ---------------------------------------------------------------- diagnostics
@@ -1517,7 +1534,7 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     if (e) return e;
     std::vector<int> spp;
     PairKeys keyed;
-    if ((e = chol_local_keys(k, spp, keyed))) return e;
+    if ((e = chol_local_keys(k, spp, keyed))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
     CholPlan P;
     if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
     int n_gram = 0, cmax = 0;
@@ -1537,7 +1554,7 @@ int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     if (e) return e;
     std::vector<int> spp;
     PairKeys keyed;
-    if ((e = chol_local_keys(k, spp, keyed))) return e;
+    if ((e = chol_local_keys(k, spp, keyed))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
     CholPlan P;
     if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
     stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
@@ -1567,7 +1584,7 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
     int e;
-    if ((e = chol_setup(c))) return e;
+    if ((e = chol_setup(c))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
     if ((e = prepare_step(c, radius, true))) return e;
     if ((e = chol_assemble(c))) return e;
     const CholDev& cd = c->chol.dev;

@@ -79,14 +79,18 @@ def _project_simple_radial(q, t, P, intr):
 def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
                  mode: str = "sequential", k_dist: float = 0.0, noise: float = 0.5,
                  outlier_frac: float = 0.02, perturb=(0.01, 0.05, 0.10),
-                 min_tri_angle_deg: float = 2.0, dropout: float = 0.0, point_seed: int | None = None) -> dict:
+                 min_tri_angle_deg: float = 2.0, dropout: float = 0.0, point_seed: int | None = None,
+                 literal_appendix_d: bool = False) -> dict:
     """Return a dict of flat arrays (keys = fields of ``xrsfm_ba_problem``) + ground truth.
     ``dropout`` > 0 removes each observation with that probability (at least two per point stay): ragged tracks with many
     distinct camera tuples, like a real reconstruction with missed detections.
     ``point_seed``: None = one random stream for everything (the historical problems).  An integer makes the cameras
     (ground truth AND perturbed initial state) a function of ``seed`` alone and draws the points, observations and their
     noise from a stream of their own: calls that differ only in ``point_seed`` are disjoint point shards of one larger
-    problem over the same cameras (bench.py --scaling weak, one shard per rank)."""
+    problem over the same cameras (bench.py --scaling weak, one shard per rank).
+    ``literal_appendix_d``: SURVEY.md Appendix D read literally — a radius-40 ring whatever the camera count (0.25-unit
+    baselines at 1000 cameras), no triangulation-angle filter, and the perturbation added to t instead of the camera centre
+    (config L0: reported once in profiles/, it is a much harder problem than the headline workload)."""
     assert n_cams >= k_obs >= 1
     rng = np.random.Generator(np.random.PCG64(seed))
     rng_cam0 = rng if point_seed is None else np.random.Generator(np.random.PCG64([seed, 999983]))
@@ -95,8 +99,10 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     # BASELINE.json config 2: 100 cameras on a radius-40 ring; a KITTI-like per-frame baseline), so the
     # ring grows with the camera count (radius 400 at 1k cameras) instead of the parallax shrinking;
     # below 100 cameras an open arc of the radius-40 ring with the same spacing.
-    radius = 40.0 * max(n_cams, 100) / 100.0
-    ang = 2 * np.pi * np.arange(n_cams) / max(n_cams, 100)
+    radius = 40.0 if literal_appendix_d else 40.0 * max(n_cams, 100) / 100.0
+    ang = 2 * np.pi * np.arange(n_cams) / (n_cams if literal_appendix_d else max(n_cams, 100))
+    if literal_appendix_d:
+        min_tri_angle_deg = 0.0
     centre = np.stack([radius * np.cos(ang), rng.normal(0, 0.1, n_cams), radius * np.sin(ang)], axis=1)
     if mode == "sequential":
         fwd = np.stack([-np.sin(ang), np.zeros(n_cams), np.cos(ang)], axis=1)      # tangent
@@ -193,6 +199,8 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     dcen = rng_cam0.normal(0, s_t, (n_cams, 3)); dcen[0:2] = 0.0
     q0 = _quat_plus(q_gt, drot)
     t0 = -np.einsum("nij,nj->ni", _rot_from_quat(q0), centre + dcen)
+    if literal_appendix_d:
+        t0 = t_gt + dcen
     t0[0:2] = t_gt[0:2]; q0[0:2] = q_gt[0:2]
     P0 = P_gt + rng.normal(0, s_p, (n_points, 3))
     cam_const = np.zeros(n_cams, np.uint8); cam_const[0:2] = 2        # bit1: t constant
@@ -225,4 +233,6 @@ CONFIGS = {
     # the dense limit of the exact path: 12 000 camera unknowns, unordered -> right-looking tile Cholesky of a full S
     # (the configuration the MFMA utilisation of the reduced solve is quoted on)
     "D": dict(n_cams=2000, n_points=200_000, k_obs=5, seed=9, mode="unordered"),
+    # BASELINE.json config 4 with SURVEY.md Appendix D read literally (radius-40 ring, no angle filter)
+    "L0": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4, literal_appendix_d=True),
 }
