@@ -125,6 +125,27 @@ def gauge_aligned_centre_diff(q1, t1, q2, t2):
     return float(np.abs(c1 - (sc * (R @ c2.T).T + m1 - sc * R @ m2)).max())
 
 
+def parity_block(arr: dict, q, t, P, cpu_prob: dict):
+    """The criterion of tests/test_gpu_parity.py::test_headline_config_camera_parity between the HIP result and the CPU port's:
+    Gauss-Newton energy of the whole difference relative to the cost, and the largest difference of the relative pose of
+    covisible camera pairs (gauge invariant, free of the drift that the reference's two-translation gauge leaves open on
+    long trajectories).  Raw parameter differences are reported next to it."""
+    from oracle import ba_oracle as bo
+    from xrsfm_amd import capi, parity
+    pairs = parity.covisible_pairs(arr["obs_cam"], arr["obs_pt"])
+    dv = parity.tangent_difference(q, t, cpu_prob["cam_q"], cpu_prob["cam_t"]).reshape(-1, 6)
+    ang, dtr = parity.relative_pose_difference(q, t, cpu_prob["cam_q"], cpu_prob["cam_t"], pairs)
+    pr = bo.Problem(**{k: np.array(v, copy=True) for k, v in dict(arr, cam_q=q, cam_t=t, points=P).items() if k in capi.ProblemArrays.FIELDS})
+    cost, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    Jd = np.einsum("nij,nj->ni", np.asarray(Fc).reshape(-1, 2, 6), dv[pr.obs_cam]) + \
+        np.einsum("nij,nj->ni", np.asarray(Ep).reshape(-1, 2, 3), (P - cpu_prob["points"])[pr.obs_pt])
+    return {"criterion": "1/2|J dx|^2 <= 1e-10 cost; relative pose of covisible cameras within 1e-6 rad / 1e-4 units "
+                         "(tests/test_gpu_parity.py::test_headline_config_camera_parity)",
+            "gn_energy_over_cost": 0.5 * float((Jd ** 2).sum()) / cost, "covisible_pairs": int(pairs.shape[0]),
+            "rel_pose_rot_rad": ang, "rel_pose_trans": dtr,
+            "raw_max_rotation_tangent": float(np.abs(dv[:, :3]).max()), "raw_max_translation": float(np.abs(dv[:, 3:]).max())}
+
+
 def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
     """oracle/ C restatement (kind "port") timed on the host cores; None if it is not built."""
     try:
@@ -377,6 +398,7 @@ def main():
                 base["rmse_diff_px"] = abs(base["final_rmse_px"] - out["final_rmse_px"])
                 base["max_cam_param_diff"] = float(max(np.abs(cpu_prob["cam_q"] - q).max(), np.abs(cpu_prob["cam_t"] - t).max()))
                 base["max_centre_diff_gauge_aligned"] = gauge_aligned_centre_diff(cpu_prob["cam_q"], cpu_prob["cam_t"], q, t)
+                base["parity"] = parity_block(arr, q, t, P, cpu_prob)
                 out["cpu_baseline"] = base
     ctx.close()
     if rank == 0:

@@ -77,3 +77,29 @@ def make_pose_problem(n=200, seed=0, model=2, outlier_frac=0.1, noise=0.5):
                               w1 * z2 + x1 * y2 - y1 * x2 + z1 * w2, w1 * w2 - x1 * x2 - y1 * y2 - z1 * z2]])
     arr["cam_t"] = (t_true + rng.normal(0, 0.05, 3))[None]
     return arr
+
+
+def relabel_points(arr, seed=0):
+    """The same problem with the points (and so the residual blocks of every camera) in another order: the summation order of
+    every per-camera sum changes, the mathematics does not.  Returns (problem, perm) with new point j = old point perm[j]."""
+    rng = np.random.default_rng(seed)
+    n = arr["points"].shape[0]
+    perm = rng.permutation(n)
+    inv = np.empty(n, np.int64); inv[perm] = np.arange(n)
+    out = dict(arr)
+    out["points"] = np.ascontiguousarray(arr["points"][perm]); out["point_const"] = np.ascontiguousarray(arr["point_const"][perm])
+    op = inv[arr["obs_pt"]].astype(np.int32)
+    order = np.lexsort((op, arr["obs_cam"]))                      # frame-major like the reference (Appendix B)
+    out["obs_cam"] = np.ascontiguousarray(arr["obs_cam"][order]); out["obs_pt"] = np.ascontiguousarray(op[order])
+    out["obs_uv"] = np.ascontiguousarray(arr["obs_uv"][order])
+    return out, perm
+
+
+def gn_energy(arr_state, dq_tangent, dP):
+    """Gauss-Newton energy 1/2 |J dx|^2 of a parameter difference dx = (camera tangent [Nc,6], points [Np,3]) at the state
+    `arr_state` (robustified Jacobian of the oracle): how much of the objective's quadratic model separates two results."""
+    pr = to_oracle(arr_state)
+    cost, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    Jd = np.einsum("nij,nj->ni", np.asarray(Fc).reshape(-1, 2, 6), dq_tangent[pr.obs_cam]) \
+        + np.einsum("nij,nj->ni", np.asarray(Ep).reshape(-1, 2, 3), dP[pr.obs_pt])
+    return 0.5 * float((Jd ** 2).sum()), cost

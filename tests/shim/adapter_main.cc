@@ -41,6 +41,7 @@ int main(int argc, char **argv) {
     // an extra 2D feature without a track in every frame: must be skipped (track_ids_ == -1)
     for (auto &fr : map.frames_) { fr.points.push_back(xrsfm::vector2()); fr.track_ids_.push_back(-1); }
     map.init_id1 = 0; map.init_id2 = 1;
+    if (std::string(argv[3]) == "lba" && argc > 6) { map.init_id1 = atoi(argv[5]); map.init_id2 = atoi(argv[6]); }     // LBA gauge cases
     xrsfm::BASolver solver;
     int refine_status = 0;
     bool extra = false, filter_dump = false;

@@ -56,6 +56,41 @@ def test_adapter_builds_and_fails_loudly_without_gpu(exe, tmp_path):
     assert np.array_equal(q, arr["cam_q"]) and np.array_equal(t, arr["cam_t"]) and np.array_equal(P, arr["points"])
 
 
+def _lba_cases():
+    z = np.load(os.path.join(ROOT, "tests", "golden", "lba_selection.npz"))
+    for i, (nc, npts, k, seed, mode, fr, i1, i2) in enumerate(z["cases"]):
+        yield i, z, H.make(int(nc), int(npts), int(k), seed=int(seed), mode="unordered" if mode else "sequential"), int(fr), int(i1), int(i2)
+
+
+def test_lba_selection_restatement_matches_fixture():
+    """oracle/lba_select.py (numpy restatement of FindLocalBundle / CovisibilityNeibors / the gauge rule,
+    /root/reference/src/optimization/ba_solver.cc:393-584) against the committed lists (tests/golden/make_golden_lba.py), plus
+    the properties the reference code guarantees: the frame itself is in both lists, at most 4 frames each, the neighbour
+    list is sorted by covisibility."""
+    from oracle import lba_select as ls
+    for i, z, arr, fr, i1, i2 in _lba_cases():
+        local, fixed, n1, n2 = ls.lba_frames_and_gauge(fr, arr["obs_cam"], arr["obs_pt"], arr["cam_q"], arr["cam_t"], arr["points"], i1, i2)
+        assert local == z[f"local{i}"].tolist() and fixed == z[f"fixed{i}"].tolist() and n1 == z[f"n1_{i}"].tolist() and n2 == z[f"n2_{i}"].tolist()
+        assert n2[0] == fr and fr in n1 and len(n1) <= 4 and len(n2) <= 4 and len(set(n2)) == len(n2)
+        cov = [int(np.intersect1d(arr["obs_pt"][arr["obs_cam"] == fr], arr["obs_pt"][arr["obs_cam"] == f]).shape[0]) for f in n1]
+        assert cov == sorted(cov, reverse=True)
+    # colmap::Percentile: index round(p/100 (n-1)), halves away from zero (util/math.h:218-233)
+    assert ls.percentile(np.array([4.0, 1.0, 3.0, 2.0]), 75) == 3.0 and ls.percentile(np.array([1.0, 2.0, 3.0]), 75) == 3.0
+    assert ls.percentile(np.array([5.0]), 75) == 5.0
+
+
+def test_adapter_lba_frame_selection_equals_restatement(exe, tmp_path):
+    """BASolver::LBA of the adapter prints the frames of its problem BEFORE it solves (ba_solver.cc:537-549), so the selection
+    can be checked without a GPU: it must be the list of the independent numpy restatement, for every fixture case (band and
+    random visibility, threshold ladder active, init frames inside and outside the local set, fewer frames than the bundle)."""
+    from oracle import lba_select as ls
+    for i, z, arr, fr, i1, i2 in _lba_cases():
+        status, q, t, P, out, err = _run(exe, arr, tmp_path, "lba", fr, i1, i2)
+        m = re.search(r"LBA:\s*((?:\d+ ?)+)", out)
+        assert m, out
+        assert [int(x) for x in m.group(1).split()] == z[f"local{i}"].tolist()
+
+
 def _subproblem(arr, frames, lba_frame=None):
     """Flat problem of the frames `frames` (ascending ids), like FlatProblem::AddFrame builds it."""
     frames = list(frames)
@@ -75,38 +110,27 @@ def _subproblem(arr, frames, lba_frame=None):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["gba", "gba_fast", "structure", "kgba", "lba"])
+@pytest.mark.parametrize("mode", ["gba", "gba_fast", "structure", "kgba"])
 def test_adapter_equals_direct_c_abi(exe, tmp_path, mode):
     from xrsfm_amd import capi
     arr = H.with_models(H.make(9, 260, 4, seed=131), seed=2)
     nc = arr["cam_q"].shape[0]
-    lba_frame = 2
-    status, q, t, P, out, err = _run(exe, arr, tmp_path, mode, lba_frame)
+    status, q, t, P, out, err = _run(exe, arr, tmp_path, mode, 2)
     assert status == 0, err
     if mode in ("gba", "gba_fast", "structure"):
-        frames = list(range(nc)); lba = None
+        frames = list(range(nc))
         kw = dict(max_iterations=50, function_tolerance=1e-5, parameter_tolerance=1e-6) if mode != "gba_fast" else \
             dict(max_iterations=20, function_tolerance=1e-4, parameter_tolerance=1e-5)
-    elif mode == "kgba":
-        frames = [i for i in range(nc) if i % 2 == 0 or i in (0, 1, 3)]; lba = None      # shim KeyFrameSelection + forced {3}
+    else:
+        frames = [i for i in range(nc) if i % 2 == 0 or i in (0, 1, 3)]      # shim KeyFrameSelection + forced {3}
         kw = dict(max_iterations=20, function_tolerance=1e-4, parameter_tolerance=1e-5, initial_radius=1e6)
         assert f"kf: {len(frames)}/{nc}" in out
-    else:
-        m = re.search(r"LBA:\s*((?:\d+ ?)+)", out)
-        frames = sorted(int(x) for x in m.group(1).split()); lba = lba_frame
-        assert lba in frames and len(frames) <= 7
-        kw = dict(max_iterations=5, function_tolerance=1e-4, parameter_tolerance=1e-5)
-    sub, frames, pts = _subproblem(arr, frames, lba)
+    sub, frames, pts = _subproblem(arr, frames, None)
     if mode == "structure":
         sub["cam_const"][:] = 3
     else:
-        fixed = [f for f in (0, 1) if f in frames]
-        if mode == "lba" and not fixed:
-            fixed = None   # fallback gauge depends on the bundle order; covered by the cost check below only
-        if fixed:
-            for f in fixed: sub["cam_const"][frames.index(f)] |= 2
-    if mode == "lba" and not [f for f in (0, 1) if f in frames]:
-        pytest.skip("local set without init frames: gauge fallback order is implementation defined")
+        for f in (0, 1):
+            if f in frames: sub["cam_const"][frames.index(f)] |= 2
     prod = H.to_product(sub)
     s = capi.solve(prod, capi.default_options(**kw))
     assert np.abs(q[frames] - prod.cam_q).max() < 1e-9 and np.abs(t[frames] - prod.cam_t).max() < 1e-9
@@ -115,6 +139,33 @@ def test_adapter_equals_direct_c_abi(exe, tmp_path, mode):
     assert np.array_equal(q[others], arr["cam_q"][others])            # frames outside the problem are untouched
     if mode in ("gba", "kgba"):
         assert "Residuals : " in out and "Termination : " in out and f"{2 * sub['obs_cam'].shape[0]}" in out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", range(7))
+def test_adapter_lba_equals_direct_c_abi(exe, tmp_path, case):
+    """BASolver::LBA through the adapter = the C-ABI on the flat problem built from the INDEPENDENT restatement of the frame
+    selection (oracle/lba_select.py; fixture tests/golden/lba_selection.npz): frames of the local set, points not seen by the
+    new frame constant (ba_solver.cc:380-382), and the gauge rule of :551-584 including its fall-back branches (no init
+    frame in the local set: the last two frames of the bundle / of the neighbour list; a single frame)."""
+    from xrsfm_amd import capi
+    i, z, arr, fr, i1, i2 = list(_lba_cases())[case]
+    arr = H.with_models(arr, seed=2 + case)
+    nc = arr["cam_q"].shape[0]
+    status, q, t, P, out, err = _run(exe, arr, tmp_path, "lba", fr, i1, i2)
+    assert status == 0, err
+    frames = z[f"local{i}"].tolist(); fixed = z[f"fixed{i}"].tolist()
+    assert fr in frames and len(frames) <= 7
+    sub, frames, pts = _subproblem(arr, frames, fr)
+    for f in fixed:
+        sub["cam_const"][frames.index(f)] |= 2
+    prod = H.to_product(sub)
+    capi.solve(prod, capi.default_options(max_iterations=5, function_tolerance=1e-4, parameter_tolerance=1e-5))
+    assert np.abs(q[frames] - prod.cam_q).max() < 1e-9 and np.abs(t[frames] - prod.cam_t).max() < 1e-9
+    assert np.abs(P[pts] - prod.points).max() < 1e-7
+    assert np.array_equal(t[fixed], arr["cam_t"][fixed])                     # the gauge frames did not move
+    others = [j for j in range(nc) if j not in frames]
+    assert np.array_equal(q[others], arr["cam_q"][others]) and np.array_equal(t[others], arr["cam_t"][others])
 
 
 @pytest.mark.gpu

@@ -695,3 +695,54 @@ def test_failure_paths_of_the_side_entry_points(lib):
     assert np.array_equal(q, q0) and np.array_equal(t, t0)
     with pytest.raises(RuntimeError, match="EINVAL"):
         capi.refine_poses([2, 7], np.stack([pa["intr_params"][0]] * 2), [(pa["points"], pa["obs_uv"], None)] * 2, np.stack([q, q]), np.stack([t, t]))
+
+
+@pytest.mark.gpu
+def test_headline_config_camera_parity(lib):
+    """BASELINE.json config 4: the camera-parameter criterion that test_headline_config_properties could not state as a plain
+    1e-5 bound (round-1 verdict).  Measured (tools/parity_spectrum.py): on this 1000-frame loop with
+    4-frame tracks and only two translations fixed (ba_solver.cc:611-614), stopping at a 1e-5 relative cost change (:628)
+    leaves the global shape of the loop — scale about the fixed pair, low-frequency bending — undetermined at the 1e-3 level:
+    the C restatement differs from ITSELF by 9e-4 in the far-side translations when its points are merely relabelled (another
+    summation order), at a Gauss-Newton energy of 1e-12 of the cost.  So the criterion is, deterministic on any box (one CPU
+    thread, fixed orders):
+      (1) same LM decisions, RMSE within 1e-6 px;
+      (2) the objective cannot tell the results apart: 1/2 |J (x_hip - x_cpu)|^2 <= 1e-10 cost  (measured 1e-12);
+      (3) what IS determined agrees: relative pose of every covisible camera pair within 1e-6 rad / 1e-4 units
+          (measured 7e-9 / 1.4e-5; the north star's 1e-5 on absolute parameters holds on the well-conditioned configs,
+          test_full_size_properties);
+      (4) the HIP result is no further from the restatement than the restatement is from itself under relabelling (x3)."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi, parity, synth
+    if not ba_cpu.available():
+        pytest.skip("oracle/_build/libba_cpu.so is not built")
+    d = synth.make_problem(**synth.CONFIGS["L"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options())
+    n_res = 2 * arr["obs_cam"].shape[0]
+    c1 = {k: np.array(v, copy=True) for k, v in arr.items()}
+    s1 = ba_cpu.solve(c1, threads=1)
+    arr_r, perm = H.relabel_points(arr, seed=1)
+    c2 = {k: np.array(v, copy=True) for k, v in arr_r.items()}
+    s2 = ba_cpu.solve(c2, threads=1)
+    P2 = np.empty_like(c2["points"]); P2[perm] = c2["points"]
+    for sc in (s1, s2):
+        assert (sc["n_successful"], sc["n_unsuccessful"]) == (s.n_successful, s.n_unsuccessful)
+        assert abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s.final_cost / n_res)) < 1e-6
+    pairs = parity.covisible_pairs(arr["obs_cam"], arr["obs_pt"])
+    assert pairs.shape[0] >= 2990
+
+    def distance(qa, ta, Pa, qb, tb, Pb):
+        dv = parity.tangent_difference(qa, ta, qb, tb).reshape(-1, 6)
+        ang, dtr = parity.relative_pose_difference(qa, ta, qb, tb, pairs)
+        e, cost = H.gn_energy(dict(arr, cam_q=qa, cam_t=ta, points=Pa), dv, Pa - Pb)
+        return float(np.abs(dv).max()), ang, dtr, e / cost
+
+    raw, ang, dtr, erel = distance(prod.cam_q, prod.cam_t, prod.points, c1["cam_q"], c1["cam_t"], c1["points"])
+    raw_cc, ang_cc, dtr_cc, erel_cc = distance(c1["cam_q"], c1["cam_t"], c1["points"], c2["cam_q"], c2["cam_t"], P2)
+    print(f"hip vs cpu: raw {raw:.2e} rel-pose {ang:.2e} rad / {dtr:.2e} energy/cost {erel:.2e};  cpu vs relabelled cpu: raw {raw_cc:.2e} "
+          f"rel-pose {ang_cc:.2e} / {dtr_cc:.2e} energy/cost {erel_cc:.2e}")
+    assert erel <= 1e-10
+    assert ang <= 1e-6 and dtr <= 1e-4
+    assert raw <= 3.0 * raw_cc + 1e-5 and dtr <= 3.0 * dtr_cc + 1e-5

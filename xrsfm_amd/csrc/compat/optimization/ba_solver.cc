@@ -173,7 +173,12 @@ std::vector<std::pair<int, int>> CovisibleFrames(const Frame &frame, const Map &
     }
     if (num_points3d) *num_points3d = n3d;
     std::vector<std::pair<int, int>> out(shared.begin(), shared.end());
-    std::sort(out.begin(), out.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) { return a.second > b.second; });
+    // most covisible first; equal counts by ascending frame id.  (The reference sorts hash-table contents on the count alone,
+    // :411-416 / :507-512: its order among ties is unspecified, so a fixed rule is one of the orders it can produce — and it
+    // makes the selection testable against an independent restatement, oracle/lba_select.py.)
+    std::sort(out.begin(), out.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+        return a.second != b.second ? a.second > b.second : a.first < b.first;
+    });
     return out;
 }
 
