@@ -23,7 +23,8 @@ def write_model(path: str, arr: dict, names=None):
     order = np.lexsort((arr["obs_pt"], arr["obs_cam"]))
     oc, op, uv = arr["obs_cam"][order], arr["obs_pt"][order], arr["obs_uv"][order]
     ptr = np.searchsorted(oc, np.arange(n_c + 1))
-    p2d_index = np.zeros(oc.shape[0], np.int64)
+    p2d_index = (np.arange(oc.shape[0]) - ptr[oc]).astype(np.int64)      # index of the 2D feature inside its image
+    rec2d = np.dtype([("x", "<f8"), ("y", "<f8"), ("track", "<u8")])
     with open(os.path.join(path, "images.bin"), "wb") as f:
         f.write(struct.pack("<Q", n_c))
         for c in range(n_c):
@@ -33,24 +34,28 @@ def write_model(path: str, arr: dict, names=None):
             f.write(((names[c] if names else f"img{c:05d}.png") + "\0").encode())
             n2 = ptr[c + 1] - ptr[c]
             f.write(struct.pack("<Q", n2 + 1))
-            for k in range(ptr[c], ptr[c + 1]):
-                p2d_index[k] = k - ptr[c]
-                f.write(struct.pack("<ddQ", uv[k, 0], uv[k, 1], int(op[k])))
-            f.write(struct.pack("<ddQ", 1.0, 2.0, NO_TRACK))          # a 2D feature without a track
+            p2 = np.empty(n2 + 1, rec2d)
+            p2["x"][:n2] = uv[ptr[c]:ptr[c + 1], 0]; p2["y"][:n2] = uv[ptr[c]:ptr[c + 1], 1]; p2["track"][:n2] = op[ptr[c]:ptr[c + 1]]
+            p2["x"][n2] = 1.0; p2["y"][n2] = 2.0; p2["track"][n2] = NO_TRACK          # a 2D feature without a track
+            f.write(p2.tobytes())
     by_pt = np.lexsort((oc, op))
     pptr = np.searchsorted(op[by_pt], np.arange(n_p + 1))
+    oc_s = oc[by_pt].astype("<i4"); p2_s = p2d_index[by_pt].astype("<i4")
+    pairs = np.stack([oc_s, p2_s], 1)                                      # (frame, 2D feature) of every observation, track-major
+    pts = np.asarray(arr["points"], "<f8")
     with open(os.path.join(path, "points3D.bin"), "wb") as f:
         f.write(struct.pack("<Q", n_p))
+        chunks = []
         for j in range(n_p):
-            f.write(struct.pack("<Q", j)); f.write(np.asarray(arr["points"][j], "<f8").tobytes())
-            f.write(bytes([0, 0, 0])); f.write(struct.pack("<d", -1.0))
-            ids = by_pt[pptr[j]:pptr[j + 1]]
-            f.write(struct.pack("<Q", len(ids)))
-            for k in ids:
-                f.write(struct.pack("<ii", int(oc[k]), int(p2d_index[k])))
+            chunks.append(struct.pack("<Qddd3Bd", j, pts[j, 0], pts[j, 1], pts[j, 2], 0, 0, 0, -1.0) + struct.pack("<Q", int(pptr[j + 1] - pptr[j]))
+                          + pairs[pptr[j]:pptr[j + 1]].tobytes())
+            if len(chunks) >= 65536:
+                f.write(b"".join(chunks)); chunks = []
+        f.write(b"".join(chunks))
 
 
-def read_model(path: str) -> dict:
+def read_model(path: str, with_points: bool = True) -> dict:
+    """with_points=False skips points3D.bin (a million-point model takes a while in a Python loop)."""
     cams, images, points = {}, {}, {}
     with open(os.path.join(path, "cameras.bin"), "rb") as f:
         (n,) = struct.unpack("<Q", f.read(8))
@@ -74,7 +79,7 @@ def read_model(path: str) -> dict:
             images[iid] = dict(q_wxyz=q, t=t, camera=cam, name=name.decode(), points=p2)
     with open(os.path.join(path, "points3D.bin"), "rb") as f:
         (n,) = struct.unpack("<Q", f.read(8))
-        for _ in range(n):
+        for _ in range(n if with_points else 0):
             (pid,) = struct.unpack("<Q", f.read(8))
             xyz = np.frombuffer(f.read(24), "<f8").copy(); f.read(3)
             (err,) = struct.unpack("<d", f.read(8)); (no,) = struct.unpack("<Q", f.read(8))
