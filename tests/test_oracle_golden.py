@@ -10,8 +10,9 @@ from oracle import ba_cpu, ba_oracle as bo
 from tests import helpers as H
 
 GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
-OTHER = {"track_filter.npz", "tag_refine.npz", "pose_graph.npz"}          # fixtures of the "next" rows (make_golden_extra.py), tested below
-GOLD = sorted(p for p in glob.glob(os.path.join(GOLD_DIR, "*.npz")) if os.path.basename(p) not in OTHER)
+OTHER = {"track_filter.npz", "tag_refine.npz", "pose_graph.npz", "lba_selection.npz"}   # fixtures of other rows, tested elsewhere
+GOLD = sorted(p for p in glob.glob(os.path.join(GOLD_DIR, "*.npz")) if os.path.basename(p) not in OTHER and not os.path.basename(p).startswith("ceres_"))
+CERES = sorted(glob.glob(os.path.join(GOLD_DIR, "ceres_*.npz")))          # real Ceres runs (bench/make_ceres_golden.py); none committed yet
 
 
 def _load(path):
@@ -136,3 +137,21 @@ def test_pose_graph_oracle_and_product_reproduce_golden(lib):
                                        gradient_tolerance=1e-12, max_iterations=500, **kw)
     assert abs(s.final_cost - float(z["out_cost"])) <= 1e-6 * s.final_cost
     assert np.abs(pos - z["out_pos"]).max() < 1e-3 and np.abs(sc - z["out_scale"]).max() < 1e-3
+
+
+def test_oracle_against_real_ceres_runs():
+    """If tests/golden/ceres_*.npz exist (bench/ceres_harness.cc run on a box with Ceres < 2.2, bench/make_ceres_golden.py), the
+    numpy oracle must reproduce Ceres' step counts, final cost (1e-9) and cameras (1e-5, the north star's tolerances).  No such
+    file is committed: Ceres / Eigen are absent from the build image and from every GPU box probed (__graft_entry__.py probe),
+    so this test SKIPS and parity stays UNPINNED against the real reference."""
+    if not CERES:
+        pytest.skip("parity unpinned: no Ceres run available (bench/ceres_harness.cc needs Ceres < 2.2 + Eigen)")
+    for path in CERES:
+        z = np.load(path)
+        arr = {k[3:]: z[k] for k in z.files if k.startswith("in_")}
+        pr = H.to_oracle(arr)
+        s = bo.solve(pr, bo.Options())
+        n_res = 2 * arr["obs_cam"].shape[0]
+        assert (s.n_successful, s.n_unsuccessful) == (int(z["n_successful"]), int(z["n_unsuccessful"])), path
+        assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(float(z["final_cost"]) / n_res)) < 1e-6
+        assert np.abs(pr.cam_q - z["out_cam_q"]).max() < 1e-5 and np.abs(pr.cam_t - z["out_cam_t"]).max() < 1e-5
