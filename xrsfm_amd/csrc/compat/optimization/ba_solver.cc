@@ -17,6 +17,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <iomanip>
 #include <iostream>
 #include <set>
@@ -27,6 +28,8 @@
 #include "xrsfm_ba.h"
 
 namespace xrsfm {
+int &BASolverFailureCount() { static int n = 0; return n; }
+
 namespace {
 
 // Flat copy of the parameter blocks of one BA call + the way back into the Map.
@@ -109,7 +112,14 @@ class FlatProblem {
         p.obs_cam = obs_cam_.data(); p.obs_pt = obs_pt_.data(); p.obs_uv = obs_uv_.data();
         const int rc = xrsfm_ba_solve(&opt, &p, summary);
         if (rc != XRSFM_BA_OK) {
-            std::cerr << "xrsfm_ba_solve failed with code " << rc << " (no CPU fallback); map left unchanged" << std::endl;
+            // The reference's call sites are void and never look at a status (ba_solver.cc:636-637 ignores Ceres' summary too),
+            // so a persistent failure (no device, out of memory) would silently yield a reconstruction without any BA: count the
+            // failures, say so every time, and stop the process if the user asked for that (XRSFM_BA_ABORT_ON_FAILURE=1).
+            const int n = ++BASolverFailureCount();
+            std::cerr << "xrsfm_ba_solve failed with code " << rc << " (no CPU fallback); map left unchanged — bundle adjustment call #"
+                      << n << " of this process that did NOT run" << std::endl;
+            const char *abort_env = std::getenv("XRSFM_BA_ABORT_ON_FAILURE");
+            if (abort_env && abort_env[0] == '1') std::abort();
             return rc;
         }
         for (size_t c = 0; c < frames_.size(); ++c) {
@@ -394,46 +404,42 @@ template <typename P> inline void Store(const RawPose &r, P &pose) {
 } // namespace
 
 void BASolver::ScalePoseGraphUnorder(const LoopInfo &loop_info, Map &map, bool use_key) {
-    // the frame every map point is re-expressed in afterwards: prefer key frames, then the smallest positive depth (:150-196)
+    // Step 1 (:150-196): the frame every map point is re-expressed in after the graph has moved.  Among the frames that see the
+    // point (the loop frame excluded) in FRONT of the camera the order of preference is: key frame before non-key frame, then the
+    // nearer one, then the lower frame id; if the point lies behind every such frame the first observing frame is kept (with
+    // its negative depth, which the reference then reports).  This is what the reference's running-best loop computes.
+    struct RefChoice { int frame = -1; double depth = -1.0; bool key = false; };
+    const auto depth_in = [&](int frame_id, const Track &track) {
+        const RawPose tcw = Load(map.frames_[frame_id].Tcw);
+        double pc[3];
+        QRot(tcw.q, track.point3d_.data(), pc);
+        return pc[2] + tcw.t[2];
+    };
+    const auto preferred = [](const RefChoice &cand, const RefChoice &cur) {      // strict: an equal candidate does not replace
+        if (cur.depth < 0) return true;
+        if (cand.key != cur.key) return cand.key;
+        return cand.depth < cur.depth;
+    };
     for (auto &track : map.tracks_) {
         if (track.outlier) continue;
-        int best_frame_id = -1;
-        double best_depth = -1.0;
-        bool is_key = false;
+        RefChoice best;
         for (const auto &obs : track.observations_) {
-            const int frame_id = obs.first;
-            if (frame_id == loop_info.frame_id) continue;
-            const auto &frame = map.frames_[frame_id];
-            const RawPose tcw = Load(frame.Tcw);
-            double pc[3];
-            QRot(tcw.q, track.point3d_.data(), pc);
-            const double depth = pc[2] + tcw.t[2];
-            if (best_frame_id == -1) {
-                best_frame_id = frame_id; best_depth = depth; is_key = frame.is_keyframe;
-            } else {
-                if (depth < 0) continue;
-                if ((!is_key && frame.is_keyframe) || best_depth < 0 || (depth < best_depth && !(is_key && !frame.is_keyframe))) {
-                    best_frame_id = frame_id; best_depth = depth; is_key = frame.is_keyframe;
-                }
-            }
+            if (obs.first == loop_info.frame_id) continue;
+            const RefChoice cand{obs.first, depth_in(obs.first, track), map.frames_[obs.first].is_keyframe};
+            if (best.frame == -1 || (cand.depth >= 0 && preferred(cand, best))) best = cand;
         }
-        track.ref_id = best_frame_id;
-        track.depth = best_depth;
-        if (track.depth < 0) {
+        track.ref_id = best.frame;
+        track.depth = best.depth;
+        if (best.depth < 0) {                          // the reference's diagnostics (stdout is observable behaviour)
             std::cout << "!!! negative depth\n";
             if (!track.observations_.empty()) {
-                const auto &it = track.observations_.begin();
-                const int track_id = map.frames_[it->first].track_ids_[it->second];
+                const auto first = track.observations_.begin();
+                const int track_id = map.frames_[first->first].track_ids_[first->second];
                 printf("-%d %d %lf\n", track_id, track.ref_id, track.depth);
-                for (const auto &obs : track.observations_) {
-                    const RawPose tcw = Load(map.frames_[obs.first].Tcw);
-                    double pc[3];
-                    QRot(tcw.q, track.point3d_.data(), pc);
-                    printf("%d %d %lf\n", track_id, obs.first, pc[2] + tcw.t[2]);
-                }
+                for (const auto &obs : track.observations_) printf("%d %d %lf\n", track_id, obs.first, depth_in(obs.first, track));
             }
         }
-        if (track.ref_id == -1) std::cout << "!!! no frame_id\n";
+        if (best.frame == -1) std::cout << "!!! no frame_id\n";
     }
 
     const size_t num_frames = map.frames_.size();

@@ -24,6 +24,11 @@ namespace xrsfm {
 int RefineFramePose(Frame &frame, const Camera &camera, const std::vector<vector3> &points3ds,
                     const std::vector<std::pair<int, int>> &id_pair_vec, const std::vector<char> &inlier_mask);
 
+// Number of GBA / KGBA / LBA calls of this process whose solve did not run (the map was left unchanged each time).  The
+// reference's call sites cannot see a status; a mapper that wants a hard error sets XRSFM_BA_ABORT_ON_FAILURE=1 or checks this at
+// the end of the reconstruction.
+int &BASolverFailureCount();
+
 class BASolver {
   public:
     BASolver() {}

@@ -236,6 +236,7 @@ struct Solver {
         std::vector<double> pos(p.pos, p.pos + 3 * (size_t)p.n_frames), sc(p.scale, p.scale + p.n_scales);
         std::vector<double> pos_c(pos.size()), sc_c(sc.size()), r_c(r.size());
         std::vector<double> diag(nv), gs(nv), gn(nv), step(nv), dl(nv), Jd(r.size());
+        std::vector<char> active(nv, 0);         // variables held on their bound for the current linearisation
         const bool constrained = p.scale_lower != nullptr;
         if (constrained) { std::vector<double> z(nv, 0.0); plus(pos.data(), sc.data(), z.data(), pos.data(), sc.data()); }   // feasible start
         double cost = g.eval(pos.data(), sc.data(), r.data());
@@ -254,15 +255,30 @@ struct Solver {
         if (nv == 0) return finish(1, cost);
         for (int it = 0;; ++it) {
             if (!reuse) {
-                // normal equations, gradient
-                H.zero();
+                // gradient first: it decides the active set of this linearisation
                 std::fill(grad.begin(), grad.end(), 0.0);
+                for_rows(pos.data(), sc.data(), [&](int ri, const Row& row) { for (int x = 0; x < row.n; ++x) grad[row.idx[x]] += row.val[x] * r[ri]; });
+                // Active set (projected-Newton rule): a scale that sits on its lower bound while the gradient pushes it further
+                // down cannot move; it is held for this step, so that the step of the OTHER variables is the one of the problem
+                // restricted to the feasible face instead of a Gauss-Newton step that keeps "using" the infeasible decrease.
+                // Ceres itself only projects and line-searches (no active set) and can stall above the constrained minimum — a
+                // deliberate deviation, tested against an independent bounded least-squares solver (tests/test_pose_graph_cpu.py).
+                std::fill(active.begin(), active.end(), 0);
+                if (constrained)
+                    for (int i = 0; i < p.n_scales; ++i)
+                        if (g.vs[i] >= 0 && sc[i] <= p.scale_lower[i] && grad[g.vs[i]] > 0.0) active[g.vs[i]] = 1;
+                // normal equations over the free variables (identity rows for the held ones)
+                H.zero();
                 for_rows(pos.data(), sc.data(), [&](int ri, const Row& row) {
                     for (int x = 0; x < row.n; ++x) {
-                        grad[row.idx[x]] += row.val[x] * r[ri];
-                        for (int y = 0; y <= x; ++y) H.at(row.idx[x], row.idx[y]) += row.val[x] * row.val[y] * ((row.idx[x] == row.idx[y] && x != y) ? 2.0 : 1.0);
+                        if (active[row.idx[x]]) continue;
+                        for (int y = 0; y <= x; ++y) {
+                            if (active[row.idx[y]]) continue;
+                            H.at(row.idx[x], row.idx[y]) += row.val[x] * row.val[y] * ((row.idx[x] == row.idx[y] && x != y) ? 2.0 : 1.0);
+                        }
                     }
                 });
+                for (int i = 0; i < nv; ++i) if (active[i]) { H.at(i, i) = 1.0; grad[i] = 0.0; }
                 // gradient tolerance on the projected gradient |x - P(x - g)|_inf
                 double gmax = 0.0;
                 {
@@ -284,7 +300,7 @@ struct Solver {
                     std::vector<double> v(nv);
                     for (int i = 0; i < nv; ++i) v[i] = gs[i] / diag[i];
                     std::fill(Jd.begin(), Jd.end(), 0.0);
-                    for_rows(pos.data(), sc.data(), [&](int ri, const Row& row) { for (int x = 0; x < row.n; ++x) Jd[ri] += row.val[x] * v[row.idx[x]]; });
+                    for_rows(pos.data(), sc.data(), [&](int ri, const Row& row) { for (int x = 0; x < row.n; ++x) Jd[ri] += row.val[x] * v[row.idx[x]]; });   // (v is 0 on held variables)
                     double q = 0.0;
                     for (double x : Jd) q += x * x;
                     alpha = q > 0.0 ? gs_norm * gs_norm / q : 0.0;
@@ -299,6 +315,7 @@ struct Solver {
                     mu *= mu_up;
                 }
                 if (!ok) { mu = max_mu; return finish(6, cost); }
+                mu = std::max(min_mu, 2.0 * mu / mu_up);          // relaxed after every successful factorisation (DoglegStrategy::ComputeGaussNewtonStep)
                 for (int i = 0; i < nv; ++i) gn[i] = -grad[i];
                 H.solve(gn.data());
                 gn_norm = 0.0;
@@ -367,7 +384,6 @@ struct Solver {
                 sum->n_successful++;
                 if (rho < 0.25) radius *= 0.5;
                 if (rho > 0.75) radius = std::max(radius, 3.0 * dl_norm);
-                mu = std::max(min_mu, 2.0 * mu / mu_up);
                 reuse = false;
             } else {
                 sum->n_unsuccessful++;

@@ -112,6 +112,7 @@ struct Solver {
     double Hs;                        // scale-scale
     std::vector<double> Hb, Hbs;      // per tag: m x m block, m border (coupling with the scale)
     std::vector<double> Hp;           // per point: 6 (lower 3x3)
+    bool scale_held = false;          // the scale is on its lower bound and held for the current step (active set)
     std::vector<double> grad;         // tangent-space gradient J^T r
 
     Solver(const xrsfm_tag_problem& pr, int stage_)
@@ -296,8 +297,8 @@ struct Solver {
             chol_small_solve(Lk, m, wk); chol_small_solve(Lk, m, uk);
             for (int a = 0; a < m; ++a) { ss -= border[a] * wk[a]; rs -= border[a] * uk[a]; }
         }
-        if (!(ss > 0)) return false;
-        const double xs = rs / ss;
+        if (!scale_held && !(ss > 0)) return false;
+        const double xs = scale_held ? 0.0 : rs / ss;          // (active set, see run())
         step[0] = S[0] * xs;
         for (int k = 0; k < T; ++k)
             for (int a = 0; a < m; ++a) step[1 + k * m + a] = S[1 + k * m + a] * (u[(size_t)k * m + a] - w[(size_t)k * m + a] * xs);
@@ -383,6 +384,12 @@ struct Solver {
             if (it >= o.max_iterations) return finish(5, cost);
             ++it;
             sum->iterations = it;
+            // Active set (projected-Newton rule): while the scale sits on its lower bound (tag_extract.hpp:227) and the gradient
+            // pushes it further down it is held, so that the tags take the step of the problem restricted to scale = bound.
+            // Ceres only projects and line-searches: its model keeps promising the infeasible decrease, rho stays small, the
+            // radius collapses and the loop stalls above the constrained minimum — a deliberate deviation (tests compare with
+            // scipy's bounded least squares).
+            scale_held = x.scale <= p.scale_lower && grad[0] > 0.0;
             if (!reuse_diagonal) for (int i = 0; i < n; ++i) dg[i] = std::min(std::max(diag(i) * S[i] * S[i], 1e-6), 1e32);
             for (int i = 0; i < n; ++i) d2[i] = dg[i] / radius;
             double model = -1.0;
