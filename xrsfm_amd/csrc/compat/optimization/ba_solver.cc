@@ -185,7 +185,7 @@ std::vector<std::pair<int, int>> CovisibleFrames(const Frame &frame, const Map &
     std::vector<std::pair<int, int>> out(shared.begin(), shared.end());
     // most covisible first; equal counts by ascending frame id.  (The reference sorts hash-table contents on the count alone,
     // :411-416 / :507-512: its order among ties is unspecified, so a fixed rule is one of the orders it can produce — and it
-    // makes the selection testable against an independent restatement, oracle/lba_select.py.)
+    // makes the selection testable against the independent numpy restatement of tests/test_adapter.py.)
     std::sort(out.begin(), out.end(), [](const std::pair<int, int> &a, const std::pair<int, int> &b) {
         return a.second != b.second ? a.second > b.second : a.first < b.first;
     });
