@@ -36,7 +36,9 @@ def main():
         for cfg, note in (("L", "default workload"), ("S", ""), ("K", "KITTI-00-sized sequential problem"),
                           ("X", "5000 cameras: 30 000 camera unknowns on the exact Cholesky path"),
                           ("R", "ragged tracks: windows of 8 frames, 35 % missed detections"),
-                          ("U", "random visibility, dense reduced camera matrix; no CPU leg")):
+                          ("U", "random visibility, dense reduced camera matrix; no CPU leg"),
+                          ("V", "3000 cameras, random visibility: implicit-Schur PCG; no CPU leg"),
+                          ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter")):
             if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
                 continue
             f.write(f"\n## config {cfg}" + (f" ({note})" if note else "") + "\n```\n" + rd(f"bench_{cfg}.json").strip() + "\n```\n")
@@ -51,6 +53,14 @@ def main():
                 m = b["more_threads"]
                 f.write(f", {m['cores']} threads: {m['value']:.3e} ({m['gpu_vs_cpu']:.0f}x)")
             f.write(f"; final RMSE difference to the CPU port {b.get('rmse_diff_px', float('nan')):.1e} px.\n")
+    if os.path.exists(os.path.join(src, "pmc_mix.md")):
+        with open(os.path.join(dst, f"{tag}_L_instruction_mix.md"), "w") as f:
+            f.write(f"# Round {tag[1:]} — instruction mix and pipe occupancy per kernel, rocprofv3 PMC (SQ counters), bench.py --config L\n\n"
+                    "Three passes (tools/pmc_mix.sh; counters only + kernel trace).  One row per kernel = average over its dispatches of the per-shader-engine "
+                    "counter rows (32 rows per dispatch: multiply by 32 for a whole launch; SQ_WAVES x 32 = waves of a launch).\n\n" + rd("pmc_mix.md"))
+    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt"):
+        if os.path.exists(os.path.join(src, extra)):
+            shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
     print("profiles written for", tag)
 
 

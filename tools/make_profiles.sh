@@ -9,10 +9,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. kernel trace + stats of the default bench command (no CPU leg: it would only add host time)
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py --config L --no-cpu --steps 2 > $OUT/stats_bench.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py --config L --no-cpu --no-extras --steps 2 > $OUT/stats_bench.log 2>&1
 # 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes (counters only, with --kernel-trace)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python $ROOT/bench.py --config L --no-cpu --steps 1 --warmup 0 > $OUT/fetch_bench.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python $ROOT/bench.py --config L --no-cpu --steps 1 --warmup 0 > $OUT/write_bench.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o fetch -- python $ROOT/bench.py --config L --no-cpu --no-extras --steps 1 --warmup 0 > $OUT/fetch_bench.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o write -- python $ROOT/bench.py --config L --no-cpu --no-extras --steps 1 --warmup 0 > $OUT/write_bench.log 2>&1
+# 2b. instruction mix / pipe occupancy of the kernels (three SQ counter passes, tools/pmc_mix.sh)
+bash $ROOT/tools/pmc_mix.sh L $TAG > /dev/null 2>&1
+cp $ROOT/gpurun_out/pmc_$TAG/mix.md $OUT/pmc_mix.md 2>/dev/null
+cd /tmp
 # 3. summaries while the databases are at hand (the .db files are too big to bring back)
 python $ROOT/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats_table.md > /dev/null
 python $ROOT/tools/pmc_summary.py $(find $OUT/fetch -name "*.db" | head -1) $(find $OUT/write -name "*.db" | head -1) $OUT/pmc_table.md $OUT/pmc_traffic_L.json > /dev/null
@@ -24,5 +28,10 @@ for cfg in L S K X R; do
   python bench.py --config $cfg --steps 5 --warmup 2 2> $OUT/bench_$cfg.err | tail -1 > $OUT/bench_$cfg.json
 done
 python bench.py --config U --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_U.err | tail -1 > $OUT/bench_U.json
+python bench.py --config V --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_V.err | tail -1 > $OUT/bench_V.json
+python bench.py --config L0 --steps 3 --warmup 1 --no-extras 2> $OUT/bench_L0.err | tail -1 > $OUT/bench_L0.json
+python tools/lba_phases.py > $OUT/lba_phases.txt 2>&1
+python tools/lba_timing.py > $OUT/lba_timing.txt 2>&1
+python __graft_entry__.py probe 2>&1 | grep "\[probe\]" > $OUT/probe.txt
 nproc > $OUT/nproc.txt
 ls -la $OUT
