@@ -28,14 +28,15 @@ def main():
     out = np.zeros((3, 64, 16), dtype=np.uint64)
     L.xrsfm_ba_debug_stamps.argtypes = [C.c_void_p]
     assert L.xrsfm_ba_debug_stamps(out.ctypes.data) == 0
-    for kern, name in enumerate(["k_schur_pairs", "k_linearize", "k_backsub"]):
+    for kern, name in enumerate(["k_schur_pairs", "k_lv_factor", "k_backsub"]):
         st = out[kern].astype(np.int64)
         ok = st[:, 0] > 0
         if not ok.any():
             continue
         st = st[ok]
-        n = int((st[0] > 0).sum())
+        n = 16
         rel = (st[:, :n] - st[:, :1])
+        rel[st[:, :n] == 0] = -1
         print(name, "samples", len(st), "cycles from wave start (median / p10 / p90) at each stamp (100 MHz counter? see deltas):")
         for i in range(n):
             col = rel[:, i]

@@ -452,6 +452,7 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
     for (int kb = 0; kb < nb; ++kb) {
+        XBA_STAMP(1, 3 + 2 * kb);
         const int b0 = 16 * kb;
         if (wave == 0) {
             // (a) lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
@@ -491,6 +492,7 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
             }
         }
         __syncthreads();
+        XBA_STAMP(1, 4 + 2 * kb);
         // (b) rows below: X = A21 * Linv11^T, one 16-row block per wave
         if (kb + 1 + wave < nb) {
             const int rb = 16 * (kb + 1 + wave);
@@ -518,6 +520,7 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
         }
         __syncthreads();
     }
+    XBA_STAMP(1, 11);
     // ---- off-diagonal blocks of Linv, block diagonals dd = 1,2,3:  Linv_ij = -Linv_ii * sum_{kb=j}^{i-1} L_i,kb Linv_kb,j  (i = j + dd).
     // Block j of a diagonal belongs to wave j: two chains of 16x16x16 products on the matrix cores with the intermediate
     // passed through the wave's own LDS scratch; one workgroup barrier per diagonal.
@@ -1005,6 +1008,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
     const int b = blockIdx.x;
     const int i = tiles[2 * b], k = tiles[2 * b + 1];
     const bool diag = (i == k);
+    XBA_STAMP(1, 0);
     const int nb = (c.tile_rows[k] + 15) >> 4;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
@@ -1063,6 +1067,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
             if (part == 0) fv[o] = fsum;
         }
     }
+    XBA_STAMP(1, 1);
     // the pivot tile: lower triangle of A_kk - update, identity on the padding rows of Linv
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -1075,7 +1080,9 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
                 Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
             }
     __syncthreads();
+    XBA_STAMP(1, 2);
     potrf_lds(A, Li, Tb, nb);
+    XBA_STAMP(1, 12);
     if (diag) {
         // Only Linv_k is stored: nothing reads the factor of a pivot tile again (updates, substitutions and the backward
         // pass use the off-diagonal tiles and Linv), and S(k,k) must keep its assembled value while other workgroups of the
@@ -1094,6 +1101,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
         sacc += __shfl_xor(sacc, 1, kWave);
         sacc += __shfl_xor(sacc, 2, kWave);
         if (part == 0) c.y[k * kNB + o] = sacc;
+        XBA_STAMP(1, 13);
         return;
     }
     // off-diagonal tile: X = (A_ik - update) -> LDS (the factor L_kk is no longer needed here), L_ik = X Linv_k^T
