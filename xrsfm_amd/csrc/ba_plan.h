@@ -4,6 +4,7 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -18,7 +19,7 @@ struct CholPlan {
     int n = 0, n_pad = 0, T = 0, n_blocks = 0, n_pairs = 0, n_writes = 0, n_tiles_nz = 0, n_levels = 0;
     int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring
     int n_hubs = 0, band = 0;
-    bool use_levels = false;
+    bool use_levels = false, panel_ll = false;
     // k_schur_pairs is launched once per LDS class: items whose staged operand fits 10 KB (16 workgroups per CU) and the rest
     size_t pairs_shm = 0, pairs_shm_big = 0;
     std::vector<int> pairs_items;    // Gram tiles of the small class | Gram tiles of the big class (tile indices) | other items (item indices)
@@ -332,6 +333,13 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         level[kk] = lv;
         n_levels = std::max(n_levels, lv + 1);
     }
+    // Deep trees (unordered / dense patterns: about one panel per level): "panel schedule" = left-looking updates per panel
+    // (split into chunks), pivot + triangular solve per panel, push-form backward substitution
+    bool panel_ll = (2 * n_levels > T);
+    if (const char* fl = std::getenv("XRSFM_BA_PANEL_LL")) panel_ll = (2 * n_levels > T) && fl[0] == '1';
+    const int panel_min_chunk = std::getenv("XRSFM_BA_PANEL_CS") ? std::atoi(std::getenv("XRSFM_BA_PANEL_CS")) : 4;
+    const int panel_chunks = std::getenv("XRSFM_BA_PANEL_WG") ? std::atoi(std::getenv("XRSFM_BA_PANEL_WG")) : 1024;
+    P.panel_ll = panel_ll;
     P.lv_cptr.assign(1, 0); P.lv_rptr.assign(1, 0); P.lv_bptr.assign(1, 0);
     P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0); P.lv_trsm_off.assign(n_levels + 1, 0);
     P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
@@ -359,9 +367,11 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         // split this level?  (few workgroups, each with a long serial list)
         const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
         const int nt = g1 - g0, nc = nt > 0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0;
-        const bool split = nt > 0 && nt <= 128 && nc > 2 * nt;
+        // (panel schedule: every level with lists worth cutting is split, into chunks of >= kPanelMinChunk products so that the
+        //  partial tile a chunk writes stays a small part of its traffic, and into <= ~kPanelChunks chunks per level)
+        const bool split = panel_ll ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt);
         if (split) {
-            const int cs = std::max(1, (nc + 511) / 512);
+            const int cs = panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks) : std::max(1, (nc + 511) / 512);
             int np = 0;
             for (int g = g0; g < g1; ++g) {
                 const int p0 = np;

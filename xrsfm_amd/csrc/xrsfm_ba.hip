@@ -100,7 +100,7 @@ struct CholHost {
     int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
     std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
     // level schedule (elimination-tree levels of the tile pattern; left-looking updates)
-    bool use_levels = false;
+    bool use_levels = false, panel_ll = false;
     int n_levels = 0;
     int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr, *lv_trsm = nullptr;
     int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
@@ -519,7 +519,7 @@ int chol_setup(xrsfm_ba_context* c) {
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
     if (6 * Nc > kCholMaxN && (!P.use_levels || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
-    h.use_levels = P.use_levels; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
+    h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.fz_off = P.fz_off;
@@ -623,7 +623,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     const int T = h.T;
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
-    if (h.use_levels && c->fused) {
+    if ((h.use_levels || h.panel_ll) && c->fused) {
         // one launch per elimination-tree level (three on a split level: partial products, their fixed-order sum, then the
         // same fused kernel with empty lists), then one per level backwards
         for (int lv = 0; lv < h.n_levels; ++lv) {
@@ -639,12 +639,20 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj);
         }
+        if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
+            for (int k = T - 1; k >= 0; --k) {
+                const int ncol = h.cols_off[k + 1] - h.cols_off[k];
+                LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
+            }
+            if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.px, d.n_cams);
+            return 0;
+        }
         for (int lv = h.n_levels - 1; lv >= 0; --lv) {
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
             LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, d.px);
         }
         return 0;
-    } else if (h.use_levels) {
+    } else if (h.use_levels || h.panel_ll) {
         // one launch per elimination-tree level and phase
         for (int lv = 0; lv < h.n_levels; ++lv) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
@@ -662,6 +670,12 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             if (ns > 0) LAUNCH(c, K_TRSM, k_ll_trsm, dim3(ns), dim3(256), shm, h.dev, h.lv_trsm + 2 * (size_t)h.lv_trsm_off[lv]);
         }
         // (the forward substitution is folded into k_potrf)
+        if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
+            for (int k = T - 1; k >= 0; --k) {
+                const int ncol = h.cols_off[k + 1] - h.cols_off[k];
+                LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
+            }
+        } else
         for (int lv = h.n_levels - 1; lv >= 0; --lv) {
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
             LAUNCH(c, K_TRISOLVE, k_ll_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi);
