@@ -615,6 +615,33 @@ def test_auto_solver_beyond_the_dense_limit(lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n_cams,panel_cols", [(150, 2), (150, 4), (95, 2), (230, 6)])
+def test_dense_pattern_panel_schedule_matches_oracle(lib, monkeypatch, n_cams, panel_cols):
+    """Unordered visibility -> a full tile pattern with one column per elimination-tree level: the panel schedule (left-looking
+    updates in chunks, 128x128 macro tiles over `panel_cols` columns at a time, fused pivot / triangular-solve kernel, push-form
+    backward substitution).  The production rule switches macro tiles on from 96 tile columns; the developer switches force
+    them here on 10-23 columns (odd counts: the last row pair is half empty) and the result must equal both the oracle and
+    the same solve without macro tiles."""
+    from xrsfm_amd import capi
+    arr = H.make(n_cams, 40 * n_cams, 5, seed=460 + n_cams, mode="unordered")
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["level_schedule"] == 0 and plan["tiles"] == (n_cams + 9) // 10
+    kw = dict(max_iterations=8, linear_solver=1)
+    monkeypatch.setenv("XRSFM_BA_PANEL_MACRO", "0")
+    prod0 = H.to_product(arr)
+    s0 = capi.solve(prod0, capi.default_options(**kw))
+    monkeypatch.setenv("XRSFM_BA_PANEL_MACRO", "1")
+    monkeypatch.setenv("XRSFM_BA_PANEL_COLS", str(panel_cols))
+    pr, s_ref, prod, s = _solve_both(dict(arr), kw)
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful) == (s0.n_successful, s0.n_unsuccessful)
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
+    assert np.abs(prod.cam_q - prod0.cam_q).max() < 1e-9 and np.abs(prod.cam_t - prod0.cam_t).max() < 1e-8
+    assert abs(s.final_cost - s0.final_cost) <= 1e-10 * s0.final_cost
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver", [1, 0], ids=["cholesky", "pcg"])
 def test_ragged_tracks_match_oracle(lib, solver):
     """Windows of 8 frames with 35 % missed detections: many distinct camera tuples, tiles whose tracks see different camera

@@ -826,11 +826,48 @@ __global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restr
 // partials of every target in list order: deterministic, no atomics.
 constexpr int kPartStride = kNB * kNB + kNB;
 
+// The operands are staged in halves of 32 columns (2 x 17 KB of LDS per workgroup, < 128 registers): four workgroups
+// share a compute unit, so that the loads of three of them are in flight while the fourth feeds the matrix cores.
+constexpr int kLdH = 34;
+typedef double v2d __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void load_half_regs(v2d (&v)[4], const double* __restrict__ src, size_t ld) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = threadIdx.x + 256 * it;          // 16-byte element index in the 64 x 32 half tile
+        v[it] = *reinterpret_cast<const v2d*>(src + (size_t)(e >> 4) * ld + (e & 15) * 2);
+    }
+}
+__device__ __forceinline__ void store_half_lds(double* dst, const v2d (&v)[4]) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        *reinterpret_cast<v2d*>(dst + (e >> 4) * kLdH + (e & 15) * 2) = v[it];
+    }
+}
+__device__ __forceinline__ void half_abt_mfma(const double* __restrict__ As, const double* __restrict__ Bs, v4d (&acc)[2][2]) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+    const int li = lane & 15, lk = lane >> 4;
+#pragma unroll
+    for (int k0 = 0; k0 < 32; k0 += 4) {
+        double a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            a[m] = As[(r0 + 16 * m + li) * kLdH + k0 + lk];
+            b[m] = Bs[(c0 + 16 * m + li) * kLdH + k0 + lk];
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n2], acc[m][n2], 0, 0, 0);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr,
                                                         const int* __restrict__ cj, double* __restrict__ Wp) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+    __shared__ __attribute__((aligned(16))) double As[kNB * kLdH];
+    __shared__ __attribute__((aligned(16))) double Bs[kNB * kLdH];
     __shared__ double yv[kNB];
-    double* As = smem; double* Bs = smem + kNB * kLdT;
     const int i = tgt[2 * blockIdx.x], k = tgt[2 * blockIdx.x + 1];
     const bool diag = (i == k);
     v4d acc[2][2];
@@ -841,28 +878,32 @@ __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __
     const int q0 = qr[2 * blockIdx.x], q1 = qr[2 * blockIdx.x + 1];
     const int t = threadIdx.x, o = t >> 2, part = t & 3;
     double sv = 0.0;
-    double2 ra[8], rb[8];
+    v2d ra[4], rb[4];
+    const double* rowA = c.S + (size_t)(i * kNB) * c.n_pad;
+    const double* rowB = c.S + (size_t)(k * kNB) * c.n_pad;
     {
         const int j = cj[q0];
-        load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
-        load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+        load_half_regs(ra, rowA + j * kNB, c.n_pad);
+        load_half_regs(rb, rowB + j * kNB, c.n_pad);
     }
-    for (int q = q0; q < q1; ++q) {
-        __syncthreads();                       // the previous product no longer reads LDS
-        store_tile_lds(As, ra);
-        store_tile_lds(Bs, rb);
-        if (diag && t < kNB) yv[t] = c.y[cj[q] * kNB + t];
+    const int ns = 2 * (q1 - q0);
+    for (int s = 0; s < ns; ++s) {
+        const int kh = s & 1;
+        __syncthreads();                       // the previous half product no longer reads LDS
+        store_half_lds(As, ra);
+        store_half_lds(Bs, rb);
+        if (diag && kh == 0 && t < kNB) yv[t] = c.y[cj[q0 + (s >> 1)] * kNB + t];
         __syncthreads();
-        if (q + 1 < q1) {
-            const int j = cj[q + 1];
-            load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
-            load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+        if (s + 1 < ns) {
+            const int col = cj[q0 + ((s + 1) >> 1)] * kNB + ((s + 1) & 1) * 32;
+            load_half_regs(ra, rowA + col, c.n_pad);
+            load_half_regs(rb, rowB + col, c.n_pad);
         }
         if (diag) {
 #pragma unroll
-            for (int m = 0; m < 16; ++m) sv += As[o * kLdT + part * 16 + m] * yv[part * 16 + m];
+            for (int m = 0; m < 8; ++m) sv += As[o * kLdH + part * 8 + m] * yv[kh * 32 + part * 8 + m];
         }
-        tile_abt_mfma(As, Bs, acc);
+        half_abt_mfma(As, Bs, acc);
     }
     double* out = Wp + (size_t)blockIdx.x * kPartStride;
     {
@@ -883,6 +924,131 @@ __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __
         sv += __shfl_xor(sv, 2, kWave);
         if (part == 0) out[kNB * kNB + o] = sv;
     }
+}
+
+// Dense part of a panel schedule: 128x128 macro tile = rows (i0,i1) x columns (k0,k1), contributions j in [q0,q1): every
+// operand tile that goes through LDS feeds two products (16 KB of traffic per 64x64x64 product instead of 32 KB) and every
+// wave runs 16 matrix instructions per 8 LDS reads.  Wave w forms the full 64x64 tile (row w>>1, column w&1); tiles above
+// the diagonal and the missing second row of an odd count are skipped.  The operands move in quarters of 16 columns through
+// a double-buffered LDS image: the stores of step s+1 and the global loads of step s+2 are issued ahead of the matrix
+// instructions of step s, one barrier per step.  mc: 8 ints per chunk (ba_plan.h); the four partial tiles land `stride`
+// partial slots apart.
+constexpr int kLdQ = 18;
+__device__ __forceinline__ void load_quarter_regs(v2d (&v)[2], const double* __restrict__ src, size_t ld) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = threadIdx.x + 256 * it;          // 16-byte element index in the 64 x 16 quarter tile
+        v[it] = *reinterpret_cast<const v2d*>(src + (size_t)(e >> 3) * ld + (e & 7) * 2);
+    }
+}
+__device__ __forceinline__ void store_quarter_lds(double* dst, const v2d (&v)[2]) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        *reinterpret_cast<v2d*>(dst + (e >> 3) * kLdQ + (e & 7) * 2) = v[it];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void k_panel2_part(CholDev c, const int* __restrict__ mc, const int* __restrict__ wg,
+                                                        double* __restrict__ Wp) {
+    __shared__ __attribute__((aligned(16))) double Rs[2][2][kNB * kLdQ];      // [buffer][row tile]
+    __shared__ __attribute__((aligned(16))) double Cs[2][2][kNB * kLdQ];      // [buffer][column tile]
+    __shared__ double yv[2][kNB];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wa = wave >> 1, wb = wave & 1;
+    const int o = t >> 2, part = t & 3, li = lane & 15, lk = lane >> 4;
+  {
+    const int* e = mc + 8 * wg[blockIdx.x];      // (one entry per workgroup: walking several made the compiler spill around the loop)
+    const int i0 = e[0], i1 = e[1], k0 = e[2], k1 = e[3], q0 = e[4], q1 = e[5], out0 = e[6], stride = e[7];
+    const int ia = wa ? i1 : i0, kb = wb ? k1 : k0;
+    const bool active = ia >= 0 && ia >= kb;
+    const bool diag = (i0 == k0);
+    v4d acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const double* row0 = c.S + (size_t)(i0 * kNB) * c.n_pad;
+    const double* row1 = c.S + (size_t)((i1 >= 0 ? i1 : i0) * kNB) * c.n_pad;
+    const double* row2 = c.S + (size_t)(k0 * kNB) * c.n_pad;
+    const double* row3 = c.S + (size_t)(k1 * kNB) * c.n_pad;
+    const int ns = 4 * (q1 - q0);
+    v2d rg0[2], rg1[2], rg2[2], rg3[2];
+    double yreg = 0.0;
+    // prologue: step 0 into buffer 0, step 1 into the registers
+    {
+        const int col = q0 * kNB;
+        load_quarter_regs(rg0, row0 + col, c.n_pad); load_quarter_regs(rg1, row1 + col, c.n_pad);
+        load_quarter_regs(rg2, row2 + col, c.n_pad); load_quarter_regs(rg3, row3 + col, c.n_pad);
+        if (diag && t < kNB) yreg = c.y[q0 * kNB + t];
+        store_quarter_lds(Rs[0][0], rg0); store_quarter_lds(Rs[0][1], rg1);
+        store_quarter_lds(Cs[0][0], rg2); store_quarter_lds(Cs[0][1], rg3);
+        if (diag && t < kNB) yv[0][t] = yreg;
+        if (ns > 1) {
+            const int col1 = q0 * kNB + 16;
+            load_quarter_regs(rg0, row0 + col1, c.n_pad); load_quarter_regs(rg1, row1 + col1, c.n_pad);
+            load_quarter_regs(rg2, row2 + col1, c.n_pad); load_quarter_regs(rg3, row3 + col1, c.n_pad);
+        }
+        __syncthreads();
+    }
+    double sv0 = 0.0, sv1 = 0.0;
+    for (int s = 0; s < ns; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < ns) {                      // operands of step s+1: registers -> the other buffer
+            store_quarter_lds(Rs[buf ^ 1][0], rg0); store_quarter_lds(Rs[buf ^ 1][1], rg1);
+            store_quarter_lds(Cs[buf ^ 1][0], rg2); store_quarter_lds(Cs[buf ^ 1][1], rg3);
+            if (diag && ((s + 1) & 3) == 0 && t < kNB) yv[((s + 1) >> 2) & 1][t] = yreg;
+        }
+        if (s + 2 < ns) {                      // operands of step s+2: global -> registers
+            const int col = (q0 + ((s + 2) >> 2)) * kNB + ((s + 2) & 3) * 16;
+            load_quarter_regs(rg0, row0 + col, c.n_pad); load_quarter_regs(rg1, row1 + col, c.n_pad);
+            load_quarter_regs(rg2, row2 + col, c.n_pad); load_quarter_regs(rg3, row3 + col, c.n_pad);
+            if (diag && ((s + 2) & 3) == 0 && t < kNB) yreg = c.y[(q0 + ((s + 2) >> 2)) * kNB + t];
+        }
+        if (diag) {
+            const double* yq = yv[(s >> 2) & 1] + (s & 3) * 16 + part * 4;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                sv0 += Rs[buf][0][o * kLdQ + part * 4 + m] * yq[m];
+                sv1 += Rs[buf][1][o * kLdQ + part * 4 + m] * yq[m];
+            }
+        }
+        if (active) {
+            const double* As = Rs[buf][wa];
+            const double* Bs = Cs[buf][wb];
+#pragma unroll
+            for (int kk = 0; kk < 16; kk += 4) {
+                double a[4], b[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    a[m] = As[(16 * m + li) * kLdQ + kk + lk];
+                    b[m] = Bs[(16 * m + li) * kLdQ + kk + lk];
+                }
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int n2 = 0; n2 < 4; ++n2) acc[m][n2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[m], b[n2], acc[m][n2], 0, 0, 0);
+            }
+        }
+        __syncthreads();                       // buffer `buf` is free for step s+2, buffer buf^1 is complete
+    }
+    if (active) {
+        double* out = Wp + (size_t)(out0 + (2 * wa + wb) * stride) * kPartStride;
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 4; ++n2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) out[(16 * m + lk + 4 * g) * kNB + 16 * n2 + li] = acc[m][n2][g];
+    }
+    if (diag) {        // forward substitution: sum_j L_kj y_j of both pivot rows, next to the partial tiles (k0,k0) and (k1,k1)
+        sv0 += __shfl_xor(sv0, 1, kWave); sv0 += __shfl_xor(sv0, 2, kWave);
+        sv1 += __shfl_xor(sv1, 1, kWave); sv1 += __shfl_xor(sv1, 2, kWave);
+        if (part == 0) {
+            Wp[(size_t)out0 * kPartStride + kNB * kNB + o] = sv0;
+            if (i1 >= 0) Wp[(size_t)(out0 + 3 * stride) * kPartStride + kNB * kNB + o] = sv1;
+        }
+    }
+  }
 }
 
 // Fixed-order sum of strided values with 8 loads in flight (a plain s += load loop is one L2 round trip per term).

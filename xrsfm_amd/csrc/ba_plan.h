@@ -34,6 +34,13 @@ struct CholPlan {
     std::vector<int> sp_rt, sp_rp;      // per split target: (i,k) and its [p0,p1) range of partials (level-relative)
     std::vector<int> sp_chunk_off, sp_rt_off;   // per level (size n_levels+1)
     int sp_max_chunks = 0;
+    // panel schedule, dense part of the pattern: an even number of consecutive single-column levels (columns K0, K0+1, ...) share
+    // one update launch of 128x128 macro tiles (k_panel2_part: rows (i0,i1) x columns (k0,k1), contributions j in [q0,q1) of
+    // [0,K0)); the later levels of the panel then only add the panel's own earlier columns inside the fused factor kernel.
+    //   per entry 8 ints: i0, i1 (-1: none), k0, k1, q0, q1, first partial index, partial stride between its four tiles
+    //   mp_wg: per level W+1 offsets into the entries (workgroup w walks entries [mp_wg[w], mp_wg[w+1])); mp_off: per level
+    //   offsets into mp_wg
+    std::vector<int> mp_chunk, mp_wg, mp_off;
     // fill lists: per structurally non-zero tile (tiles_nz order) its 6x6 blocks: entry >= 0 off-diagonal block id,
     // entry < 0 the diagonal block of camera -(entry+1)
     std::vector<int> tf_ptr, tf_ent;
@@ -337,24 +344,54 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     // (split into chunks), pivot + triangular solve per panel, push-form backward substitution
     bool panel_ll = (2 * n_levels > T);
     if (const char* fl = std::getenv("XRSFM_BA_PANEL_LL")) panel_ll = (2 * n_levels > T) && fl[0] == '1';
-    const int panel_min_chunk = std::getenv("XRSFM_BA_PANEL_CS") ? std::atoi(std::getenv("XRSFM_BA_PANEL_CS")) : 4;
-    const int panel_chunks = std::getenv("XRSFM_BA_PANEL_WG") ? std::atoi(std::getenv("XRSFM_BA_PANEL_WG")) : 1024;
+    const int panel_min_chunk = 4, panel_chunks = 1024;      // (measured on config D: 512 / 768 / 1400 / 2048 chunks are 3-10 % slower)
     P.panel_ll = panel_ll;
     P.lv_cptr.assign(1, 0); P.lv_rptr.assign(1, 0); P.lv_bptr.assign(1, 0);
     P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0); P.lv_trsm_off.assign(n_levels + 1, 0);
     P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
+    P.mp_off.assign(n_levels + 1, 0);
     P.fz_off.assign(n_levels + 1, 0); P.fz_dptr.assign(1, 0);
+    std::vector<int> level_cols(n_levels, 0), level_first(n_levels, -1);
+    for (int kk = 0; kk < T; ++kk) { if (level_cols[level[kk]]++ == 0) level_first[level[kk]] = kk; }
+    std::vector<int> first_j(T, 0);          // contributions below first_j[k] reach column k through a macro-tile launch
+    const int macro_chunks = 512;
+    // macro tiles pay off from ~100 tile columns (config U, 45 columns: 25.7 ms without, 28.1 ms with); developer switches
+    bool macro_on = T >= 96;
+    if (const char* fl = std::getenv("XRSFM_BA_PANEL_MACRO")) macro_on = fl[0] == '1';
+    // (wider panels were measured on config D: 4 / 8 columns leave the update time where it is and lengthen the lists of the
+    //  fused factor kernel: 237 -> 250 / 266 ms)
+    const int panel_cols_max = std::getenv("XRSFM_BA_PANEL_COLS") ? std::atoi(std::getenv("XRSFM_BA_PANEL_COLS")) : 2;
+    // number of consecutive single-column levels lv, lv+1, ... (columns k0, k0+1, ...) that can share one macro-tile launch: the
+    // pattern is full to the left of k0 and below; an even count <= panel_cols_max, 0 = none
+    auto dense_panel = [&](int lv) {
+        if (!panel_ll || !macro_on || level_cols[lv] != 1) return 0;
+        const int k0 = level_first[lv];
+        if (k0 < 2 || first_j[k0] != 0) return 0;
+        for (int i = k0; i < T; ++i)
+            for (int j = 0; j < k0; ++j) if (!nz[(size_t)i * T + j]) return 0;
+        int np = 0;
+        while (np < panel_cols_max && lv + np < n_levels && level_cols[lv + np] == 1 && level_first[lv + np] == k0 + np) {
+            bool full = true;
+            for (int i = k0 + np; i < T && full; ++i) full = nz[(size_t)i * T + k0 + np] != 0;
+            if (!full) break;
+            ++np;
+        }
+        return np & ~1;
+    };
     struct FzEnt { int i, k; };
     std::vector<FzEnt> fz_ents;
     for (int lv = 0; lv < n_levels; ++lv) {
         fz_ents.clear();
+        const int panel_cols = dense_panel(lv);
+        const bool macro = panel_cols > 0;
+        for (int q = 1; q < panel_cols; ++q) first_j[level_first[lv] + q] = level_first[lv];
         for (int kk = 0; kk < T; ++kk) {
             if (level[kk] != lv) continue;
             for (int i = kk; i < T; ++i) {
                 if (!nz[(size_t)i * T + kk]) continue;
                 if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
                 std::vector<int> contrib;
-                for (int j = 0; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
+                for (int j = first_j[kk]; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
                 fz_ents.push_back({i, kk});
                 if (contrib.empty()) continue;
                 P.lv_tgt.push_back(i); P.lv_tgt.push_back(kk);
@@ -369,7 +406,52 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         const int nt = g1 - g0, nc = nt > 0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0;
         // (panel schedule: every level with lists worth cutting is split, into chunks of >= kPanelMinChunk products so that the
         //  partial tile a chunk writes stays a small part of its traffic, and into <= ~kPanelChunks chunks per level)
-        const bool split = panel_ll ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt);
+        const bool second = level_cols[lv] == 1 && first_j[level_first[lv]] > 0;      // second column of a macro pair: one contribution left
+        const bool split = !macro && !second && (panel_ll ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt));
+        if (macro) {
+            // every macro target's j range is cut into chunks of >= panel_min_chunk steps, ~macro_chunks chunks per level (about two
+            // rounds of resident workgroups: measured faster than one round of equal shares, whose partial-tile stores all
+            // land at the same moment); a workgroup walks the entries [mp_wg[w], mp_wg[w+1]) - here one each
+            // macro targets: column pair cp = (K0 + 2cp, K0 + 2cp + 1) x row pairs from that column pair's own rows downwards
+            const int K0 = level_first[lv], ncp = panel_cols / 2;
+            struct Tgt { int i0, i1, k0, k1; };
+            std::vector<Tgt> tg;
+            for (int cp = 0; cp < ncp; ++cp)
+                for (int i0 = K0 + 2 * cp; i0 < T; i0 += 2) tg.push_back({i0, (i0 + 1 < T) ? i0 + 1 : -1, K0 + 2 * cp, K0 + 2 * cp + 1});
+            const int nm = (int)tg.size();
+            const int cs = std::max(panel_min_chunk, (int)(((long long)nm * K0 + macro_chunks - 1) / macro_chunks));
+            std::vector<int> pieces(nm, 0);       // partial slots per macro target
+            struct Ent { int m, q0, q1, piece; };
+            std::vector<Ent> ents;
+            std::vector<int> wg_first;
+            for (int m = 0; m < nm; ++m)
+                for (int q = 0; q < K0; q += cs) {
+                    wg_first.push_back((int)ents.size());
+                    ents.push_back({m, q, std::min(K0, q + cs), pieces[m]++});
+                }
+            const int W = (int)ents.size();
+            wg_first.push_back((int)ents.size());
+            std::vector<int> base(nm + 1, 0);
+            for (int m = 0; m < nm; ++m) base[m + 1] = base[m] + 4 * pieces[m];
+            const int e_off = (int)P.mp_chunk.size() / 8;
+            for (const Ent& en : ents) {
+                const Tgt& g = tg[en.m];
+                const int e[8] = {g.i0, g.i1, g.k0, g.k1, en.q0, en.q1, base[en.m] + en.piece, pieces[en.m]};
+                P.mp_chunk.insert(P.mp_chunk.end(), e, e + 8);
+            }
+            for (int w = 0; w <= W; ++w) P.mp_wg.push_back(e_off + wg_first[w]);
+            for (int m = 0; m < nm; ++m) {
+                const Tgt& g = tg[m];
+                for (int a2 = 0; a2 < 2; ++a2)
+                    for (int b2 = 0; b2 < 2; ++b2) {
+                        const int ia = a2 ? g.i1 : g.i0, kb = b2 ? g.k1 : g.k0;
+                        if (ia < 0 || ia < kb) continue;
+                        P.sp_rt.push_back(ia); P.sp_rt.push_back(kb);
+                        P.sp_rp.push_back(base[m] + (2 * a2 + b2) * pieces[m]); P.sp_rp.push_back(base[m] + (2 * a2 + b2 + 1) * pieces[m]);
+                    }
+            }
+            P.sp_max_chunks = std::max(P.sp_max_chunks, base[nm]);
+        }
         if (split) {
             const int cs = panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks) : std::max(1, (nc + 511) / 512);
             int np = 0;
@@ -386,21 +468,22 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         }
         for (const FzEnt& e : fz_ents) {        // work list of the fused level kernel
             P.fz_tile.push_back(e.i); P.fz_tile.push_back(e.k);
-            if (!split)
-                for (int j = 0; j < e.k; ++j)
+            if (!split && !macro)
+                for (int j = first_j[e.k]; j < e.k; ++j)
                     if (nz[(size_t)e.k * T + j]) P.fz_dj.push_back((e.i == e.k || nz[(size_t)e.i * T + j]) ? j : ~j);
             P.fz_dptr.push_back((int)P.fz_dj.size());
         }
         P.fz_off[lv + 1] = (int)P.fz_tile.size() / 2;
         P.sp_chunk_off[lv + 1] = (int)P.sp_tgt.size() / 2;
         P.sp_rt_off[lv + 1] = (int)P.sp_rt.size() / 2;
+        P.mp_off[lv + 1] = (int)P.mp_wg.size();
         for (int kk = 0; kk < T; ++kk) {
             if (level[kk] != lv) continue;
             P.lv_k.push_back(kk);
             // forward: row tiles j < k (none on a split level: the diagonal target's chunks form L_kj y_j with the tile
             // they already hold); backward: column tiles i > k   (CSR aligned with lv_k)
-            if (!split)
-                for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.lv_rj.push_back(j);
+            if (!split && !macro)
+                for (int j = first_j[kk]; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.lv_rj.push_back(j);
             P.lv_rptr.push_back((int)P.lv_rj.size());
             for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) P.lv_bi.push_back(i);
             P.lv_bptr.push_back((int)P.lv_bi.size());

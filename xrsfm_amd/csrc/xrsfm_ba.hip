@@ -106,7 +106,8 @@ struct CholHost {
     int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
     std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;      // per level offsets (size n_levels+1)
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
-    std::vector<int> sp_chunk_off, sp_rt_off;
+    std::vector<int> sp_chunk_off, sp_rt_off, mp_off;
+    int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
     double* sp_work = nullptr;
     int *fz_tile = nullptr, *fz_dptr = nullptr, *fz_dj = nullptr, *tile_cam = nullptr;   // fused level kernel (ba_plan.h)
     std::vector<int> fz_off;
@@ -522,7 +523,7 @@ int chol_setup(xrsfm_ba_context* c) {
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
-    h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.fz_off = P.fz_off;
+    h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.mp_off = P.mp_off; h.fz_off = P.fz_off;
     int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     BatchUpload up(c);
@@ -534,7 +535,7 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.lv_cj, P.lv_cj); up.add(&h.lv_trsm, P.lv_trsm);
     up.add(&h.lv_rptr, P.lv_rptr); up.add(&h.lv_rj, P.lv_rj);
     up.add(&h.lv_bptr, P.lv_bptr); up.add(&h.lv_bi, P.lv_bi);
-    up.add(&h.sp_tgt, P.sp_tgt); up.add(&h.sp_q, P.sp_q);
+    up.add(&h.sp_tgt, P.sp_tgt); up.add(&h.sp_q, P.sp_q); up.add(&h.mp_chunk, P.mp_chunk); up.add(&h.mp_wg, P.mp_wg);
     up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp);
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
     up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
@@ -569,7 +570,6 @@ int chol_setup(xrsfm_ba_context* c) {
             (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-            (void)hipFuncSetAttribute((const void*)k_ll_update_part, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_schur_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
             (void)hipFuncSetAttribute((const void*)k_schur_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
             done_for[c->device] = 1;
@@ -628,13 +628,16 @@ int chol_factor_solve(xrsfm_ba_context* c) {
         // same fused kernel with empty lists), then one per level backwards
         for (int lv = 0; lv < h.n_levels; ++lv) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
-            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv];
-            if (nch > 0) {
-                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), shm, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
+            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
+            const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
+            if (nmc > 0)
+                LAUNCH(c, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
+            else if (nch > 0)
+                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
                        h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
+            if (nrt > 0)
+                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
-            }
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
             if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj);
@@ -656,11 +659,15 @@ int chol_factor_solve(xrsfm_ba_context* c) {
         // one launch per elimination-tree level and phase
         for (int lv = 0; lv < h.n_levels; ++lv) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
-            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv];
-            if (nch > 0) {      // thin level: chunks of the contribution lists in parallel, then a fixed-order sum
-                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), shm, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
-                       h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
+            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
+            const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
+            if (nmc > 0 || nch > 0) {      // chunks of the contribution lists in parallel, then a fixed-order sum
+                if (nmc > 0)
+                    LAUNCH(c, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
+                else
+                    LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
+                           h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
+                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
             } else if (nt > 0)
                 LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
