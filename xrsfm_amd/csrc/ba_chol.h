@@ -448,51 +448,56 @@ __device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f6
 // The factorisation proper, on a tile that is already in LDS: A (lower triangle valid, upper zero) becomes L, Li becomes
 // L^-1 (Li must hold the identity on the padding rows >= 16 nb and zeros elsewhere).  Called by all 256 threads of the
 // workgroup after a barrier; ends with a barrier.
+// (a) of potrf_lds: wave-level factorisation + inverse of the 16x16 diagonal block at (b0,b0), in registers
+__device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kLdT], int b0, int lane) {
+    const int li = lane & 15;
+    // lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
+    double a[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) a[cc] = A[b0 + li][b0 + cc];
+    // Right-looking elimination and the inverse of the triangular factor in ONE sweep: at step jj the pivot u_jj and
+    // column jj of the (unscaled) factor are final, so step jj of the forward substitution L X = I (lane = column of
+    // X) can run next to the elimination step — both use the same 15-jj broadcasts, and the two fma streams are
+    // independent.  L[i][jj] = a[jj]_i * s_jj with s_jj = 1/sqrt(u_jj).
+    double lcol[16];          // running right-hand side of column `li`; entry r becomes Linv[r][li] at step r
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lcol[r] = (r == li) ? 1.0 : 0.0;
+#pragma unroll
+    for (int jj = 0; jj < 16; ++jj) {
+        const double ujj = row_bcast(a[jj], jj);
+        const double sj = fast_rsqrt(ujj);
+        const double tl = a[jj] * (sj * sj);              // u_ij / u_jj
+        const double x = lcol[jj] * sj;
+        const double xs = x * sj;
+        lcol[jj] = x;
+#pragma unroll
+        for (int cc = jj + 1; cc < 16; ++cc) {
+            const double bv = row_bcast(a[jj], cc);       // u_{cc,jj}
+            a[cc] = fma(-tl, bv, a[cc]);
+            lcol[cc] = fma(-bv, xs, lcol[cc]);
+        }
+        a[jj] *= sj;                                       // column jj of L (rows >= jj)
+        __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later steps from being hoisted (register pressure)
+    }
+    if (lane < 16) {
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) {
+            A[b0 + lane][b0 + cc] = (cc <= lane) ? a[cc] : 0.0;
+            Li[b0 + cc][b0 + lane] = lcol[cc];               // Linv[r][col]: zero above the diagonal by construction
+        }
+    }
+}
+
 __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT], double (*Tb)[16][17], int nb) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    // Look-ahead: wave 0 factors diagonal block kb+1 as soon as it has updated it, while waves 1..3 finish the rest of the
+    // trailing update of step kb (they would otherwise wait at a barrier for the 2 us the in-register factorisation takes).
+    if (wave == 0) potrf_block16(A, Li, 0, lane);
+    __syncthreads();
     for (int kb = 0; kb < nb; ++kb) {
         XBA_STAMP(1, 3 + 2 * kb);
         const int b0 = 16 * kb;
-        if (wave == 0) {
-            // (a) lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
-            double a[16];
-#pragma unroll
-            for (int cc = 0; cc < 16; ++cc) a[cc] = A[b0 + li][b0 + cc];
-            // Right-looking elimination and the inverse of the triangular factor in ONE sweep: at step jj the pivot u_jj and
-            // column jj of the (unscaled) factor are final, so step jj of the forward substitution L X = I (lane = column of
-            // X) can run next to the elimination step — both use the same 15-jj broadcasts, and the two fma streams are
-            // independent.  L[i][jj] = a[jj]_i * s_jj with s_jj = 1/sqrt(u_jj).
-            double lcol[16];          // running right-hand side of column `li`; entry r becomes Linv[r][li] at step r
-#pragma unroll
-            for (int r = 0; r < 16; ++r) lcol[r] = (r == li) ? 1.0 : 0.0;
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) {
-                const double ujj = row_bcast(a[jj], jj);
-                const double sj = fast_rsqrt(ujj);
-                const double tl = a[jj] * (sj * sj);              // u_ij / u_jj
-                const double x = lcol[jj] * sj;
-                const double xs = x * sj;
-                lcol[jj] = x;
-#pragma unroll
-                for (int cc = jj + 1; cc < 16; ++cc) {
-                    const double bv = row_bcast(a[jj], cc);       // u_{cc,jj}
-                    a[cc] = fma(-tl, bv, a[cc]);
-                    lcol[cc] = fma(-bv, xs, lcol[cc]);
-                }
-                a[jj] *= sj;                                       // column jj of L (rows >= jj)
-                __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later steps from being hoisted (register pressure)
-            }
-            if (lane < 16) {
-#pragma unroll
-                for (int cc = 0; cc < 16; ++cc) {
-                    A[b0 + lane][b0 + cc] = (cc <= lane) ? a[cc] : 0.0;
-                    Li[b0 + cc][b0 + lane] = lcol[cc];               // Linv[r][col]: zero above the diagonal by construction
-                }
-            }
-        }
-        __syncthreads();
-        XBA_STAMP(1, 4 + 2 * kb);
         // (b) rows below: X = A21 * Linv11^T, one 16-row block per wave
         if (kb + 1 + wave < nb) {
             const int rb = 16 * (kb + 1 + wave);
@@ -504,12 +509,28 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
             for (int g = 0; g < 4; ++g) A[rb + lk + 4 * g][b0 + li] = acc[g];
         }
         __syncthreads();
-        // (c) trailing update A_ij -= X_i X_j^T for kb < j <= i < 4, blocks dealt round-robin to the waves
-        {
+        XBA_STAMP(1, 4 + 2 * kb);
+        // (c) trailing update A_ij -= X_i X_j^T for kb < j <= i < nb: wave 0 takes the next diagonal block and factors it,
+        // the other blocks are dealt round-robin to waves 1..3
+        if (wave == 0) {
+            if (kb + 1 < nb) {
+                const int i = kb + 1;
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k0 = 0; k0 < 16; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * i + li][b0 + k0 + lk], A[16 * i + li][b0 + k0 + lk], acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * i + li] -= acc[g];
+                __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own block is written
+                __builtin_amdgcn_wave_barrier();
+                potrf_block16(A, Li, 16 * i, lane);
+            }
+        } else {
             int idx = 0;
             for (int i = kb + 1; i < nb; ++i)
-                for (int j = kb + 1; j <= i; ++j, ++idx) {
-                    if ((idx & 3) != wave) continue;
+                for (int j = kb + 1; j <= i; ++j) {
+                    if (i == kb + 1) continue;                 // (kb+1,kb+1): wave 0
+                    if ((idx++ % 3) + 1 != wave) continue;
                     v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                     for (int k0 = 0; k0 < 16; k0 += 4)

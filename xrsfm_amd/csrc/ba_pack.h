@@ -246,7 +246,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         } else {
             // (key, idx) order.  Large inputs: ki is in ascending idx order, so a stable LSD radix sort over the key fields
             // yields it; one pass per camera field (kbits wide) and a last one for the long-track flag
-            if (ki.size() < 100000) {                    // small calls (LBA): the bucket arrays would cost more than the sort
+            if (ki.size() < 2048) {                      // tiny calls: the bucket arrays would cost more than the sort
                 std::sort(ki.begin(), ki.end(), [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; });
             } else {
                 // parallel stable LSD radix sort: every piece of the input counts its digits, a pass over digits x pieces turns
