@@ -37,6 +37,7 @@ def main():
                           ("X", "5000 cameras: 30 000 camera unknowns on the exact Cholesky path"),
                           ("R", "ragged tracks: windows of 8 frames, 35 % missed detections"),
                           ("U", "random visibility, dense reduced camera matrix; no CPU leg"),
+                          ("D", "2000 cameras, random visibility: the dense limit of the exact path (panel schedule); no CPU leg"),
                           ("V", "3000 cameras, random visibility: implicit-Schur PCG; no CPU leg"),
                           ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter")):
             if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
@@ -58,6 +59,13 @@ def main():
             f.write(f"# Round {tag[1:]} — instruction mix and pipe occupancy per kernel, rocprofv3 PMC (SQ counters), bench.py --config L\n\n"
                     "Three passes (tools/pmc_mix.sh; counters only + kernel trace).  One row per kernel = average over its dispatches of the per-shader-engine "
                     "counter rows (32 rows per dispatch: multiply by 32 for a whole launch; SQ_WAVES x 32 = waves of a launch).\n\n" + rd("pmc_mix.md"))
+    if os.path.exists(os.path.join(src, "kernel_stats_table_D.md")):
+        with open(os.path.join(dst, f"{tag}_D_kernel_stats.md"), "w") as f:
+            f.write(f"# Round {tag[1:]} — rocprofv3 kernel-trace summary, bench.py --config D --no-cpu --steps 1 --warmup 1 (dense reduced solve: 12 000 camera unknowns, 188 tile columns)\n\n"
+                    "k_panel2_part = 128x128 macro-tile left-looking update of two tile columns, k_ll_update_reduce = fixed-order sum of its partial tiles, "
+                    "k_lv_factor = pivot factorisation + triangular solve of one tile column, k_bwd = backward substitution.\n\n" + rd("kernel_stats_table_D.md"))
+            if os.path.exists(os.path.join(src, "mfma_rate.txt")):
+                f.write("\n## Sustained rate of v_mfma_f64_16x16x4_f64 with nothing else in the loop (tools/bench_mfma.hip)\n\n```\n" + rd("mfma_rate.txt") + "```\n")
     for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt"):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))

@@ -30,6 +30,11 @@ done
 python bench.py --config U --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_U.err | tail -1 > $OUT/bench_U.json
 python bench.py --config V --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_V.err | tail -1 > $OUT/bench_V.json
 python bench.py --config L0 --steps 3 --warmup 1 --no-extras 2> $OUT/bench_L0.err | tail -1 > $OUT/bench_L0.json
+python bench.py --config D --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_D.err | tail -1 > $OUT/bench_D.json
+# 5. the dense reduced solve (config D): per-kernel table, and the sustained FP64 matrix-core rate of the instruction it uses
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsD -o stats -- python $ROOT/bench.py --config D --no-cpu --no-extras --steps 1 --warmup 1 > $OUT/statsD_bench.log 2>&1; \
+  python $ROOT/tools/rocprof_summary.py $(find $OUT/statsD -name "*.db" | head -1) $OUT/kernel_stats_table_D.md > /dev/null; rm -rf $OUT/statsD )
+[ -x tools/bench_mfma ] && tools/bench_mfma > $OUT/mfma_rate.txt 2>&1
 python tools/lba_phases.py > $OUT/lba_phases.txt 2>&1
 python tools/lba_timing.py > $OUT/lba_timing.txt 2>&1
 python __graft_entry__.py probe 2>&1 | grep "\[probe\]" > $OUT/probe.txt
