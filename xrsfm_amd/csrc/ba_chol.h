@@ -115,8 +115,8 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 #pragma unroll
                 for (int m = 0; m < 3; ++m) Vst[(6 * cidx + i) * Cp + 3 * (t - t0) + m] = V[3 * i + m];
         }
-        __builtin_amdgcn_s_waitcnt(0);                 // vmcnt/lgkmcnt(0): staged operand (and dtab) are in LDS
-        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the staged operand (and dtab) are in LDS.  Not vmcnt: the stores
+        __builtin_amdgcn_wave_barrier();               // of the diagonal terms issued just before are still in flight and stay so
         XBA_STAMP(0, 6);
         for (int k0 = 0; k0 < C4; k0 += 4) {
             double a[NI];
@@ -168,7 +168,19 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
     if (GRAM) { it.first_tile = entry; it.n_tiles = 1; }
     else it = d.items[entry];
     if (GRAM || it.n_tiles == 1) {
+        // (Gram tile) the destination table of its camera pairs and the lane's entry in the camera-major scatter buffer are
+        // requested before anything else: two dependent loads whose latency then hides behind the operand loads and the
+        // diagonal terms instead of sitting in front of the Gram stage
+        int dt0 = -1, dt1 = -1;
+        if (GRAM) {
+            const int C0 = d.tile_ncam[it.first_tile];
+            const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[it.first_tile];
+            if (lane < C0 * C0) dt0 = src[lane];
+            if (lane + kWave < C0 * C0) dt1 = src[lane + kWave];
+        }
         const SlotCtx s = load_slot(d, it.first_tile, lane);
+        const int cp = d.slot_campos_g[s.slot];
+        const int cidx_raw = GRAM ? (int)d.slot_cidx[s.slot] : 0;
         const int L = d.tile_stride[it.first_tile];
         double V[18];
 #pragma unroll
@@ -189,7 +201,6 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 pairs_diag(F, V, hc, d.gp + 3 * (size_t)s.pt, o28);
             }
             XBA_STAMP(0, 4);
-            const int cp = d.slot_campos_g[s.slot];
             const int Cg = GRAM ? d.tile_ncam[it.first_tile] : 0;
             if (L > 0) {
                 // Regular tile: sum the 28 values over the tracks through the wave's LDS (the region the operand V is staged
@@ -218,7 +229,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 // Gram tile with ragged tracks: the same through LDS, per DISTINCT camera of the tile: the lane that owns
                 // (camera c, value k) adds the entries of the lanes whose observation is in camera c, in lane order; the
                 // first of them holds the camera's entry in the scatter buffer.
-                const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
+                const int cidx = s.valid ? cidx_raw : -1;
                 double* red = smem;
                 const int nq = 14 * Cg;
                 unsigned long long m0 = 0, m1 = 0, m2 = 0;                  // lane masks of the cameras of q = lane, lane+64, lane+128
@@ -266,17 +277,15 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             const int T = __popcll(headmask);
             const int nvalid = __popcll(__ballot(s.valid));
             const int t = __popcll(headmask & ((2ull << lane) - 1ull)) - 1;        // rank of the lane's track in the tile
-            const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : 0;
+            const int cidx = s.valid ? cidx_raw : 0;
             int passes = 1;
             (void)gram_lds_need(C, T, &passes);                             // one staging round, or two with half the tracks each
             const int Th = (T + passes - 1) / passes;
             const int R = 6 * C, Rp = (R + 15) & ~15, Cp = ((3 * Th + 3) & ~3) + 2;
             double* Vst = smem;                                             // only the R rows that hold data are staged
             int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [C][C] destination of block (cb > ca) at [ca][cb], -1 none
-            {
-                const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[it.first_tile];
-                for (int e = lane; e < C * C; e += kWave) dtab[e] = src[e];
-            }
+            if (lane < C * C) dtab[lane] = dt0;
+            if (lane + kWave < C * C) dtab[lane + kWave] = dt1;
             const bool dense = nvalid == T * C;
             switch (Rp >> 4) {                             // 16-row operand tiles
                 case 1: gram_tile<1>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;

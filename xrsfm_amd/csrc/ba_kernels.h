@@ -241,9 +241,11 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
     int long_pt = -1;
     for (int tl = 0; tl < (LONG ? it.n_tiles : 1); ++tl) {
         const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
+        const int cp = d.slot_campos_g[s.slot];        // (requested with the slot record, not after the arithmetic)
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double cs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        if (s.valid) {
+        double spk[3] = {1.0, 1.0, 1.0};               // point scaling, kept for the gradient norm after the reduction (a reload
+        if (s.valid) {                                 // there would be a third dependent memory round trip)
             const CamRec& c = d.cam[s.cam];
             double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
             double t[3] = {c.t[0], c.t[1], c.t[2]};
@@ -263,6 +265,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
             const double mp = d.pt_const[s.pt] ? 0.0 : sw;
             const double* sc = d.scale_c + 6 * (size_t)s.cam;
             const double* sp = d.scale_p + 3 * (size_t)s.pt;
+            spk[0] = sp[0]; spk[1] = sp[1]; spk[2] = sp[2];
             double F[12], E[6];
 #pragma unroll
             for (int row = 0; row < 2; ++row) {
@@ -274,9 +277,9 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
                 F[6 * row + 3] = j[0] * mt * sc[3];
                 F[6 * row + 4] = j[1] * mt * sc[4];
                 F[6 * row + 5] = j[2] * mt * sc[5];
-                E[3 * row + 0] = (j[0] * M[0] + j[1] * M[3] + j[2] * M[6]) * mp * sp[0];
-                E[3 * row + 1] = (j[0] * M[1] + j[1] * M[4] + j[2] * M[7]) * mp * sp[1];
-                E[3 * row + 2] = (j[0] * M[2] + j[1] * M[5] + j[2] * M[8]) * mp * sp[2];
+                E[3 * row + 0] = (j[0] * M[0] + j[1] * M[3] + j[2] * M[6]) * mp * spk[0];
+                E[3 * row + 1] = (j[0] * M[1] + j[1] * M[4] + j[2] * M[7]) * mp * spk[1];
+                E[3 * row + 2] = (j[0] * M[2] + j[1] * M[5] + j[2] * M[8]) * mp * spk[2];
             }
             const size_t ns = (size_t)d.n_slots;
             d.rt[s.slot] = r0; d.rt[ns + s.slot] = r1;
@@ -299,7 +302,6 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
             const int tile = it.first_tile + tl;
             const int stride = d.tile_stride[tile];
             const int Cg = LONG ? 0 : d.tile_ncam[tile];
-            const int cp = d.slot_campos_g[s.slot];
             if (stride > 0) {
                 strided_reduce<12>(cs, stride, lane);
                 if (cp >= 0) {
@@ -351,8 +353,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
                 for (int k = 0; k < 6; ++k) H[k] = v[k];
                 double* g = d.gp + 3 * (size_t)s.pt;
                 g[0] = v[6]; g[1] = v[7]; g[2] = v[8];
-                const double* sp = d.scale_p + 3 * (size_t)s.pt;       // max-norm of the unscaled point gradient
-                gm = fmax(gm, fmax(fabs(v[6] / sp[0]), fmax(fabs(v[7] / sp[1]), fabs(v[8] / sp[2]))));
+                gm = fmax(gm, fmax(fabs(v[6] / spk[0]), fmax(fabs(v[7] / spk[1]), fabs(v[8] / spk[2]))));   // max-norm of the unscaled point gradient
             }
         } else if (lane == 0) {
 #pragma unroll
@@ -378,7 +379,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
 // 128 VGPRs: 4 waves per SIMD (measured 118 -> 98 us at config L; 5 waves spill and are slower)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_linearize(Dev d, double huber_a) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // wave-uniform: item / tile records through scalar loads
     if (item >= d.n_items) return;
     const Item it = d.items[item];
     if (it.n_tiles > 1) linearize_item<true>(d, it, item, lane, huber_a);
@@ -388,7 +389,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) 
 // Cost only (1/2 sum rho is formed on the host side of the reduction), candidate state.
 __global__ __launch_bounds__(kBlock) void k_cost(Dev d, double huber_a) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // wave-uniform: item / tile records through scalar loads
     if (item >= d.n_items) return;
     const Item it = d.items[item];
     double cost = 0.0;
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(Dev d) {
 __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __restrict__ pvec) {
     if (d.st->done) return;
     const int lane = threadIdx.x & (kWave - 1);
-    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // wave-uniform: item / tile records through scalar loads
     if (item >= d.n_items) return;
     const Item it = d.items[item];
     if (it.n_tiles == 1) {
@@ -885,7 +886,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
         return;
     }
     const int lane = threadIdx.x & (kWave - 1);
-    const int item = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));   // wave-uniform: item / tile records through scalar loads
     if (item >= d.n_items) return;
     const Item it = d.items[item];
     const size_t ns = (size_t)d.n_slots;
@@ -896,13 +897,19 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
         double w[3] = {0, 0, 0};
         // what the head lane of a track needs after the reduction depends on the point only: every lane of the track requests
         // it now (same addresses: one transaction), so that it does not cost a third memory round trip after the shuffles
-        double hh[6] = {0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0};
+        double hh[6] = {0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0}, spv[3] = {0, 0, 0}, Pv[3] = {0, 0, 0};
+        bool var = false;
         if (s.valid) {
             const double* h = d.Hinv + 6 * (size_t)s.pt;
             const double* g = d.gp + 3 * (size_t)s.pt;
+            const double* sp = d.scale_p + 3 * (size_t)s.pt;
+            const double* P = d.P + 3 * (size_t)s.pt;
 #pragma unroll
             for (int k = 0; k < 6; ++k) hh[k] = h[k];
             gg[0] = g[0]; gg[1] = g[1]; gg[2] = g[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { spv[k] = sp[k]; Pv[k] = P[k]; }
+            var = !d.pt_const[s.pt];
         }
         if (s.valid) {
             const double* y = d.px + 6 * (size_t)s.cam;
@@ -920,17 +927,14 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
             u[0] = hh[0] * a0 + hh[1] * a1 + hh[2] * a2;
             u[1] = hh[1] * a0 + hh[3] * a1 + hh[4] * a2;
             u[2] = hh[2] * a0 + hh[4] * a1 + hh[5] * a2;
-            const double* sp = d.scale_p + 3 * (size_t)s.pt;
-            const double* P = d.P + 3 * (size_t)s.pt;
             double* Pc = d.P_cand + 3 * (size_t)s.pt;
             double* yo = d.yp + 3 * (size_t)s.pt;
-            const bool var = !d.pt_const[s.pt];
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double dl = var ? -u[k] * sp[k] : 0.0;
-                const double pn = P[k] + dl;
+                const double dl = var ? -u[k] * spv[k] : 0.0;
+                const double pn = Pv[k] + dl;
                 Pc[k] = pn; yo[k] = u[k];
-                const double df = pn - P[k];
+                const double df = pn - Pv[k];
                 step2 += df * df;
             }
         }
