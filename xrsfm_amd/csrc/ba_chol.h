@@ -192,13 +192,22 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             for (int k = 0; k < 28; ++k) o28[k] = 0.0;
             XBA_STAMP(0, 1);
             if (s.valid) {
+                // the point's factor of Hinv and gradient are requested with the Jacobian records (left where they are used, the
+                // compiler issues them after the first batch of loads has returned: one more memory round trip per tile)
+                double hcv[6], gv[3];
+                {
+                    const double* hc = d.Hc + 6 * (size_t)s.pt;
+                    const double* g = d.gp + 3 * (size_t)s.pt;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) hcv[k] = hc[k];
+                    gv[0] = g[0]; gv[1] = g[1]; gv[2] = g[2];
+                }
                 double F[12], E[6];
                 load_FE(d, s.slot, s.cam, s.pt, F, E);
                 XBA_STAMP(0, 2);
-                const double* hc = d.Hc + 6 * (size_t)s.pt;
-                pairs_V(F, E, hc, V);
+                pairs_V(F, E, hcv, V);
                 XBA_STAMP(0, 3);
-                pairs_diag(F, V, hc, d.gp + 3 * (size_t)s.pt, o28);
+                pairs_diag(F, V, hcv, gv, o28);
             }
             XBA_STAMP(0, 4);
             const int Cg = GRAM ? d.tile_ncam[it.first_tile] : 0;
@@ -1196,7 +1205,7 @@ __global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict
 //      off-diagonal workgroup: L_ik = (A_ik - ...) Linv_k^T.
 // Ceres solves the same system with a supernodal sparse Cholesky (ba_solver.cc:74); this is the exact solve, restated.
 __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
-                                                   const int* __restrict__ dj) {
+                                                   const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Tb[3][16][17];
@@ -1297,6 +1306,23 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
         sacc += __shfl_xor(sacc, 1, kWave);
         sacc += __shfl_xor(sacc, 2, kWave);
         if (part == 0) c.y[k * kNB + o] = sacc;
+        if (px) {
+            // last level of the tree: no column has tiles below it, so the backward substitution of the level is x_k = Linv_k^T y_k,
+            // formed here (one launch and one kernel boundary less per solve); solution also in camera order, as k_lv_bwd writes it
+            __syncthreads();
+            if (part == 0) yv[o] = sacc;
+            __syncthreads();
+            double s2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) s2 += Li[part * 16 + m][o] * yv[part * 16 + m];
+            s2 += __shfl_xor(s2, 1, kWave);
+            s2 += __shfl_xor(s2, 2, kWave);
+            if (part == 0) {
+                c.x[k * kNB + o] = s2;
+                const int cam = (o < 6 * kCamsPerTileDev) ? tile_cam[k * kCamsPerTileDev + o / 6] : -1;
+                if (cam >= 0) px[6 * (size_t)cam + o % 6] = s2;
+            }
+        }
         XBA_STAMP(1, 13);
         return;
     }

@@ -912,12 +912,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
             var = !d.pt_const[s.pt];
         }
         if (s.valid) {
-            const double* y = d.px + 6 * (size_t)s.cam;
+            const double* yp = d.px + 6 * (size_t)s.cam;
+            const double y[6] = {yp[0], yp[1], yp[2], yp[3], yp[4], yp[5]};
+            r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
             double F[12];
             load_FE(d, s.slot, s.cam, s.pt, F, E);
 #pragma unroll
             for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
-            r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
         seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);

@@ -639,8 +639,11 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                 LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
+            // the columns of the last level have nothing below them: their backward substitution rides in the same launch
+            const bool with_bwd = !h.panel_ll && lv == h.n_levels - 1;
             if (nf > 0)
-                LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj);
+                LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
+                       (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr);
         }
         if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
             for (int k = T - 1; k >= 0; --k) {
@@ -650,7 +653,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.px, d.n_cams);
             return 0;
         }
-        for (int lv = h.n_levels - 1; lv >= 0; --lv) {
+        for (int lv = h.n_levels - 2; lv >= 0; --lv) {      // (the last level: inside its k_lv_factor launch)
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
             LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, d.px);
         }
