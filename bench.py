@@ -353,6 +353,15 @@ def main():
         roofline = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                     "traffic": traffic, "traffic_source": traffic_source, "kernel": dom, "avg_launch_us": avg_s * 1e6, "launches": launches,
                     "algorithmic_bytes_per_launch": alg}
+        # every HBM-streaming kernel of the run by the same rule (the dominant one can change from round to round: in round 1
+        # it was k_schur_pairs at 0.39; its fraction stays visible here whichever kernel leads)
+        per_kernel = {}
+        for ms_k, k in sorted(cands, reverse=True):
+            n_k = kernels[k][1]
+            b_k = algorithmic_bytes(k, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
+            per_kernel[k] = {"avg_launch_us": ms_k * 1e3 / n_k, "launches": n_k, "algorithmic_bytes_per_launch": b_k,
+                             "frac": b_k / (ms_k * 1e-3 / n_k) / 1e9 / HBM_PEAK_GBS}
+        roofline["streaming_kernels"] = per_kernel
         # the whole LM iteration against BASELINE.md section 4: B_iter(0) = B_lin + B_prep + B_back, plus the explicit-S terms
         # (the nnzb off-diagonal 6x6 blocks written once; SURVEY 8d's B_S would also count a second read of J, N_obs*144,
         # which the fused S assembly does not do: reported separately)
