@@ -99,9 +99,9 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         const int t0 = h * Th, tn = min(Th, T - t0);           // tracks t0 .. t0+tn-1 in this round
         const int C4 = (3 * tn + 3) & ~3;
         if (dense && passes == 1) {
-            // dense (regular) tile: only the K padding columns 3T..Cp-1 need zeros (rows beyond R are never staged: reads are
-            // clamped, results discarded)
-            const int padc = Cp - 3 * tn;
+            // dense (regular) tile: only the K padding columns 3T..C4-1 the products read need zeros — none when 3T is a multiple
+            // of 4 (16 tracks of 4 cameras) — (rows beyond R are never staged: reads are clamped, results discarded)
+            const int padc = C4 - 3 * tn;
             for (int e = lane; e < R * padc; e += kWave) {
                 const int row = e / padc, cc = 3 * tn + (e - row * padc);
                 Vst[row * Cp + cc] = 0.0;
