@@ -190,12 +190,13 @@ def host_inclusive(arr: dict, opt, n_cams: int, n_points: int):
     first = None
     for rep in range(2):
         prob = capi.ProblemArrays(**{k: np.array(v, copy=True) for k, v in arr.items()})
+        dst = (prob.cam_q, prob.cam_t, prob.points)      # results go back into the caller's own storage, as in the adapter
         t0 = time.perf_counter()
         ctx = capi.Context(prob)
         t1 = time.perf_counter()
         s = ctx.run(opt)
         t2 = time.perf_counter()
-        ctx.download()
+        ctx.download(out=dst)
         t3 = time.perf_counter()
         ctx.close()
         t4 = time.perf_counter()

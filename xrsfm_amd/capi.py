@@ -272,9 +272,18 @@ class Context:
     def reset(self):
         check(self.lib.xrsfm_ba_reset(self._h), "xrsfm_ba_reset")
 
-    def download(self):
+    def download(self, out=None):
+        """out: optional (cam_q, cam_t, points) arrays to write into (the C++ adapter writes into the map's own storage; fresh
+        numpy arrays of tens of MB cost their first-touch page faults on top of the copy)."""
         p = self.problem
-        q = np.empty_like(p.cam_q); t = np.empty_like(p.cam_t); P = p.points.copy()
+        if out is None:
+            q = np.empty_like(p.cam_q); t = np.empty_like(p.cam_t); P = p.points.copy()
+        else:
+            q, t, P = out
+            assert q.shape == p.cam_q.shape and t.shape == p.cam_t.shape and P.shape == p.points.shape
+            assert all(a.dtype == np.float64 and a.flags.c_contiguous for a in (q, t, P))
+            if P is not p.points:
+                P[...] = p.points      # points that take no part in the problem keep their input value
         check(self.lib.xrsfm_ba_download(self._h, _dp(q), _dp(t), _dp(P)), "xrsfm_ba_download")
         return q, t, P
 

@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -832,6 +833,12 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
     if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st});
+    // What is left is host memory.  A large context holds ~0.5 KB per observation in vectors whose release (munmap: page-table
+    // teardown) takes ~10 ms per million observations: a detached thread does it, the caller (one BA call of a mapper) goes on.
+    // Small contexts are deleted in place (a thread costs more than their release).
+    if (c->pk.n_obs > 200000) {
+        try { std::thread([c] { delete c; }).detach(); return; } catch (...) { /* no thread: release here */ }
+    }
     delete c;
 }
 
