@@ -641,12 +641,14 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
             // the columns of the last level have nothing below them: their backward substitution rides in the same launch
-            const bool with_bwd = !h.panel_ll && lv == h.n_levels - 1;
+            // (a single-tile system — LBA-sized calls — is its own last level on either schedule)
+            const bool with_bwd = (!h.panel_ll || T == 1) && lv == h.n_levels - 1;
             if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
                        (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr);
         }
         if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
+            if (T == 1) return 0;               // solved inside the factor launch
             for (int k = T - 1; k >= 0; --k) {
                 const int ncol = h.cols_off[k + 1] - h.cols_off[k];
                 LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
