@@ -262,7 +262,8 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
             const double r0 = pr.r0 * sw, r1 = pr.r1 * sw;
             const unsigned cc = d.cam_const[s.cam];
             const double mq = (cc & 1u) ? 0.0 : sw, mt = (cc & 2u) ? 0.0 : sw;
-            const double mp = d.pt_const[s.pt] ? 0.0 : sw;
+            const bool pt_fixed = d.pt_const[s.pt] != 0;     // read once: a second read after the stores below is a reload (char aliases)
+            const double mp = pt_fixed ? 0.0 : sw;
             const double* sc = d.scale_c + 6 * (size_t)s.cam;
             const double* sp = d.scale_p + 3 * (size_t)s.pt;
             spk[0] = sp[0]; spk[1] = sp[1]; spk[2] = sp[2];
@@ -293,7 +294,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
                 cs[k] = F[k] * F[k] + F[6 + k] * F[6 + k];
                 cs[6 + k] = F[k] * r0 + F[6 + k] * r1;
             }
-            if (s.head && (!is_long || tl == 0) && !d.pt_const[s.pt])
+            if (s.head && (!is_long || tl == 0) && !pt_fixed)
                 xn2 += Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
             if (is_long && lane == 0 && tl == 0) long_pt = s.pt;
         }
