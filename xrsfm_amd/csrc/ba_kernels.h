@@ -242,6 +242,10 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
     for (int tl = 0; tl < (LONG ? it.n_tiles : 1); ++tl) {
         const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
         const int cp = d.slot_campos_g[s.slot];        // (requested with the slot record, not after the arithmetic)
+        const int tile = it.first_tile + tl;           // the tile's descriptors likewise (scalar loads)
+        const int stride = d.tile_stride[tile];
+        const int Cg = LONG ? 0 : d.tile_ncam[tile];
+        const int maxlen = d.tile_maxlen[tile];
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double cs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         double spk[3] = {1.0, 1.0, 1.0};               // point scaling, kept for the gradient norm after the reduction (a reload
@@ -300,9 +304,6 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
         }
         {   // camera-side terms: one partial per camera of the tile for a regular tile (wave pre-reduction) and for a Gram tile
             // with ragged tracks (sum per distinct camera through LDS, like k_schur_pairs), one per observation otherwise
-            const int tile = it.first_tile + tl;
-            const int stride = d.tile_stride[tile];
-            const int Cg = LONG ? 0 : d.tile_ncam[tile];
             if (stride > 0) {
                 strided_reduce<12>(cs, stride, lane);
                 if (cp >= 0) {
@@ -346,7 +347,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
                 for (int k = 0; k < 6; ++k) out[k] = make_double2(cs[2 * k], cs[2 * k + 1]);
             }
         }
-        seg_reduce<9>(v, s.pt, lane, d.tile_maxlen[it.first_tile + tl]);
+        seg_reduce<9>(v, s.pt, lane, maxlen);
         if (!is_long) {
             if (s.head) {
                 double* H = d.Hpp + 6 * (size_t)s.pt;
@@ -894,6 +895,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
     double model = 0.0, step2 = 0.0;
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
+        const int maxlen = d.tile_maxlen[it.first_tile];
         double E[6], v0 = 0.0, v1 = 0.0, r0 = 0.0, r1 = 0.0;
         double w[3] = {0, 0, 0};
         // what the head lane of a track needs after the reduction depends on the point only: every lane of the track requests
@@ -922,7 +924,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
             for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
-        seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);
+        seg_reduce<3>(w, s.pt, lane, maxlen);
         double u[3] = {0, 0, 0};
         if (s.head) {
             const double a0 = gg[0] - w[0], a1 = gg[1] - w[1], a2 = gg[2] - w[2];
