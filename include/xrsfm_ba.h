@@ -301,7 +301,8 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], 
 
 /* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
  * (0 natural, 1 nested dissection of a band/ring), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
- * [6] level schedule used (else right-looking), [7] structurally non-zero tiles after fill.  cam_offset (may be NULL):
+ * [6] level schedule used (else the panel schedule of deep elimination trees: dense / unordered patterns), [7] structurally
+ * non-zero tiles after fill.  cam_offset (may be NULL):
  * [n_cams] first row of each camera in the elimination order. */
 int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *cam_offset);
 
