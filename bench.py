@@ -418,7 +418,12 @@ def main():
                 out["mfma_utilisation"] = mfma_utilisation() if args.config in ("L", "S") else None
             except Exception as exc:       # the side measurement must never cost the headline line
                 out["mfma_utilisation"] = {"error": str(exc)}
-        print(json.dumps(out))
+        try:        # RCCL prints its version banner through C stdio: flush it first, so that the JSON line is the last line on stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
