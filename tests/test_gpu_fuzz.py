@@ -55,3 +55,20 @@ def test_random_problem_matches_oracle(lib, seed):
     assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful), (seed, solver)
     assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
     assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [63, 96, 234, 264, 270])
+def test_random_problem_exact_solver(lib, seed):
+    """Seeds that tools/fuzz_extended.py found failing on the exact (Cholesky) path in round 2: regular tiles of 14-camera tracks
+    (the per-camera sum of the diagonal terms over a tile's tracks read its last scatter position from a retired lane)."""
+    from xrsfm_amd import capi
+    arr, _ = _problem(seed)
+    pr = H.to_oracle(arr)
+    s_ref = bo.solve(pr, bo.Options(linear_solver="exact", max_iterations=6))
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options(linear_solver=1, max_iterations=6))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5

@@ -170,7 +170,11 @@ def test_edge_cases(lib):
                                                      (60, 700, 2, "sequential"), (130, 1500, 4, "sequential"),
                                                      (257, 2500, 3, "sequential"),
                                                      # ragged tracks (missed detections): non-dense Gram tiles
-                                                     (40, 1200, 8, "ragged"), (90, 2500, 12, "ragged")])
+                                                     (40, 1200, 8, "ragged"), (90, 2500, 12, "ragged"),
+                                                     # regular tiles of 14 / 19 / 21-camera tracks (not Gram tiles: more than 10 cameras):
+                                                     # the per-camera sum over the tracks takes 4-5 rounds of 64 values, and
+                                                     # the last round's source lanes (shuffle) lie beyond its active lanes
+                                                     (32, 300, 14, "sequential"), (19, 200, 19, "unordered"), (21, 150, 21, "unordered")])
 def test_cholesky_reduced_system(lib, n_cams, n_pts, k_obs, mode):
     """Explicit reduced camera matrix S and the tile Cholesky solve against the oracle's dense Schur complement."""
     import scipy.linalg as sla

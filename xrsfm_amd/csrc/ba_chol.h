@@ -223,13 +223,17 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                     for (int k = 0; k < 14; ++k) red[lane * kRedLd + k] = o28[14 * h + k];
                     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
                     __builtin_amdgcn_wave_barrier();
-                    for (int q = lane; q < 14 * L; q += kWave) {
-                        const int r = q / 14, k = q - 14 * r;
-                        const double* src = red + r * kRedLd + k;
-                        double sum = 0.0;
-                        for (int t = 0; t < T; ++t) sum += src[t * L * kRedLd];
-                        const int cpr = __shfl(cp, r, kWave);                // lanes < L are the writers of the tile
-                        d.scat[28 * (size_t)cpr + 14 * h + k] = sum;
+                    for (int q0 = 0; q0 < 14 * L; q0 += kWave) {                 // uniform trip count: the shuffle below reads lanes
+                        const int q = q0 + lane;                                 // that a per-lane loop bound would already have retired
+                        const bool on = q < 14 * L;                              // (L = 14, 19, ...: the last round's source lane)
+                        const int r = on ? q / 14 : 0, k = q - 14 * r;
+                        const int cpr = __shfl(cp, r, kWave);                    // lanes < L are the writers of the tile
+                        if (on) {
+                            const double* src = red + r * kRedLd + k;
+                            double sum = 0.0;
+                            for (int t = 0; t < T; ++t) sum += src[t * L * kRedLd];
+                            d.scat[28 * (size_t)cpr + 14 * h + k] = sum;
+                        }
                     }
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
