@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid (GPU box): more seeds of tests/test_gpu_fuzz.py's random problems against the numpy oracle, exact solver only,
 with the panel schedule's macro tiles and panel widths forced on and off (they are plan-time switches).
-usage: python tools/fuzz_extended.py [first_seed] [n] [big|tiny]"""
+usage: python tools/fuzz_extended.py [first_seed] [n] [big|tiny|pcg]"""
 import math
 import os
 import sys
@@ -62,7 +62,7 @@ def main():
         except (ValueError, RuntimeError):      # the generators' parameter draws are not valid for every seed
             continue
         if not big and not tiny:
-            solver = 1
+            solver = 0 if (len(sys.argv) > 3 and sys.argv[3] == "pcg") else 1
         for var in ("XRSFM_BA_PANEL_MACRO", "XRSFM_BA_PANEL_COLS", "XRSFM_BA_PANEL_LL"):
             os.environ.pop(var, None)
         mode = seed % 4
