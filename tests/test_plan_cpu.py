@@ -109,3 +109,29 @@ def test_large_unordered_problem_is_refused_before_the_symbolic_factorisation(li
     with pytest.raises(RuntimeError, match="-6"):
         capi.debug_chol_plan(capi.ProblemArrays(**arr))
     assert time.perf_counter() - t0 < 20.0
+
+
+@pytest.mark.parametrize("mode,n_cams,k_obs,env", [
+    ("unordered", 150, 5, {}),                                                        # panel schedule, chunks
+    ("unordered", 150, 5, {"XRSFM_BA_PANEL_MACRO": "1"}),                             # + 128x128 macro tiles, 2 columns
+    ("unordered", 150, 5, {"XRSFM_BA_PANEL_MACRO": "1", "XRSFM_BA_PANEL_COLS": "4"}),
+    ("unordered", 95, 5, {"XRSFM_BA_PANEL_MACRO": "1"}),                              # odd / even numbers of tile columns
+    ("unordered", 230, 5, {"XRSFM_BA_PANEL_MACRO": "1", "XRSFM_BA_PANEL_COLS": "6"}),
+    ("unordered", 60, 12, {}),
+    ("sequential", 130, 4, {}), ("sequential", 257, 3, {}), ("sequential", 400, 4, {}), ("sequential", 560, 4, {}),   # level schedules
+])
+def test_schedule_covers_the_factorisation(monkeypatch, mode, n_cams, k_obs, env):
+    """XRSFM_BA_PLAN_CHECK makes the plan verify itself (ba_plan.h): every structurally non-zero tile (i,k) receives each
+    contribution L_ij L_kj^T, j < k, exactly once — from a macro-tile entry, a chunk of a split level or its own list in the
+    fused factor kernel — and the forward substitution of row k each L_kj y_j exactly once.  (A mutation that drops one macro
+    chunk makes the call fail with EINTERNAL.)"""
+    monkeypatch.setenv("XRSFM_BA_PLAN_CHECK", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    arr = H.make(n_cams, 20 * n_cams, k_obs, seed=300 + n_cams, mode=mode)
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["tiles"] <= 96                      # the check covers plans of up to 96 tile columns
+    if mode == "unordered":
+        assert plan["level_schedule"] == 0 and plan["levels"] == plan["tiles"]
+    else:
+        assert plan["level_schedule"] == 1

@@ -61,6 +61,7 @@ typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b <
 // produce.  Internal code: AUTO takes the implicit-Schur PCG path, which treats every observation on its own; an explicit
 // CHOLESKY request is refused with XRSFM_BA_EINVAL.
 constexpr int kErrDuplicateObs = -100;
+constexpr int kErrPlanCheck = -101;      // XRSFM_BA_PLAN_CHECK: the schedule does not cover the factorisation (internal error)
 
 // Pairs (a = slot, b = slot + dd in the same track) -> block (cam_b, cam_a), cam_b > cam_a.  `keyed` lists everything that
 // WRITES a partial block, as (block key, index into pair_dst):
@@ -492,6 +493,43 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     }
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);
+    if (std::getenv("XRSFM_BA_PLAN_CHECK") && T <= 96) {
+        // Self-check of the fused schedule (tests/test_plan_cpu.py, no GPU): every structurally non-zero tile (i,k) must receive
+        // each contribution j < k with L_ij and L_kj non-zero exactly once — from a macro-tile entry, a chunk of a split level or
+        // its own list in the fused factor kernel — and the forward substitution of row k each L_kj y_j exactly once.
+        std::vector<int> upd((size_t)T * T * T, 0), fwd((size_t)T * T, 0);
+        auto U = [&](int i, int k2, int j) -> int& { return upd[((size_t)i * T + k2) * T + j]; };
+        for (size_t e = 0; e < P.mp_chunk.size() / 8; ++e) {
+            const int* m = &P.mp_chunk[8 * e];
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int ia = a ? m[1] : m[0], kb = b ? m[3] : m[2];
+                    if (ia < 0 || ia < kb) continue;
+                    for (int j = m[4]; j < m[5]; ++j) U(ia, kb, j)++;
+                }
+            if (m[0] == m[2]) for (int j = m[4]; j < m[5]; ++j) { fwd[(size_t)m[2] * T + j]++; if (m[1] >= 0) fwd[(size_t)m[1] * T + j]++; }
+        }
+        for (size_t e = 0; e < P.sp_tgt.size() / 2; ++e) {
+            const int i = P.sp_tgt[2 * e], k2 = P.sp_tgt[2 * e + 1];
+            for (int q = P.sp_q[2 * e]; q < P.sp_q[2 * e + 1]; ++q) { U(i, k2, P.lv_cj[q])++; if (i == k2) fwd[(size_t)k2 * T + P.lv_cj[q]]++; }
+        }
+        for (size_t e = 0; e < P.fz_tile.size() / 2; ++e) {
+            const int i = P.fz_tile[2 * e], k2 = P.fz_tile[2 * e + 1];
+            for (int q = P.fz_dptr[e]; q < P.fz_dptr[e + 1]; ++q) {
+                const int dj = P.fz_dj[q], j = dj >= 0 ? dj : ~dj;
+                if (i == k2) { U(k2, k2, j)++; fwd[(size_t)k2 * T + j]++; }
+                else if (dj >= 0) U(i, k2, j)++;
+            }
+        }
+        for (int k2 = 0; k2 < T; ++k2)
+            for (int j = 0; j < T; ++j) {
+                if (fwd[(size_t)k2 * T + j] != ((j < k2 && nz[(size_t)k2 * T + j]) ? 1 : 0)) return kErrPlanCheck;
+                for (int i = k2; i < T; ++i) {
+                    const int want = (j < k2 && nz[(size_t)i * T + k2] && nz[(size_t)i * T + j] && nz[(size_t)k2 * T + j]) ? 1 : 0;
+                    if (U(i, k2, j) != want) return kErrPlanCheck;
+                }
+            }
+    }
     P.one_k.resize(T);
     for (int t = 0; t < T; ++t) P.one_k[t] = t;
     {

@@ -515,7 +515,7 @@ int chol_setup(xrsfm_ba_context* c) {
         c->have_pattern = true;
     }
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
+    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     timer.mark("plan");
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
@@ -1589,7 +1589,7 @@ int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     PairKeys keyed;
     if ((e = chol_local_keys(k, spp, keyed))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e;
+    if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
     stats[6] = P.use_levels ? 1 : 0; stats[7] = P.n_tiles_nz;
     if (cam_offset) for (int i = 0; i < k.n_cams; ++i) cam_offset[i] = P.cam_off[i];
