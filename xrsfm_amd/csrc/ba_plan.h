@@ -521,6 +521,41 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 else if (dj >= 0) U(i, k2, j)++;
             }
         }
+        // ... and, level by level, the fixed-order sum of a target reads exactly the partial slots that were written for it
+        for (int lv = 0; lv < n_levels; ++lv) {
+            std::vector<long long> owner;                    // partial slot (level-relative) -> target key i * T + k, -1 unwritten
+            auto put = [&](int slot, int i, int k2) {
+                if (slot < 0) return false;
+                if ((size_t)slot >= owner.size()) owner.resize(slot + 1, -1);
+                if (owner[slot] != -1) return false;         // two writers of one slot
+                owner[slot] = (long long)i * T + k2;
+                return true;
+            };
+            if (P.mp_off[lv + 1] - P.mp_off[lv] > 1) {
+                for (int w = P.mp_off[lv]; w + 1 < P.mp_off[lv + 1]; ++w)
+                    for (int e = P.mp_wg[w]; e < P.mp_wg[w + 1]; ++e) {
+                        const int* m = &P.mp_chunk[8 * (size_t)e];
+                        for (int a = 0; a < 2; ++a)
+                            for (int b = 0; b < 2; ++b) {
+                                const int ia = a ? m[1] : m[0], kb = b ? m[3] : m[2];
+                                if (ia < 0 || ia < kb) continue;
+                                if (!put(m[6] + (2 * a + b) * m[7], ia, kb)) return kErrPlanCheck;
+                            }
+                    }
+            } else {
+                for (int c2 = P.sp_chunk_off[lv]; c2 < P.sp_chunk_off[lv + 1]; ++c2)
+                    if (!put(c2 - P.sp_chunk_off[lv], P.sp_tgt[2 * (size_t)c2], P.sp_tgt[2 * (size_t)c2 + 1])) return kErrPlanCheck;
+            }
+            size_t read = 0;
+            for (int r = P.sp_rt_off[lv]; r < P.sp_rt_off[lv + 1]; ++r) {
+                const long long key = (long long)P.sp_rt[2 * (size_t)r] * T + P.sp_rt[2 * (size_t)r + 1];
+                for (int q = P.sp_rp[2 * (size_t)r]; q < P.sp_rp[2 * (size_t)r + 1]; ++q, ++read)
+                    if (q < 0 || (size_t)q >= owner.size() || owner[q] != key) return kErrPlanCheck;
+            }
+            size_t written = 0;
+            for (long long o2 : owner) written += (o2 != -1);
+            if (read != written || (long long)owner.size() > (long long)P.sp_max_chunks) return kErrPlanCheck;
+        }
         for (int k2 = 0; k2 < T; ++k2)
             for (int j = 0; j < T; ++j) {
                 if (fwd[(size_t)k2 * T + j] != ((j < k2 && nz[(size_t)k2 * T + j]) ? 1 : 0)) return kErrPlanCheck;
