@@ -213,6 +213,23 @@ def test_cholesky_reduced_system(lib, n_cams, n_pts, k_obs, mode):
     ctx.close()
 
 
+@pytest.mark.gpu
+def test_regular_tiles_of_every_track_length_match_oracle(lib):
+    """Every track sees every camera: regular tiles with L = n_cams cameras per track, 2 <= L <= 32 (Gram tiles up to 10 cameras,
+    the per-pair path beyond; the per-camera sums over a tile's tracks take 1-7 rounds of 64 values).  Three LM iterations on
+    the exact path against the oracle: same decisions, same cost, same cameras."""
+    from xrsfm_amd import capi
+    for L in list(range(2, 25)) + [28, 32]:
+        arr = H.make(L, 120, L, seed=700 + L, mode="unordered", min_tri_angle_deg=0.5)
+        st = capi.debug_pack(H.to_product(arr))
+        assert st["regular_tiles"] >= st["tiles"] - 1, L
+        pr, s_ref, prod, s = _solve_both(dict(arr), dict(max_iterations=3, linear_solver=1))
+        n_res = 2 * arr["obs_cam"].shape[0]
+        assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful), L
+        assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6, L
+        assert np.abs(prod.cam_q - pr.cam_q).max() < 1e-5 and np.abs(prod.cam_t - pr.cam_t).max() < 1e-5, L
+
+
 @pytest.mark.parametrize("solver", [0, 1])
 def test_solver_variants_agree(lib, solver):
     """PCG (tol 1e-12) and Cholesky follow the same LM trajectory as the oracle's exact solve."""
