@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer aid (GPU box): more seeds of tests/test_gpu_fuzz.py's random problems against the numpy oracle, exact solver only,
 with the panel schedule's macro tiles and panel widths forced on and off (they are plan-time switches).
-usage: python tools/fuzz_extended.py [first_seed] [n] [big|tiny|pcg]"""
+usage: python tools/fuzz_extended.py [first_seed] [n] [big|bigchol|tiny|pcg]"""
 import math
 import os
 import sys
@@ -52,7 +52,7 @@ def _tiny_problem(seed):
 def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 40
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    big = len(sys.argv) > 3 and sys.argv[3] in ("big", "bigchol")
     tiny = len(sys.argv) > 3 and sys.argv[3] == "tiny"
     bad = 0
     ran = 0
@@ -61,6 +61,8 @@ def main():
             arr, solver = _big_problem(seed) if big else (_tiny_problem(seed) if tiny else _problem(seed))
         except (ValueError, RuntimeError):      # the generators' parameter draws are not valid for every seed
             continue
+        if len(sys.argv) > 3 and sys.argv[3] == "bigchol":
+            solver = 1
         if not big and not tiny:
             solver = 0 if (len(sys.argv) > 3 and sys.argv[3] == "pcg") else 1
         for var in ("XRSFM_BA_PANEL_MACRO", "XRSFM_BA_PANEL_COLS", "XRSFM_BA_PANEL_LL"):
