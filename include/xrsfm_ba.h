@@ -153,6 +153,16 @@ int xrsfm_ba_download(xrsfm_ba_context *ctx, double *cam_q, double *cam_t, doubl
 
 void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
 
+/* The library keeps process-wide caches between calls (the reference builds a fresh ceres::Problem per call,
+ * ba_solver.cc:596,645,536; BASolver::LBA runs once per registered frame): device blocks and streams returned by
+ * xrsfm_ba_destroy, and — for contexts above 200k observations — the release of their host arrays on one library-owned
+ * thread.  xrsfm_ba_quiesce() waits for every deferred release and frees the cached device memory; it also returns the
+ * bytes that were cached (device) through *cached_bytes (may be NULL).  Never required for correctness: the thread is joined
+ * when the library is unloaded (dlclose / process exit), so no library code runs after the unload; cached device blocks
+ * that were not released through this call stay with the process until it exits (the library does not call into the HIP
+ * runtime from a static destructor).  An embedder that dlcloses the library should call this first. */
+int xrsfm_ba_quiesce(uint64_t *cached_bytes);
+
 /* One-shot convenience = create + run + download into problem->{cam_q,cam_t,points} + destroy:
  * the call that replaces ceres::Solve(options, &problem, &summary). */
 int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm_ba_summary *summary);
@@ -210,6 +220,11 @@ typedef struct xrsfm_pg_options {
     double function_tolerance, parameter_tolerance, gradient_tolerance;   /* Ceres defaults 1e-6, 1e-8, 1e-10 */
     double initial_radius;      /* 1e16 (ba_solver.cc:261) */
     int32_t verbose;
+    /* 0 (default): bounded parameters are handled as Ceres handles them — projection in Plus + projected Armijo line search on
+     * every step, nothing else (trust_region_minimizer.cc); with an active bound the loop may stop above the constrained minimum,
+     * exactly as upstream does.  1: additionally hold a parameter that sits on its bound while the gradient pushes it outwards
+     * (projected-Newton active set) — a deliberate DEVIATION from the reference that reaches the constrained minimum. */
+    int32_t bounds_active_set;
 } xrsfm_pg_options;
 
 typedef struct xrsfm_pg_summary {

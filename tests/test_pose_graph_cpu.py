@@ -86,18 +86,26 @@ def test_lower_bound_is_respected():
 
 def test_active_lower_bounds_reach_the_constrained_minimum():
     """Scales that want to shrink below their bound (ba_solver.cc:245-252 bounds them at 0.2; here 0.97 so that several are
-    active): the active-set step of pose_graph.h holds them on the bound and the remaining variables reach the constrained
-    minimum of scipy's bounded least squares."""
+    active).  Default = Ceres' handling of bounds (projection + projected line search only): feasible, decreases the cost and
+    stays within 2x of the constrained minimum — upstream's loop has no active set and may stop above it.  With
+    bounds_active_set=1 (opt-in deviation) the held scales let the remaining variables reach the constrained minimum of
+    scipy's bounded least squares."""
     prob, _ = _loop_problem(seed=2, drift=0.9, weight_o=0.0)
     prob["scale_lower"] = np.where(np.isfinite(prob["scale_lower"]), 0.97, -np.inf)
     p_ref, s_ref, cost_ref, _ = po.solve(**prob)
     free = np.isfinite(prob["scale_lower"])
     n_active_ref = int((s_ref[free] <= 0.97 + 1e-9).sum())
     assert n_active_ref >= 2                                         # the case really has active bounds
-    pos, sc, s = capi.pose_graph_solve(**prob, function_tolerance=1e-13, parameter_tolerance=1e-13)
+    # Ceres-faithful default
+    pos0, sc0, s0 = capi.pose_graph_solve(**prob)
+    assert (sc0[free] >= 0.97 - 1e-12).all()
+    assert s0.final_cost < s0.initial_cost and cost_ref * (1 - 1e-9) <= s0.final_cost <= 2.0 * cost_ref
+    # opt-in active set
+    pos, sc, s = capi.pose_graph_solve(**prob, function_tolerance=1e-13, parameter_tolerance=1e-13, bounds_active_set=1)
     assert (sc[free] >= 0.97 - 1e-12).all()
     assert abs(s.final_cost - cost_ref) <= 1e-6 * cost_ref
     assert int((sc[free] <= 0.97 + 1e-9).sum()) == n_active_ref and np.abs(sc - s_ref).max() < 1e-4 and np.abs(pos - p_ref).max() < 1e-3
+    assert s.final_cost <= s0.final_cost * (1 + 1e-12)
 
 
 def test_degenerate_inputs():

@@ -82,17 +82,24 @@ def test_stage1_tight_tolerances_reach_the_oracle_minimum(capi):
 
 def test_scale_lower_bound_is_enforced(capi):
     sc = make_scene(seed=3, s_true=0.05)            # the unconstrained optimum is far below the bound
-    out = capi.tag_refine(sc["frame_q"], sc["frame_t"], sc["corners"], *sc["tag_obs"], sc["tag_length"], stages=1)
     q, t, s, c = to.solve_stage1(sc["corners"], sc["tag_length"])
-    assert out["scale"] >= 0.2 and abs(out["scale"] - 0.2) < 1e-9 and abs(s - 0.2) < 1e-9
-    # Active set (tag_refine.h: the scale is held while it sits on the bound and the gradient pushes it down): the tags take the
-    # step of the problem restricted to scale = 0.2, and the solve reaches the constrained minimum of the independent bounded
-    # least-squares solver (scipy) — within the function tolerance by default, to round-off with tight tolerances.  (The
-    # restated Ceres loop WITHOUT it stalled up to 2x above that minimum.)
+    assert abs(s - 0.2) < 1e-9
+    # Default = Ceres' handling of the bound (tag_extract.hpp:227 -> SetParameterLowerBound; projected Plus + projected Armijo
+    # search only): feasible, on the bound, large cost decrease; its loop may stop up to 2x above the constrained minimum (the
+    # model keeps promising the infeasible decrease), as upstream's does.
+    out = capi.tag_refine(sc["frame_q"], sc["frame_t"], sc["corners"], *sc["tag_obs"], sc["tag_length"], stages=1)
     s1 = out["summaries"][0]
-    assert s1.final_cost < 0.1 * s1.initial_cost and c * (1 - 1e-9) <= s1.final_cost <= c * (1 + 1e-4)
+    assert out["scale"] >= 0.2 and abs(out["scale"] - 0.2) < 1e-9
+    assert s1.final_cost < 0.1 * s1.initial_cost and c * (1 - 1e-9) <= s1.final_cost <= 2.0 * c
+    # Opt-in active set (bounds_active_set=1, a documented deviation): the scale is held while it sits on the bound and the
+    # gradient pushes it down, the tags take the step of the problem restricted to scale = 0.2, and the solve reaches the
+    # constrained minimum of the independent bounded least-squares solver (scipy) — within the function tolerance by default,
+    # to round-off with tight tolerances.
+    act = capi.tag_refine(sc["frame_q"], sc["frame_t"], sc["corners"], *sc["tag_obs"], sc["tag_length"], stages=1, bounds_active_set=1)
+    a1 = act["summaries"][0]
+    assert abs(act["scale"] - 0.2) < 1e-9 and c * (1 - 1e-9) <= a1.final_cost <= c * (1 + 1e-4)
     tight = capi.tag_refine(sc["frame_q"], sc["frame_t"], sc["corners"], *sc["tag_obs"], sc["tag_length"], stages=1,
-                            function_tolerance=1e-15, parameter_tolerance=1e-14, gradient_tolerance=1e-13)
+                            function_tolerance=1e-15, parameter_tolerance=1e-14, gradient_tolerance=1e-13, bounds_active_set=1)
     assert tight["scale"] == 0.2 and abs(tight["summaries"][0].final_cost - c) <= 1e-9 * c
     assert _rot_dist(tight["tag_q"], q) < 1e-6 and np.abs(tight["tag_t"] - t).max() < 1e-6
 

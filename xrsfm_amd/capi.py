@@ -37,7 +37,8 @@ class CPgProblem(C.Structure):
 
 class CPgOptions(C.Structure):
     _fields_ = [("max_iterations", C.c_int32), ("function_tolerance", C.c_double), ("parameter_tolerance", C.c_double),
-                ("gradient_tolerance", C.c_double), ("initial_radius", C.c_double), ("verbose", C.c_int32)]
+                ("gradient_tolerance", C.c_double), ("initial_radius", C.c_double), ("verbose", C.c_int32),
+                ("bounds_active_set", C.c_int32)]
 
 
 class CPgSummary(C.Structure):
@@ -87,7 +88,7 @@ EXPORTS = [
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
-    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses",
+    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -176,6 +177,16 @@ def device_count() -> int:
     return n.value
 
 
+def quiesce() -> int:
+    """xrsfm_ba_quiesce: wait for deferred context releases, free the cached device blocks; returns the bytes that were cached."""
+    n = C.c_uint64(0)
+    lib = load()
+    lib.xrsfm_ba_quiesce.argtypes = [C.POINTER(C.c_uint64)]
+    lib.xrsfm_ba_quiesce.restype = C.c_int
+    check(lib.xrsfm_ba_quiesce(C.byref(n)), "xrsfm_ba_quiesce")
+    return int(n.value)
+
+
 def default_options(**kw) -> COptions:
     o = COptions()
     load().xrsfm_ba_default_options(C.byref(o))
@@ -206,8 +217,12 @@ class ProblemArrays:
         self.obs_cam = np.ascontiguousarray(np.asarray(arr["obs_cam"], np.int32))
         self.obs_pt = np.ascontiguousarray(np.asarray(arr["obs_pt"], np.int32))
         self.obs_uv = f64(arr["obs_uv"], (-1, 2))
-        assert self.cam_t.shape[0] == n_c and self.cam_intr.shape[0] == n_c and self.cam_const.shape[0] == n_c
-        assert self.obs_pt.shape[0] == self.obs_cam.shape[0] == self.obs_uv.shape[0]
+        if not (self.cam_t.shape[0] == n_c and self.cam_intr.shape[0] == n_c and self.cam_const.shape[0] == n_c):
+            raise ValueError("cam_q / cam_t / cam_intr / cam_const disagree on the number of cameras")
+        if not (self.obs_pt.shape[0] == self.obs_cam.shape[0] == self.obs_uv.shape[0]):
+            raise ValueError("obs_cam / obs_pt / obs_uv disagree on the number of observations")
+        if self.point_const.shape[0] != self.points.shape[0] or self.intr_model.shape[0] != self.intr_params.shape[0]:
+            raise ValueError("point_const / points or intr_model / intr_params disagree in length")
 
     @property
     def n_cams(self): return self.cam_q.shape[0]
@@ -280,8 +295,11 @@ class Context:
             q = np.empty_like(p.cam_q); t = np.empty_like(p.cam_t); P = p.points.copy()
         else:
             q, t, P = out
-            assert q.shape == p.cam_q.shape and t.shape == p.cam_t.shape and P.shape == p.points.shape
-            assert all(a.dtype == np.float64 and a.flags.c_contiguous for a in (q, t, P))
+            # (not `assert`: stripped under python -O, and the C function writes through these pointers unchecked)
+            if not (q.shape == p.cam_q.shape and t.shape == p.cam_t.shape and P.shape == p.points.shape):
+                raise ValueError("download(out=...): shapes must equal the problem's cam_q / cam_t / points")
+            if not all(a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable for a in (q, t, P)):
+                raise ValueError("download(out=...): arrays must be writable C-contiguous float64")
             if P is not p.points:
                 P[...] = p.points      # points that take no part in the problem keep their input value
         check(self.lib.xrsfm_ba_download(self._h, _dp(q), _dp(t), _dp(P)), "xrsfm_ba_download")

@@ -258,13 +258,15 @@ struct Solver {
                 // gradient first: it decides the active set of this linearisation
                 std::fill(grad.begin(), grad.end(), 0.0);
                 for_rows(pos.data(), sc.data(), [&](int ri, const Row& row) { for (int x = 0; x < row.n; ++x) grad[row.idx[x]] += row.val[x] * r[ri]; });
-                // Active set (projected-Newton rule): a scale that sits on its lower bound while the gradient pushes it further
-                // down cannot move; it is held for this step, so that the step of the OTHER variables is the one of the problem
-                // restricted to the feasible face instead of a Gauss-Newton step that keeps "using" the infeasible decrease.
-                // Ceres itself only projects and line-searches (no active set) and can stall above the constrained minimum — a
-                // deliberate deviation, tested against an independent bounded least-squares solver (tests/test_pose_graph_cpu.py).
+                // Default (options.bounds_active_set = 0) = what Ceres does with bounds: Plus projects onto the box and every step
+                // goes through the projected Armijo search, nothing else; such a loop can stop above the constrained minimum,
+                // and so does upstream (ba_solver.cc:245-266 -> ceres::Solve).
+                // bounds_active_set = 1 (a deliberate DEVIATION): projected-Newton active set — a scale that sits
+                // on its lower bound while the gradient pushes it further down is held for this step, so that the step of the
+                // OTHER variables is the one of the problem restricted to the feasible face; reaches the constrained minimum of an
+                // independent bounded least-squares solver (tests/test_pose_graph_cpu.py).
                 std::fill(active.begin(), active.end(), 0);
-                if (constrained)
+                if (constrained && o.bounds_active_set)
                     for (int i = 0; i < p.n_scales; ++i)
                         if (g.vs[i] >= 0 && sc[i] <= p.scale_lower[i] && grad[g.vs[i]] > 0.0) active[g.vs[i]] = 1;
                 // normal equations over the free variables (identity rows for the held ones)
@@ -315,7 +317,8 @@ struct Solver {
                     mu *= mu_up;
                 }
                 if (!ok) { mu = max_mu; return finish(6, cost); }
-                mu = std::max(min_mu, 2.0 * mu / mu_up);          // relaxed after every successful factorisation (DoglegStrategy::ComputeGaussNewtonStep)
+                mu = std::max(min_mu, 2.0 * mu / mu_up);          // relaxed after a successful step in Ceres (DoglegStrategy::StepAccepted: mu = max(min_mu, 2 mu / mu_increase_factor));
+                                                                  // done here after the factorisation instead — equivalent, because this loop only re-factorises after an accepted step
                 for (int i = 0; i < nv; ++i) gn[i] = -grad[i];
                 H.solve(gn.data());
                 gn_norm = 0.0;

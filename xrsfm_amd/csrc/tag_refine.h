@@ -384,12 +384,13 @@ struct Solver {
             if (it >= o.max_iterations) return finish(5, cost);
             ++it;
             sum->iterations = it;
-            // Active set (projected-Newton rule): while the scale sits on its lower bound (tag_extract.hpp:227) and the gradient
-            // pushes it further down it is held, so that the tags take the step of the problem restricted to scale = bound.
-            // Ceres only projects and line-searches: its model keeps promising the infeasible decrease, rho stays small, the
-            // radius collapses and the loop stalls above the constrained minimum — a deliberate deviation (tests compare with
-            // scipy's bounded least squares).
-            scale_held = x.scale <= p.scale_lower && grad[0] > 0.0;
+            // Default (options.bounds_active_set = 0): the bound scale >= scale_lower (tag_extract.hpp:227) is handled as Ceres
+            // handles it — projected Plus + projected Armijo search only; with the bound active its model keeps promising the
+            // infeasible decrease, rho stays small, the radius collapses and the loop stops above the constrained minimum, as
+            // upstream does.  bounds_active_set = 1 (deliberate DEVIATION): while the scale sits on its bound and
+            // the gradient pushes it further down it is held, so that the tags take the step of the problem restricted to
+            // scale = bound (tests compare that mode with scipy's bounded least squares).
+            scale_held = o.bounds_active_set && x.scale <= p.scale_lower && grad[0] > 0.0;
             if (!reuse_diagonal) for (int i = 0; i < n; ++i) dg[i] = std::min(std::max(diag(i) * S[i] * S[i], 1e-6), 1e32);
             for (int i = 0; i < n; ++i) d2[i] = dg[i] / radius;
             double model = -1.0;

@@ -12,6 +12,8 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -33,6 +35,8 @@
 #include "tag_refine.h"
 
 using namespace xba;
+static_assert(kCamsPerTileDev == kCamsPerTile, "k_lv_factor / k_lv_bwd index tile_cam with the device constant, the plan fills it with the host constant");
+static_assert(kNB == kPlanTile, "tile size of the kernels (ba_chol.h) and of the plan (ba_plan.h)");
 
 #define HIPCHK(expr)                                                                           \
     do {                                                                                       \
@@ -224,6 +228,26 @@ struct BundleCache {
 };
 BundleCache g_bundles;
 
+// Deferred release of the host side of large contexts (xrsfm_ba_destroy).  One joinable thread, started on first use.
+struct Reaper {
+    static constexpr size_t kReaperBacklog = 4;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<xrsfm_ba_context*> q;
+    std::thread th;
+    bool started = false, stop = false;
+    bool push(xrsfm_ba_context* c);
+    void loop();
+    void drain();          // blocks until everything handed over so far is released
+    size_t busy = 0;
+    ~Reaper() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv.notify_all();
+        if (started && th.joinable()) th.join();
+    }
+};
+Reaper g_reaper;
+
 template <typename T>
 int dev_alloc(xrsfm_ba_context* c, T** p, size_t n) {
     if (n == 0) n = 1;
@@ -338,6 +362,8 @@ __global__ void k_publish(const double* __restrict__ scal, double* __restrict__ 
 }
 
 int fetch_scalars(xrsfm_ba_context* c) {
+    const bool tail_published = c->published;
+    c->published = false;               // (cleared on every exit path, errors included)
     HIPCHK(hipGetLastError());          // a failed launch since the last sync point
     if (c->profiling || !c->h_scal_dev) {
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, c->stream));
@@ -346,7 +372,7 @@ int fetch_scalars(xrsfm_ba_context* c) {
         return 0;
     }
     unsigned long long want;
-    if (c->published) { want = c->seq; c->published = false; }         // k_lin_tail hands the block over itself
+    if (tail_published) want = c->seq;                                  // k_lin_tail hands the block over itself
     else {
         want = ++c->seq;
         hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, c->stream, c->d.scal, c->h_scal_dev, want);
@@ -371,6 +397,10 @@ int fetch_scalars(xrsfm_ba_context* c) {
 enum { LIN_SKIP_CAMLIN = 1, LIN_FINAL = 2 };    // LIN_FINAL: gradient max-norm and the hand-over to the host follow this linearisation
 int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step, int flags = 0) {
     const Dev& own = c->d;
+    // "the tail of the previous linearisation has already done this" never outlives that linearisation (an error return
+    // between a linearisation and its fetch_scalars(), or a debug entry point that skips the fetch, must not make a later
+    // caller skip k_gradmax_cams / k_publish and read stale scalars)
+    c->gradmax_done = false; c->published = false;
     if (d.n_cams > 0 && !(flags & LIN_SKIP_CAMLIN)) LAUNCH(c, K_SMALL, k_cam_lin, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), kWavesPerBlock * kWave * 13 * sizeof(double), d, huber_a);
     if (!c->fused && d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camlin, (const PcgStatus*)nullptr);
@@ -800,6 +830,36 @@ static int no_throw(F&& f) {
     catch (...) { return XRSFM_BA_EINTERNAL; }
 }
 
+bool Reaper::push(xrsfm_ba_context* c) {
+    try {
+        std::lock_guard<std::mutex> g(mu);
+        if (stop || q.size() + busy >= kReaperBacklog) return false;
+        if (!started) { th = std::thread([this] { loop(); }); started = true; }
+        q.push_back(c);
+    } catch (...) { return false; }          // no thread / no memory: the caller releases in place
+    cv.notify_all();
+    return true;
+}
+void Reaper::loop() {
+    std::unique_lock<std::mutex> lk(mu);
+    while (true) {
+        cv.wait(lk, [this] { return stop || !q.empty(); });
+        if (q.empty()) { if (stop) return; continue; }
+        xrsfm_ba_context* c = q.front();
+        q.pop_front();
+        ++busy;
+        lk.unlock();
+        delete c;
+        lk.lock();
+        --busy;
+        cv.notify_all();
+    }
+}
+void Reaper::drain() {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [this] { return q.empty() && busy == 0; });
+}
+
 extern "C" {
 
 void xrsfm_ba_default_options(xrsfm_ba_options* o) {
@@ -836,12 +896,23 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
     if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st});
     // What is left is host memory.  A large context holds ~0.5 KB per observation in vectors whose release (munmap: page-table
-    // teardown) takes ~10 ms per million observations: a detached thread does it, the caller (one BA call of a mapper) goes on.
-    // Small contexts are deleted in place (a thread costs more than their release).
-    if (c->pk.n_obs > 200000) {
-        try { std::thread([c] { delete c; }).detach(); return; } catch (...) { /* no thread: release here */ }
-    }
+    // teardown) takes ~10 ms per million observations: ONE reaper thread does it, the caller (one BA call of a mapper) goes on.
+    // The thread is joined when the library is unloaded (g_reaper's destructor: dlclose / process exit), so no library code
+    // runs after the unload; at most kReaperBacklog contexts wait, a further one is released in place.  Small contexts are
+    // deleted in place (a hand-over costs more than their release).
+    if (c->pk.n_obs > 200000 && g_reaper.push(c)) return;
     delete c;
+}
+
+int xrsfm_ba_quiesce(uint64_t* cached_bytes) {
+    g_reaper.drain();
+    size_t n;
+    { std::lock_guard<std::mutex> g(g_cache.mu); n = g_cache.cached_bytes; }
+    if (cached_bytes) *cached_bytes = (uint64_t)n;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XRSFM_BA_OK;      // nothing can be cached without a device
+    g_cache.release_all();
+    return XRSFM_BA_OK;
 }
 
 static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out);
@@ -1178,7 +1249,7 @@ int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm
 void xrsfm_pg_default_options(xrsfm_pg_options* o) {
     if (!o) return;
     o->max_iterations = 100; o->function_tolerance = 1e-6; o->parameter_tolerance = 1e-8; o->gradient_tolerance = 1e-10;
-    o->initial_radius = 1e16; o->verbose = 0;
+    o->initial_radius = 1e16; o->verbose = 0; o->bounds_active_set = 0;
 }
 
 static int pg_solve_impl(const xrsfm_pg_options* opt, xrsfm_pg_problem* p, xrsfm_pg_summary* summary) {
@@ -1205,7 +1276,7 @@ void xrsfm_tag_default_options(xrsfm_pg_options* o) {
     if (!o) return;
     o->max_iterations = 500;            // tag_extract.hpp:231
     o->function_tolerance = 1e-6; o->parameter_tolerance = 1e-8; o->gradient_tolerance = 1e-10;
-    o->initial_radius = 1e4; o->verbose = 0;
+    o->initial_radius = 1e4; o->verbose = 0; o->bounds_active_set = 0;
 }
 
 static int tag_refine_impl(const xrsfm_pg_options* opt, xrsfm_tag_problem* p, int32_t stages, xrsfm_pg_summary* summaries) {
