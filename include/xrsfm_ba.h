@@ -329,6 +329,13 @@ int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context *ctx, int n_pairs, const i
  * receives the assembled reduced camera matrix before factorisation, [6 n_cams][6 n_cams] row-major, symmetric. */
 int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context *ctx, double radius, double *y, double *S_dense);
 
+/* After debug_cholesky_solve: one back-substitution (k_backsub) from the camera solution it left.  Outputs in the
+ * library's PACKED order (for comparing two builds of the library on the same problem, tools/backsub_waves_probe.py):
+ * per work item the model-decrease and squared point-step partials [n_items] (n_items = debug_pack stats), candidate
+ * points and scaled point steps [n_points_packed][3], candidate cameras [n_cams][4] / [n_cams][3].  Any pointer may be NULL. */
+int xrsfm_ba_debug_backsub(xrsfm_ba_context *ctx, double *part_model, double *part_step2, double *cand_points,
+                           double *point_step, double *cand_cam_q, double *cand_cam_t);
+
 #ifdef __cplusplus
 }
 #endif

@@ -24,9 +24,32 @@ def lib_sources():
     return srcs
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
+# Hardening / probe builds of the same sources (tests/test_gpu_hardening.py, tools/backsub_waves_probe.py): name -> extra flags
+VARIANTS = {
+    "poison": ["-DXBA_POISON"],                 # dead per-lane temporaries hold NaN instead of 0: results must not change by a bit
+    "backsub_w5": ["-DXBA_BACKSUB_WAVES=5"],    # k_backsub register-allocated for 5 waves per SIMD (round-2 finding xi)
+}
+
+
+def variant_path(name: str) -> str:
+    return os.path.join(LIBDIR, f"libxrsfm_ba_{name}.so")
+
+
+def build_lib(force: bool = False, verbose: bool = False, variant: str | None = None) -> str:
     """hipcc --offload-arch=gfx950 -> xrsfm_amd/lib/libxrsfm_ba.so (cross-compiles without a GPU)."""
     srcs = lib_sources()
+    if variant is not None:
+        out = variant_path(variant)
+        if not force and _newer(out, srcs):
+            return out
+        hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+        os.makedirs(LIBDIR, exist_ok=True)
+        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-Wno-deprecated-declarations",
+               *VARIANTS[variant], "-o", out, os.path.join(CSRC, "xrsfm_ba.hip"), "-ldl"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=ROOT)
+        return out
     if not force and _newer(LIB, srcs):
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"

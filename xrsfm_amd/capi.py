@@ -88,7 +88,7 @@ EXPORTS = [
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
-    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce",
+    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce", "xrsfm_ba_debug_backsub",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -130,6 +130,8 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_schur_product.restype = C.c_int
     lib.xrsfm_ba_debug_cholesky_solve.argtypes = [vp, C.c_double, _c_double_p, _c_double_p]
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
+    lib.xrsfm_ba_debug_backsub.argtypes = [vp] + [_c_double_p] * 6
+    lib.xrsfm_ba_debug_backsub.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
     lib.xrsfm_pg_default_options.argtypes = [C.POINTER(CPgOptions)]
@@ -330,6 +332,16 @@ class Context:
         S = np.zeros((n, n)) if want_S else None
         check(self.lib.xrsfm_ba_debug_cholesky_solve(self._h, radius, _dp(y), _dp(S)), "debug_cholesky_solve")
         return y, S
+
+    def debug_backsub(self) -> dict:
+        """After debug_cholesky_solve: one k_backsub launch; per-item partials and the candidate state in PACKED order."""
+        st = debug_pack(self.problem)
+        ni, npk, nc = st["items"], st["active_points"], self.problem.n_cams
+        out = dict(part_model=np.zeros(ni), part_step2=np.zeros(ni), cand_points=np.zeros((npk, 3)), point_step=np.zeros((npk, 3)),
+                   cand_cam_q=np.zeros((nc, 4)), cand_cam_t=np.zeros((nc, 3)))
+        check(self.lib.xrsfm_ba_debug_backsub(self._h, *[_dp(out[k]) for k in ("part_model", "part_step2", "cand_points", "point_step",
+                                                                                  "cand_cam_q", "cand_cam_t")]), "debug_backsub")
+        return out
 
     def debug_set_block_pattern(self, row_col: np.ndarray):
         rc = np.ascontiguousarray(row_col, np.int32).reshape(-1, 2)

@@ -182,14 +182,14 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
         const int cp = d.slot_campos_g[s.slot];
         const int cidx_raw = GRAM ? (int)d.slot_cidx[s.slot] : 0;
         const int L = d.tile_stride[it.first_tile];
-        double V[18];
+        double V[18];                 // (lanes without an observation: never staged, never a pair partner — XBA_POISON checks it)
 #pragma unroll
-        for (int k = 0; k < 18; ++k) V[k] = 0.0;
+        for (int k = 0; k < 18; ++k) V[k] = XBA_DEAD;
         int npair = 0, pbase = 0;
         {
             double o28[28];
 #pragma unroll
-            for (int k = 0; k < 28; ++k) o28[k] = 0.0;
+            for (int k = 0; k < 28; ++k) o28[k] = XBA_DEAD;
             XBA_STAMP(0, 1);
             if (s.valid) {
                 // the point's factor of Hinv and gradient are requested with the Jacobian records (left where they are used, the

@@ -96,6 +96,23 @@ __device__ unsigned long long g_stamps[3][64][16];
 #define XBA_STAMP(kern, i) do {} while (0)
 #endif
 
+// Parity-hardening build (-DXBA_POISON, tests/test_gpu_hardening.py): every per-lane temporary of the streaming kernels that a lane
+// without an observation (or a lane that is not the head of its track) is NOT supposed to read is initialised with NaN
+// instead of 0.  The result of a solve must not change by one bit: a value that leaks from such a lane through a shuffle,
+// a reduction or a store turns into NaN and fails the test.  (Lanes whose values ARE read under a 0/1 mask — the operands of
+// seg_reduce / strided_reduce — must hold zeros and keep them.)
+#ifdef XBA_POISON
+#define XBA_DEAD (__builtin_nan(""))
+#define XBA_DEAD1 (__builtin_nan(""))
+#else
+#define XBA_DEAD 0.0
+#define XBA_DEAD1 1.0
+#endif
+// Register-allocation probe (-DXBA_BACKSUB_WAVES=5, tools/backsub_waves_probe.py): k_backsub built for 5 waves per SIMD.
+#ifndef XBA_BACKSUB_WAVES
+#define XBA_BACKSUB_WAVES 0
+#endif
+
 // ---------------------------------------------------------------- wave helpers
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -248,7 +265,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
         const int maxlen = d.tile_maxlen[tile];
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double cs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-        double spk[3] = {1.0, 1.0, 1.0};               // point scaling, kept for the gradient norm after the reduction (a reload
+        double spk[3] = {XBA_DEAD1, XBA_DEAD1, XBA_DEAD1};   // point scaling, kept for the gradient norm after the reduction (a reload
         if (s.valid) {                                 // there would be a third dependent memory round trip)
             const CamRec& c = d.cam[s.cam];
             double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
@@ -692,17 +709,22 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
     const Item it = d.items[item];
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
-        double F[12], E[6], v0 = 0.0, v1 = 0.0;
-        double w[3] = {0, 0, 0};
+        double F[12], E[6], v0 = XBA_DEAD, v1 = XBA_DEAD;
+#ifdef XBA_POISON
+        for (int k = 0; k < 12; ++k) F[k] = XBA_DEAD;
+        for (int k = 0; k < 6; ++k) E[k] = XBA_DEAD;
+#endif
+        double w[3] = {0, 0, 0};                   // operand of the segmented sum: zeros on lanes without an observation
         if (s.valid) {
             load_FE(d, s.slot, s.cam, s.pt, F, E);
+            v0 = 0.0; v1 = 0.0;
             const double* p = pvec + 6 * (size_t)s.cam;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { const double pk = p[k]; v0 += F[k] * pk; v1 += F[6 + k] * pk; }
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
         seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);
-        double u[3] = {0, 0, 0};
+        double u[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
         if (s.head) {
             const double* h = d.Hinv + 6 * (size_t)s.pt;
             u[0] = h[0] * w[0] + h[1] * w[1] + h[2] * w[2];
@@ -856,32 +878,51 @@ __global__ __launch_bounds__(kPcgBlock) void k_pcg_p(Dev d, const double* __rest
 // y: the camera's 6 entries of the (scaled) solution.  camrec_cand (optional): the candidate's linearisation record is
 // written as well (the level-scheduled backward substitution produces the candidate cameras tile by tile, ba_chol.h).
 __device__ __forceinline__ void cam_update_one(const Dev& d, int c, const double* y, CamLin* __restrict__ camrec_cand) {
-    const CamRec cur = d.cam[c];
-    CamRec nxt = cur;
+    // (field by field: a `CamRec nxt = cur` copy lived in scratch memory — 96 bytes of private segment for the whole kernel)
+    const CamRec& cur = d.cam[c];
+    const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
+    const double t[3] = {cur.t[0], cur.t[1], cur.t[2]};
+    double tn[3] = {t[0], t[1], t[2]};
     const unsigned cc = d.cam_const[c];
     const bool active = d.cam_act[c] > 0.0;
     const double* sc = d.scale_c + 6 * (size_t)c;
     double step2 = 0.0, xn2 = 0.0;
-    if (active && !(cc & 1u)) {
+    const bool rot = active && !(cc & 1u);
+    double qn[4] = {q[0], q[1], q[2], q[3]};
+    if (rot) {
         const double dl[3] = {-y[0] * sc[0], -y[1] * sc[1], -y[2] * sc[2]};
-        quat_plus(cur.q, dl, nxt.q);
-        for (int k = 0; k < 4; ++k) { const double df = nxt.q[k] - cur.q[k]; step2 += df * df; xn2 += cur.q[k] * cur.q[k]; }
+        quat_plus(q, dl, qn);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const double df = qn[k] - q[k]; step2 += df * df; xn2 += q[k] * q[k]; }
     }
     if (active && !(cc & 2u)) {
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
-            nxt.t[k] = cur.t[k] + (-y[3 + k] * sc[3 + k]);
-            const double df = nxt.t[k] - cur.t[k]; step2 += df * df; xn2 += cur.t[k] * cur.t[k];
+            tn[k] = t[k] + (-y[3 + k] * sc[3 + k]);
+            const double df = tn[k] - t[k]; step2 += df * df; xn2 += t[k] * t[k];
         }
     }
-    d.cam_cand[c] = nxt;
+    CamRec& out = d.cam_cand[c];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out.q[k] = qn[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out.t[k] = tn[k];
+    out.pad = cur.pad;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) out.intr[k] = cur.intr[k];
     d.campart[c] = step2;
     d.campart[d.n_cams + c] = xn2;
-    if (camrec_cand) cam_lin_one(d, c, nxt.q, camrec_cand);
+    if (camrec_cand) cam_lin_one(d, c, qn, camrec_cand);
 }
 
 // y_p = Hinv (g_p - sum E^T F y_c); model cost change; candidate points.
 // Workgroups >= n_item_blocks: candidate cameras from the camera part of the solution (thread = camera; cam_update_one).
-__global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
+#if XBA_BACKSUB_WAVES > 0
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(XBA_BACKSUB_WAVES, XBA_BACKSUB_WAVES)))
+#else
+__global__ __launch_bounds__(kBlock)
+#endif
+void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
     if ((int)blockIdx.x >= n_item_blocks) {
         const int c = (blockIdx.x - n_item_blocks) * kBlock + threadIdx.x;
         if (c < d.n_cams) cam_update_one(d, c, d.px + 6 * (size_t)c, camrec_cand);
@@ -896,11 +937,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int maxlen = d.tile_maxlen[it.first_tile];
-        double E[6], v0 = 0.0, v1 = 0.0, r0 = 0.0, r1 = 0.0;
-        double w[3] = {0, 0, 0};
+        double E[6] = {XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD};
+        double v0 = XBA_DEAD, v1 = XBA_DEAD, r0 = XBA_DEAD, r1 = XBA_DEAD;      // read by lanes with an observation only
+        double w[3] = {0, 0, 0};                                                // operand of the segmented sum: zeros on the other lanes
         // what the head lane of a track needs after the reduction depends on the point only: every lane of the track requests
         // it now (same addresses: one transaction), so that it does not cost a third memory round trip after the shuffles
-        double hh[6] = {0, 0, 0, 0, 0, 0}, gg[3] = {0, 0, 0}, spv[3] = {0, 0, 0}, Pv[3] = {0, 0, 0};
+        double hh[6] = {XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD}, gg[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
+        double spv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD}, Pv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
         bool var = false;
         if (s.valid) {
             const double* h = d.Hinv + 6 * (size_t)s.pt;
@@ -920,12 +963,13 @@ __global__ __launch_bounds__(kBlock) void k_backsub(Dev d, int n_item_blocks, Ca
             r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
             double F[12];
             load_FE(d, s.slot, s.cam, s.pt, F, E);
+            v0 = 0.0; v1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
         }
         seg_reduce<3>(w, s.pt, lane, maxlen);
-        double u[3] = {0, 0, 0};
+        double u[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};      // head lanes compute it, the lanes of the track fetch it from their head
         if (s.head) {
             const double a0 = gg[0] - w[0], a1 = gg[1] - w[1], a2 = gg[2] - w[2];
             u[0] = hh[0] * a0 + hh[1] * a1 + hh[2] * a2;

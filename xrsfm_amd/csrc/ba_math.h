@@ -112,18 +112,18 @@ __device__ __forceinline__ double huber(double s, double a, double& rho1) {
 
 // EigenQuaternionParameterization::Plus (full angle, left multiplication), q = xyzw.
 __device__ __forceinline__ void quat_plus(const double q[4], const double d[3], double out[4]) {
+    // (computed unconditionally, selected at the end: with the two branches writing through `out` the compiler kept the
+    //  caller's array in scratch memory)
     const double n = sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
-    if (n > 0.0) {
-        const double s = sin(n) / n;
-        const double ax = s * d[0], ay = s * d[1], az = s * d[2], aw = cos(n);
-        const double bx = q[0], by = q[1], bz = q[2], bw = q[3];
-        out[3] = aw * bw - (ax * bx + ay * by + az * bz);
-        out[0] = aw * bx + bw * ax + (ay * bz - az * by);
-        out[1] = aw * by + bw * ay + (az * bx - ax * bz);
-        out[2] = aw * bz + bw * az + (ax * by - ay * bx);
-    } else {
-        out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
-    }
+    const bool nz = n > 0.0;
+    const double s = sin(n) / (nz ? n : 1.0);
+    const double ax = s * d[0], ay = s * d[1], az = s * d[2], aw = cos(n);
+    const double bx = q[0], by = q[1], bz = q[2], bw = q[3];
+    const double ow = aw * bw - (ax * bx + ay * by + az * bz);
+    const double ox = aw * bx + bw * ax + (ay * bz - az * by);
+    const double oy = aw * by + bw * ay + (az * bx - ax * bz);
+    const double oz = aw * bz + bw * az + (ax * by - ay * bx);
+    out[0] = nz ? ox : bx; out[1] = nz ? oy : by; out[2] = nz ? oz : bz; out[3] = nz ? ow : bw;
 }
 
 // Inverse of a symmetric positive definite 3x3 given as upper triangle {00,01,02,11,12,22}.

@@ -1713,6 +1713,32 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
     return 0;
 }
 
+int xrsfm_ba_debug_backsub(xrsfm_ba_context* c, double* part_model, double* part_step2, double* cand_points, double* point_step,
+                           double* cand_cam_q, double* cand_cam_t) {
+    if (!c) return XRSFM_BA_EINVAL;
+    if (!c->linearized) return XRSFM_BA_ESTATE;
+    HIPCHK(hipSetDevice(c->device));
+    Dev& d = c->d;
+    const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cdiv(d.n_cams, kBlock);
+    if (nbi + nbc > 0) hipLaunchKernelGGL(k_backsub, dim3(nbi + nbc), dim3(kBlock), 0, c->stream, d, nbi, (CamLin*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    const size_t ni = (size_t)d.n_items, np = (size_t)d.n_pts;
+    if (part_model && ni) HIPCHK(hipMemcpy(part_model, d.part + 2 * ni, ni * sizeof(double), hipMemcpyDeviceToHost));
+    if (part_step2 && ni) HIPCHK(hipMemcpy(part_step2, d.part + 3 * ni, ni * sizeof(double), hipMemcpyDeviceToHost));
+    if (cand_points && np) HIPCHK(hipMemcpy(cand_points, d.P_cand, 3 * np * sizeof(double), hipMemcpyDeviceToHost));
+    if (point_step && np) HIPCHK(hipMemcpy(point_step, d.yp, 3 * np * sizeof(double), hipMemcpyDeviceToHost));
+    if ((cand_cam_q || cand_cam_t) && d.n_cams) {
+        std::vector<CamRec> cams(d.n_cams);
+        HIPCHK(hipMemcpy(cams.data(), d.cam_cand, sizeof(CamRec) * (size_t)d.n_cams, hipMemcpyDeviceToHost));
+        for (int i = 0; i < d.n_cams; ++i) {
+            if (cand_cam_q) for (int j = 0; j < 4; ++j) cand_cam_q[4 * (size_t)i + j] = cams[i].q[j];
+            if (cand_cam_t) for (int j = 0; j < 3; ++j) cand_cam_t[3 * (size_t)i + j] = cams[i].t[j];
+        }
+    }
+    return 0;
+}
+
 #ifdef XBA_TIMELINE
 int xrsfm_ba_debug_stamps(unsigned long long* out) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(xba::g_stamps), sizeof(unsigned long long) * 3 * 64 * 16) == hipSuccess ? 0 : XRSFM_BA_ENODEV;

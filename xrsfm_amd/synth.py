@@ -236,3 +236,146 @@ CONFIGS = {
     # BASELINE.json config 4 with SURVEY.md Appendix D read literally (radius-40 ring, no angle filter)
     "L0": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4, literal_appendix_d=True),
 }
+
+
+def _next_prime(n: int) -> int:
+    p = max(2, int(n))
+    while any(p % q == 0 for q in range(2, int(p ** 0.5) + 1)):
+        p += 1
+    return p
+
+
+def make_collection(n_cams: int, n_points: int, seed: int = 0, cams_per_cluster: int = 150, track_alpha: float = 1.45,
+                    max_track: int = 80, cross_cluster: float = 0.15, shuffle_ids: bool = True, noise: float = 0.5,
+                    outlier_frac: float = 0.02, perturb=(0.01, 0.05, 0.10), min_tri_angle_deg: float = 2.0) -> dict:
+    """Synthetic *unordered photo collection* with viewpoint clusters (the shape of BASELINE.json config 5, 1DSfM Trafalgar:
+    /root/reference/src/rec_1dsfm.cc:66-98 reconstructs ~7.5k internet photos of one plaza; the data set itself is not
+    available offline, so this is a generator of that SIZE and SHAPE, not Trafalgar).
+      * landmarks (clusters) on a ring, 25 units apart; the photos of a landmark are taken from 12-35 units away within
+        +-60 degrees of its outward direction and look at it (+ jitter);
+      * the points of a landmark lie on its "facade" (4 units wide, 5 high, 1 deep);
+      * track lengths follow a power law (2 + Pareto(track_alpha), capped at max_track): most points are seen by 2-4 photos, a
+        few by dozens; a track draws its photos from the point's landmark and, with probability `cross_cluster` per
+        observation, from the two neighbouring landmarks, among the photos that really see the point (in frame, depth > 1);
+      * camera ids are shuffled (an internet collection has no temporal order), so the reduced camera matrix has NO band: each
+        landmark is a dense diagonal block, neighbouring landmarks are coupled by the cross-cluster observations.
+    Same flat arrays, noise model, perturbation and gauge convention (frames 0 and 1 keep their translation) as make_problem()."""
+    rng = np.random.Generator(np.random.PCG64([seed, 424243]))
+    K = max(3, int(round(n_cams / cams_per_cluster)))
+    intr = KITTI_INTR
+    f, cx, cy, _ = intr
+    a = 2 * np.pi * np.arange(K) / K
+    R = 25.0 * K / (2 * np.pi)
+    lm = np.stack([R * np.cos(a), np.zeros(K), R * np.sin(a)], axis=1)
+    cl_of_cam = np.sort(rng.integers(0, K, n_cams))
+    th = a[cl_of_cam] + np.deg2rad(rng.uniform(-60, 60, n_cams))
+    rho = rng.uniform(12.0, 35.0, n_cams)
+    centre = lm[cl_of_cam] + np.stack([rho * np.cos(th), rng.normal(0, 0.3, n_cams), rho * np.sin(th)], axis=1)
+    target = lm[cl_of_cam] + rng.normal(0, 1.5, (n_cams, 3)) * np.array([1.0, 0.3, 1.0])
+    fwd = target - centre
+    fwd /= np.linalg.norm(fwd, axis=1, keepdims=True)
+    up = np.array([0.0, -1.0, 0.0])
+    xc = np.cross(-up[None, :], fwd); xc /= np.linalg.norm(xc, axis=1, keepdims=True)
+    yc = np.cross(fwd, xc)
+    Rcw = np.stack([xc, yc, fwd], axis=1)                 # rows = camera axes in world
+    q_gt = _quat_from_rot(Rcw)
+    Rq = _rot_from_quat(q_gt)
+    t_gt = -np.einsum("nij,nj->ni", Rq, centre)
+    cam_first = np.searchsorted(cl_of_cam, np.arange(K + 1))
+
+    cl_of_pt = np.sort(rng.integers(0, K, n_points))
+    pt_first = np.searchsorted(cl_of_pt, np.arange(K + 1))
+    P_gt = np.empty((n_points, 3))
+    want = np.minimum(max_track, 2 + np.floor(rng.pareto(track_alpha, n_points) * 1.6)).astype(np.int64)
+    obs_cam_l, obs_pt_l = [], []
+    cos_min = np.cos(np.deg2rad(min_tri_angle_deg))
+    for k in range(K):
+        p0, p1 = pt_first[k], pt_first[k + 1]
+        if p1 == p0:
+            continue
+        near = np.concatenate([np.arange(cam_first[kk % K], cam_first[kk % K + 1]) for kk in (k - 1, k, k + 1)]) if K >= 3 else np.arange(n_cams)
+        near = np.unique(near)
+        own = cl_of_cam[near] == k
+        tang = np.array([-np.sin(a[k]), 0.0, np.cos(a[k])]); outw = np.array([np.cos(a[k]), 0.0, np.sin(a[k])])
+        # short tracks (the bulk) draw from 48 random candidate photos, long ones from every photo around the landmark
+        allp = np.arange(p0, p1)
+        for todo, ncand in ((allp[want[allp] <= 12], 48), (allp[want[allp] > 12], near.size)):
+            ncand = min(ncand, near.size)
+            for _round in range(80):
+                if todo.size == 0:
+                    break
+                m = todo.size
+                pw = lm[k] + rng.normal(0, 2.0, (m, 1)) * tang + rng.uniform(-2.5, 2.5, (m, 1)) * np.array([0, 1.0, 0]) + rng.normal(0, 0.5, (m, 1)) * outw
+                if ncand < near.size:        # distinct candidates: an arithmetic progression modulo a prime >= near.size, out-of-range entries masked
+                    start = rng.integers(0, near.size, (m, 1)); stride = rng.integers(1, near.size, (m, 1))
+                    pos = (start + stride * np.arange(ncand)[None, :]) % _next_prime(near.size)
+                    inr = pos < near.size
+                    pos = np.where(inr, pos, 0)
+                else:
+                    pos = np.broadcast_to(np.arange(near.size)[None, :], (m, near.size)); inr = np.ones((m, near.size), bool)
+                cid = near[pos]                                                   # [m, ncand]
+                Pc = np.einsum("mcij,mj->mci", Rq[cid], pw) + t_gt[cid]
+                z = Pc[..., 2]
+                zs = np.where(z > 1e-9, z, 1e-9)
+                u = f * Pc[..., 0] / zs + cx; v = f * Pc[..., 1] / zs + cy
+                vis = inr & (z > 1.0) & (u >= 0) & (u < IMG_W) & (v >= 0) & (v < IMG_H)
+                # random keys: photos of the own landmark first, a photo of a neighbour is preferred with probability cross_cluster
+                key = rng.random((m, ncand))
+                key = np.where(own[pos] | (rng.random((m, ncand)) < cross_cluster), key, key + 1.0)
+                key = np.where(vis, key, np.inf)
+                Lw = want[todo]
+                srt = np.argsort(key, axis=1)
+                cid = np.take_along_axis(cid, srt, axis=1); kk = np.take_along_axis(key, srt, axis=1)
+                take = (np.arange(ncand)[None, :] < Lw[:, None]) & np.isfinite(kk)
+                ok = take.sum(1) >= 2
+                if min_tri_angle_deg > 0:
+                    c8 = cid[:, :8]                         # widest pair among the first (up to) 8 photos of the track
+                    rays = pw[:, None, :] - centre[c8]
+                    rays /= np.linalg.norm(rays, axis=2, keepdims=True)
+                    cosang = np.einsum("mik,mjk->mij", rays, rays)
+                    valid8 = take[:, :8]
+                    cosang = np.where(valid8[:, :, None] & valid8[:, None, :], cosang, 1.0)
+                    ok &= cosang.min(axis=(1, 2)) < cos_min
+                good = np.nonzero(ok)[0]
+                P_gt[todo[good]] = pw[good]
+                rows, cols = np.nonzero(take[good])
+                obs_pt_l.append(todo[good][rows]); obs_cam_l.append(cid[good][rows, cols])
+                todo = todo[~ok]
+            if todo.size:
+                raise RuntimeError("make_collection: could not place all points of a landmark")
+    obs_pt = np.concatenate(obs_pt_l); obs_cam = np.concatenate(obs_cam_l)
+    if shuffle_ids:
+        perm = rng.permutation(n_cams)            # new id of old camera c = perm[c]
+        inv = np.empty(n_cams, np.int64); inv[perm] = np.arange(n_cams)
+        obs_cam = perm[obs_cam]
+        q_gt, t_gt, centre, cl_of_cam = q_gt[inv], t_gt[inv], centre[inv], cl_of_cam[inv]
+    pperm = rng.permutation(n_points)             # points in no particular order either
+    pinv = np.empty(n_points, np.int64); pinv[pperm] = np.arange(n_points)
+    obs_pt = pperm[obs_pt]; P_gt = P_gt[pinv]
+    order = np.lexsort((obs_pt, obs_cam))
+    obs_pt = obs_pt[order].astype(np.int32); obs_cam = obs_cam[order].astype(np.int32)
+    uv, _ = _project_simple_radial(q_gt[obs_cam], t_gt[obs_cam], P_gt[obs_pt], intr)
+    uv = uv + rng.normal(0, noise, uv.shape)
+    n_obs = uv.shape[0]
+    out = rng.random(n_obs) < outlier_frac
+    uv[out] += rng.uniform(-30, 30, (int(out.sum()), 2))
+    s_rot, s_t, s_p = perturb
+    drot = rng.normal(0, s_rot, (n_cams, 3)); drot[0:2] = 0.0
+    dcen = rng.normal(0, s_t, (n_cams, 3)); dcen[0:2] = 0.0
+    q0 = _quat_plus(q_gt, drot)
+    t0 = -np.einsum("nij,nj->ni", _rot_from_quat(q0), centre + dcen)
+    t0[0:2] = t_gt[0:2]; q0[0:2] = q_gt[0:2]
+    P0 = P_gt + rng.normal(0, s_p, (n_points, 3))
+    cam_const = np.zeros(n_cams, np.uint8); cam_const[0:2] = 2
+    return dict(
+        cam_q=np.ascontiguousarray(q0), cam_t=np.ascontiguousarray(t0), cam_const=cam_const,
+        cam_intr=np.zeros(n_cams, np.int32), intr_model=np.array([2], np.int32),
+        intr_params=np.array([[intr[0], intr[1], intr[2], intr[3], 0, 0, 0, 0]], np.float64),
+        points=np.ascontiguousarray(P0), point_const=np.zeros(n_points, np.uint8),
+        obs_cam=obs_cam, obs_pt=obs_pt, obs_uv=np.ascontiguousarray(uv),
+        gt_q=q_gt, gt_t=t_gt, gt_points=P_gt, cluster_of_cam=cl_of_cam,
+    )
+
+
+# BASELINE.json config 5 at its size (docs/en/benchmark.md:93,111: ~7.5k registered frames; ~10M observations estimated)
+CONFIGS["T"] = dict(n_cams=7500, n_points=1_800_000, seed=12)
