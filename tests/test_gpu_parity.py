@@ -795,6 +795,9 @@ def test_headline_config_camera_parity(lib):
     assert erel <= 1e-10
     assert ang <= 1e-6 and dtr <= 1e-4
     assert raw <= 3.0 * raw_cc + 1e-5 and dtr <= 3.0 * dtr_cc + 1e-5
+    # ... and the plain absolute difference keeps an explicit bound (the north star's 1e-5 is NOT met here — measured 3e-5 ..
+    # 1.3e-3 depending on the CPU run's summation order; this catches a regression of the weak modes beyond that)
+    assert raw <= 2e-3
 
 
 @pytest.mark.gpu
@@ -857,3 +860,84 @@ def test_config5_shape_properties(lib):
     prod2 = H.to_product(dict(arr, cam_q=q, cam_t=t, points=P))
     s3 = capi.solve(prod2)
     assert s3.n_successful <= 2 and abs(s3.final_cost - s.final_cost) <= 2e-5 * s.final_cost
+
+
+@pytest.mark.gpu
+def test_config_L0_numbers(lib):
+    """BASELINE.json config 4 with SURVEY Appendix D read literally (1000 cameras on a radius-40 ring: 0.25-unit baselines, no
+    triangulation-angle filter; synth config L0).  A much harder, ill-conditioned problem than the headline workload: the FP64
+    LM trajectories of two exact solvers part at accept / reject decisions (round 2 measured 35 LM iterations on the GPU
+    against 36 in the C restatement, RMSE difference 1.5e-5 px, relative poses within 1.3e-4 rad / 1.8e-3).  Asserted here so
+    that the numbers are a test, not a line in profiles/: iteration counts within +-2, reference-style RMSE within 2e-5 px,
+    relative pose of covisible pairs within 5e-4 rad / 5e-3, and the cost of the returned state is the reported one."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi, parity, synth
+    if not ba_cpu.available():
+        pytest.skip("oracle/_build/libba_cpu.so is not built")
+    d = synth.make_problem(**synth.CONFIGS["L0"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options())
+    c1 = {k: np.array(v, copy=True) for k, v in arr.items()}
+    s1 = ba_cpu.solve(c1, threads=8)
+    n_res = 2 * arr["obs_cam"].shape[0]
+    it_gpu, it_cpu = s.n_successful + s.n_unsuccessful, s1["n_successful"] + s1["n_unsuccessful"]
+    d_rmse = abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s1["final_cost"] / n_res))
+    pairs = parity.covisible_pairs(arr["obs_cam"], arr["obs_pt"])
+    ang, dtr = parity.relative_pose_difference(prod.cam_q, prod.cam_t, c1["cam_q"], c1["cam_t"], pairs)
+    print(f"L0: LM iterations gpu {it_gpu} cpu {it_cpu}, |d rmse| {d_rmse:.2e} px, rel-pose {ang:.2e} rad / {dtr:.2e}")
+    assert abs(it_gpu - it_cpu) <= 2
+    assert d_rmse <= 2e-5
+    assert ang <= 5e-4 and dtr <= 5e-3
+    ref = H.to_oracle(dict(arr, cam_q=prod.cam_q, cam_t=prod.cam_t, points=prod.points))
+    assert abs(bo.evaluate(ref, ref.cam_q, ref.cam_t, ref.points, want_jac=False) - s.final_cost) <= 1e-9 * s.final_cost
+
+
+@pytest.mark.gpu
+def test_config5_size_properties(lib):
+    """BASELINE.json config 5 AT ITS SIZE: 7500 photos / 1.8M points / ~8M observations (docs/en/benchmark.md:93,111 give ~7.5k
+    registered frames for 1DSfM Trafalgar; the data set is not available offline, so synth.make_collection generates an
+    unordered collection of that size with viewpoint clusters, power-law track lengths and shuffled camera ids — no band in
+    the reduced camera matrix, 45 000 camera unknowns: far beyond the exact path, AUTO takes the implicit-Schur PCG).  No oracle
+    finishes at this size, so the checks are the size-independent ones (rec_1dsfm.cc:66-98 runs GBA on exactly this shape):
+    termination by a Ceres rule, cost of the returned state (oracle evaluation) = reported cost, bit-reproducibility of a
+    second run, the gradient max-norm of the objective falls by > 1e2, the RMSE approaches the noise level."""
+    import time
+    from xrsfm_amd import capi, synth
+    t0 = time.time()
+    d = synth.make_collection(**synth.CONFIGS["T"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    n_obs = arr["obs_cam"].shape[0]
+    assert arr["cam_q"].shape[0] >= 7500 and arr["points"].shape[0] >= 1_500_000 and n_obs >= 8_000_000
+    t1 = time.time()
+    ctx = capi.Context(H.to_product(arr))
+    opt = capi.default_options(max_iterations=20, function_tolerance=1e-4, parameter_tolerance=1e-5)     # GBA fast (ba_solver.cc:630-634)
+    s = ctx.run(opt)
+    t2 = time.time()
+    q, t, P = ctx.download()
+    ctx.reset()
+    s2 = ctx.run(opt)
+    q2, t2_, P2 = ctx.download()
+    ctx.close()
+    t3 = time.time()
+    print(f"config T: {n_obs} obs, generate {t1 - t0:.1f} s, create+solve {t2 - t1:.1f} s ({s.n_successful}+{s.n_unsuccessful} LM, "
+          f"{s.pcg_iterations} PCG iterations, solve {s.total_time_s:.2f} s), second run {t3 - t2:.1f} s, rmse {math.sqrt(s.initial_cost / n_obs):.3f} -> "
+          f"{math.sqrt(s.final_cost / n_obs):.3f} px, termination {s.termination}/{s.termination_reason}")
+    assert s.linear_solver_used == capi.SOLVER_PCG and s.pcg_iterations > 0
+    assert s.termination in (0, 1) and s.termination_reason in (2, 3, 5)       # tolerance exit, or the iteration cap of GBA-fast
+    assert s.final_cost < 0.05 * s.initial_cost
+    assert s2.final_cost == s.final_cost and (s2.n_successful, s2.n_unsuccessful) == (s.n_successful, s.n_unsuccessful)
+    assert np.array_equal(q, q2) and np.array_equal(t, t2_) and np.array_equal(P, P2)
+    ref = H.to_oracle(dict(arr, cam_q=q, cam_t=t, points=P))
+    assert abs(bo.evaluate(ref, ref.cam_q, ref.cam_t, ref.points, want_jac=False) - s.final_cost) <= 1e-9 * s.final_cost
+
+    def grad_max(state):
+        pr = H.to_oracle(state)
+        _, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+        gc = bo._scatter_add(pr.cam_q.shape[0], pr.obs_cam, np.einsum("nij,ni->nj", np.asarray(Fc).reshape(-1, 2, 6), rt))
+        gp = bo._scatter_add(pr.points.shape[0], pr.obs_pt, np.einsum("nij,ni->nj", np.asarray(Ep).reshape(-1, 2, 3), rt))
+        return max(float(np.abs(gc).max()), float(np.abs(gp).max()))
+
+    g0, g1 = grad_max(arr), grad_max(dict(arr, cam_q=q, cam_t=t, points=P))
+    print(f"config T: gradient max-norm {g0:.3e} -> {g1:.3e}")
+    assert g1 < 1e-2 * g0
