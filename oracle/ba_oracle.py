@@ -84,6 +84,30 @@ class Options:
     linear_solver: str = "exact"         # "exact" (Schur + Cholesky) | "pcg"
     pcg_tol: float = 1e-12
     pcg_max_iter: int = 500
+    # Sensitivity switches (tools/oracle_sensitivity.py; every default = the recalled Ceres 2.0/2.1 behaviour of SURVEY.md
+    # Appendix A, which is UNPINNED against real Ceres): each flips ONE recalled detail so that its effect on step counts and
+    # the final RMSE can be tabulated.  Never set by tests of the product.
+    alt: str = ""        # one of ALT_DETAILS, or "" for the restatement as recalled
+
+
+# recalled detail -> what the alternative does
+ALT_DETAILS = {
+    "accept_before_tolerance": "a step that triggers the parameter / function tolerance exit is ACCEPTED first if rho allows it (Ceres "
+                               "<= 1.11 order) instead of being discarded (TrustRegionMinimizer::Minimize of 1.12+: tolerance tests precede IsStepSuccessful)",
+    "min_relative_decrease_1e-4": "min_relative_decrease 1e-4 instead of the default 1e-3",
+    "jacobi_scaling_off": "jacobi_scaling = false",
+    "jacobi_scaling_plain_inverse": "column scaling 1/|col| (guarded) instead of 1/(1 + |col|)",
+    "jacobi_scaling_unrobustified": "column norms of the Jacobian BEFORE the loss correction",
+    "lm_diagonal_unclamped": "LM diagonal diag(J^T J)/radius without the clamp to [1e-6, 1e32]",
+    "lm_diagonal_min_1e-9": "min_lm_diagonal 1e-9",
+    "radius_halving_on_reject": "rejected step: radius /= 2 every time (no doubling decrease factor)",
+    "radius_factor_capped_at_2": "accepted step: radius grows by at most 2 (min(3, .) -> min(2, .))",
+    "invalid_step_is_plain_reject": "a step with model_cost_change <= 0 is handled like any rejected step (no invalid-step counter)",
+    "gradient_norm_plain": "gradient tolerance on |g|_inf instead of |x - Plus(x, -g)|_inf",
+    "x_norm_includes_constant_blocks": "the parameter-tolerance test uses |x| over ALL parameters, constant blocks included",
+    "function_tolerance_vs_candidate_cost": "function tolerance |dcost| <= ftol * candidate cost instead of the current cost",
+    "huber_scaling_plain_sqrt_rho1": "(control) identical arithmetic, written as r*sqrt(rho') with rho' recomputed: must change nothing",
+}
 
 
 @dataclasses.dataclass
@@ -414,13 +438,30 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         return math.sqrt(float((q_[qvar] ** 2).sum() + (t_[tvar] ** 2).sum() + (P_[pvar] ** 2).sum()))
 
     a = opt.huber_a
+    alt = opt.alt
+    if alt and alt not in ALT_DETAILS:
+        raise ValueError(f"unknown sensitivity switch {alt!r}")
+    min_rel_decrease = 1e-4 if alt == "min_relative_decrease_1e-4" else opt.min_relative_decrease
+    min_lm_diag = 1e-9 if alt == "lm_diagonal_min_1e-9" else opt.min_lm_diagonal
+    if alt == "x_norm_includes_constant_blocks":
+        def x_norm(q_, t_, P_):          # noqa: F811
+            return math.sqrt(float((q_[cam_act] ** 2).sum() + (t_[cam_act] ** 2).sum() + (P_[act] ** 2).sum()))
     cost, rt, Fc, Ep = evaluate(problem, q, t, P, a)
     summ.initial_cost = cost
     # Jacobi scaling, computed once at iteration 0: 1/(1+||col||)
     ci, pi = problem.obs_cam, problem.obs_pt
-    cn_c = np.sqrt(_scatter_add(q.shape[0], ci, np.sum(Fc * Fc, axis=1)))
-    cn_p = np.sqrt(_scatter_add(P.shape[0], pi, np.sum(Ep * Ep, axis=1)))
+    Fn, En = Fc, Ep
+    if alt == "jacobi_scaling_unrobustified":
+        r_, _valid, Jr_, Jt_, JP_ = project(problem, q, t, P, True)
+        Fn = np.concatenate([Jr_, Jt_], axis=2) * (Fc != 0).any(axis=1, keepdims=True)     # constant blocks stay zero
+        En = JP_ * (Ep != 0).any(axis=1, keepdims=True)
+    cn_c = np.sqrt(_scatter_add(q.shape[0], ci, np.sum(Fn * Fn, axis=1)))
+    cn_p = np.sqrt(_scatter_add(P.shape[0], pi, np.sum(En * En, axis=1)))
     sc_c = 1.0 / (1.0 + cn_c); sc_p = 1.0 / (1.0 + cn_p)
+    if alt == "jacobi_scaling_off":
+        sc_c = np.ones_like(cn_c); sc_p = np.ones_like(cn_p)
+    elif alt == "jacobi_scaling_plain_inverse":
+        sc_c = 1.0 / np.where(cn_c > 0, cn_c, 1.0); sc_p = 1.0 / np.where(cn_p > 0, cn_p, 1.0)
 
     def linearize(rt_, Fc_, Ep_):
         return _Linearization(problem, rt_, Fc_ * sc_c[ci][:, None, :], Ep_ * sc_p[pi][:, None, :])
@@ -429,7 +470,9 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         # Ceres: |x - Plus(x, -g)|_inf with the unscaled gradient
         gc = lin_.gc / sc_c; gp = lin_.gp / sc_p
         m = 0.0
-        if qvar.any():
+        if qvar.any() and alt == "gradient_norm_plain":
+            m = max(m, float(np.abs(gc[qvar, 0:3]).max()))
+        elif qvar.any():
             m = max(m, float(np.abs(q_[qvar] - quat_plus(q_[qvar], -gc[qvar, 0:3])).max()))
         if tvar.any():
             m = max(m, float(np.abs(gc[tvar, 3:6]).max()))
@@ -458,8 +501,11 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         if it >= opt.max_iterations:
             return finish("NO_CONVERGENCE: max iterations", cost)
         it += 1
-        diag_c = np.clip(np.einsum("nii->ni", lin.Hcc), opt.min_lm_diagonal, opt.max_lm_diagonal)
-        diag_p = np.clip(np.einsum("nii->ni", lin.Hpp), opt.min_lm_diagonal, opt.max_lm_diagonal)
+        diag_c = np.clip(np.einsum("nii->ni", lin.Hcc), min_lm_diag, opt.max_lm_diagonal)
+        diag_p = np.clip(np.einsum("nii->ni", lin.Hpp), min_lm_diag, opt.max_lm_diagonal)
+        if alt == "lm_diagonal_unclamped":
+            diag_c = np.einsum("nii->ni", lin.Hcc).copy(); diag_p = np.einsum("nii->ni", lin.Hpp).copy()
+            diag_c[diag_c == 0] = 1e-300; diag_p[diag_p == 0] = 1e-300      # (constant blocks: keep the system non-singular)
         Dc2 = diag_c / radius; Dp2 = diag_p / radius
         if opt.linear_solver == "exact":
             yc, yp, k = _solve_exact(problem, lin, Dc2, Dp2)
@@ -470,6 +516,13 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         # step = -y; model residual m = Js*step
         mres = -(np.einsum("nki,ni->nk", lin.Fs, yc[ci]) + np.einsum("nki,ni->nk", lin.Es, yp[pi]))
         model_change = -float(np.sum(mres * (lin.rt + 0.5 * mres)))
+        if ((not ok) or not (model_change > 0.0)) and alt == "invalid_step_is_plain_reject":
+            radius /= decrease; decrease *= 2.0
+            summ.n_unsuccessful += 1
+            summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=False, invalid=True))
+            if radius < opt.min_radius:
+                return finish("CONVERGENCE: min trust region radius", cost)
+            continue
         if (not ok) or not (model_change > 0.0):
             invalid += 1
             summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=False, invalid=True))
@@ -487,20 +540,28 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         cost2 = evaluate(problem, q2, t2, P2, a, want_jac=False)
         step_norm = math.sqrt(float(((q2 - q)[qvar] ** 2).sum() + ((t2 - t)[tvar] ** 2).sum()
                                     + ((P2 - P)[pvar] ** 2).sum()))
-        if step_norm <= opt.parameter_tolerance * (xn + opt.parameter_tolerance):
-            summ.trace.append(dict(it=it, cost=cost2, radius=radius, ok=None, step_norm=step_norm))
-            return finish("CONVERGENCE: parameter tolerance", cost)
         cost_change = cost - cost2
-        if abs(cost_change) <= opt.function_tolerance * cost:
-            summ.trace.append(dict(it=it, cost=cost2, radius=radius, ok=None, step_norm=step_norm))
-            return finish("CONVERGENCE: function tolerance", cost)
         rel = cost_change / model_change
-        if rel > opt.min_relative_decrease:
+
+        def tolerance_exit(kind):
+            summ.trace.append(dict(it=it, cost=cost2, radius=radius, ok=None, step_norm=step_norm))
+            if alt == "accept_before_tolerance" and rel > min_rel_decrease:
+                nonlocal q, t, P
+                q, t, P = q2, t2, P2
+                summ.n_successful += 1
+                return finish("CONVERGENCE: " + kind, cost2)
+            return finish("CONVERGENCE: " + kind, cost)
+
+        if step_norm <= opt.parameter_tolerance * (xn + opt.parameter_tolerance):
+            return tolerance_exit("parameter tolerance")
+        if abs(cost_change) <= opt.function_tolerance * (cost2 if alt == "function_tolerance_vs_candidate_cost" else cost):
+            return tolerance_exit("function tolerance")
+        if rel > min_rel_decrease:
             q, t, P = q2, t2, P2
             xn = x_norm(q, t, P)
             cost, rt, Fc, Ep = evaluate(problem, q, t, P, a)
             lin = linearize(rt, Fc, Ep)
-            radius = min(opt.max_radius, radius / max(1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) ** 3))
+            radius = min(opt.max_radius, radius / max(0.5 if alt == "radius_factor_capped_at_2" else 1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) ** 3))
             decrease = 2.0
             summ.n_successful += 1
             summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=True, step_norm=step_norm,
@@ -509,6 +570,8 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
                 return finish("CONVERGENCE: gradient tolerance", cost)
         else:
             radius /= decrease; decrease *= 2.0
+            if alt == "radius_halving_on_reject":
+                decrease = 2.0
             summ.n_unsuccessful += 1
             summ.trace.append(dict(it=it, cost=cost, radius=radius, ok=False, step_norm=step_norm,
                                    rel=rel, model_change=model_change))

@@ -236,19 +236,32 @@ def _fuzz_one(gen, seed, solver_override):
     d_cam = max(np.abs(prod.cam_q - pr.cam_q).max(), np.abs(prod.cam_t - pr.cam_t).max())
     if same and d_rmse < 1e-6 and d_cam < 1e-5:
         return "strict"
-    # Not within the strict bounds.  Accepted only if the two CPU restatements (numpy oracle, C port: different summation
-    # orders, both FP64) are at least as far apart from each other on this problem as the HIP result is from the oracle
-    # (x3): ill-conditioned problems (50-100 px RMSE with clamped residuals, 200+ cameras with only two translations fixed)
-    # where the LM trajectory itself is sensitive to rounding.  Anything else is a failure.
-    if not ba_cpu.available():
-        ba_cpu.build()
-    cp = {k: np.array(arr[k], copy=True) for k in arr}
-    sc = ba_cpu.solve(cp, max_iterations=6, threads=1)
-    c_same = (sc["n_successful"], sc["n_unsuccessful"]) == (s_ref.n_successful, s_ref.n_unsuccessful)
-    c_rmse = abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s_ref.final_cost / n_res))
-    c_cam = max(np.abs(cp["cam_q"] - pr.cam_q).max(), np.abs(cp["cam_t"] - pr.cam_t).max())
+    # Not within the strict bounds.  Accepted only if a CPU restatement of the SAME algorithm is at least as far from the
+    # oracle's exact solve on this problem as the HIP result is (x3):
+    #   * exact path: the C port (oracle/ba_cpu.c: another summation order, block-envelope Cholesky, FP64) — ill-conditioned
+    #     problems (50-100 px RMSE with clamped residuals) where the LM trajectory itself is sensitive to rounding;
+    #   * PCG path: the oracle's own implicit-Schur PCG (same iteration, same 1e-12 stopping rule) — on 200+ cameras with only
+    #     two translations fixed, cond(S) ~ 1e10 and a relative residual of 1e-12 leaves the weak (gauge-like) modes of the step
+    #     undetermined at the 1e-3 level: a property of the truncated solve, not of the kernels.
+    # Anything else is a failure.
+    if solver == 0:
+        pp = H.to_oracle(arr)
+        sp = bo.solve(pp, bo.Options(linear_solver="pcg", pcg_tol=1e-12, pcg_max_iter=2000, max_iterations=6))
+        c_same = (sp.n_successful, sp.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+        c_rmse = abs(math.sqrt(sp.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res))
+        c_cam = max(np.abs(pp.cam_q - pr.cam_q).max(), np.abs(pp.cam_t - pr.cam_t).max())
+        who = "oracle PCG"
+    else:
+        if not ba_cpu.available():
+            ba_cpu.build()
+        cp = {k: np.array(arr[k], copy=True) for k in arr}
+        sc = ba_cpu.solve(cp, max_iterations=6, threads=1)
+        c_same = (sc["n_successful"], sc["n_unsuccessful"]) == (s_ref.n_successful, s_ref.n_unsuccessful)
+        c_rmse = abs(math.sqrt(sc["final_cost"] / n_res) - math.sqrt(s_ref.final_cost / n_res))
+        c_cam = max(np.abs(cp["cam_q"] - pr.cam_q).max(), np.abs(cp["cam_t"] - pr.cam_t).max())
+        who = "C port"
     explained = (same or not c_same) and d_rmse <= max(1e-6, 3 * c_rmse) and d_cam <= max(1e-5, 3 * c_cam)
-    return "explained" if explained else f"FAIL seed {seed} solver {solver}: steps {same} d_rmse {d_rmse:.2e} d_cam {d_cam:.2e} | C port: steps {c_same} {c_rmse:.2e} {c_cam:.2e}"
+    return "explained" if explained else f"FAIL seed {seed} solver {solver}: steps {same} d_rmse {d_rmse:.2e} d_cam {d_cam:.2e} | {who}: steps {c_same} {c_rmse:.2e} {c_cam:.2e}"
 
 
 @pytest.mark.gpu

@@ -51,9 +51,39 @@ def run(lib, cfg, path):
     return dict(np.load(path))
 
 
+REPRO_CHILD = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import torch  # noqa: F401
+from xrsfm_amd import capi, synth
+d = synth.make_problem(**synth.CONFIGS[sys.argv[1]])
+prob = capi.ProblemArrays(**{k: np.array(d[k], copy=True) for k in capi.ProblemArrays.FIELDS})
+s = capi.solve(prob)
+print("RESULT", s.n_successful, s.n_unsuccessful, repr(s.final_cost))
+"""
+
+
+def repro(cfg):
+    """Round-2 sources (commit c63e5f7) with k_backsub built for 5 waves per SIMD — (A) as they were, (B) with only
+    cam_update_one / quat_plus of the current tree (no CamRec copy in scratch memory): LM trajectories of a full solve.
+    The libraries are built by hand from a checkout of that commit (finding xi)."""
+    out = {}
+    for name in ("r02_w5", "r02_w5_noscratch"):
+        lib = os.path.join(ROOT, "xrsfm_amd", "lib", f"libxrsfm_ba_{name}.so")
+        if not os.path.exists(lib):
+            out[name] = "library not built"; continue
+        env = dict(os.environ); env["XRSFM_BA_LIB"] = lib
+        r = subprocess.run([sys.executable, "-c", REPRO_CHILD % ROOT, cfg], env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT")]
+        out[name] = line[0] if line else ("rc %d: " % r.returncode) + r.stderr[-400:]
+    return out
+
+
 def main():
     from xrsfm_amd import _build
     cfg = sys.argv[1] if len(sys.argv) > 1 else "S"
+    if len(sys.argv) > 2 and sys.argv[2] == "repro":
+        print(json.dumps(repro(cfg), indent=1)); return
     libs = {"shipped": None, "backsub_w5": _build.build_lib(variant="backsub_w5"), "poison": _build.build_lib(variant="poison")}
     res = {}
     with tempfile.TemporaryDirectory() as td:

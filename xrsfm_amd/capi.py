@@ -130,8 +130,9 @@ def load(path: str | None = None):
     lib.xrsfm_ba_debug_schur_product.restype = C.c_int
     lib.xrsfm_ba_debug_cholesky_solve.argtypes = [vp, C.c_double, _c_double_p, _c_double_p]
     lib.xrsfm_ba_debug_cholesky_solve.restype = C.c_int
-    lib.xrsfm_ba_debug_backsub.argtypes = [vp] + [_c_double_p] * 6
-    lib.xrsfm_ba_debug_backsub.restype = C.c_int
+    if hasattr(lib, "xrsfm_ba_debug_backsub"):      # (absent in the round-2 repro builds of tools/backsub_waves_probe.py)
+        lib.xrsfm_ba_debug_backsub.argtypes = [vp] + [_c_double_p] * 6
+        lib.xrsfm_ba_debug_backsub.restype = C.c_int
     lib.xrsfm_ba_debug_set_block_pattern.argtypes = [vp, C.c_int, _c_int32_p]
     lib.xrsfm_ba_debug_set_block_pattern.restype = C.c_int
     lib.xrsfm_pg_default_options.argtypes = [C.POINTER(CPgOptions)]

@@ -50,18 +50,27 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 //  * long tracks: lane loops over all later observations of its track.
 constexpr int kRedLd = 15;      // row stride (doubles) of the LDS reduction buffer of k_schur_pairs: 64 x 15 x 8 B
 
+// UPPER = false: hc = lower factor {c00 c10 c20 c11 c21 c22} stored by k_point_prep;  UPPER = true: hc = upper factor
+// {c00 c01 c02 c11 c12 c22} of point_factor() (formed in the kernel).  Either way hc hc^T = Hinv and V = W hc.
+template <bool UPPER>
 __device__ __forceinline__ void pairs_V(const double* F, const double* E, const double* __restrict__ hc, double* V) {
-    const double c00 = hc[0], c10 = hc[1], c20 = hc[2], c11 = hc[3], c21 = hc[4], c22 = hc[5];
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
         const double w0 = F[a] * E[0] + F[6 + a] * E[3], w1 = F[a] * E[1] + F[6 + a] * E[4], w2 = F[a] * E[2] + F[6 + a] * E[5];
-        V[3 * a + 0] = w0 * c00 + w1 * c10 + w2 * c20;
-        V[3 * a + 1] = w1 * c11 + w2 * c21;
-        V[3 * a + 2] = w2 * c22;
+        if (UPPER) {
+            V[3 * a + 0] = w0 * hc[0];
+            V[3 * a + 1] = w0 * hc[1] + w1 * hc[3];
+            V[3 * a + 2] = w0 * hc[2] + w1 * hc[4] + w2 * hc[5];
+        } else {
+            V[3 * a + 0] = w0 * hc[0] + w1 * hc[1] + w2 * hc[2];
+            V[3 * a + 1] = w1 * hc[3] + w2 * hc[4];
+            V[3 * a + 2] = w2 * hc[5];
+        }
     }
 }
 
 // diagonal block of S and reduced rhs of one observation:  F^T F - V V^T (upper triangle, 21) | -V C^T g (6) | 0
+template <bool UPPER>
 __device__ __forceinline__ void pairs_diag(const double* F, const double* V, const double* __restrict__ hc,
                                            const double* __restrict__ g, double* o28) {
     int idx = 0;
@@ -72,7 +81,10 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
             o28[idx++] = F[a] * F[c2] + F[6 + a] * F[6 + c2]
                          - (V[3 * a] * V[3 * c2] + V[3 * a + 1] * V[3 * c2 + 1] + V[3 * a + 2] * V[3 * c2 + 2]);
     const double g0 = g[0], g1 = g[1], g2 = g[2];
-    const double u0 = hc[0] * g0 + hc[1] * g1 + hc[2] * g2, u1 = hc[3] * g1 + hc[4] * g2, u2 = hc[5] * g2;
+    // u = hc^T g
+    const double u0 = UPPER ? hc[0] * g0 : hc[0] * g0 + hc[1] * g1 + hc[2] * g2;
+    const double u1 = UPPER ? hc[1] * g0 + hc[3] * g1 : hc[3] * g1 + hc[4] * g2;
+    const double u2 = UPPER ? hc[2] * g0 + hc[4] * g1 + hc[5] * g2 : hc[5] * g2;
 #pragma unroll
     for (int a = 0; a < 6; ++a) o28[21 + a] = -(V[3 * a] * u0 + V[3 * a + 1] * u1 + V[3 * a + 2] * u2);
     o28[27] = 0.0;
@@ -155,10 +167,12 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 // GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
 // needs do not shape its allocation: 118 VGPRs, no spills); GRAM = false: per-pair tiles and long tracks.  The two
 // instantiations write disjoint outputs and run concurrently on two streams.
-template <bool GRAM>
+// PREP = true: the damped point block's factor is formed here from Hpp and the radius (point_factor(): no k_point_prep launch,
+// no Hinv / Hc arrays); false: read from d.Hc (round-2 schedule, XRSFM_BA_PREP_FUSED=0).
+template <bool GRAM, bool PREP>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
-                   int n_obs_pairs, double* __restrict__ scat2) {
+                   int n_obs_pairs, double* __restrict__ scat2, double radius) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     XBA_STAMP(0, 0);
@@ -196,7 +210,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 // compiler issues them after the first batch of loads has returned: one more memory round trip per tile)
                 double hcv[6], gv[3];
                 {
-                    const double* hc = d.Hc + 6 * (size_t)s.pt;
+                    const double* hc = (PREP ? d.Hpp : d.Hc) + 6 * (size_t)s.pt;
                     const double* g = d.gp + 3 * (size_t)s.pt;
 #pragma unroll
                     for (int k = 0; k < 6; ++k) hcv[k] = hc[k];
@@ -204,10 +218,13 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 }
                 double F[12], E[6];
                 load_FE(d, s.slot, s.cam, s.pt, F, E);
+                if (PREP) { double hf[6]; point_factor(hcv, radius, hf);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) hcv[k] = hf[k]; }
                 XBA_STAMP(0, 2);
-                pairs_V(F, E, hcv, V);
+                pairs_V<PREP>(F, E, hcv, V);
                 XBA_STAMP(0, 3);
-                pairs_diag(F, V, hcv, gv, o28);
+                pairs_diag<PREP>(F, V, hcv, gv, o28);
             }
             XBA_STAMP(0, 4);
             const int Cg = GRAM ? d.tile_ncam[it.first_tile] : 0;
@@ -343,13 +360,20 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
     for (int sa = s_begin + lane; sa < s_end; sa += kWave) {
         if (d.slot_cam[sa] < 0) continue;
         const int pt = d.slot_pt[sa];
-        const double* hc = d.Hc + 6 * (size_t)pt;
+        double hc[6];
+        {
+            const double* hp = (PREP ? d.Hpp : d.Hc) + 6 * (size_t)pt;
+            double hv[6];
+            for (int k = 0; k < 6; ++k) hv[k] = hp[k];
+            if (PREP) point_factor(hv, radius, hc);
+            else for (int k = 0; k < 6; ++k) hc[k] = hv[k];
+        }
         double Va[18];
         {
             double Fa[12], Ea[6], o28[28];
             load_FE(d, sa, d.slot_cam[sa], pt, Fa, Ea);
-            pairs_V(Fa, Ea, hc, Va);
-            pairs_diag(Fa, Va, hc, d.gp + 3 * (size_t)pt, o28);
+            pairs_V<PREP>(Fa, Ea, hc, Va);
+            pairs_diag<PREP>(Fa, Va, hc, d.gp + 3 * (size_t)pt, o28);
             double* out = d.scat + 28 * (size_t)d.slot_campos_g[sa];
             for (int k = 0; k < 28; ++k) out[k] = o28[k];
         }
@@ -359,7 +383,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             const int sb = sa + dd;
             double Fb[12], Eb[6], Vb[18];
             load_FE(d, sb, d.slot_cam[sb], pt, Fb, Eb);
-            pairs_V(Fb, Eb, hc, Vb);
+            pairs_V<PREP>(Fb, Eb, hc, Vb);
             double* out = scat2 + 36 * (size_t)pair_dst[pbase + dd - 1];
             for (int rb = 0; rb < 6; ++rb)
                 for (int ca = 0; ca < 6; ++ca)
@@ -373,44 +397,57 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
 // rb is ordered before ca), on diagonal tiles the camera blocks S_cc + D_c^2 and a unit pivot on the padding rows (tile slots
 // without a camera stay decoupled) — and written once.  Diagonal tiles also write their 64 rows of the right-hand side
 // b = g_c + rb in elimination order (padding rows 0).
-__global__ __launch_bounds__(256) void k_tile_fill(CholDev c, Dev d, const int* __restrict__ tiles, const int* __restrict__ tptr,
-                                                   const int* __restrict__ tent, const double* __restrict__ Sblk,
-                                                   const int* __restrict__ blk_rc) {
-    __shared__ double A[kNB][kNB + 1];
-    __shared__ double rl[kNB];
-    const int ti = tiles[2 * blockIdx.x], tj = tiles[2 * blockIdx.x + 1];
+// Compose tile q = (ti,tj) in LDS (row stride LD doubles) and, for a diagonal tile, its 64 right-hand-side rows in rl.
+// Called by all 256 threads; ends with a barrier.
+struct FillLists { const int* tiles; const int* tptr; const int* tent; const double* Sblk; const int* blk_rc;
+                   double radius; };      // radius > 0: the LM diagonal of the camera blocks is formed here (no k_point_prep launch), else read from d.Dc2
+template <int LD>
+__device__ __forceinline__ void compose_tile(const CholDev& c, const Dev& d, const FillLists& f, int q, double* A, double* rl) {
+    const int ti = f.tiles[2 * q], tj = f.tiles[2 * q + 1];
     const int t = threadIdx.x;
     const int nrows = c.tile_rows[ti];
     for (int e = t; e < kNB * kNB; e += 256) {
         const int r = e >> 6, col = e & 63;
-        A[r][col] = (ti == tj && r == col && r >= nrows) ? 1.0 : 0.0;
+        A[r * LD + col] = (ti == tj && r == col && r >= nrows) ? 1.0 : 0.0;
     }
-    if (t < kNB) rl[t] = 0.0;
+    if (rl && t < kNB) rl[t] = 0.0;
     __syncthreads();
-    const int q0 = tptr[blockIdx.x], q1 = tptr[blockIdx.x + 1];
+    const int q0 = f.tptr[q], q1 = f.tptr[q + 1];
     for (int w = t; w < (q1 - q0) * 36; w += 256) {
-        const int ent = tent[q0 + w / 36], e = w % 36, r = e / 6, col = e % 6;
+        const int ent = f.tent[q0 + w / 36], e = w % 36, r = e / 6, col = e % 6;
         if (ent >= 0) {
-            const int orow = c.cam_off[blk_rc[2 * ent]], ocol = c.cam_off[blk_rc[2 * ent + 1]];
-            const double v = -Sblk[36 * (size_t)ent + e];
-            if (orow > ocol) A[(orow & 63) + r][(ocol & 63) + col] = v;
-            else A[(ocol & 63) + col][(orow & 63) + r] = v;
+            const int orow = c.cam_off[f.blk_rc[2 * ent]], ocol = c.cam_off[f.blk_rc[2 * ent + 1]];
+            const double v = -f.Sblk[36 * (size_t)ent + e];
+            if (orow > ocol) A[((orow & 63) + r) * LD + (ocol & 63) + col] = v;
+            else A[((ocol & 63) + col) * LD + (orow & 63) + r] = v;
         } else {
             const int cam = -ent - 1, o = c.cam_off[cam] & 63;
             const double* S = d.camS + 28 * (size_t)cam;
             if (col >= r) {
                 double v = S[6 * r - r * (r - 1) / 2 + (col - r)];      // packed upper triangle (r, col)
-                if (r == col) v += d.Dc2[6 * (size_t)cam + r];
-                A[o + col][o + r] = v;
+                if (r == col) v += f.radius > 0.0 ? clampd(d.camlin[12 * (size_t)cam + r], kLmDiagMin, kLmDiagMax) / f.radius : d.Dc2[6 * (size_t)cam + r];
+                A[(o + col) * LD + o + r] = v;
             }
-            if (e < 6) rl[o + e] = d.camlin[12 * (size_t)cam + 6 + e] + S[21 + e];
+            if (rl && e < 6) rl[o + e] = d.camlin[12 * (size_t)cam + 6 + e] + S[21 + e];
         }
     }
     __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_tile_fill(CholDev c, Dev d, const int* __restrict__ tiles, const int* __restrict__ tptr,
+                                                   const int* __restrict__ tent, const double* __restrict__ Sblk,
+                                                   const int* __restrict__ blk_rc, double radius) {
+    __shared__ double A[kNB * (kNB + 1)];
+    __shared__ double rl[kNB];
+    const FillLists f{tiles, tptr, tent, Sblk, blk_rc, radius};
+    const int q = blockIdx.x;
+    const int ti = tiles[2 * q], tj = tiles[2 * q + 1];
+    const int t = threadIdx.x;
+    compose_tile<kNB + 1>(c, d, f, q, A, rl);
     double* base = c.S + (size_t)(ti * kNB) * c.n_pad + tj * kNB;
     for (int e = t; e < kNB * kNB; e += 256) {
         const int r = e >> 6, col = e & 63;
-        base[(size_t)r * c.n_pad + col] = A[r][col];
+        base[(size_t)r * c.n_pad + col] = A[r * (kNB + 1) + col];
     }
     if (ti == tj && t < kNB) c.rhs[ti * kNB + t] = rl[t];
 }
@@ -446,20 +483,6 @@ __device__ __forceinline__ double row_bcast(double v, int l) {
         case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v); default: return row_bcast_c<15>(v);
     }
 }
-__device__ __forceinline__ double fast_rcp(double u) {               // v_rcp_f64 + 2 Newton steps
-    double r = __builtin_amdgcn_rcp(u);
-    double e = fma(-u, r, 1.0); r = fma(r, e, r);
-    e = fma(-u, r, 1.0); r = fma(r, e, r);
-    return r;
-}
-__device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f64 + 2 Newton steps
-    double y = __builtin_amdgcn_rsq(u);
-    double h = 0.5 * u;
-    y = y * fma(-h * y, y, 1.5);
-    y = y * fma(-h * y, y, 1.5);
-    return y;
-}
-
 // Diagonal tile: L = chol(A) and Linv = L^-1, blocked 16x16.
 //   per block column kb: (a) wave 0 factors the 16x16 diagonal block in registers (lane = row; column
 //   broadcasts are DPP row_newbcast moves, one reciprocal per column, square roots applied once at the end) and
@@ -484,23 +507,50 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     double lcol[16];          // running right-hand side of column `li`; entry r becomes Linv[r][li] at step r
 #pragma unroll
     for (int r = 0; r < 16; ++r) lcol[r] = (r == li) ? 1.0 : 0.0;
+    // Software-pipelined over the columns.  A wave issues in order, and the reciprocal square root of a pivot (v_rsq_f64 + two
+    // Newton steps) is a chain of 7 dependent instructions: left to the compiler it is issued in one piece in front of the
+    // 15 - jj column updates of the step (16 x [chain + updates] = 2.1 us per block, and the pivot tile of every elimination
+    // level is on the critical path of the LM iteration).  Here the update of the NEXT pivot column comes first, its v_rsq_f64
+    // is issued right away, and the six Newton instructions are dealt out between six groups of the remaining column updates
+    // (scheduling barriers pin the order), so the chain's latency hides behind independent work.  Same operations on the same
+    // values as the plain loop (fast_rsqrt spelled out): bit-identical factor.
+#define XBA_POTRF_UPD(cc)                                                \
+    {                                                                    \
+        const double bv_ = row_bcast(a[jj], (cc)); /* u_{cc,jj} */       \
+        a[(cc)] = fma(-tl, bv_, a[(cc)]);                                \
+        lcol[(cc)] = fma(-bv_, xs, lcol[(cc)]);                          \
+    }
+    double sj = fast_rsqrt(row_bcast(a[0], 0));
 #pragma unroll
     for (int jj = 0; jj < 16; ++jj) {
-        const double ujj = row_bcast(a[jj], jj);
-        const double sj = fast_rsqrt(ujj);
         const double tl = a[jj] * (sj * sj);              // u_ij / u_jj
         const double x = lcol[jj] * sj;
         const double xs = x * sj;
         lcol[jj] = x;
+        double y = 0.0, h = 0.0, m = 0.0, e = 0.0;
+        if (jj + 1 < 16) {
+            XBA_POTRF_UPD(jj + 1)
+            const double un = row_bcast(a[jj + 1], jj + 1);
+            y = __builtin_amdgcn_rsq(un);
+            h = 0.5 * un;
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int cc = jj + 1; cc < 16; ++cc) {
-            const double bv = row_bcast(a[jj], cc);       // u_{cc,jj}
-            a[cc] = fma(-tl, bv, a[cc]);
-            lcol[cc] = fma(-bv, xs, lcol[cc]);
+        for (int st = 0; st < 6; ++st) {
+#pragma unroll
+            for (int cc = jj + 2 + st; cc < 16; cc += 6) XBA_POTRF_UPD(cc)
+            if (jj + 1 < 16) {                           // y <- y * fma(-h y, y, 1.5), twice: three instructions each
+                if (st % 3 == 0) m = h * y;
+                else if (st % 3 == 1) e = fma(-m, y, 1.5);
+                else y = y * e;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         a[jj] *= sj;                                       // column jj of L (rows >= jj)
+        sj = y;
         __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later steps from being hoisted (register pressure)
     }
+#undef XBA_POTRF_UPD
     if (lane < 16) {
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) {
@@ -1208,13 +1258,31 @@ __global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict
 //   3. diagonal workgroup: stores L_kk, Linv_k and the forward substitution y_k = Linv_k (rhs_k - sum_j L_kj y_j);
 //      off-diagonal workgroup: L_ik = (A_ik - ...) Linv_k^T.
 // Ceres solves the same system with a supernodal sparse Cholesky (ba_solver.cc:74); this is the exact solve, restated.
+// FILL (first level of the tree; its lists are empty): the tiles are not read from S but composed here from the block values
+// (what k_tile_fill does: one launch and a global round trip of every level-0 tile less per LM iteration; a single-tile
+// system — LBA-sized calls — has no fill launch at all); workgroups >= n_factor compose the tiles of the other columns.
+struct LvFill { Dev d; FillLists f; const int* fz_q; const int* rest; int n_factor; };
+template <bool FILL>
 __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
-                                                   const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px) {
+                                                   const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
+                                                   LvFill lf) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Tb[3][16][17];
     __shared__ double yv[kNB], fv[kNB];
     const int b = blockIdx.x;
+    if (FILL && b >= lf.n_factor) {        // a tile of a later column: compose and store (k_tile_fill)
+        const int q = lf.rest[b - lf.n_factor];
+        const int ti = lf.f.tiles[2 * q], tj = lf.f.tiles[2 * q + 1];
+        compose_tile<kLdT>(c, lf.d, lf.f, q, &A[0][0], yv);
+        double* base = c.S + (size_t)(ti * kNB) * c.n_pad + tj * kNB;
+        for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
+            const int r = e >> 6, col = e & 63;
+            base[(size_t)r * c.n_pad + col] = A[r][col];
+        }
+        if (ti == tj && threadIdx.x < kNB) c.rhs[ti * kNB + threadIdx.x] = yv[threadIdx.x];
+        return;
+    }
     const int i = tiles[2 * b], k = tiles[2 * b + 1];
     const bool diag = (i == k);
     XBA_STAMP(1, 0);
@@ -1228,6 +1296,21 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
     double* Sik = c.S + (size_t)(i * kNB) * ld + k * kNB;
     // the assembled tiles, in the accumulator layout of tile_abt_mfma (requested now, used after the update phase)
     v4d skk[2][2], sik[2][2], akk[2][2], aik[2][2];
+    if (FILL) {
+        // off-diagonal tile first (composed in Li's storage, kept in registers), then the pivot tile straight into A
+        if (!diag) compose_tile<kLdT>(c, lf.d, lf.f, lf.fz_q[2 * b + 1], &Li[0][0], nullptr);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    sik[m][n2][g] = diag ? 0.0 : Li[r0 + 16 * m + lk + 4 * g][c0 + 16 * n2 + li];
+                    skk[m][n2][g] = 0.0; akk[m][n2][g] = 0.0; aik[m][n2][g] = 0.0;
+                }
+        __syncthreads();
+        compose_tile<kLdT>(c, lf.d, lf.f, lf.fz_q[2 * b], &A[0][0], yv);      // yv: the 64 rhs rows of tile k
+    } else {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1239,9 +1322,10 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
                 sik[m][n2][g] = diag ? 0.0 : Sik[(size_t)r * ld + col];
                 akk[m][n2][g] = 0.0; aik[m][n2][g] = 0.0;
             }
+    }
     double fsum = 0.0;              // (diagonal workgroup) this thread's share of sum_j L_kj y_j, row o
     if (t < kNB) fv[t] = 0.0;
-    {
+    if (!FILL) {
         double* As = &A[0][0]; double* Bs = &Li[0][0];
         const int qa = dptr[b], qb = dptr[b + 1];
         double2 ra[8], rb[8];
@@ -1278,6 +1362,9 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
     }
     XBA_STAMP(1, 1);
     // the pivot tile: lower triangle of A_kk - update, identity on the padding rows of Linv
+    // (FILL: A already holds the composed pivot tile — lower triangle, zeros above — and yv its right-hand side)
+    double rhs_k = 0.0;
+    if (FILL && t < kNB) rhs_k = yv[t];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1285,7 +1372,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = r0 + 16 * m + lk + 4 * g, col = c0 + 16 * n2 + li;
-                A[r][col] = (col <= r) ? skk[m][n2][g] - akk[m][n2][g] : 0.0;
+                if (!FILL) A[r][col] = (col <= r) ? skk[m][n2][g] - akk[m][n2][g] : 0.0;
                 Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
             }
     __syncthreads();
@@ -1302,7 +1389,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
             const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
             reinterpret_cast<double2*>(lo)[e] = make_double2((col <= r) ? Li[r][col] : 0.0, (col + 1 <= r) ? Li[r][col + 1] : 0.0);
         }
-        if (t < kNB) yv[t] = c.rhs[k * kNB + t] - fv[t];
+        if (t < kNB) yv[t] = (FILL ? rhs_k : c.rhs[k * kNB + t]) - fv[t];
         __syncthreads();
         double sacc = 0.0;
 #pragma unroll

@@ -917,12 +917,15 @@ __device__ __forceinline__ void cam_update_one(const Dev& d, int c, const double
 
 // y_p = Hinv (g_p - sum E^T F y_c); model cost change; candidate points.
 // Workgroups >= n_item_blocks: candidate cameras from the camera part of the solution (thread = camera; cam_update_one).
+// PREP = true: the damped point block is factored here from Hpp and the radius (point_factor(), u = C (C^T a)); false: read
+// Hinv as k_point_prep stored it (PCG path, XRSFM_BA_PREP_FUSED=0).
+template <bool PREP>
 #if XBA_BACKSUB_WAVES > 0
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(XBA_BACKSUB_WAVES, XBA_BACKSUB_WAVES)))
 #else
 __global__ __launch_bounds__(kBlock)
 #endif
-void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
+void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, double radius) {
     if ((int)blockIdx.x >= n_item_blocks) {
         const int c = (blockIdx.x - n_item_blocks) * kBlock + threadIdx.x;
         if (c < d.n_cams) cam_update_one(d, c, d.px + 6 * (size_t)c, camrec_cand);
@@ -946,7 +949,7 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
         double spv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD}, Pv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
         bool var = false;
         if (s.valid) {
-            const double* h = d.Hinv + 6 * (size_t)s.pt;
+            const double* h = (PREP ? d.Hpp : d.Hinv) + 6 * (size_t)s.pt;
             const double* g = d.gp + 3 * (size_t)s.pt;
             const double* sp = d.scale_p + 3 * (size_t)s.pt;
             const double* P = d.P + 3 * (size_t)s.pt;
@@ -972,9 +975,18 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
         double u[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};      // head lanes compute it, the lanes of the track fetch it from their head
         if (s.head) {
             const double a0 = gg[0] - w[0], a1 = gg[1] - w[1], a2 = gg[2] - w[2];
-            u[0] = hh[0] * a0 + hh[1] * a1 + hh[2] * a2;
-            u[1] = hh[1] * a0 + hh[3] * a1 + hh[4] * a2;
-            u[2] = hh[2] * a0 + hh[4] * a1 + hh[5] * a2;
+            if (PREP) {
+                double cf[6];
+                point_factor(hh, radius, cf);                     // Hinv = C C^T, C upper {c00 c01 c02 c11 c12 c22}
+                const double s0 = cf[0] * a0, s1 = cf[1] * a0 + cf[3] * a1, s2 = cf[2] * a0 + cf[4] * a1 + cf[5] * a2;
+                u[0] = cf[0] * s0 + cf[1] * s1 + cf[2] * s2;
+                u[1] = cf[3] * s1 + cf[4] * s2;
+                u[2] = cf[5] * s2;
+            } else {
+                u[0] = hh[0] * a0 + hh[1] * a1 + hh[2] * a2;
+                u[1] = hh[1] * a0 + hh[3] * a1 + hh[4] * a2;
+                u[2] = hh[2] * a0 + hh[4] * a1 + hh[5] * a2;
+            }
             double* Pc = d.P_cand + 3 * (size_t)s.pt;
             double* yo = d.yp + 3 * (size_t)s.pt;
 #pragma unroll
@@ -1014,13 +1026,23 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { wsum[k] = wave_sum(wsum[k]); wsum[k] = __shfl(wsum[k], 0, kWave); }
         pt0 = __shfl(pt0, 0, kWave);
-        const double* h = d.Hinv + 6 * (size_t)pt0;
+        const double* h = (PREP ? d.Hpp : d.Hinv) + 6 * (size_t)pt0;
         const double* g = d.gp + 3 * (size_t)pt0;
         const double a0 = g[0] - wsum[0], a1 = g[1] - wsum[1], a2 = g[2] - wsum[2];
         double u[3];
-        u[0] = h[0] * a0 + h[1] * a1 + h[2] * a2;
-        u[1] = h[1] * a0 + h[3] * a1 + h[4] * a2;
-        u[2] = h[2] * a0 + h[4] * a1 + h[5] * a2;
+        if (PREP) {
+            const double hv[6] = {h[0], h[1], h[2], h[3], h[4], h[5]};
+            double cf[6];
+            point_factor(hv, radius, cf);
+            const double s0 = cf[0] * a0, s1 = cf[1] * a0 + cf[3] * a1, s2 = cf[2] * a0 + cf[4] * a1 + cf[5] * a2;
+            u[0] = cf[0] * s0 + cf[1] * s1 + cf[2] * s2;
+            u[1] = cf[3] * s1 + cf[4] * s2;
+            u[2] = cf[5] * s2;
+        } else {
+            u[0] = h[0] * a0 + h[1] * a1 + h[2] * a2;
+            u[1] = h[1] * a0 + h[3] * a1 + h[4] * a2;
+            u[2] = h[2] * a0 + h[4] * a1 + h[5] * a2;
+        }
         if (lane == 0) {
             const double* sp = d.scale_p + 3 * (size_t)pt0;
             const double* P = d.P + 3 * (size_t)pt0;

@@ -138,4 +138,41 @@ __device__ __forceinline__ void sym3_inverse(const double h[6], double inv[6]) {
 
 __device__ __forceinline__ double clampd(double v, double lo, double hi) { return fmin(fmax(v, lo), hi); }
 
+__device__ __forceinline__ double fast_rcp(double u) {               // v_rcp_f64 + 2 Newton steps
+    double r = __builtin_amdgcn_rcp(u);
+    double e = fma(-u, r, 1.0); r = fma(r, e, r);
+    e = fma(-u, r, 1.0); r = fma(r, e, r);
+    return r;
+}
+__device__ __forceinline__ double fast_rsqrt(double u) {             // v_rsq_f64 + 2 Newton steps
+    double y = __builtin_amdgcn_rsq(u);
+    double h = 0.5 * u;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+// LM damping of Ceres' LevenbergMarquardtStrategy: D^2 = clamp(diag(J^T J), min_lm_diagonal, max_lm_diagonal) / radius
+constexpr double kLmDiagMin = 1e-6, kLmDiagMax = 1e32;
+
+// Damped point block H = Hpp + D^2 (Hpp: upper triangle {00,01,02,11,12,22}) -> upper-triangular C = L^-T of its Cholesky
+// factor H = L L^T, so that H^-1 = C C^T: out = {c00, c01, c02, c11, c12, c22}.  What k_point_prep used to store per point
+// (48 + 48 bytes written, read again by the S assembly and the back-substitution) is ~45 instructions on the 48 bytes of Hpp
+// the consumers load instead.  Three reciprocal square roots, no division.
+__device__ __forceinline__ void point_factor(const double h[6], double radius, double c[6]) {
+    const double ir = 1.0 / radius;
+    const double h00 = fma(clampd(h[0], kLmDiagMin, kLmDiagMax), ir, h[0]);
+    const double h11 = fma(clampd(h[3], kLmDiagMin, kLmDiagMax), ir, h[3]);
+    const double h22 = fma(clampd(h[5], kLmDiagMin, kLmDiagMax), ir, h[5]);
+    const double r0 = fast_rsqrt(h00);
+    const double l10 = h[1] * r0, l20 = h[2] * r0;
+    const double r1 = fast_rsqrt(fmax(fma(-l10, l10, h11), 1e-300));
+    const double l21 = fma(-l20, l10, h[4]) * r1;
+    const double r2 = fast_rsqrt(fmax(fma(-l21, l21, fma(-l20, l20, h22)), 1e-300));
+    const double m10 = -l10 * r0 * r1;
+    const double m21 = -l21 * r1 * r2;
+    const double m20 = -fma(l20, r0, l21 * m10) * r2;
+    c[0] = r0; c[1] = m10; c[2] = m20; c[3] = r1; c[4] = m21; c[5] = r2;
+}
+
 }  // namespace xba

@@ -51,6 +51,8 @@ struct CholPlan {
     //                 (it then also contributes to tile (i,k)), ~j otherwise;
     //   split level:  empty lists (k_ll_update_part + k_ll_update_reduce have updated the tiles and the right-hand side in place).
     std::vector<int> fz_tile, fz_dptr, fz_dj, fz_off;
+    std::vector<int> fz_q;              // per fused-kernel entry: index in tiles_nz of (k,k) and of (i,k) (fill lists tf_ptr / tf_ent)
+    std::vector<int> fill_rest;         // tiles_nz indices of the tiles whose column is not in level 0
     std::vector<int> tile_cam;          // [T][kCamsPerTile] camera in slot q of tile t, -1 = none (backward kernel: candidate cameras)
 };
 
@@ -313,9 +315,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { P.tiles_nz.push_back(kk); P.tiles_nz.push_back(j); }
     }
     P.n_tiles_nz = (int)P.tiles_nz.size() / 2;
+    std::vector<int> tile_id((size_t)T * T, -1);
+    for (int q = 0; q < P.n_tiles_nz; ++q) tile_id[(size_t)P.tiles_nz[2 * q] * T + P.tiles_nz[2 * q + 1]] = q;
     {
-        std::vector<int> tile_id((size_t)T * T, -1);
-        for (int q = 0; q < P.n_tiles_nz; ++q) tile_id[(size_t)P.tiles_nz[2 * q] * T + P.tiles_nz[2 * q + 1]] = q;
         std::vector<int> cnt(P.n_tiles_nz + 1, 0);
         auto tile_of_block = [&](int b) {
             const int ti = P.cam_off[blk_rc[2 * b]] / kPlanTile, tj = P.cam_off[blk_rc[2 * b + 1]] / kPlanTile;
@@ -493,6 +495,15 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     }
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);
+    // tile fill fused into the first level's factor launch (k_lv_factor<true>): every workgroup of a level-0 column composes
+    // its tiles (k,k) and (i,k) from the block values itself; the tiles of all other columns are composed by extra workgroups
+    // of the same launch (fill_rest)
+    P.fz_q.resize(P.fz_tile.size());
+    for (size_t e = 0; e < P.fz_tile.size() / 2; ++e) {
+        const int i = P.fz_tile[2 * e], k2 = P.fz_tile[2 * e + 1];
+        P.fz_q[2 * e] = tile_id[(size_t)k2 * T + k2]; P.fz_q[2 * e + 1] = tile_id[(size_t)i * T + k2];
+    }
+    for (int q = 0; q < P.n_tiles_nz; ++q) if (level[P.tiles_nz[2 * q + 1]] != 0) P.fill_rest.push_back(q);
     if (std::getenv("XRSFM_BA_PLAN_CHECK") && T <= 96) {
         // Self-check of the fused schedule (tests/test_plan_cpu.py, no GPU): every structurally non-zero tile (i,k) must receive
         // each contribution j < k with L_ij and L_kj non-zero exactly once — from a macro-tile entry, a chunk of a split level or

@@ -115,6 +115,8 @@ struct CholHost {
     int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
     double* sp_work = nullptr;
     int *fz_tile = nullptr, *fz_dptr = nullptr, *fz_dj = nullptr, *tile_cam = nullptr;   // fused level kernel (ba_plan.h)
+    int *fz_q = nullptr, *fill_rest = nullptr; int n_fill_rest = 0;    // tile fill inside the first level's launch
+    bool S_filled = false;                                   // chol_assemble ran k_tile_fill (else the first level composes its tiles)
     std::vector<int> fz_off;
     int* zero2 = nullptr;                                    // two zeros: an empty CSR row list
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
@@ -146,6 +148,10 @@ struct xrsfm_ba_context {
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
     bool linearized = false;
     bool fused = true;              // fused level kernels / linearisation tail (XRSFM_BA_FUSED=0: the launch-per-phase schedule, A/B aid)
+    bool prep_fused = true;         // Cholesky path: damped point blocks factored inside k_schur_pairs / k_backsub, LM diagonal of the
+                                    // cameras inside the tile fill: no k_point_prep launch (XRSFM_BA_PREP_FUSED=0: round-2 schedule)
+    double step_radius = 0.0;       // radius of the step being assembled / solved (prepare_step)
+    bool step_prep = false;         // ... and whether its kernels form the point factors themselves
     bool gradmax_done = false, published = false;    // the linearisation tail did these in its own launch
     double* part2 = nullptr; unsigned* ticket = nullptr;      // k_lin_tail
     // Second set of linearisation buffers: every LM step linearises at the CANDIDATE point right after the back-substitution
@@ -463,7 +469,10 @@ int gradient_max(xrsfm_ba_context* c, double* out) {
 // Everything that depends on the radius: D^2, Hpp^-1, diagonal blocks of S and the reduced right-hand side.
 int prepare_step(xrsfm_ba_context* c, double radius, bool with_blocks = false) {
     Dev& d = c->d;
-    const double dmin = 1e-6, dmax = 1e32;
+    const double dmin = kLmDiagMin, dmax = kLmDiagMax;
+    c->step_radius = radius;
+    c->step_prep = with_blocks && c->prep_fused;
+    if (c->step_prep) return 0;     // Cholesky path: k_schur_pairs / k_backsub / the tile fill form what they need from Hpp, camlin and the radius
     {
         const int nbp = cdiv(d.n_pts, kBlock), nbc = cdiv((long long)d.n_cams * 6, kBlock);
         if (nbp + nbc > 0) LAUNCH(c, K_SMALL, k_point_prep, dim3(nbp + nbc), dim3(kBlock), 0, d, radius, dmin, dmax, nbp);
@@ -570,6 +579,7 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp);
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
     up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
+    up.add(&h.fz_q, P.fz_q); up.add(&h.fill_rest, P.fill_rest); h.n_fill_rest = (int)P.fill_rest.size();
     up.add(&h.tile_cam, P.tile_cam);
     const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
     up.add(&h.zero2, two_zeros);
@@ -601,8 +611,10 @@ int chol_setup(xrsfm_ba_context* c) {
             (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
             done_for[c->device] = 1;
         }
     }
@@ -616,8 +628,10 @@ int chol_setup(xrsfm_ba_context* c) {
     return 0;
 }
 
-// Assemble the reduced camera matrix in dense tile storage (after prepare_step)
-int chol_assemble(xrsfm_ba_context* c) {
+// Assemble the reduced camera matrix (after prepare_step): block values, and — unless the fused level schedule composes the
+// tiles inside its first launch (chol_factor_solve) — the dense tile storage.  materialize: always fill the tiles here
+// (diagnostics that read S before the factorisation).
+int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
     Dev& d = c->d;
     CholHost& h = c->chol;
     const int n_obs_pairs = h.n_pairs - c->pk.n_gt_cells;
@@ -625,26 +639,36 @@ int chol_assemble(xrsfm_ba_context* c) {
         // stream: it is usually tiny and would otherwise add its full latency); the profile counts the pass
         Timed t_(c, K_SCHUR_PAIRS);
         const bool fork = h.n_pairs_other > 0 && h.aux;
+        const double radius = c->step_radius;
+        auto launch_pairs = [&](bool gram, int n, size_t shm, hipStream_t st, const int* items) {
+            if (gram) {
+                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+                else hipLaunchKernelGGL((k_schur_pairs<true, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+            } else {
+                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+                else hipLaunchKernelGGL((k_schur_pairs<false, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+            }
+        };
         if (fork) {
             HIPCHK(hipEventRecord(h.ev_fork, c->stream));
             HIPCHK(hipStreamWaitEvent(h.aux, h.ev_fork, 0));
-            hipLaunchKernelGGL(k_schur_pairs<false>, dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, h.aux, d, h.pairs_items + h.n_pairs_small + h.n_pairs_big,
-                               h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+            launch_pairs(false, h.n_pairs_other, h.pairs_shm, h.aux, h.pairs_items + h.n_pairs_small + h.n_pairs_big);
             HIPCHK(hipEventRecord(h.ev_join, h.aux));
         } else if (h.n_pairs_other > 0) {
-            hipLaunchKernelGGL(k_schur_pairs<false>, dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, c->stream, d, h.pairs_items + h.n_pairs_small + h.n_pairs_big,
-                               h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+            launch_pairs(false, h.n_pairs_other, h.pairs_shm, c->stream, h.pairs_items + h.n_pairs_small + h.n_pairs_big);
         }
-        if (h.n_pairs_small > 0)
-            hipLaunchKernelGGL(k_schur_pairs<true>, dim3(h.n_pairs_small), dim3(kWave), h.pairs_shm, c->stream, d, h.pairs_items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
-        if (h.n_pairs_big > 0)
-            hipLaunchKernelGGL(k_schur_pairs<true>, dim3(h.n_pairs_big), dim3(kWave), h.pairs_shm_big, c->stream, d, h.pairs_items + h.n_pairs_small, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2);
+        if (h.n_pairs_small > 0) launch_pairs(true, h.n_pairs_small, h.pairs_shm, c->stream, h.pairs_items);
+        if (h.n_pairs_big > 0) launch_pairs(true, h.n_pairs_big, h.pairs_shm_big, c->stream, h.pairs_items + h.n_pairs_small);
         if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
     if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
-    if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc);
+    static const bool fill_in_level0 = [] { const char* e = std::getenv("XRSFM_BA_FILL_FUSED"); return !(e && e[0] == '0'); }();
+    h.S_filled = materialize || !fill_in_level0 || !((h.use_levels || h.panel_ll) && c->fused);
+    if (h.S_filled && h.n_tiles_nz > 0)
+        LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc,
+               c->step_prep ? c->step_radius : 0.0);
     return 0;
 }
 
@@ -673,9 +697,18 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             // the columns of the last level have nothing below them: their backward substitution rides in the same launch
             // (a single-tile system — LBA-sized calls — is its own last level on either schedule)
             const bool with_bwd = (!h.panel_ll || T == 1) && lv == h.n_levels - 1;
-            if (nf > 0)
-                LAUNCH(c, K_POTRF, k_lv_factor, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
-                       (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr);
+            LvFill lf{};
+            if (lv == 0 && !h.S_filled) {
+                // first level: its workgroups compose their tiles from the block values (no k_tile_fill launch, no round trip
+                // through S); trailing workgroups compose the tiles of all other columns
+                lf.d = d; lf.f = FillLists{h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, c->step_prep ? c->step_radius : 0.0};
+                lf.fz_q = h.fz_q; lf.rest = h.fill_rest; lf.n_factor = nf;
+                if (nf + h.n_fill_rest > 0)
+                    LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + h.n_fill_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
+                           (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr, lf);
+            } else if (nf > 0)
+                LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
+                       (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr, lf);
         }
         if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
@@ -771,7 +804,11 @@ int finish_step(xrsfm_ba_context* c, double huber_a, bool speculate) {
     const bool cams_done = c->fused;
     {
         const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cams_done ? cdiv(d.n_cams, kBlock) : 0;
-        if (nbi + nbc > 0) LAUNCH(c, K_BACKSUB, k_backsub, dim3(nbi + nbc), dim3(kBlock), 0, d, nbi, (cams_done && speculate) ? c->alt.camrec : (CamLin*)nullptr);
+        CamLin* cr = (cams_done && speculate) ? c->alt.camrec : (CamLin*)nullptr;
+        if (nbi + nbc > 0) {
+            if (c->step_prep) LAUNCH(c, K_BACKSUB, k_backsub<true>, dim3(nbi + nbc), dim3(kBlock), 0, d, nbi, cr, c->step_radius);
+            else LAUNCH(c, K_BACKSUB, k_backsub<false>, dim3(nbi + nbc), dim3(kBlock), 0, d, nbi, cr, c->step_radius);
+        }
     }
     if (d.n_cams > 0 && !cams_done) LAUNCH(c, K_SMALL, k_cam_update, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (speculate) {
@@ -1014,6 +1051,8 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
     {
         const char* fz = std::getenv("XRSFM_BA_FUSED");
         c->fused = !(fz && fz[0] == '0');
+        const char* pf = std::getenv("XRSFM_BA_PREP_FUSED");
+        c->prep_fused = !(pf && pf[0] == '0');
     }
     // (the scatter buffers need no clearing: every entry is written before it is read)
     if (hipMemsetAsync(d.scal, 0, sizeof(double) * S_COUNT, c->stream) != hipSuccess || hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream) != hipSuccess ||
@@ -1690,7 +1729,7 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
     int e;
     if ((e = chol_setup(c))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
     if ((e = prepare_step(c, radius, true))) return e;
-    if ((e = chol_assemble(c))) return e;
+    if ((e = chol_assemble(c, S_dense != nullptr))) return e;      // (the fused fill of the first level is what a plain call runs)
     const CholDev& cd = c->chol.dev;
     if (S_dense) {
         std::vector<double> h((size_t)cd.n_pad * cd.n_pad);
@@ -1720,7 +1759,10 @@ int xrsfm_ba_debug_backsub(xrsfm_ba_context* c, double* part_model, double* part
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
     const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cdiv(d.n_cams, kBlock);
-    if (nbi + nbc > 0) hipLaunchKernelGGL(k_backsub, dim3(nbi + nbc), dim3(kBlock), 0, c->stream, d, nbi, (CamLin*)nullptr);
+    if (nbi + nbc > 0) {
+        if (c->step_prep) hipLaunchKernelGGL(k_backsub<true>, dim3(nbi + nbc), dim3(kBlock), 0, c->stream, d, nbi, (CamLin*)nullptr, c->step_radius);
+        else hipLaunchKernelGGL(k_backsub<false>, dim3(nbi + nbc), dim3(kBlock), 0, c->stream, d, nbi, (CamLin*)nullptr, c->step_radius);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     const size_t ni = (size_t)d.n_items, np = (size_t)d.n_pts;
