@@ -106,7 +106,6 @@ ALT_DETAILS = {
     "gradient_norm_plain": "gradient tolerance on |g|_inf instead of |x - Plus(x, -g)|_inf",
     "x_norm_includes_constant_blocks": "the parameter-tolerance test uses |x| over ALL parameters, constant blocks included",
     "function_tolerance_vs_candidate_cost": "function tolerance |dcost| <= ftol * candidate cost instead of the current cost",
-    "huber_scaling_plain_sqrt_rho1": "(control) identical arithmetic, written as r*sqrt(rho') with rho' recomputed: must change nothing",
 }
 
 
