@@ -315,7 +315,7 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], 
                              int32_t *slot_campos_g);
 
 /* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
- * (0 natural, 1 nested dissection of a band/ring), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
+ * (0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee of an unordered collection), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
  * [6] level schedule used (else the panel schedule of deep elimination trees: dense / unordered patterns), [7] structurally
  * non-zero tiles after fill.  cam_offset (may be NULL):
  * [n_cams] first row of each camera in the elimination order. */

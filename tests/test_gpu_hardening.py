@@ -196,16 +196,27 @@ def _run_variant(lib_path, out):
 @pytest.mark.gpu
 def test_poisoned_dead_lanes_change_nothing(lib, tmp_path):
     """libxrsfm_ba_poison.so = the same sources built with -DXBA_POISON: every per-lane temporary a lane without an observation
-    (or a non-head lane) must not read holds NaN instead of 0.  Whole solves must come out bit-identical: a value leaking from
-    such a lane through a shuffle, an LDS sum or a store would turn into NaN (or at least change a bit)."""
+    (or a non-head lane) must not read holds NaN instead of 0.  Whole solves must come out bit-identical to the build without
+    the poison (both compiled without FP contraction, so that they evaluate the same expression trees): a value leaking from
+    such a lane through a shuffle, an LDS sum or a store turns into NaN, and one that only reaches an fmax / a comparison
+    (where NaN is silently dropped) still changes bits."""
     from xrsfm_amd import _build
     poison = _build.build_lib(variant="poison")
-    a = _run_variant(None, str(tmp_path / "normal.npz"))
+    strict = _build.build_lib(variant="strict")          # same flags (-ffp-contract=off) without the poison
+    a = _run_variant(strict, str(tmp_path / "strict.npz"))
     b = _run_variant(poison, str(tmp_path / "poison.npz"))
     assert sorted(a.files) == sorted(b.files) and len(a.files) >= 40
     for k in a.files:
         assert np.isfinite(b[k]).all(), k
         assert np.array_equal(a[k], b[k]), k
+    # ... and the shipped build (FP contraction on) solves the same problems to the same result up to rounding
+    c = _run_variant(None, str(tmp_path / "shipped.npz"))
+    for k in a.files:
+        if k.endswith("_s"):
+            assert np.array_equal(a[k][2:4], c[k][2:4]), k                 # LM step counts
+            assert abs(a[k][1] - c[k][1]) <= 1e-7 * abs(a[k][1]), k       # final cost
+        elif not k.endswith("_P"):
+            assert np.abs(a[k] - c[k]).max() < 1e-5, k                      # cameras (gauge-weak problems: see _fuzz_one)
 
 
 # ------------------------------------------------------------------------------------------------ extended fuzz, budgeted

@@ -897,8 +897,10 @@ def test_config_L0_numbers(lib):
 def test_config5_size_properties(lib):
     """BASELINE.json config 5 AT ITS SIZE: 7500 photos / 1.8M points / ~8M observations (docs/en/benchmark.md:93,111 give ~7.5k
     registered frames for 1DSfM Trafalgar; the data set is not available offline, so synth.make_collection generates an
-    unordered collection of that size with viewpoint clusters, power-law track lengths and shuffled camera ids — no band in
-    the reduced camera matrix, 45 000 camera unknowns: far beyond the exact path, AUTO takes the implicit-Schur PCG).  No oracle
+    unordered collection of that size with viewpoint clusters, power-law track lengths and shuffled camera ids — 45 000 camera
+    unknowns, no band in the natural order: until round 2 only the implicit-Schur PCG ran at this size (block-Jacobi: 1800
+    iterations per LM step, 10 s per solve); with the reverse Cuthill-McKee order of the camera graph the exact tile Cholesky
+    does).  No oracle
     finishes at this size, so the checks are the size-independent ones (rec_1dsfm.cc:66-98 runs GBA on exactly this shape):
     termination by a Ceres rule, cost of the returned state (oracle evaluation) = reported cost, bit-reproducibility of a
     second run, the gradient max-norm of the objective falls by > 1e2, the RMSE approaches the noise level."""
@@ -918,18 +920,28 @@ def test_config5_size_properties(lib):
     ctx.reset()
     s2 = ctx.run(opt)
     q2, t2_, P2 = ctx.download()
-    ctx.close()
     t3 = time.time()
     print(f"config T: {n_obs} obs, generate {t1 - t0:.1f} s, create+solve {t2 - t1:.1f} s ({s.n_successful}+{s.n_unsuccessful} LM, "
-          f"{s.pcg_iterations} PCG iterations, solve {s.total_time_s:.2f} s), second run {t3 - t2:.1f} s, rmse {math.sqrt(s.initial_cost / n_obs):.3f} -> "
-          f"{math.sqrt(s.final_cost / n_obs):.3f} px, termination {s.termination}/{s.termination_reason}")
-    assert s.linear_solver_used == capi.SOLVER_PCG and s.pcg_iterations > 0
+          f"solver {s.linear_solver_used}, {s.pcg_iterations} PCG iterations, solve {s.total_time_s:.2f} s), second run {t3 - t2:.1f} s ({s2.total_time_s:.2f} s), "
+          f"rmse {math.sqrt(s.initial_cost / n_obs):.3f} -> {math.sqrt(s.final_cost / n_obs):.3f} px, termination {s.termination}/{s.termination_reason}")
+    # round 3: the reverse Cuthill-McKee order of the camera graph (ba_plan.h) keeps the exact solve affordable at this size
+    assert s.linear_solver_used == capi.SOLVER_CHOLESKY
     assert s.termination in (0, 1) and s.termination_reason in (2, 3, 5)       # tolerance exit, or the iteration cap of GBA-fast
     assert s.final_cost < 0.05 * s.initial_cost
     assert s2.final_cost == s.final_cost and (s2.n_successful, s2.n_unsuccessful) == (s.n_successful, s.n_unsuccessful)
     assert np.array_equal(q, q2) and np.array_equal(t, t2_) and np.array_equal(P, P2)
     ref = H.to_oracle(dict(arr, cam_q=q, cam_t=t, points=P))
     assert abs(bo.evaluate(ref, ref.cam_q, ref.cam_t, ref.points, want_jac=False) - s.final_cost) <= 1e-9 * s.final_cost
+    # the implicit-Schur PCG (the only path at this size until round 2) from the same start: the same LM decisions, the same
+    # cost up to what a truncated linear solve leaves
+    ctx.reset()
+    sp = ctx.run(capi.default_options(max_iterations=20, function_tolerance=1e-4, parameter_tolerance=1e-5, linear_solver=capi.SOLVER_PCG))
+    ctx.close()
+    print(f"config T, PCG: {sp.n_successful}+{sp.n_unsuccessful} LM, {sp.pcg_iterations} PCG iterations, solve {sp.total_time_s:.2f} s, "
+          f"rmse {math.sqrt(sp.final_cost / n_obs):.6f} vs {math.sqrt(s.final_cost / n_obs):.6f} px")
+    assert sp.linear_solver_used == capi.SOLVER_PCG and sp.pcg_iterations > 0
+    assert (sp.n_successful, sp.n_unsuccessful) == (s.n_successful, s.n_unsuccessful)
+    assert abs(math.sqrt(sp.final_cost / n_obs) - math.sqrt(s.final_cost / n_obs)) < 1e-4
 
     def grad_max(state):
         pr = H.to_oracle(state)
@@ -941,3 +953,37 @@ def test_config5_size_properties(lib):
     g0, g1 = grad_max(arr), grad_max(dict(arr, cam_q=q, cam_t=t, points=P))
     print(f"config T: gradient max-norm {g0:.3e} -> {g1:.3e}")
     assert g1 < 1e-2 * g0
+
+
+@pytest.mark.gpu
+def test_clustered_collection_exact_path_matches_c_restatement(lib, monkeypatch):
+    """600 photos in 10 viewpoint clusters, shuffled ids (3600 camera unknowns: inside the dense limit, but the plan takes the
+    reverse Cuthill-McKee order because it keeps two thirds of the tiles).  The exact path in that order against (i) the same
+    library forced to the natural order (XRSFM_BA_RCM=0: the dense panel schedule the round-2 tests validated) — the
+    elimination order must not change the solution beyond rounding — and (ii) the C restatement (natural order,
+    block-envelope Cholesky): same LM decisions, RMSE within 1e-6 px, cameras within 1e-5."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi, synth
+    d = synth.make_collection(600, 30000, seed=5, cams_per_cluster=60)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    assert capi.debug_chol_plan(H.to_product(arr))["ordering"] == 2
+    n_res = 2 * arr["obs_cam"].shape[0]
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options(max_iterations=8))
+    assert s.linear_solver_used == capi.SOLVER_CHOLESKY
+    monkeypatch.setenv("XRSFM_BA_RCM", "0")
+    assert capi.debug_chol_plan(H.to_product(arr))["ordering"] == 0
+    nat = H.to_product(arr)
+    sn = capi.solve(nat, capi.default_options(max_iterations=8))
+    monkeypatch.delenv("XRSFM_BA_RCM")
+    assert (s.n_successful, s.n_unsuccessful) == (sn.n_successful, sn.n_unsuccessful)
+    assert abs(s.final_cost - sn.final_cost) <= 1e-9 * sn.final_cost
+    assert np.abs(prod.cam_q - nat.cam_q).max() < 1e-7 and np.abs(prod.cam_t - nat.cam_t).max() < 1e-6
+    if ba_cpu.available():
+        c1 = {k: np.array(v, copy=True) for k, v in arr.items()}
+        s1 = ba_cpu.solve(c1, max_iterations=3, threads=8)
+        p3 = H.to_product(arr)
+        s3 = capi.solve(p3, capi.default_options(max_iterations=3))
+        assert (s3.n_successful, s3.n_unsuccessful) == (s1["n_successful"], s1["n_unsuccessful"])
+        assert abs(math.sqrt(s3.final_cost / n_res) - math.sqrt(s1["final_cost"] / n_res)) < 1e-6
+        assert np.abs(p3.cam_q - c1["cam_q"]).max() < 1e-5 and np.abs(p3.cam_t - c1["cam_t"]).max() < 1e-5

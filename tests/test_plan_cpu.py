@@ -135,3 +135,23 @@ def test_schedule_covers_the_factorisation(monkeypatch, mode, n_cams, k_obs, env
         assert plan["level_schedule"] == 0 and plan["levels"] == plan["tiles"]
     else:
         assert plan["level_schedule"] == 1
+
+
+def test_clustered_collection_takes_the_rcm_order():
+    """An unordered photo collection with viewpoint clusters (synth.make_collection: 10 landmarks on a ring, shuffled camera ids):
+    in the natural order the tile pattern of the reduced camera matrix fills in completely; the reverse Cuthill-McKee order of
+    the camera graph recovers the band of neighbouring landmarks (ordering 2) and the symbolic factorisation keeps a fraction
+    of the tiles.  Random visibility (config U: no clusters) keeps the natural order."""
+    from xrsfm_amd import synth
+    d = synth.make_collection(1500, 60000, seed=5)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, 1500)
+    dense = plan["tiles"] * (plan["tiles"] + 1) // 2
+    assert plan["ordering"] == 2 and plan["tiles"] == 150 and plan["tiles_nz"] < 0.75 * dense
+    # the order follows the landmarks: cameras of one landmark are (nearly) contiguous in the elimination order
+    rank = np.argsort(np.argsort(plan["cam_offset"]))
+    spread = [np.ptp(rank[d["cluster_of_cam"] == k]) for k in range(10)]
+    assert np.median(spread) < 450                                   # a landmark has ~150 cameras, its neighbours 300 more
+    u = H.make(500, 20000, 5, seed=5, mode="unordered")
+    assert capi.debug_chol_plan(H.to_product(u))["ordering"] == 0

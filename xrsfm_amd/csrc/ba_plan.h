@@ -17,7 +17,9 @@ constexpr int kCamsPerTile = 10;     // 10 cameras = 60 rows per tile + 4 identi
 
 struct CholPlan {
     int n = 0, n_pad = 0, T = 0, n_blocks = 0, n_pairs = 0, n_writes = 0, n_tiles_nz = 0, n_levels = 0;
-    int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring
+    int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring, 2 reverse Cuthill-McKee (unordered
+                                     // collections with viewpoint clusters: banded fill instead of a dense factor)
+    long long tile_products = 0;     // 64x64x64 tile products of one factorisation (symbolic count; 2 * 64^3 flop each)
     int n_hubs = 0, band = 0;
     bool use_levels = false, panel_ll = false;
     // k_schur_pairs is launched once per LDS class: items whose staged operand fits 10 KB (16 workgroups per CU) and the rest
@@ -163,6 +165,90 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
 }
 
 namespace plan_detail {
+// Reverse Cuthill-McKee order of the camera graph (edges = the off-diagonal blocks of S): breadth-first from a pseudo-peripheral
+// camera, neighbours by ascending degree, reversed; components one after the other.  Returns cameras in elimination order.
+// Deterministic (ties by camera id), O(edges log degree).
+inline std::vector<int> rcm_order(int Nc, const std::vector<int>& blk_rc, int n_blocks) {
+    std::vector<int> deg(Nc + 1, 0);
+    for (int b = 0; b < n_blocks; ++b) { deg[blk_rc[2 * b] + 1]++; deg[blk_rc[2 * b + 1] + 1]++; }
+    std::vector<int> ptr(Nc + 1, 0);
+    for (int c = 0; c < Nc; ++c) ptr[c + 1] = ptr[c] + deg[c + 1];
+    std::vector<int> adj(ptr[Nc]), fill(ptr.begin(), ptr.end() - 1);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int r = blk_rc[2 * b], c = blk_rc[2 * b + 1];
+        adj[fill[r]++] = c; adj[fill[c]++] = r;
+    }
+    auto degree = [&](int c) { return ptr[c + 1] - ptr[c]; };
+    for (int c = 0; c < Nc; ++c)
+        std::sort(adj.begin() + ptr[c], adj.begin() + ptr[c + 1], [&](int a, int b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
+    std::vector<int> order; order.reserve(Nc);
+    std::vector<int> lvl(Nc, -1), queue;
+    std::vector<char> done(Nc, 0);
+    // breadth-first search from `root` over the cameras not yet ordered; returns the last camera reached and the depth
+    auto bfs = [&](int root, int* depth) {
+        queue.clear(); queue.push_back(root); lvl[root] = 0;
+        size_t head = 0;
+        while (head < queue.size()) {
+            const int u = queue[head++];
+            for (int q = ptr[u]; q < ptr[u + 1]; ++q) { const int v = adj[q]; if (!done[v] && lvl[v] < 0) { lvl[v] = lvl[u] + 1; queue.push_back(v); } }
+        }
+        int last = queue.back();
+        *depth = lvl[last];
+        // among the deepest cameras take the one of smallest degree (George-Liu)
+        for (size_t i = queue.size(); i-- > 0 && lvl[queue[i]] == *depth;)
+            if (degree(queue[i]) < degree(last) || (degree(queue[i]) == degree(last) && queue[i] < last)) last = queue[i];
+        for (int u : queue) lvl[u] = -1;
+        return last;
+    };
+    std::vector<int> by_degree(Nc);
+    for (int c = 0; c < Nc; ++c) by_degree[c] = c;
+    std::sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
+    for (int start : by_degree) {
+        if (done[start]) continue;
+        int root = start, depth = -1;
+        for (int iter = 0; iter < 8; ++iter) {            // pseudo-peripheral camera of this component
+            int d2 = 0;
+            const int far = bfs(root, &d2);
+            if (d2 <= depth) break;
+            depth = d2; root = far;
+        }
+        queue.clear(); queue.push_back(root); done[root] = 1;
+        size_t head = 0;
+        while (head < queue.size()) {
+            const int u = queue[head++];
+            order.push_back(u);
+            for (int q = ptr[u]; q < ptr[u + 1]; ++q) { const int v = adj[q]; if (!done[v]) { done[v] = 1; queue.push_back(v); } }
+        }
+    }
+    std::reverse(order.begin(), order.end());
+    return order;
+}
+
+// Symbolic factorisation of the 64x64 tile pattern for the cameras in `order` (10 per tile): number of tile products
+// sum_k |R_k| (|R_k| + 1) / 2 of one factorisation, or -1 as soon as it exceeds `budget`.
+inline long long count_tile_products(int Nc, const std::vector<int>& blk_rc, int n_blocks, const std::vector<int>& order, int cams_per_tile,
+                                     long long budget) {
+    const int T = (Nc + cams_per_tile - 1) / cams_per_tile;
+    std::vector<int> tile_of(Nc);
+    for (int r = 0; r < Nc; ++r) tile_of[order[r]] = r / cams_per_tile;
+    std::vector<char> nz((size_t)T * T, 0);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int ti = tile_of[blk_rc[2 * b]], tj = tile_of[blk_rc[2 * b + 1]];
+        nz[(size_t)std::max(ti, tj) * T + std::min(ti, tj)] = 1;
+    }
+    long long total = 0;
+    std::vector<int> R;
+    for (int k = 0; k < T; ++k) {
+        R.clear();
+        for (int i = k + 1; i < T; ++i) if (nz[(size_t)i * T + k]) R.push_back(i);
+        total += (long long)R.size() * ((long long)R.size() + 1) / 2;
+        if (total > budget) return -1;
+        for (size_t a = 0; a < R.size(); ++a)
+            for (size_t b2 = 0; b2 <= a; ++b2) nz[(size_t)R[a] * T + R[b2]] = 1;
+    }
+    return total;
+}
+
 inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<int>& extra, const std::vector<int>& keep,
                     std::vector<std::vector<int>>& g) {
     if (hi <= lo) { if (!extra.empty()) g.push_back(extra); return; }
@@ -197,6 +283,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                            const std::vector<unsigned long long>* pattern, CholPlan& P,
                            long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX) {
     const int Nc = k.n_cams, ns = k.n_slots;
+    PhaseTimer timer("plan");
     P = CholPlan();
     P.spp = spp;
     P.n = 6 * Nc;
@@ -220,6 +307,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     }
     const int n_blocks = P.n_blocks = (int)P.blk_ptr.size() - 1;
     const std::vector<int>& blk_rc = P.blk_rc;
+    timer.mark("  blocks + destinations");
 
     // ---- elimination order.  Band width w of the camera graph (circular distance of the camera pairs).  A few
     // long-range pairs (loop closures, re-observed landmarks) must not destroy the band structure of a sequential
@@ -275,8 +363,25 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         P.n_hubs = 0;
         std::vector<int> all;
         for (int c = 0; c < Nc; ++c) all.push_back(c);
+        // Unordered collections (BASELINE config 5, rec_1dsfm.cc:66-98: internet photos have no temporal order) are not random
+        // graphs: photos cluster around landmarks, and a bandwidth-reducing order turns the dense reduced camera matrix of
+        // the natural order into a band whose fill is a small fraction of it (synthetic collection of 7500 photos: 15 % of
+        // the tiles, 6e11 instead of 4e13 flop per factorisation) — the exact solve Ceres' SPARSE_SCHUR performs then stays
+        // affordable far beyond `max_dense_unknowns`.  Reverse Cuthill-McKee of the camera graph; taken only if the symbolic
+        // factorisation says it pays (<= 60 % of the natural order's tile products, within the work budget), from 48 tile
+        // columns (480 cameras) on; random visibility (no clusters) keeps the natural order / the PCG path.
+        const int Tn = (Nc + kCamsPerTile - 1) / kCamsPerTile;
+        const char* rcm_env = std::getenv("XRSFM_BA_RCM");
+        if (Tn >= 48 && !(rcm_env && rcm_env[0] == '0')) {
+            const long long budget = 12000000;              // tile products of one factorisation: 6.3e12 flop, ~0.25 s
+            const std::vector<int> rcm = plan_detail::rcm_order(Nc, blk_rc, n_blocks);
+            const long long pr = plan_detail::count_tile_products(Nc, blk_rc, n_blocks, rcm, kCamsPerTile, budget);
+            const long long pn = (6LL * Nc <= max_dense_unknowns) ? plan_detail::count_tile_products(Nc, blk_rc, n_blocks, all, kCamsPerTile, budget) : -1;
+            if (pr >= 0 && (pn < 0 || pr * 10 <= pn * 6)) { all = rcm; P.ordering = 2; }
+        }
         groups.push_back(all);
     }
+    timer.mark("  elimination order");
     P.cam_off.assign(Nc, 0);
     int T = 0;
     for (const auto& g : groups) {
@@ -290,7 +395,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.tile_cam.assign((size_t)T * kCamsPerTile, -1);
     for (int c = 0; c < Nc; ++c) P.tile_cam[(size_t)(P.cam_off[c] / kPlanTile) * kCamsPerTile + (P.cam_off[c] % kPlanTile) / 6] = c;
     if (6LL * Nc > max_dense_unknowns &&
-        (P.ordering != 1 || (unsigned long long)P.n_pad * (unsigned long long)P.n_pad * sizeof(double) > max_tile_bytes)) return XRSFM_BA_ETOOBIG;
+        (P.ordering == 0 || (unsigned long long)P.n_pad * (unsigned long long)P.n_pad * sizeof(double) > max_tile_bytes)) return XRSFM_BA_ETOOBIG;
 
     // ---- tile pattern + symbolic factorisation
     std::vector<char> nz((size_t)T * T, 0);
@@ -304,6 +409,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         std::vector<int> R;
         for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) R.push_back(i);
         for (int i : R) P.rows_flat.push_back(i);
+        P.tile_products += (long long)R.size() * ((long long)R.size() + 1) / 2;
         for (size_t a = 0; a < R.size(); ++a)
             for (size_t b2 = 0; b2 <= a; ++b2) { nz[(size_t)R[a] * T + R[b2]] = 1; P.pairs_flat.push_back(R[a]); P.pairs_flat.push_back(R[b2]); }
         P.rows_off[kk + 1] = (int)P.rows_flat.size();
@@ -315,6 +421,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { P.tiles_nz.push_back(kk); P.tiles_nz.push_back(j); }
     }
     P.n_tiles_nz = (int)P.tiles_nz.size() / 2;
+    timer.mark("  symbolic factorisation");
     std::vector<int> tile_id((size_t)T * T, -1);
     for (int q = 0; q < P.n_tiles_nz; ++q) tile_id[(size_t)P.tiles_nz[2 * q] * T + P.tiles_nz[2 * q + 1]] = q;
     {
@@ -334,6 +441,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int b = 0; b < n_blocks; ++b) P.tf_ent[fill[tile_of_block(b)]++] = b;
     }
 
+    timer.mark("  fill lists");
     // ---- elimination-tree levels of the (filled) tile pattern and the per-level work lists
     std::vector<int> level(T, 0);
     int n_levels = 0;
@@ -493,6 +601,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         }
         P.lv_k_off[lv + 1] = (int)P.lv_k.size();
     }
+    timer.mark("  level lists");
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);
     // tile fill fused into the first level's factor launch (k_lv_factor<true>): every workgroup of a level-0 column composes

@@ -121,7 +121,7 @@ struct CholHost {
     int* zero2 = nullptr;                                    // two zeros: an empty CSR row list
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
-    int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring
+    int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee
 };
 
 struct xrsfm_ba_context {
@@ -558,7 +558,8 @@ int chol_setup(xrsfm_ba_context* c) {
     timer.mark("plan");
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
-    if (6 * Nc > kCholMaxN && (!P.use_levels || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
+    // (... or a reverse Cuthill-McKee order whose symbolic factorisation stays within the work budget of ba_plan.h: panel schedule)
+    if (6 * Nc > kCholMaxN && (!(P.use_levels || P.ordering == 2) || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
