@@ -72,6 +72,14 @@ def weak_scaled_shard(cfg: dict, rank: int, world: int) -> dict:
     return synth.make_problem(**cfg) if world == 1 else synth.make_problem(**cfg, point_seed=rank)
 
 
+def make_config(name: str) -> dict:
+    """The synthetic problem of a named configuration (xrsfm_amd/synth.py: CONFIGS).  T = BASELINE.json config 5 at its size
+    (unordered photo collection with viewpoint clusters), everything else the BAL-style generator of SURVEY.md Appendix D."""
+    from xrsfm_amd import synth
+    cfg = dict(synth.CONFIGS[name])
+    return synth.make_collection(**cfg) if name == "T" else synth.make_problem(**cfg)
+
+
 def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, nnzb: int = 0):
     """ALGORITHMIC HBM bytes of one launch, J-stored accounting of SURVEY.md section 8(d) / DESIGN.md section 5
     (FP64 values, int32 indices).  None for kernels that are latency- or MFMA-bound."""
@@ -249,12 +257,39 @@ def mfma_utilisation():
             "dtype": "f64", "instruction": "v_mfma_f64_16x16x4_f64"}
 
 
+def mapper_bench(args):
+    """--config M: the mapper-shaped call sequence (IncrementalMapper::Reconstruct, incremental_mapper.cc:33-88: GBA once, LBA +
+    filters per frame, KGBA + FilterPoints3d on the geometric schedule) of a 300-frame sequential reconstruction through the
+    source-compatible BASolver adapter on the test shim of base/map.h.  One replay warms the process up (allocation caches,
+    code objects), the second is reported: wall time of everything the replay does (host-side frame selection, packing,
+    upload, solve, download included — the adapter's real cost) and per-call percentiles per call class.  Not the headline
+    metric: a separate line for BASELINE config 1's call pattern."""
+    import torch  # noqa: F401  (one HIP runtime for the child's library as well)
+    from xrsfm_amd import mapper_replay
+    arr = mapper_replay.sequence_problem()
+    r = mapper_replay.run(arr, repeats=2)
+    if r["status"] != 0:
+        raise SystemExit(f"mapper replay failed: status {r['status']}: {r['stderr']}")
+    rep = r["replays"][1]
+    ba_ms = sum(rep["classes"][k]["total_ms"] for k in ("GBA", "LBA", "KGBA"))
+    out = {"metric": "mapper-shaped BA replay: wall time of the BA calls of one incremental reconstruction", "value": ba_ms, "unit": "ms",
+           "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": rep["wall_ms"], "higher_is_better": False, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+           "config": {"workload": f"{arr['cam_q'].shape[0]} frames arriving one by one / {arr['points'].shape[0]} tracks / {arr['obs_cam'].shape[0]} observations; "
+                                  "GBA once, LBA + FilterPointsFrame per frame, KGBA + FilterPoints3d when registered > 1.2 x last (incremental_mapper.cc:77)",
+                      "parallelism": "single GPU, one-shot xrsfm_ba_solve per call through the BASolver adapter (tests/shim)"},
+           "calls": rep["classes"], "replay_wall_ms": rep["wall_ms"], "first_replay_wall_ms": r["replays"][0]["wall_ms"],
+           "same_end_state_in_both_replays": r["same_end_state"],
+           "free_device_bytes_after_replay": [x["free_bytes"] for x in r["replays"]], "tracks_filtered": r["n_outlier_tracks"]}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "K", "U", "X", "R", "V", "D", "L0"]))
+    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "K", "U", "X", "R", "V", "D", "L0", "T", "M"]))
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
@@ -263,6 +298,9 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the host-inclusive one-shot solve and the config-D MFMA measurement")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+
+    if args.config == "M":
+        return mapper_bench(args)
 
     import torch
     import torch.distributed as dist
@@ -290,7 +328,7 @@ def main():
             dist.all_reduce(sizes)
         n_points, n_obs = int(sizes[0].item()), int(sizes[1].item())      # of the whole job
     else:
-        full = synth.make_problem(**cfg)
+        full = make_config(args.config)
         arr = {k: full[k] for k in capi.ProblemArrays.FIELDS}
         n_cams, n_points, n_obs = arr["cam_q"].shape[0], arr["points"].shape[0], arr["obs_cam"].shape[0]
         local = shard_problem(arr, rank, world)
@@ -372,6 +410,14 @@ def main():
             b_k = algorithmic_bytes(k, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
             per_kernel[k] = {"avg_launch_us": ms_k * 1e3 / n_k, "launches": n_k, "algorithmic_bytes_per_launch": b_k,
                              "frac": b_k / (ms_k * 1e-3 / n_k) / 1e9 / HBM_PEAK_GBS}
+        if world == 1 and os.path.exists(pmc):
+            # the whole per-kernel PMC table (bytes per launch, FETCH_SIZE + WRITE_SIZE passes of an earlier run), and the measured
+            # traffic next to the algorithmic bytes of every streaming kernel: `traffic` above is the dominant kernel's entry only
+            table = json.load(open(pmc))
+            roofline["traffic_table"] = {"source": traffic_source, "bytes_per_launch": table}
+            for k, rec in per_kernel.items():
+                hits = [v for kk, v in table.items() if kk == k or kk.startswith(k + "<")]
+                rec["traffic"] = sum(hits) if hits else None
         roofline["streaming_kernels"] = per_kernel
         # the whole LM iteration against BASELINE.md section 4: B_iter(0) = B_lin + B_prep + B_back, plus the explicit-S terms
         # (the nnzb off-diagonal 6x6 blocks written once; SURVEY 8d's B_S would also count a second read of J, N_obs*144,
@@ -394,7 +440,8 @@ def main():
             "unit": "cam-pts*iter/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic BAL-style {args.config}: {n_cams} cams / {n_points} points / {n_obs} obs, "
+            "config": {"workload": ("synthetic clustered photo collection (shape and size of BASELINE config 5) " if args.config == "T" else "synthetic BAL-style ")
+                                   + f"{args.config}: {n_cams} cams / {n_points} points / {n_obs} obs, "
                                    f"GBA accurate (ba_solver.cc:626-629), seed {cfg['seed']}"
                                    + (f"; {args.scaling} scaling: " + ("this problem split over the ranks" if args.scaling == "strong"
                                                                       else f"{world} config-sized point shards over the same cameras") if world > 1 else ""),

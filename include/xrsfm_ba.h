@@ -163,6 +163,11 @@ void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
  * runtime from a static destructor).  An embedder that dlcloses the library should call this first. */
 int xrsfm_ba_quiesce(uint64_t *cached_bytes);
 
+/* Free and total memory of HIP device `device` as the runtime reports them (hipMemGetInfo): for embedders that watch the
+ * footprint of a long mapping session (tests/test_mapper_replay.py asserts that replaying a reconstruction twice leaves it
+ * unchanged).  XRSFM_BA_ENODEV without a device. */
+int xrsfm_ba_device_memory(int device, uint64_t *free_bytes, uint64_t *total_bytes);
+
 /* One-shot convenience = create + run + download into problem->{cam_q,cam_t,points} + destroy:
  * the call that replaces ceres::Solve(options, &problem, &summary). */
 int xrsfm_ba_solve(const xrsfm_ba_options *opt, xrsfm_ba_problem *problem, xrsfm_ba_summary *summary);

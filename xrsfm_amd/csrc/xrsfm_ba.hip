@@ -953,6 +953,17 @@ int xrsfm_ba_quiesce(uint64_t* cached_bytes) {
     return XRSFM_BA_OK;
 }
 
+int xrsfm_ba_device_memory(int device, uint64_t* free_bytes, uint64_t* total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return XRSFM_BA_ENODEV;
+    HIPCHK(hipSetDevice(device));
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (uint64_t)f;
+    if (total_bytes) *total_bytes = (uint64_t)t;
+    return XRSFM_BA_OK;
+}
+
 static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out);
 
 int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** out) {

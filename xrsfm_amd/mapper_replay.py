@@ -1,0 +1,67 @@
+"""Driver of tests/shim/mapper_main (the mapper-shaped call sequence of IncrementalMapper::Reconstruct,
+/root/reference/src/mapper/incremental_mapper.cc:33-88, through the source-compatible BASolver adapter on the test shim of
+base/map.h).  Used by tests/test_mapper_replay.py and bench.py --config M; measurement / test helper, not part of the library."""
+from __future__ import annotations
+
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "shim")
+EXE = os.path.join(SHIM, "_build", "mapper_main")
+CLASSES = ("GBA", "LBA", "KGBA", "filters+refine")
+
+
+def build() -> str:
+    subprocess.run(["make", "-C", SHIM, "_build/mapper_main"], check=True, capture_output=True)
+    return EXE
+
+
+def dump(arr: dict, path: str) -> None:
+    with open(path, "wb") as f:
+        f.write(struct.pack("4i", arr["cam_q"].shape[0], arr["points"].shape[0], arr["obs_cam"].shape[0], arr["intr_model"].shape[0]))
+        for k, dt in (("cam_q", "f8"), ("cam_t", "f8"), ("cam_intr", "i4"), ("intr_model", "i4"), ("intr_params", "f8"),
+                      ("points", "f8"), ("obs_cam", "i4"), ("obs_pt", "i4"), ("obs_uv", "f8")):
+            f.write(np.ascontiguousarray(arr[k], dtype=dt).tobytes())
+
+
+def sequence_problem(n_frames: int = 300, n_points: int = 45000, k_obs: int = 8, seed: int = 21, dropout: float = 0.25) -> dict:
+    """A sequential reconstruction: `n_frames` frames on the generator's trajectory, every point seen in a window of `k_obs`
+    consecutive frames with missed detections (ragged tracks), frame poses / points perturbed like a PnP / triangulation
+    result.  ~n_points * k_obs * (1 - dropout) / n_frames features per frame (900 at the defaults)."""
+    from xrsfm_amd import capi, synth
+    d = synth.make_problem(n_frames, n_points, k_obs, seed=seed, dropout=dropout, min_tri_angle_deg=1.0)
+    return {k: d[k] for k in capi.ProblemArrays.FIELDS}
+
+
+def run(arr: dict, repeats: int = 1, timeout: float = 1800.0) -> dict:
+    """Replays the reconstruction `repeats` times in ONE process.  Returns dict(status, same_end_state, cam_q, cam_t, points,
+    n_outlier_tracks, replays=[{classes: {name: {count,total_ms,p50,p90,p99,max}}, wall_ms, free_bytes}])."""
+    exe = build()
+    with tempfile.TemporaryDirectory() as td:
+        inp, out = os.path.join(td, "in.bin"), os.path.join(td, "out.bin")
+        dump(arr, inp)
+        p = subprocess.run([exe, inp, out, str(repeats)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, timeout=timeout)
+        if not os.path.exists(out):
+            raise RuntimeError(f"mapper_main failed (rc {p.returncode}): {p.stderr[-2000:]}")
+        raw = open(out, "rb").read()
+    nc, npt = arr["cam_q"].shape[0], arr["points"].shape[0]
+    status, same = struct.unpack("2i", raw[:8])
+    off = 8
+    cams = np.frombuffer(raw, dtype="f8", count=7 * nc, offset=off).reshape(nc, 7); off += 56 * nc
+    pts = np.frombuffer(raw, dtype="f8", count=3 * npt, offset=off).reshape(npt, 3); off += 24 * npt
+    n_out = struct.unpack("i", raw[off:off + 4])[0]; off += 4
+    replays = []
+    for _ in range(repeats):
+        rec = np.frombuffer(raw, dtype="f8", count=27, offset=off); off += 27 * 8
+        classes = {}
+        for c, name in enumerate(CLASSES):
+            v = rec[6 * c:6 * c + 6]
+            classes[name] = dict(count=int(v[0]), total_ms=float(v[1]), p50=float(v[2]), p90=float(v[3]), p99=float(v[4]), max=float(v[5]))
+        replays.append(dict(classes=classes, wall_ms=float(rec[24]), free_bytes=int(rec[25])))
+    return dict(status=status, same_end_state=bool(same), cam_q=cams[:, :4].copy(), cam_t=cams[:, 4:].copy(), points=pts.copy(),
+                n_outlier_tracks=n_out, replays=replays, returncode=p.returncode, stderr=p.stderr[-2000:])
