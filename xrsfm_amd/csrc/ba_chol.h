@@ -50,6 +50,35 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 //  * long tracks: lane loops over all later observations of its track.
 constexpr int kRedLd = 15;      // row stride (doubles) of the LDS reduction buffer of k_schur_pairs: 64 x 15 x 8 B
 
+// Store plan of the Gram product's epilogue.  Which accumulator element (product p of the NI(NI+1)/2, register g of 4) of
+// which lane belongs to which camera pair (ra < rb) and where inside its 6x6 block depends on the camera count C of the
+// tile and the lane alone: computed on the host once (gram_store_plan), one int per element = (ra * C + rb) << 6 | (6 i + j),
+// -1 for elements that belong to no block (diagonal blocks, rows / columns beyond 6 C, the upper triangle).  The kernel
+// reads its 4 ints per product with one 16-byte load instead of two divisions by 6, three range tests and the index
+// arithmetic per element (266 integer VALU + ~150 SALU instructions per tile before, profiles/r02_L_instruction_mix.md).
+// Layout: for C = 2..10 a block of NP x 64 int4 (product-major, lane-minor: one coalesced load per product).
+struct GramPlan { const int4* tab; int off[kGramMaxCams + 1]; };      // off[C]: first int4 of C's block
+
+inline std::vector<int> gram_store_plan(int (&off)[kGramMaxCams + 1]) {
+    std::vector<int> tab;
+    for (int C = 0; C <= kGramMaxCams; ++C) {
+        off[C] = (int)tab.size() / 4;
+        if (C < 2) continue;
+        const int R = 6 * C, NI = (R + 15) / 16;
+        for (int I = 0; I < NI; ++I)
+            for (int J = 0; J <= I; ++J)
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int li = lane & 15, lk = lane >> 4;
+                    const int col = 16 * J + li, ra = col / 6, j = col - 6 * ra;
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = 16 * I + lk + 4 * g, rb = row / 6, i = row - 6 * rb;
+                        tab.push_back((row < R && col < R && rb > ra) ? (((ra * C + rb) << 6) | (6 * i + j)) : -1);
+                    }
+                }
+    }
+    return tab;
+}
+
 // UPPER = false: hc = lower factor {c00 c10 c20 c11 c21 c22} stored by k_point_prep;  UPPER = true: hc = upper factor
 // {c00 c01 c02 c11 c12 c22} of point_factor() (formed in the kernel).  Either way hc hc^T = Hinv and V = W hc.
 template <bool UPPER>
@@ -98,7 +127,7 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
 template <int NI>
 __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int Cp, int C, const int* __restrict__ dtab,
                                           double* __restrict__ scat2, int lane, const double (&V)[18], bool valid, int t, int cidx,
-                                          int T, int Th, int passes, bool dense) {
+                                          int T, int Th, int passes, bool dense, const int4* __restrict__ plan) {
     static_assert(NI >= 1 && NI <= 4, "a Gram tile has at most 10 cameras = 60 operand rows (ba_pack.h: kGramMaxCams)");
     const int li = lane & 15, lk = lane >> 4;
     v4d acc[NI * (NI + 1) / 2];
@@ -144,24 +173,19 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         __builtin_amdgcn_wave_barrier();
     }
     XBA_STAMP(0, 7);
-    int p = 0;
+    // blocks (camera rb > camera ra) to their destinations, by the store plan of the tile's camera count
+    const int4* pl = plan + lane;
 #pragma unroll
-    for (int I = 0; I < NI; ++I)
+    for (int p = 0; p < NI * (NI + 1) / 2; ++p) {
+        const int4 e4 = pl[p * kWave];
+        const int e[4] = {e4.x, e4.y, e4.z, e4.w};
 #pragma unroll
-        for (int J = 0; J <= I; ++J) {
-            const int col = 16 * J + li;
-            const int ra = col / 6, j = col - 6 * ra;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = 16 * I + lk + 4 * g;
-                const int rb = row / 6, i = row - 6 * rb;
-                if (row < R && col < R && rb > ra) {
-                    const int dst = dtab[ra * C + rb];
-                    if (dst >= 0) scat2[36 * (size_t)dst + 6 * i + j] = acc[p][g];
-                }
+        for (int g = 0; g < 4; ++g)
+            if (e[g] >= 0) {
+                const int dst = dtab[e[g] >> 6];
+                if (dst >= 0) scat2[36 * (size_t)dst + (e[g] & 63)] = acc[p][g];
             }
-            ++p;
-        }
+    }
 }
 
 // GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
@@ -172,7 +196,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 template <bool GRAM, bool PREP>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
-                   int n_obs_pairs, double* __restrict__ scat2, double radius) {
+                   int n_obs_pairs, double* __restrict__ scat2, double radius, GramPlan gplan) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     XBA_STAMP(0, 0);
@@ -318,10 +342,10 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             if (lane + kWave < C * C) dtab[lane + kWave] = dt1;
             const bool dense = nvalid == T * C;
             switch (Rp >> 4) {                             // 16-row operand tiles
-                case 1: gram_tile<1>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
-                case 2: gram_tile<2>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
-                case 3: gram_tile<3>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
-                default: gram_tile<4>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense); break;
+                case 1: gram_tile<1>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
+                case 2: gram_tile<2>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
+                case 3: gram_tile<3>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
+                default: gram_tile<4>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
             }
             XBA_STAMP(0, 8);
             return;

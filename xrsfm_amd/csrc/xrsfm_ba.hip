@@ -100,6 +100,7 @@ struct CholHost {
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
     int* pairs_items = nullptr; int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
+    GramPlan gplan{};                             // store plan of the Gram epilogue (ba_chol.h)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // the non-Gram items run concurrently
     // right-looking schedule (dense patterns): one panel after the other
     int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
@@ -585,9 +586,13 @@ int chol_setup(xrsfm_ba_context* c) {
     const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
     up.add(&h.zero2, two_zeros);
     up.add(&h.pairs_items, P.pairs_items);
+    const std::vector<int> gplan_tab = gram_store_plan(h.gplan.off);      // must outlive up.flush()
+    int* d_gplan = nullptr;
+    up.add(&d_gplan, gplan_tab);
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
     up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
     TRYC(up.flush());
+    h.gplan.tab = reinterpret_cast<const int4*>(d_gplan);
     timer.mark("uploads");
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
@@ -643,11 +648,11 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         const double radius = c->step_radius;
         auto launch_pairs = [&](bool gram, int n, size_t shm, hipStream_t st, const int* items) {
             if (gram) {
-                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
-                else hipLaunchKernelGGL((k_schur_pairs<true, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+                else hipLaunchKernelGGL((k_schur_pairs<true, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
             } else {
-                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
-                else hipLaunchKernelGGL((k_schur_pairs<false, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+                else hipLaunchKernelGGL((k_schur_pairs<false, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
             }
         };
         if (fork) {
