@@ -52,6 +52,26 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def test_torchrun_launch_line_of_the_driver(tmp_path):
+    """The driver's own launch line for N > 1 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py --gpus N ...`), with the stand-in device layer: both ranks come up, rendezvous on
+    127.0.0.1, and exactly one JSON line leaves the job."""
+    port = _free_port()
+    argv = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "S", "--no-cpu"]
+    script = tmp_path / "bench_standin.py"
+    script.write_text(DRIVER.format(root=ROOT, argv=argv))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "sharded x2" in j["config"]["parallelism"]
+    logs = [eval(l[4:]) for l in p.stdout.splitlines() if l.startswith("LOG")]
+    assert sorted(log[1][2] for log in logs) == [0, 1] and all(log[1][:2] == ("comm", 2) and log[1][3:] == (128, sum(range(128))) for log in logs)
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_two_rank_launch_contract(tmp_path, scaling):
     port = _free_port()

@@ -543,9 +543,11 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
         const double bv_ = row_bcast(a[jj], (cc)); /* u_{cc,jj} */       \
         a[(cc)] = fma(-tl, bv_, a[(cc)]);                                \
         lcol[(cc)] = fma(-bv_, xs, lcol[(cc)]);                          \
+        asm volatile("" : "+v"(lcol[(cc)]));   /* pin it here: left alone the compiler sinks every update of the inverse behind the   \
+                                                  factorisation and keeps all 120 broadcast values alive for it (240 registers, through AGPRs) */ \
     }
     double sj = fast_rsqrt(row_bcast(a[0], 0));
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int jj = 0; jj < 16; ++jj) {
         const double tl = a[jj] * (sj * sj);              // u_ij / u_jj
         const double x = lcol[jj] * sj;
@@ -559,9 +561,9 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
             h = 0.5 * un;
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int st = 0; st < 6; ++st) {
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int cc = jj + 2 + st; cc < 16; cc += 6) XBA_POTRF_UPD(cc)
             if (jj + 1 < 16) {                           // y <- y * fma(-h y, y, 1.5), twice: three instructions each
                 if (st % 3 == 0) m = h * y;
@@ -591,6 +593,7 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
     // trailing update of step kb (they would otherwise wait at a barrier for the 2 us the in-register factorisation takes).
     if (wave == 0) potrf_block16(A, Li, 0, lane);
     __syncthreads();
+#pragma clang loop unroll(disable)          // (one copy of the in-register factorisation in the loop, not nb: the kernel must stay in the instruction cache)
     for (int kb = 0; kb < nb; ++kb) {
         XBA_STAMP(1, 3 + 2 * kb);
         const int b0 = 16 * kb;
@@ -1292,6 +1295,10 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
                                                    LvFill lf) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
+    __shared__ double Xs[kNB][kLdT];      // off-diagonal workgroup: A_ik - update, parked here while the pivot tile is factored (it used
+                                          // to stay in 64 registers across potrf_lds: with them the in-register 16x16 factorisation
+                                          // ran out of architectural VGPRs and copied every broadcast value through AGPRs — 4 of its 8
+                                          // instructions per column update; 109 KB of LDS = one workgroup per CU, the grid has <= 1 per CU anyway)
     __shared__ double Tb[3][16][17];
     __shared__ double yv[kNB], fv[kNB];
     const int b = blockIdx.x;
@@ -1398,6 +1405,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
                 const int r = r0 + 16 * m + lk + 4 * g, col = c0 + 16 * n2 + li;
                 if (!FILL) A[r][col] = (col <= r) ? skk[m][n2][g] - akk[m][n2][g] : 0.0;
                 Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
+                if (!diag) Xs[r][col] = sik[m][n2][g] - aik[m][n2][g];
             }
     __syncthreads();
     XBA_STAMP(1, 2);
@@ -1441,20 +1449,13 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
         XBA_STAMP(1, 13);
         return;
     }
-    // off-diagonal tile: X = (A_ik - update) -> LDS (the factor L_kk is no longer needed here), L_ik = X Linv_k^T
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) A[r0 + 16 * m + lk + 4 * g][c0 + 16 * n2 + li] = sik[m][n2][g] - aik[m][n2][g];
-    __syncthreads();
+    // off-diagonal tile: L_ik = X Linv_k^T with X = A_ik - update (in Xs since before the factorisation)
     v4d acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_abt_mfma(&A[0][0], &Li[0][0], acc);
+    tile_abt_mfma(&Xs[0][0], &Li[0][0], acc);
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll

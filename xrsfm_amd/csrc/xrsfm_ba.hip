@@ -386,11 +386,23 @@ int fetch_scalars(xrsfm_ba_context* c) {
         HIPCHK(hipGetLastError());
     }
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(c->h_scal + S_COUNT);
+    // Watchdog: a collective that never completes (a rank that died, ranks that disagree on the call sequence) would otherwise
+    // leave every other rank spinning here for ever.  XRSFM_BA_WATCHDOG_S (default 300 s without progress; 0 = off).
+    static const double watchdog_s = [] { const char* e = std::getenv("XRSFM_BA_WATCHDOG_S"); return e ? std::atof(e) : 300.0; }();
+    std::chrono::steady_clock::time_point t_wait{};
+    bool waiting = false;
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want; ++spins) {
         if ((spins & 0xfffff) == 0xfffff) {                 // every ~1M polls: has the stream died?
             const hipError_t q = hipStreamQuery(c->stream);
             if (q == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == want) break; return XRSFM_BA_ENODEV; }
             if (q != hipErrorNotReady) return XRSFM_BA_ENODEV;
+            const auto now = std::chrono::steady_clock::now();
+            if (!waiting) { waiting = true; t_wait = now; }
+            else if (watchdog_s > 0.0 && std::chrono::duration<double>(now - t_wait).count() > watchdog_s) {
+                fprintf(stderr, "[xrsfm_ba] rank %d of %d: the device has made no progress for %.0f s%s\n", c->rank, c->n_ranks, watchdog_s,
+                        c->multi() ? " — an all-reduce that never completed? every rank must make the same calls in the same order (XRSFM_BA_WATCHDOG_S)" : "");
+                return c->multi() ? XRSFM_BA_ECOMM : XRSFM_BA_ENODEV;
+            }
         }
         __builtin_ia32_pause();
     }

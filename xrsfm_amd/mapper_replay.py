@@ -31,10 +31,12 @@ def dump(arr: dict, path: str) -> None:
 
 def sequence_problem(n_frames: int = 300, n_points: int = 45000, k_obs: int = 8, seed: int = 21, dropout: float = 0.25) -> dict:
     """A sequential reconstruction: `n_frames` frames on the generator's trajectory, every point seen in a window of `k_obs`
-    consecutive frames with missed detections (ragged tracks), frame poses / points perturbed like a PnP / triangulation
-    result.  ~n_points * k_obs * (1 - dropout) / n_frames features per frame (900 at the defaults)."""
+    consecutive frames with missed detections (ragged tracks).  Frame poses and points start a few pixels off (rotation
+    0.002 rad, centre 0.01, points 0.02 units: what PnP and a two-view triangulation leave; the generator's default
+    perturbation — 19 px median — is beyond the 16 px of the per-frame outlier filter, th_rpe_lba, and would have every new
+    track filtered before its first LBA).  ~n_points * k_obs * (1 - dropout) / n_frames features per frame (900 at the defaults)."""
     from xrsfm_amd import capi, synth
-    d = synth.make_problem(n_frames, n_points, k_obs, seed=seed, dropout=dropout, min_tri_angle_deg=1.0)
+    d = synth.make_problem(n_frames, n_points, k_obs, seed=seed, dropout=dropout, min_tri_angle_deg=1.0, perturb=(0.002, 0.01, 0.02))
     return {k: d[k] for k in capi.ProblemArrays.FIELDS}
 
 
