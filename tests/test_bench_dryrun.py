@@ -44,7 +44,10 @@ capi.comm_unique_id = lambda: bytes(range(128))
 import bench
 sys.argv = ["bench.py"] + {argv!r}
 bench.main()
-print("LOG", LOG)
+if os.environ.get("DRYRUN_LOG_DIR"):          # (under one launcher the ranks share a pipe: their lines may run into each other)
+    open(os.path.join(os.environ["DRYRUN_LOG_DIR"], "rank%s.log" % os.environ.get("RANK", "0")), "w").write(repr(LOG))
+else:
+    print("LOG", LOG)
 '''
 
 
@@ -61,14 +64,15 @@ def test_torchrun_launch_line_of_the_driver(tmp_path):
     script = tmp_path / "bench_standin.py"
     script.write_text(DRIVER.format(root=ROOT, argv=argv))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["DRYRUN_LOG_DIR"] = str(tmp_path)
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
+    assert len(lines) == 1, p.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "sharded x2" in j["config"]["parallelism"]
-    logs = [eval(l[4:]) for l in p.stdout.splitlines() if l.startswith("LOG")]
+    logs = [eval(open(os.path.join(str(tmp_path), f"rank{r}.log")).read()) for r in range(2)]
     assert sorted(log[1][2] for log in logs) == [0, 1] and all(log[1][:2] == ("comm", 2) and log[1][3:] == (128, sum(range(128))) for log in logs)
 
 

@@ -58,3 +58,30 @@ def test_product_code_does_not_touch_the_oracle():
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 for pat in ("import oracle", "from oracle", "oracle/", "ba_oracle", "ba_cpu", "libba_cpu"):
                     assert pat not in txt, f"{f} references the test oracle ({pat})"
+
+
+def test_streaming_kernels_do_not_spill(tmp_path):
+    """The gfx950 code object of the streaming kernels — every instantiation of k_schur_pairs, k_linearize, k_backsub,
+    k_schur_matvec, k_schur_prep, k_cost — has no spilled VGPRs and no private (scratch) segment.  Round 3 found a build of
+    k_schur_pairs with 26 spilled VGPRs in its common path that produced wrong blocks of S from ~1300 tiles on,
+    non-deterministically; the fix was to instantiate the kernel per operand height, and this test keeps
+    it that way (hipcc cross-compiles the device code here, no GPU needed)."""
+    import re
+    import shutil
+    import subprocess
+    from xrsfm_amd import _build
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    asm = tmp_path / "xba.s"
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-Wno-unused-value",
+                    "-Wno-deprecated-declarations", os.path.join(_build.CSRC, "xrsfm_ba.hip"), "-o", str(asm)], check=True, capture_output=True)
+    text = asm.read_text()
+    seen = 0
+    for blk in text.split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if not any(k in name for k in ("k_schur_pairs", "k_linearize", "k_backsub", "k_schur_matvec", "k_schur_prep", "k_cost")):
+            continue
+        seen += 1
+        spills = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
+        assert spills == 0 and scratch == 0, (name, spills, scratch)
+    assert seen >= 15          # 10 instantiations of k_schur_pairs + the others

@@ -193,8 +193,12 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 // instantiations write disjoint outputs and run concurrently on two streams.
 // PREP = true: the damped point block's factor is formed here from Hpp and the radius (point_factor(): no k_point_prep launch,
 // no Hinv / Hc arrays); false: read from d.Hc (round-2 schedule, XRSFM_BA_PREP_FUSED=0).
-template <bool GRAM, bool PREP>
-__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(4, 4)))
+// NIK: GRAM = true — the operand height of the tiles of this launch in 16-row MFMA tiles (1..4; ba_plan.h sorts the Gram tiles
+// into one launch per height, so the 80 accumulator registers of a 10-camera tile exist only in the instantiation that
+// needs them; a single instantiation with a switch spilled 21-26 VGPRs in its common path, and one such build produced
+// wrong blocks at scale — DESIGN.md section 5); GRAM = false — 0.
+template <bool GRAM, bool PREP, int NIK>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu((GRAM && NIK < 4) ? 4 : (GRAM ? 3 : 2), (GRAM && NIK < 4) ? 4 : 3)))      // no instantiation may spill (tests/test_capi_cpu.py)
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
                    int n_obs_pairs, double* __restrict__ scat2, double radius, GramPlan gplan) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -341,12 +345,8 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             if (lane < C * C) dtab[lane] = dt0;
             if (lane + kWave < C * C) dtab[lane + kWave] = dt1;
             const bool dense = nvalid == T * C;
-            switch (Rp >> 4) {                             // 16-row operand tiles
-                case 1: gram_tile<1>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
-                case 2: gram_tile<2>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
-                case 3: gram_tile<3>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
-                default: gram_tile<4>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]); break;
-            }
+            (void)Rp;
+            gram_tile<(NIK > 0 ? NIK : 1)>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]);
             XBA_STAMP(0, 8);
             return;
         }

@@ -253,7 +253,14 @@ __global__ void k_cam_lin(Dev d) {
 template <bool LONG>
 __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int item, int lane, double huber_a) {
     constexpr bool is_long = LONG;
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    // long item: the 9 sums that carry over its tiles live in the wave's slice of the dynamic LDS (lane 0 only; the slice is
+    // otherwise used by Gram tiles, which a long item never is) — in registers they cost the loop a spilled value
+    extern __shared__ __attribute__((aligned(16))) double lin_smem_acc[];
+    double* acc = lin_smem_acc + (threadIdx.x >> 6) * (kWave * 13);
+    if (is_long && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    }
     double cost = 0.0, xn2 = 0.0, gm = 0.0;
     int long_pt = -1;
     for (int tl = 0; tl < (LONG ? it.n_tiles : 1); ++tl) {

@@ -26,6 +26,8 @@ struct CholPlan {
     size_t pairs_shm = 0, pairs_shm_big = 0;
     std::vector<int> pairs_items;    // Gram tiles of the small class | Gram tiles of the big class (tile indices) | other items (item indices)
     int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
+    int gram_n[8] = {0};             // Gram tiles per launch bucket 2 * (NI - 1) + (0 small | 1 big LDS class), in pairs_items order
+    size_t gram_shm[8] = {0};        // dynamic LDS of each bucket's launch
     std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, one_k, tiles_nz;
     std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
     std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_trsm, lv_rptr, lv_rj, lv_bptr, lv_bi;     // level schedule
@@ -688,11 +690,14 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.one_k.resize(T);
     for (int t = 0; t < T; ++t) P.one_k[t] = t;
     {
+        // S-assembly launches: one per (operand height NI = ceil(6 C / 16), LDS class) of the Gram tiles — the kernel is
+        // instantiated per NI so that the 10 accumulators of a 10-camera tile do not shape (and spill) the register allocation
+        // of the 4-camera tiles everything else consists of — and one for the other items
         const size_t base = (size_t)64 * 15 * sizeof(double);      // reduction buffer of the diagonal terms (kRedLd)
         const size_t small_cap = kGramSmallLds;
         const int n_items = (int)k.items.size() / 2;
-        std::vector<int> big, other;
-        P.pairs_shm = base; P.pairs_shm_big = base;
+        std::vector<int> bucket[8], other;
+        for (int b = 0; b < 8; ++b) P.gram_shm[b] = base;
         for (int it = 0; it < n_items; ++it) {
             const int t = k.items[2 * it];
             if (k.items[2 * it + 1] != 1 || k.tile_ncam[t] <= 0) { other.push_back(it); continue; }   // per-pair path, long tracks
@@ -702,12 +707,20 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             int passes = 1;
             const size_t need = std::max(base, (size_t)gram_lds_need(C, ntrk, &passes));
             // (Gram classes list the TILE itself: one dependent load less at the head of every workgroup)
-            if (need <= small_cap) { P.pairs_items.push_back(t); P.pairs_shm = std::max(P.pairs_shm, need); }
-            else { big.push_back(t); P.pairs_shm_big = std::max(P.pairs_shm_big, need); }
+            const int b = 2 * ((6 * C + 15) / 16 - 1) + (need <= small_cap ? 0 : 1);
+            bucket[b].push_back(t);
+            P.gram_shm[b] = std::max(P.gram_shm[b], need);
         }
-        P.n_pairs_small = (int)P.pairs_items.size();
-        P.n_pairs_big = (int)big.size(); P.n_pairs_other = (int)other.size();
-        P.pairs_items.insert(P.pairs_items.end(), big.begin(), big.end());
+        P.pairs_items.clear();
+        for (int b = 0; b < 8; ++b) {
+            P.gram_n[b] = (int)bucket[b].size();
+            P.pairs_items.insert(P.pairs_items.end(), bucket[b].begin(), bucket[b].end());
+        }
+        P.n_pairs_small = 0; P.n_pairs_big = 0;
+        for (int b = 0; b < 8; ++b) ((b & 1) ? P.n_pairs_big : P.n_pairs_small) += P.gram_n[b];
+        P.pairs_shm = base; P.pairs_shm_big = base;
+        for (int b = 0; b < 8; ++b) ((b & 1) ? P.pairs_shm_big : P.pairs_shm) = std::max((b & 1) ? P.pairs_shm_big : P.pairs_shm, P.gram_shm[b]);
+        P.n_pairs_other = (int)other.size();
         P.pairs_items.insert(P.pairs_items.end(), other.begin(), other.end());
     }
     return 0;

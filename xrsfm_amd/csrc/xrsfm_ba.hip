@@ -101,6 +101,7 @@ struct CholHost {
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
     int* pairs_items = nullptr; int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
     GramPlan gplan{};                             // store plan of the Gram epilogue (ba_chol.h)
+    int gram_n[8] = {0}; size_t gram_shm[8] = {0};   // Gram tiles / dynamic LDS per launch bucket (ba_plan.h)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // the non-Gram items run concurrently
     // right-looking schedule (dense patterns): one panel after the other
     int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
@@ -575,6 +576,7 @@ int chol_setup(xrsfm_ba_context* c) {
     if (6 * Nc > kCholMaxN && (!(P.use_levels || P.ordering == 2) || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
+    for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.mp_off = P.mp_off; h.fz_off = P.fz_off;
@@ -629,10 +631,13 @@ int chol_setup(xrsfm_ba_context* c) {
             (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+#define XBA_PAIRS_ATTR(NI) \
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max); \
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            XBA_PAIRS_ATTR(1) XBA_PAIRS_ATTR(2) XBA_PAIRS_ATTR(3) XBA_PAIRS_ATTR(4)
+#undef XBA_PAIRS_ATTR
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
             done_for[c->device] = 1;
         }
     }
@@ -658,25 +663,39 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         Timed t_(c, K_SCHUR_PAIRS);
         const bool fork = h.n_pairs_other > 0 && h.aux;
         const double radius = c->step_radius;
-        auto launch_pairs = [&](bool gram, int n, size_t shm, hipStream_t st, const int* items) {
-            if (gram) {
-                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
-                else hipLaunchKernelGGL((k_schur_pairs<true, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
-            } else {
-                if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
-                else hipLaunchKernelGGL((k_schur_pairs<false, false>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
-            }
+        auto launch_other = [&](hipStream_t st) {
+            const int* items = h.pairs_items + h.n_pairs_small + h.n_pairs_big;
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+            else hipLaunchKernelGGL((k_schur_pairs<false, false, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+        };
+        auto launch_gram = [&](auto ni, int n, size_t shm, const int* items) {
+            constexpr int NI = decltype(ni)::value;
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
         };
         if (fork) {
             HIPCHK(hipEventRecord(h.ev_fork, c->stream));
             HIPCHK(hipStreamWaitEvent(h.aux, h.ev_fork, 0));
-            launch_pairs(false, h.n_pairs_other, h.pairs_shm, h.aux, h.pairs_items + h.n_pairs_small + h.n_pairs_big);
+            launch_other(h.aux);
             HIPCHK(hipEventRecord(h.ev_join, h.aux));
         } else if (h.n_pairs_other > 0) {
-            launch_pairs(false, h.n_pairs_other, h.pairs_shm, c->stream, h.pairs_items + h.n_pairs_small + h.n_pairs_big);
+            launch_other(c->stream);
         }
-        if (h.n_pairs_small > 0) launch_pairs(true, h.n_pairs_small, h.pairs_shm, c->stream, h.pairs_items);
-        if (h.n_pairs_big > 0) launch_pairs(true, h.n_pairs_big, h.pairs_shm_big, c->stream, h.pairs_items + h.n_pairs_small);
+        {   // Gram tiles: one launch per (operand height, LDS class) that occurs
+            const int* items = h.pairs_items;
+            for (int b = 0; b < 8; ++b) {
+                const int n = h.gram_n[b];
+                if (n > 0) {
+                    switch (b >> 1) {
+                        case 0: launch_gram(std::integral_constant<int, 1>{}, n, h.gram_shm[b], items); break;
+                        case 1: launch_gram(std::integral_constant<int, 2>{}, n, h.gram_shm[b], items); break;
+                        case 2: launch_gram(std::integral_constant<int, 3>{}, n, h.gram_shm[b], items); break;
+                        default: launch_gram(std::integral_constant<int, 4>{}, n, h.gram_shm[b], items); break;
+                    }
+                }
+                items += n;
+            }
+        }
         if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
     if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
