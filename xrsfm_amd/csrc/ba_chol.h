@@ -173,6 +173,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         __builtin_amdgcn_wave_barrier();
     }
     XBA_STAMP(0, 7);
+#ifndef XBA_NO_STORE_PLAN
     // blocks (camera rb > camera ra) to their destinations, by the store plan of the tile's camera count
     const int4* pl = plan + lane;
 #pragma unroll
@@ -186,6 +187,28 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
                 if (dst >= 0) scat2[36 * (size_t)dst + (e[g] & 63)] = acc[p][g];
             }
     }
+#else
+    // (A/B build -DXBA_NO_STORE_PLAN: the index arithmetic per accumulator element of rounds 1-2)
+    (void)plan;
+    int p = 0;
+#pragma unroll
+    for (int I = 0; I < NI; ++I)
+#pragma unroll
+        for (int J = 0; J <= I; ++J) {
+            const int col = 16 * J + li;
+            const int ra = col / 6, j = col - 6 * ra;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = 16 * I + lk + 4 * g;
+                const int rb = row / 6, i = row - 6 * rb;
+                if (row < R && col < R && rb > ra) {
+                    const int dst = dtab[ra * C + rb];
+                    if (dst >= 0) scat2[36 * (size_t)dst + 6 * i + j] = acc[p][g];
+                }
+            }
+            ++p;
+        }
+#endif
 }
 
 // GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
@@ -546,35 +569,42 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
         asm volatile("" : "+v"(lcol[(cc)]));   /* pin it here: left alone the compiler sinks every update of the inverse behind the   \
                                                   factorisation and keeps all 120 broadcast values alive for it (240 registers, through AGPRs) */ \
     }
-    double sj = fast_rsqrt(row_bcast(a[0], 0));
+    // The chain from one pivot to the next needs only the RECIPROCAL of the pivot (u_ij / u_jj and x_j / u_jj): v_rcp_f64 + two
+    // Newton steps = 5 dependent instructions, against 8 for the reciprocal square root and its square; the square roots
+    // (scaling of column jj of L and of row jj of the inverse) are applied after the sweep, 16 independent chains.
+    double piv[16];
+    piv[0] = row_bcast(a[0], 0);
+    double rj = fast_rcp(piv[0]);
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < 16; ++jj) {
-        const double tl = a[jj] * (sj * sj);              // u_ij / u_jj
-        const double x = lcol[jj] * sj;
-        const double xs = x * sj;
-        lcol[jj] = x;
-        double y = 0.0, h = 0.0, m = 0.0, e = 0.0;
+        const double tl = a[jj] * rj;                      // u_ij / u_jj
+        const double xs = lcol[jj] * rj;
+        double r = 0.0, un = 1.0, e = 0.0;
         if (jj + 1 < 16) {
             XBA_POTRF_UPD(jj + 1)
-            const double un = row_bcast(a[jj + 1], jj + 1);
-            y = __builtin_amdgcn_rsq(un);
-            h = 0.5 * un;
+            un = row_bcast(a[jj + 1], jj + 1);
+            piv[jj + 1] = un;
+            r = __builtin_amdgcn_rcp(un);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma clang loop unroll(full)
-        for (int st = 0; st < 6; ++st) {
+        for (int st = 0; st < 4; ++st) {
 #pragma clang loop unroll(full)
-            for (int cc = jj + 2 + st; cc < 16; cc += 6) XBA_POTRF_UPD(cc)
-            if (jj + 1 < 16) {                           // y <- y * fma(-h y, y, 1.5), twice: three instructions each
-                if (st % 3 == 0) m = h * y;
-                else if (st % 3 == 1) e = fma(-m, y, 1.5);
-                else y = y * e;
+            for (int cc = jj + 2 + st; cc < 16; cc += 4) XBA_POTRF_UPD(cc)
+            if (jj + 1 < 16) {                           // r <- r + r (1 - u r), twice: two instructions each (fast_rcp spelled out)
+                if (st % 2 == 0) e = fma(-un, r, 1.0);
+                else r = fma(r, e, r);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        a[jj] *= sj;                                       // column jj of L (rows >= jj)
-        sj = y;
+        rj = r;
         __builtin_amdgcn_sched_barrier(0);     // keep the broadcasts of later steps from being hoisted (register pressure)
+    }
+#pragma clang loop unroll(full)
+    for (int jj = 0; jj < 16; ++jj) {
+        const double sj = fast_rsqrt(piv[jj]);
+        a[jj] *= sj;                                       // column jj of L (rows >= jj)
+        lcol[jj] *= sj;                                    // row jj of the inverse
     }
 #undef XBA_POTRF_UPD
     if (lane < 16) {
