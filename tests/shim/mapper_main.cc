@@ -52,18 +52,21 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
         track_obs[in.op[i]].push_back({in.oc[i], (int)fr.points.size()});
         fr.points.push_back(p2); fr.track_ids_.push_back(-1); full[in.oc[i]].push_back(in.op[i]);
     }
+    // a track enters the Map when it is triangulated (the reference appends it to map.tracks_ then); until then it is kept out
+    // of every pass over map.tracks_ by its outlier flag (FilterPoints3d would count a track without observations as filtered)
     std::vector<char> active(in.np, 0);
+    for (auto &tr : map.tracks_) tr.outlier = true;
     auto reset_point = [&](int tid) { for (int k = 0; k < 3; ++k) map.tracks_[tid].point3d_.data()[k] = in.P[3 * tid + k]; };
     auto attach = [&](int f, int feat, int tid) { map.frames_[f].track_ids_[feat] = tid; map.tracks_[tid].observations_[f] = feat; };
     auto triangulate_frame = [&](int f) {
         for (size_t i = 0; i < full[f].size(); ++i) {
             const int tid = full[f][i];
-            if (map.tracks_[tid].outlier) continue;            // filtered earlier: stays out (the reference may re-triangulate it)
+            if (active[tid] && map.tracks_[tid].outlier) continue;      // filtered earlier: stays out (the reference may re-triangulate it)
             if (active[tid]) { attach(f, (int)i, tid); continue; }
             int nreg = 0;
             for (auto &o : track_obs[tid]) nreg += map.frames_[o.first].registered;
             if (nreg < 2) continue;
-            active[tid] = 1; reset_point(tid);
+            active[tid] = 1; map.tracks_[tid].outlier = false; reset_point(tid);
             for (auto &o : track_obs[tid]) if (map.frames_[o.first].registered) attach(o.first, o.second, tid);
         }
     };
@@ -153,7 +156,7 @@ int main(int argc, char **argv) {
     for (size_t r = 1; r < states.size(); ++r) same = same && states[r].size() == states[0].size() && memcmp(states[r].data(), states[0].data(), states[0].size() * 8) == 0;
     fwrite(&same, 4, 1, o);
     if (!states.empty()) fwrite(states[0].data(), 8, states[0].size(), o);
-    int32_t n_out = 0;
+    int32_t n_out = 0;            // tracks that were in the map and have been filtered (+ those no two registered frames ever saw)
     for (auto &tr : map.tracks_) n_out += tr.outlier ? 1 : 0;
     fwrite(&n_out, 4, 1, o);
     for (int r = 0; r < repeats; ++r) {

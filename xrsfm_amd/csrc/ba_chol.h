@@ -173,7 +173,9 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         __builtin_amdgcn_wave_barrier();
     }
     XBA_STAMP(0, 7);
-#ifndef XBA_NO_STORE_PLAN
+#ifdef XBA_STORE_PLAN
+    // (A/B build -DXBA_STORE_PLAN, measured and not adopted: 107.6-111.4 us per launch at config L against 103.6 us for the index
+    //  arithmetic below — the 16-byte plan loads are one more dependent memory round trip at the end of every tile)
     // blocks (camera rb > camera ra) to their destinations, by the store plan of the tile's camera count
     const int4* pl = plan + lane;
 #pragma unroll
@@ -188,7 +190,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
             }
     }
 #else
-    // (A/B build -DXBA_NO_STORE_PLAN: the index arithmetic per accumulator element of rounds 1-2)
+    // blocks (camera rb > camera ra) to their destinations (dtab: [C][C], -1 = the pair never occurs in the tile)
     (void)plan;
     int p = 0;
 #pragma unroll
