@@ -44,6 +44,13 @@ MODEL_INFO = {
     3: (5, 0, 1, 2, 3, 4),    # RADIAL         :155-177 (single k)
     4: (8, 0, 1, 2, 3, 4),    # OPENCV         :179-209
 }
+# Extension (NOT one of the reference's camera models): id 5 = BAL-style radial camera {f, k1, k2}, no principal point,
+# uv = f (1 + k1 r^2 + k2 r^4) xy with the reference's sign convention xy = pc.hnormalized().  It exists for the
+# "bal9" mode of SURVEY.md section 8(d) / BASELINE.json north_star ("2x9 camera blocks"): a camera whose cam_const has bit 2
+# (value 4) set keeps its intrinsics block VARIABLE — the reference always holds it constant (ba_solver.cc:602-606, 655-659,
+# 389) — and then contributes a 9-wide block {rotation 3, translation 3, f, k1, k2}.
+MODEL_BAL = 5
+INTR_VARIABLE = 4
 
 
 @dataclasses.dataclass
@@ -51,7 +58,7 @@ class Problem:
     """Flat SoA view of one BA call (the same arrays the C-ABI takes)."""
     cam_q: np.ndarray        # [Nc,4] x,y,z,w (Eigen coeffs order, ba_solver.cc:346)
     cam_t: np.ndarray        # [Nc,3]
-    cam_const: np.ndarray    # [Nc] uint8  bit0: q constant, bit1: t constant
+    cam_const: np.ndarray    # [Nc] uint8  bit0: q constant, bit1: t constant, bit2: intrinsics VARIABLE (model 5 only: bal9 mode)
     cam_intr: np.ndarray     # [Nc] int32
     intr_model: np.ndarray   # [Ni] int32
     intr_params: np.ndarray  # [Ni,8]
@@ -154,10 +161,13 @@ def _intrinsics_per_obs(model: np.ndarray, prm: np.ndarray):
         if m.any():
             fx[m] = prm[m, ifx]; fy[m] = prm[m, ify]
             cx[m] = prm[m, icx]; cy[m] = prm[m, icy]
+    m = model == MODEL_BAL
+    if m.any():
+        fx[m] = prm[m, 0]; fy[m] = prm[m, 0]; cx[m] = 0.0; cy[m] = 0.0
     return fx, fy, cx, cy
 
 
-def project(problem: Problem, q=None, t=None, P=None, want_jac=True):
+def project(problem: Problem, q=None, t=None, P=None, want_jac=True, intr=None, want_intr_jac=False):
     """Per-observation residual and (unrobustified) Jacobian blocks.
 
     Returns r [No,2], valid [No] and, if want_jac, J_rot [No,2,3] (w.r.t. the
@@ -180,9 +190,9 @@ def project(problem: Problem, q=None, t=None, P=None, want_jac=True):
     xn = Pc[:, 0] * iz
     yn = Pc[:, 1] * iz
 
-    intr = problem.cam_intr[ci]
-    model = problem.intr_model[intr]
-    prm = problem.intr_params[intr]
+    intr_idx = problem.cam_intr[ci]
+    model = problem.intr_model[intr_idx]
+    prm = (problem.intr_params if intr is None else intr)[intr_idx]
     fx, fy, cx, cy = _intrinsics_per_obs(model, prm)
 
     n = ci.shape[0]
@@ -219,6 +229,17 @@ def project(problem: Problem, q=None, t=None, P=None, want_jac=True):
         D10[m] = y * rad_x + 2 * p2 * y + 2 * p1 * x
         D11[m] = 1 + rad + y * rad_y + 2 * p2 * x + 6 * p1 * y
 
+    m = model == MODEL_BAL                      # extension: f (1 + k1 r2 + k2 r2^2) xy
+    if m.any():
+        k1, k2 = prm[m, 1], prm[m, 2]
+        x, y, rr = xn[m], yn[m], r2[m]
+        rad = k1 * rr + k2 * rr * rr
+        du[m] = x * rad; dv[m] = y * rad
+        rad_x = 2 * k1 * x + 4 * k2 * rr * x
+        rad_y = 2 * k1 * y + 4 * k2 * rr * y
+        D00[m] = 1 + rad + x * rad_x; D01[m] = x * rad_y
+        D10[m] = y * rad_x; D11[m] = 1 + rad + y * rad_y
+
     r = np.empty((n, 2))
     r[:, 0] = fx * (xn + du) + cx - problem.obs_uv[:, 0]
     r[:, 1] = fy * (yn + dv) + cy - problem.obs_uv[:, 1]
@@ -237,6 +258,16 @@ def project(problem: Problem, q=None, t=None, P=None, want_jac=True):
     J_P = np.einsum("nij,njk->nik", Jproj, M)
     # row^T * (-2 [RP]x) = -2 * (row x RP)
     J_rot = -2.0 * np.cross(Jproj, RP[:, None, :])
+    if want_intr_jac:
+        # d r / d (f, k1, k2) of model 5 (zero for the reference's models, whose intrinsics are always constant)
+        J_i = np.zeros((n, 2, 3))
+        m = (model == MODEL_BAL) & valid
+        if m.any():
+            x, y, rr, f = xn[m], yn[m], r2[m], fx[m]
+            J_i[m, 0, 0] = x + du[m]; J_i[m, 1, 0] = y + dv[m]
+            J_i[m, 0, 1] = f * x * rr; J_i[m, 1, 1] = f * y * rr
+            J_i[m, 0, 2] = f * x * rr * rr; J_i[m, 1, 2] = f * y * rr * rr
+        return r, valid, J_rot, J_t, J_P, J_i
     return r, valid, J_rot, J_t, J_P
 
 
@@ -269,11 +300,19 @@ def quat_plus(q: np.ndarray, d: np.ndarray) -> np.ndarray:
 # ----------------------------------------------------------------------------
 # evaluation: cost, robustified residuals and tangent Jacobian blocks
 # ----------------------------------------------------------------------------
-def evaluate(problem: Problem, q, t, P, a=HUBER_A, want_jac=True):
-    if want_jac:
-        r, valid, Jr, Jt, JP = project(problem, q, t, P, True)
+def wide(problem: Problem) -> bool:
+    """bal9 mode: some camera keeps its intrinsics variable (cam_const bit 2) -> 9-wide camera blocks for the whole problem."""
+    return bool(((problem.cam_const & INTR_VARIABLE) != 0).any())
+
+
+def evaluate(problem: Problem, q, t, P, a=HUBER_A, want_jac=True, intr=None):
+    is_wide = wide(problem)
+    if want_jac and is_wide:
+        r, valid, Jr, Jt, JP, Ji = project(problem, q, t, P, True, intr=intr, want_intr_jac=True)
+    elif want_jac:
+        r, valid, Jr, Jt, JP = project(problem, q, t, P, True, intr=intr)
     else:
-        r, valid = project(problem, q, t, P, False)
+        r, valid = project(problem, q, t, P, False, intr=intr)
     s = np.sum(r * r, axis=1)
     rho, rho1 = huber(s, a)
     cost = 0.5 * float(np.sum(rho))
@@ -281,13 +320,15 @@ def evaluate(problem: Problem, q, t, P, a=HUBER_A, want_jac=True):
         return cost
     sw = np.sqrt(rho1)
     rt = r * sw[:, None]
-    Fc = np.concatenate([Jr, Jt], axis=2) * sw[:, None, None]   # [No,2,6] (rot, t)
+    Fc = np.concatenate([Jr, Jt] + ([Ji] if is_wide else []), axis=2) * sw[:, None, None]   # [No,2,6] (rot, t) | [No,2,9] (+ f, k1, k2)
     Ep = JP * sw[:, None, None]                                 # [No,2,3]
     # constant blocks are removed from the program (A.4): zero their columns
     qc = (problem.cam_const[problem.obs_cam] & 1) != 0
     tc = (problem.cam_const[problem.obs_cam] & 2) != 0
     Fc[qc, :, 0:3] = 0.0
     Fc[tc, :, 3:6] = 0.0
+    if is_wide:
+        Fc[(problem.cam_const[problem.obs_cam] & INTR_VARIABLE) == 0, :, 6:9] = 0.0
     pc = problem.point_const[problem.obs_pt] != 0
     Ep[pc] = 0.0
     return cost, rt, Fc, Ep
@@ -309,11 +350,12 @@ class _Linearization:
         self.rt, self.Fs, self.Es = rt, Fs, Es
         Nc, Np = problem.cam_q.shape[0], problem.points.shape[0]
         ci, pi = problem.obs_cam, problem.obs_pt
-        self.Hcc = np.zeros((Nc, 6, 6)); np.add.at(self.Hcc, ci, np.einsum("nki,nkj->nij", Fs, Fs))
+        W = Fs.shape[2]
+        self.Hcc = np.zeros((Nc, W, W)); np.add.at(self.Hcc, ci, np.einsum("nki,nkj->nij", Fs, Fs))
         self.Hpp = np.zeros((Np, 3, 3)); np.add.at(self.Hpp, pi, np.einsum("nki,nkj->nij", Es, Es))
-        self.gc = np.zeros((Nc, 6)); np.add.at(self.gc, ci, np.einsum("nki,nk->ni", Fs, rt))
+        self.gc = np.zeros((Nc, W)); np.add.at(self.gc, ci, np.einsum("nki,nk->ni", Fs, rt))
         self.gp = np.zeros((Np, 3)); np.add.at(self.gp, pi, np.einsum("nki,nk->ni", Es, rt))
-        self.W = np.einsum("nki,nkj->nij", Fs, Es)          # [No,6,3] = F^T E
+        self.W = np.einsum("nki,nkj->nij", Fs, Es)          # [No,W,3] = F^T E
 
 
 def _active_points(problem: Problem) -> np.ndarray:
@@ -326,13 +368,14 @@ def _solve_exact(problem: Problem, lin: _Linearization, Dc2, Dp2):
     """(Js^T Js + D^2) y = Js^T r via exact Schur complement (Appendix A.7)."""
     import scipy.linalg as sla
     Nc = problem.cam_q.shape[0]
+    Wc = lin.Hcc.shape[1]                                  # camera block width: 6, or 9 in bal9 mode
     ci, pi = problem.obs_cam, problem.obs_pt
     Hpp_d = lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3))
     Hinv = np.linalg.inv(Hpp_d)
     # dense reduced camera matrix
-    S = np.zeros((Nc * 6, Nc * 6))
+    S = np.zeros((Nc * Wc, Nc * Wc))
     for c in range(Nc):
-        S[6 * c:6 * c + 6, 6 * c:6 * c + 6] = lin.Hcc[c] + np.diag(Dc2[c])
+        S[Wc * c:Wc * c + Wc, Wc * c:Wc * c + Wc] = lin.Hcc[c] + np.diag(Dc2[c])
     WH = np.einsum("nij,njk->nik", lin.W, Hinv[pi])        # [No,6,3]
     b = lin.gc - _scatter_add(Nc, ci, np.einsum("nij,nj->ni", WH, lin.gp[pi]))
     order = np.argsort(pi, kind="stable")
@@ -341,7 +384,7 @@ def _solve_exact(problem: Problem, lin: _Linearization, Dc2, Dp2):
     import scipy.sparse as sp
     lens = np.diff(ptr)
     rows_l, cols_l, vals_l = [], [], []
-    i6 = np.arange(6)
+    i6 = np.arange(Wc)
     for L in np.unique(lens):
         if L == 0:
             continue
@@ -351,14 +394,14 @@ def _solve_exact(problem: Problem, lin: _Linearization, Dc2, Dp2):
             for b_ in range(L):
                 blk = np.einsum("nij,nkj->nik", WH[idx[:, a_]], lin.W[idx[:, b_]])  # [n,6,6]
                 ca, cb = ci[idx[:, a_]], ci[idx[:, b_]]
-                rows = np.broadcast_to(6 * ca[:, None, None] + i6[None, :, None], blk.shape)
-                cols = np.broadcast_to(6 * cb[:, None, None] + i6[None, None, :], blk.shape)
+                rows = np.broadcast_to(Wc * ca[:, None, None] + i6[None, :, None], blk.shape)
+                cols = np.broadcast_to(Wc * cb[:, None, None] + i6[None, None, :], blk.shape)
                 rows_l.append(rows.reshape(-1)); cols_l.append(cols.reshape(-1)); vals_l.append(blk.reshape(-1))
     if vals_l:
         S -= sp.coo_matrix((np.concatenate(vals_l), (np.concatenate(rows_l), np.concatenate(cols_l))),
                            shape=S.shape).toarray()
     cf = sla.cho_factor(S, lower=True, check_finite=False)
-    yc = sla.cho_solve(cf, b.reshape(-1), check_finite=False).reshape(Nc, 6)
+    yc = sla.cho_solve(cf, b.reshape(-1), check_finite=False).reshape(Nc, Wc)
     yp = _back_substitute(problem, lin, Hinv, yc)
     return yc, yp, 0
 
@@ -387,7 +430,7 @@ def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter):
     Hinv = np.linalg.inv(lin.Hpp + np.einsum("ni,ij->nij", Dp2, np.eye(3)))
     WH = np.einsum("nij,njk->nik", lin.W, Hinv[pi])
     b = lin.gc - _scatter_add(Nc, ci, np.einsum("nij,nj->ni", WH, lin.gp[pi]))
-    Scc = lin.Hcc + np.einsum("ni,ij->nij", Dc2, np.eye(6)) \
+    Scc = lin.Hcc + np.einsum("ni,ij->nij", Dc2, np.eye(lin.Hcc.shape[1])) \
         - _scatter_add(Nc, ci, np.einsum("nij,nkj->nik", WH, lin.W))
     Minv = np.linalg.inv(Scc)
 
@@ -398,7 +441,7 @@ def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter):
         zz = v - np.einsum("nki,ni->nk", lin.Es, u[pi])
         return Dc2 * p + _scatter_add(Nc, ci, np.einsum("nki,nk->ni", lin.Fs, zz))
 
-    x = np.zeros((Nc, 6)); r = b.copy()
+    x = np.zeros((Nc, lin.Hcc.shape[1])); r = b.copy()
     z = np.einsum("nij,nj->ni", Minv, r); p = z.copy()
     rz = float(np.sum(r * z)); bnorm = float(np.linalg.norm(b)); it = 0
     if bnorm == 0.0:
@@ -423,18 +466,27 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
     opt = opt or Options()
     summ = Summary()
     q = problem.cam_q.copy(); t = problem.cam_t.copy(); P = problem.points.copy()
+    intr = np.array(problem.intr_params, dtype=float, copy=True)      # state too in bal9 mode (intrinsics of cameras with bit 2)
+    is_wide = wide(problem)
+    ivar = (problem.cam_const & INTR_VARIABLE) != 0
+    if is_wide:
+        idx = problem.cam_intr[ivar]
+        if (problem.intr_model[idx] != MODEL_BAL).any() or np.unique(problem.cam_intr, return_counts=True)[1][np.searchsorted(np.unique(problem.cam_intr), idx)].max() > 1:
+            raise ValueError("variable intrinsics: model 5 with one intrinsics entry per camera")
     qvar = (problem.cam_const & 1) == 0
     tvar = (problem.cam_const & 2) == 0
     act = _active_points(problem)
     pvar = (problem.point_const == 0) & act
     # cameras without observations are not part of the program (ba_solver.cc:350-352)
     cam_act = np.zeros(q.shape[0], bool); cam_act[problem.obs_cam] = True
-    qvar &= cam_act; tvar &= cam_act
+    qvar &= cam_act; tvar &= cam_act; ivar = ivar & cam_act
     summ.num_residuals = 2 * problem.obs_cam.shape[0]
-    summ.num_effective_params = int(3 * qvar.sum() + 3 * tvar.sum() + 3 * pvar.sum())
+    summ.num_effective_params = int(3 * qvar.sum() + 3 * tvar.sum() + 3 * pvar.sum() + 3 * ivar.sum())
+    iv_rows = problem.cam_intr[ivar]             # rows of intr_params that are variable blocks {f, k1, k2}
 
     def x_norm(q_, t_, P_):
-        return math.sqrt(float((q_[qvar] ** 2).sum() + (t_[tvar] ** 2).sum() + (P_[pvar] ** 2).sum()))
+        i2 = float((intr[iv_rows, 0:3] ** 2).sum()) if is_wide else 0.0
+        return math.sqrt(float((q_[qvar] ** 2).sum() + (t_[tvar] ** 2).sum() + (P_[pvar] ** 2).sum()) + i2)
 
     a = opt.huber_a
     alt = opt.alt
@@ -445,13 +497,13 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
     if alt == "x_norm_includes_constant_blocks":
         def x_norm(q_, t_, P_):          # noqa: F811
             return math.sqrt(float((q_[cam_act] ** 2).sum() + (t_[cam_act] ** 2).sum() + (P_[act] ** 2).sum()))
-    cost, rt, Fc, Ep = evaluate(problem, q, t, P, a)
+    cost, rt, Fc, Ep = evaluate(problem, q, t, P, a, intr=intr)
     summ.initial_cost = cost
     # Jacobi scaling, computed once at iteration 0: 1/(1+||col||)
     ci, pi = problem.obs_cam, problem.obs_pt
     Fn, En = Fc, Ep
     if alt == "jacobi_scaling_unrobustified":
-        r_, _valid, Jr_, Jt_, JP_ = project(problem, q, t, P, True)
+        r_, _valid, Jr_, Jt_, JP_ = project(problem, q, t, P, True, intr=intr)
         Fn = np.concatenate([Jr_, Jt_], axis=2) * (Fc != 0).any(axis=1, keepdims=True)     # constant blocks stay zero
         En = JP_ * (Ep != 0).any(axis=1, keepdims=True)
     cn_c = np.sqrt(_scatter_add(q.shape[0], ci, np.sum(Fn * Fn, axis=1)))
@@ -475,6 +527,8 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
             m = max(m, float(np.abs(q_[qvar] - quat_plus(q_[qvar], -gc[qvar, 0:3])).max()))
         if tvar.any():
             m = max(m, float(np.abs(gc[tvar, 3:6]).max()))
+        if is_wide and ivar.any():
+            m = max(m, float(np.abs(gc[ivar, 6:9]).max()))
         if pvar.any():
             m = max(m, float(np.abs(gp[pvar]).max()))
         return m
@@ -486,6 +540,8 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         summ.termination = term
         summ.final_cost = cost_
         problem.cam_q[:] = q; problem.cam_t[:] = t; problem.points[:] = P
+        if is_wide:
+            problem.intr_params[:] = intr
         return summ
 
     if grad_max(lin, q, t, P) <= opt.gradient_tolerance:
@@ -536,9 +592,13 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         q2 = q.copy(); q2[qvar] = quat_plus(q[qvar], dc[qvar, 0:3])
         t2 = t + dc[:, 3:6]
         P2 = P + dp
-        cost2 = evaluate(problem, q2, t2, P2, a, want_jac=False)
+        intr2 = intr
+        if is_wide:
+            dc[~ivar, 6:9] = 0.0
+            intr2 = intr.copy(); intr2[iv_rows, 0:3] = intr[iv_rows, 0:3] + dc[ivar, 6:9]
+        cost2 = evaluate(problem, q2, t2, P2, a, want_jac=False, intr=intr2)
         step_norm = math.sqrt(float(((q2 - q)[qvar] ** 2).sum() + ((t2 - t)[tvar] ** 2).sum()
-                                    + ((P2 - P)[pvar] ** 2).sum()))
+                                    + ((P2 - P)[pvar] ** 2).sum() + ((intr2 - intr) ** 2).sum()))
         cost_change = cost - cost2
         rel = cost_change / model_change
 
@@ -547,6 +607,7 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
             if alt == "accept_before_tolerance" and rel > min_rel_decrease:
                 nonlocal q, t, P
                 q, t, P = q2, t2, P2
+                intr[:] = intr2
                 summ.n_successful += 1
                 return finish("CONVERGENCE: " + kind, cost2)
             return finish("CONVERGENCE: " + kind, cost)
@@ -557,8 +618,9 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
             return tolerance_exit("function tolerance")
         if rel > min_rel_decrease:
             q, t, P = q2, t2, P2
+            intr = intr2
             xn = x_norm(q, t, P)
-            cost, rt, Fc, Ep = evaluate(problem, q, t, P, a)
+            cost, rt, Fc, Ep = evaluate(problem, q, t, P, a, intr=intr)
             lin = linearize(rt, Fc, Ep)
             radius = min(opt.max_radius, radius / max(0.5 if alt == "radius_factor_capped_at_2" else 1.0 / 3.0, 1.0 - (2.0 * rel - 1.0) ** 3))
             decrease = 2.0

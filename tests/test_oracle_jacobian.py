@@ -30,6 +30,8 @@ def _ref_residual(q, t, P, model, k, uv):
         fx, fy, cx, cy = k[0], k[0], k[1], k[2]; rad = k[3] * (x * x + y * y); du, dv = x * rad, y * rad
     elif model == 3:
         fx, fy, cx, cy = k[0], k[1], k[2], k[3]; rad = k[4] * (x * x + y * y); du, dv = x * rad, y * rad
+    elif model == 5:        # extension (not a reference model): BAL-style {f, k1, k2}, no principal point — bal9 mode
+        fx, fy, cx, cy = k[0], k[0], 0.0, 0.0; r2 = x * x + y * y; rad = k[1] * r2 + k[2] * r2 * r2; du, dv = x * rad, y * rad
     else:
         fx, fy, cx, cy = k[0], k[1], k[2], k[3]; k1, k2, p1, p2 = k[4], k[5], k[6], k[7]
         x2, xy_, y2 = x * x, x * y, y * y; r2 = x2 + y2; rad = k1 * r2 + k2 * r2 * r2
@@ -104,3 +106,44 @@ def test_plus_jacobian_matrix_is_the_derivative_of_plus():
         d = np.zeros((1, 3)); d[0, a] = h
         num[:, a] = (bo.quat_plus(q[None], d)[0] - bo.quat_plus(q[None], -d)[0]) / (2 * h)
     assert np.abs(num - plusJ).max() < 1e-9
+
+
+def test_bal9_jacobians_match_autodiff():
+    """Extension model 5 {f, k1, k2} with variable intrinsics (bal9 mode): residual and all four Jacobian blocks — rotation
+    (through the quaternion parameterisation), translation, point, and d r / d (f, k1, k2) — against torch.autograd."""
+    arr = H.make_bal9(8, 60, 4, seed=111)
+    arr["intr_params"][:, 1] = np.linspace(-0.05, 0.08, 8); arr["intr_params"][:, 2] = np.linspace(0.03, -0.04, 8)
+    pr = H.to_oracle(arr)
+    r, valid, Jr, Jt, JP, Ji = bo.project(pr, want_intr_jac=True)
+    assert valid.all()
+    for i in range(0, pr.obs_cam.shape[0], 2):
+        c, p = pr.obs_cam[i], pr.obs_pt[i]
+        ii = pr.cam_intr[c]
+        q = torch.tensor(pr.cam_q[c]); t = torch.tensor(pr.cam_t[c]); P = torch.tensor(pr.points[p])
+        k = torch.tensor(pr.intr_params[ii]); uv = torch.tensor(pr.obs_uv[i])
+        f = lambda qq, tt, PP, kk: _ref_residual(qq, tt, PP, 5, kk, uv)
+        Jq, Jtt, JPP, Jk = torch.autograd.functional.jacobian(f, (q, t, P, k))
+        x, y, z, w = [float(v) for v in q]
+        plusJ = torch.tensor([[w, z, -y], [-z, w, x], [y, -x, w], [-x, -y, -z]], dtype=torch.float64)
+        Jd = Jq @ plusJ
+        scale = max(1.0, float(Jd.abs().max()), float(JPP.abs().max()), float(Jk.abs().max()))
+        assert np.abs(r[i] - f(q, t, P, k).numpy()).max() <= 1e-12 * max(1.0, np.abs(r[i]).max())
+        assert np.abs(Jr[i] - Jd.numpy()).max() <= 1e-12 * scale and np.abs(Jt[i] - Jtt.numpy()).max() <= 1e-12 * scale
+        assert np.abs(JP[i] - JPP.numpy()).max() <= 1e-12 * scale
+        assert np.abs(Ji[i] - Jk.numpy()[:, :3]).max() <= 1e-12 * scale and np.abs(Jk.numpy()[:, 3:]).max() == 0.0
+
+
+def test_bal9_oracle_solve_converges_and_moves_intrinsics():
+    arr = H.make_bal9(12, 600, 4, seed=5)
+    pr = H.to_oracle(arr)
+    s = bo.solve(pr, bo.Options())
+    n = arr["obs_cam"].shape[0]
+    assert s.num_effective_params == 3 * 12 + 3 * 10 + 3 * 600 + 3 * 12          # rotations, translations (two fixed), points, intrinsics
+    assert s.final_cost < 0.05 * s.initial_cost and np.sqrt(s.final_cost / n) < 2.0
+    assert np.abs(pr.intr_params[:, :3] - arr["intr_params"][:, :3]).max() > 1e-3     # the intrinsics took part
+    assert np.array_equal(pr.intr_params[:, 3:], arr["intr_params"][:, 3:])
+    # with bit 2 clear the same problem is the ordinary 6-wide one: intrinsics untouched
+    arr6 = dict(arr); arr6["cam_const"] = (arr["cam_const"] & 3).astype(np.uint8)
+    pr6 = H.to_oracle(arr6)
+    s6 = bo.solve(pr6, bo.Options())
+    assert np.array_equal(pr6.intr_params, arr["intr_params"]) and s6.num_effective_params == s.num_effective_params - 36

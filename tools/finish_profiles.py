@@ -39,12 +39,18 @@ def main():
                           ("U", "random visibility, dense reduced camera matrix; no CPU leg"),
                           ("D", "2000 cameras, random visibility: the dense limit of the exact path (panel schedule); no CPU leg"),
                           ("V", "3000 cameras, random visibility: implicit-Schur PCG; no CPU leg"),
-                          ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter")):
+                          ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter"),
+                          ("T", "BASELINE config 5 at its size: 7500 photos in viewpoint clusters / 1.8M points / 8.1M observations, shuffled ids; exact path in the reverse Cuthill-McKee order; no CPU leg"),
+                          ("T_pcg", "the same through the implicit-Schur PCG (the only path at this size until round 2)"),
+                          ("M", "mapper-shaped replay through the BASolver adapter: a different metric (wall time of the BA calls of a 300-frame incremental reconstruction)")):
             if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
                 continue
             f.write(f"\n## config {cfg}" + (f" ({note})" if note else "") + "\n```\n" + rd(f"bench_{cfg}.json").strip() + "\n```\n")
             d = json.loads(rd(f"bench_{cfg}.json"))
             b = d.get("cpu_baseline") or {}
+            if cfg == "M":
+                f.write(f"\n{d['value']:.1f} ms of BA calls, {d['ms_per_step']:.1f} ms for the whole replay.\n")
+                continue
             f.write(f"\n{d['ms_per_step']:.2f} ms per solve ({d['lm_iterations_per_step']:.0f} LM iterations), {d['value']:.3e} {d['unit']}")
             if not b:
                 f.write(".\n")

@@ -31,6 +31,9 @@ python bench.py --config U --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_U.err | t
 python bench.py --config V --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_V.err | tail -1 > $OUT/bench_V.json
 python bench.py --config L0 --steps 3 --warmup 1 --no-extras 2> $OUT/bench_L0.err | tail -1 > $OUT/bench_L0.json
 python bench.py --config D --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_D.err | tail -1 > $OUT/bench_D.json
+python bench.py --config T --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_T.err | tail -1 > $OUT/bench_T.json
+python bench.py --config T --steps 1 --warmup 0 --no-cpu --no-extras --solver pcg 2> $OUT/bench_T_pcg.err | tail -1 > $OUT/bench_T_pcg.json
+python bench.py --config M 2> $OUT/bench_M.err | tail -1 > $OUT/bench_M.json
 # 5. the dense reduced solve (config D): per-kernel table, and the sustained FP64 matrix-core rate of the instruction it uses
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsD -o stats -- python $ROOT/bench.py --config D --no-cpu --no-extras --steps 1 --warmup 1 > $OUT/statsD_bench.log 2>&1; \
   python $ROOT/tools/rocprof_summary.py $(find $OUT/statsD -name "*.db" | head -1) $OUT/kernel_stats_table_D.md > /dev/null; rm -rf $OUT/statsD )
