@@ -77,12 +77,24 @@ def make_config(name: str) -> dict:
     (unordered photo collection with viewpoint clusters), everything else the BAL-style generator of SURVEY.md Appendix D."""
     from xrsfm_amd import synth
     cfg = dict(synth.CONFIGS[name])
+    if name == "Lb9":            # config 4 with 9-wide camera blocks: every camera's {f, k1, k2} is a variable (bal9 mode)
+        return synth.to_bal9(synth.make_problem(**cfg))
     return synth.make_collection(**cfg) if name == "T" else synth.make_problem(**cfg)
 
 
-def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, nnzb: int = 0):
+def algorithmic_bytes(kernel: str, n_obs: int, n_pts: int, n_cams: int, nnzb: int = 0, width: int = 6):
     """ALGORITHMIC HBM bytes of one launch, J-stored accounting of SURVEY.md section 8(d) / DESIGN.md section 5
-    (FP64 values, int32 indices).  None for kernels that are latency- or MFMA-bound."""
+    (FP64 values, int32 indices).  None for kernels that are latency- or MFMA-bound.  width = 9: the bal9 rows of the same
+    section (B_lin = 232, B_pcg(1) = 192, explicit-S blocks of 648 bytes), cameras with 3 intrinsics more."""
+    if width == 9:
+        w, ws = 9, 45                                  # camera block width, entries of a symmetric diagonal block
+        table9 = {
+            "k_linearize": n_obs * (24 + 16 + 2 * 8 * (w + 3)) + n_pts * 24 + n_cams * 80,
+            "k_schur_pairs": n_obs * (16 + 2 * 8 * (w + 3)) + n_pts * 72 + n_cams * 8 * (ws + w) + nnzb * 8 * w * w,
+            "k_backsub": n_obs * (16 + 2 * 8 * (w + 3)) + n_pts * 144 + n_cams * 8 * w,
+            "k_cost": n_obs * 24 + n_pts * 24 + n_cams * 80,
+        }
+        return table9.get(kernel)
     table = {
         # read uv + 2 idx, write r[2] + Jc[2x6] + Jp[2x3]; read points and cameras            (B_lin)
         "k_linearize": n_obs * (24 + 160) + n_pts * 24 + n_cams * 56,
@@ -289,7 +301,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "K", "U", "X", "R", "V", "D", "L0", "T", "M"]))
+    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "K", "U", "X", "R", "V", "D", "L0", "T", "M", "Lb9"]))
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
@@ -383,12 +395,14 @@ def main():
     kernel_table = {k: {"ms": round(v[0], 4), "launches": v[1]} for k, v in kernels.items() if v[1] > 0}
     roofline = None
     # dominant kernel = largest HIP-event total among the HBM-streaming kernels
-    cands = [(v[0], k) for k, v in kernels.items() if v[1] > 0 and algorithmic_bytes(k, 1, 1, 1) is not None]
+    cands = [(v[0], k) for k, v in kernels.items()
+             if v[1] > 0 and algorithmic_bytes(k, 1, 1, 1, 0, 9 if args.config == "Lb9" else 6) is not None]
     if cands:
         _, dom = max(cands)
         ms, launches = kernels[dom]
         avg_s = ms * 1e-3 / launches
-        alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
+        width = 9 if args.config == "Lb9" else 6
+        alg = algorithmic_bytes(dom, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local), width)
         ach = alg / avg_s / 1e9
         traffic = None
         traffic_source = None
@@ -407,7 +421,7 @@ def main():
         per_kernel = {}
         for ms_k, k in sorted(cands, reverse=True):
             n_k = kernels[k][1]
-            b_k = algorithmic_bytes(k, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local))
+            b_k = algorithmic_bytes(k, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local), width)
             per_kernel[k] = {"avg_launch_us": ms_k * 1e3 / n_k, "launches": n_k, "algorithmic_bytes_per_launch": b_k,
                              "frac": b_k / (ms_k * 1e-3 / n_k) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and os.path.exists(pmc):
@@ -422,7 +436,7 @@ def main():
         # the whole LM iteration against BASELINE.md section 4: B_iter(0) = B_lin + B_prep + B_back, plus the explicit-S terms
         # (the nnzb off-diagonal 6x6 blocks written once; SURVEY 8d's B_S would also count a second read of J, N_obs*144,
         # which the fused S assembly does not do: reported separately)
-        if last.linear_solver_used == 1 and world == 1:
+        if last.linear_solver_used == 1 and world == 1 and width == 6:
             nnzb = count_offdiag_blocks(local)
             b_iter = (prob.n_obs * (184 + 160 + 168) + prob.n_points * (24 + 72 + 144) + n_cams * (56 + 216 + 160) + nnzb * 288)
             t_iter = dt / max(iters, 1)
@@ -455,7 +469,11 @@ def main():
             "termination_reason": last.termination_reason,
             "roofline": roofline, "cpu_baseline": None, "kernels": kernel_table,
         }
-        if world == 1 and not args.no_cpu:
+        if args.config == "Lb9":
+            out["config"]["workload"] += "; bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks"
+            out["cpu_baseline_note"] = ("the C restatement under oracle/ is 6-wide; bal9 parity is checked against the numpy oracle "
+                                        "in tests/test_gpu_bal9.py, and no CPU time is quoted for this configuration")
+        if world == 1 and not args.no_cpu and args.config != "Lb9":
             res = cpu_baseline(arr, n_cams, n_points, opt.max_iterations)
             if res is not None:
                 base, cpu_prob = res

@@ -50,6 +50,16 @@ extern "C" {
  * (problem.SetParameterBlockConstant, ba_solver.cc:611-621) */
 #define XRSFM_BA_CONST_Q 1u
 #define XRSFM_BA_CONST_T 2u
+/* bal9 mode (BASELINE.json north_star "2x9 camera blocks") — NOT something the reference does: it
+ * always holds the intrinsics block of ReProjectionCost (cost_factor_ceres.h:42-46, kNumParams) constant (ba_solver.cc:
+ * 602-606, 655-659, 389).  A camera with this bit keeps its intrinsics VARIABLE and contributes a 9-wide block {rotation 3,
+ * translation 3, f, k1, k2}.  Requirements (XRSFM_BA_EINVAL otherwise): camera model 5 below, one intrinsics entry per such
+ * camera; exact solver on one rank.  The refined {f, k1, k2} come back in problem->intr_params (xrsfm_ba_solve) /
+ * xrsfm_ba_download_intrinsics.  The adapter never sets it. */
+#define XRSFM_BA_INTR_VARIABLE 4u
+/* Camera models: 0..4 = the reference's (camera_model.hpp:93-209); 5 = extension for BAL-style problems: params {f, k1, k2},
+ * no principal point, uv = f (1 + k1 r^2 + k2 r^4) xy with the reference's sign convention xy = pc.hnormalized(). */
+#define XRSFM_BA_MODEL_BAL 5
 
 /* One BA call = one ceres::Problem of the reference (ba_solver.cc:596,645,536).
  * Observation order is free (the reference's is frame-major, ba_solver.cc:598-601). */
@@ -63,7 +73,7 @@ typedef struct xrsfm_ba_problem {
     const uint8_t *cam_const;   /* [n_cams]     XRSFM_BA_CONST_* bits, NULL = all free   */
     const int32_t *cam_intr;    /* [n_cams]     index into intr_*                        */
     const int32_t *intr_model;  /* [n_intr]     XRSFM_BA_<MODEL>                         */
-    const double *intr_params;  /* [n_intr][8]  camera.params_ (zero padded)             */
+    double *intr_params;        /* [n_intr][8]  camera.params_ (zero padded); read only, except in bal9 mode (XRSFM_BA_INTR_VARIABLE): in/out */
     double *points;             /* [n_points][3] track.point3d_            in/out        */
     const uint8_t *point_const; /* [n_points]   non-zero = constant (SetUpLBA :380-382), NULL = all free */
     const int32_t *obs_cam;     /* [n_obs] */
@@ -150,6 +160,10 @@ int xrsfm_ba_reset(xrsfm_ba_context *ctx);
 /* Copy the current state back into caller arrays laid out like the problem
  * (cam_q [n_cams][4], cam_t [n_cams][3], points [n_points][3]); NULL skips one. */
 int xrsfm_ba_download(xrsfm_ba_context *ctx, double *cam_q, double *cam_t, double *points);
+
+/* bal9 mode: intrinsics {f, k1, k2} of the cameras with XRSFM_BA_INTR_VARIABLE into intr_params [n_intr][8] (other rows and
+ * columns untouched); a no-op for ordinary problems. */
+int xrsfm_ba_download_intrinsics(xrsfm_ba_context *ctx, double *intr_params);
 
 void xrsfm_ba_destroy(xrsfm_ba_context *ctx);
 
@@ -333,6 +347,12 @@ int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context *ctx, int n_pairs, const i
 /* After debug_linearize: solve S(radius) y = b with the Cholesky path; y [n_cams][6].  If S_dense != NULL it
  * receives the assembled reduced camera matrix before factorisation, [6 n_cams][6 n_cams] row-major, symmetric. */
 int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context *ctx, double radius, double *y, double *S_dense);
+
+/* bal9 contexts: linearise at the current state with Jacobi scaling (cost; per observation r [n_obs][2], Jc [n_obs][2][9],
+ * Jp [n_obs][2][3]; per camera diag(Hcc), g_c [n_cams][9]) and, if y != NULL, solve the reduced system at `radius`
+ * (y [n_cams][9], scaled coordinates).  Any output pointer may be NULL. */
+int xrsfm_ba_debug_wide(xrsfm_ba_context *ctx, double huber_a, double radius, double *cost, double *r, double *Jc, double *Jp,
+                        double *Hcc_diag, double *gc, double *y);
 
 /* After debug_cholesky_solve: one back-substitution (k_backsub) from the camera solution it left.  Outputs in the
  * library's PACKED order (for comparing two builds of the library on the same problem, tools/backsub_waves_probe.py):

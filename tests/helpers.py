@@ -249,14 +249,4 @@ def make_bal9(n_cams=12, n_pts=600, k_obs=4, seed=5, **kw):
     """bal9 mode (BASELINE north_star "2x9 camera blocks"): every camera has its own intrinsics of the extension
     model 5 {f, k1, k2} (no principal point) and keeps them VARIABLE (cam_const bit 2): 9-wide camera blocks.  Same geometry and
     observations as make() (the KITTI principal point is subtracted from the observations), intrinsics start 1 % / 0.01 off."""
-    arr = dict(make(n_cams, n_pts, k_obs, seed=seed, **kw))
-    rng = np.random.default_rng(9000 + seed)
-    f, cx, cy = synth.KITTI_INTR[0], synth.KITTI_INTR[1], synth.KITTI_INTR[2]
-    arr["obs_uv"] = np.ascontiguousarray(arr["obs_uv"] - np.array([cx, cy]))
-    arr["cam_intr"] = np.arange(n_cams, dtype=np.int32)
-    arr["intr_model"] = np.full(n_cams, 5, np.int32)
-    prm = np.zeros((n_cams, 8))
-    prm[:, 0] = f * (1 + rng.normal(0, 0.01, n_cams)); prm[:, 1] = rng.normal(0, 0.01, n_cams); prm[:, 2] = rng.normal(0, 0.01, n_cams)
-    arr["intr_params"] = prm
-    arr["cam_const"] = (np.asarray(arr["cam_const"], np.uint8) | 4).astype(np.uint8)
-    return arr
+    return synth.to_bal9(make(n_cams, n_pts, k_obs, seed=seed, **kw), seed)

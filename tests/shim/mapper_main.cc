@@ -54,6 +54,7 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
     }
     // a track enters the Map when it is triangulated (the reference appends it to map.tracks_ then); until then it is kept out
     // of every pass over map.tracks_ by its outlier flag (FilterPoints3d would count a track without observations as filtered)
+    const double th_rpe_lba = 16, th_angle_lba = 1.5, th_rpe_gba = 16, th_angle_gba = 1.5;      // incremental_mapper.h:20-23
     std::vector<char> active(in.np, 0);
     for (auto &tr : map.tracks_) tr.outlier = true;
     auto reset_point = [&](int tid) { for (int k = 0; k < 3; ++k) map.tracks_[tid].point3d_.data()[k] = in.P[3 * tid + k]; };
@@ -66,6 +67,24 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
             int nreg = 0;
             for (auto &o : track_obs[tid]) nreg += map.frames_[o.first].registered;
             if (nreg < 2) continue;
+            // TriangulateFramePoint(map, frame_id, th_angle_lba) creates a point only from rays that meet at a sufficient angle
+            // (forward-moving cameras: two consecutive frames rarely do): wait for more observers otherwise
+            {
+                double best = 0.0;
+                const double *P = &in.P[3 * (size_t)tid];
+                std::vector<xrsfm::vector3> cen;
+                for (auto &o : track_obs[tid]) if (map.frames_[o.first].registered) cen.push_back(map.frames_[o.first].Tcw.center());
+                for (size_t a = 0; a < cen.size(); ++a)
+                    for (size_t b = a + 1; b < cen.size(); ++b) {
+                        double ra[3], rb[3], na = 0, nb = 0, dot = 0;
+                        for (int k = 0; k < 3; ++k) { ra[k] = P[k] - cen[a].v[k]; rb[k] = P[k] - cen[b].v[k]; na += ra[k] * ra[k]; nb += rb[k] * rb[k]; dot += ra[k] * rb[k]; }
+                        const double cs = dot / std::sqrt(na * nb);
+                        double ang = std::acos(cs > 1 ? 1 : (cs < -1 ? -1 : cs));
+                        ang = std::min(ang, 3.14159265358979323846 - ang);
+                        best = std::max(best, ang);
+                    }
+                if (best < 1.3 * th_angle_lba * 0.017453292519943295) continue;
+            }
             active[tid] = 1; map.tracks_[tid].outlier = false; reset_point(tid);
             for (auto &o : track_obs[tid]) if (map.frames_[o.first].registered) attach(o.first, o.second, tid);
         }
@@ -80,7 +99,6 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
         std::sort(mine.begin(), mine.end());
     };
     xrsfm::BASolver solver;
-    const double th_rpe_lba = 16, th_angle_lba = 1.5, th_rpe_gba = 16, th_angle_gba = 1.5;      // incremental_mapper.h:20-23
     auto timed = [&](int cls, auto &&fn) { const double t0 = now_ms(); fn(); st.ms[cls].push_back(now_ms() - t0); };
     const double t_begin = now_ms();
     // 1. initial pair + GBA

@@ -127,3 +127,23 @@ def test_gram_tiles_and_item_classes(kind):
         assert g["gram_tiles"] >= 0.9 * n_tiles
     if kind == "wide":
         assert g["gram_tiles"] == 0 and g["items_other"] == g["items"]
+
+
+def test_bal9_problems_pack_per_observation_and_plan_with_nine_rows_per_camera(lib):
+    """bal9 mode (cam_const bit 2): no Gram tiles, no regular-tile pre-reductions (the 9-wide kernels work per observation and
+    per pair), 7 cameras x 9 rows per 64-row tile in the plan; the bit is refused for the reference's camera models and for
+    shared intrinsics entries."""
+    from xrsfm_amd import capi
+    arr = H.make_bal9(40, 2000, 4, seed=5)
+    st = capi.debug_pack(H.to_product(arr))
+    g = capi.debug_pack_gram(H.to_product(arr))
+    assert st["regular_tiles"] == 0 and g["gram_tiles"] == 0 and g["items_other"] == st["items"] and st["cam_entries"] == arr["obs_cam"].shape[0]
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    off = plan["cam_offset"]
+    assert plan["tiles"] == 6 and np.all(off % 64 % 9 == 0) and np.all(off % 64 <= 54) and len(set(off.tolist())) == 40
+    bad = dict(arr); bad["cam_intr"] = np.zeros(40, np.int32)
+    with pytest.raises(RuntimeError):
+        capi.debug_pack(H.to_product(bad))
+    bad = dict(arr); bad["intr_model"] = np.full(40, 2, np.int32)
+    with pytest.raises(RuntimeError):
+        capi.debug_pack(H.to_product(bad))

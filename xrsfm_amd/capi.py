@@ -88,7 +88,7 @@ EXPORTS = [
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
-    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce", "xrsfm_ba_debug_backsub", "xrsfm_ba_device_memory",
+    "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce", "xrsfm_ba_debug_backsub", "xrsfm_ba_device_memory", "xrsfm_ba_download_intrinsics", "xrsfm_ba_debug_wide",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -333,6 +333,30 @@ class Context:
         S = np.zeros((n, n)) if want_S else None
         check(self.lib.xrsfm_ba_debug_cholesky_solve(self._h, radius, _dp(y), _dp(S)), "debug_cholesky_solve")
         return y, S
+
+    def download_intrinsics(self) -> np.ndarray:
+        """bal9 mode: intr_params with the refined {f, k1, k2} of the cameras that keep their intrinsics variable."""
+        out = np.array(self.problem.intr_params, copy=True)
+        self.lib.xrsfm_ba_download_intrinsics.argtypes = [C.c_void_p, _c_double_p]
+        self.lib.xrsfm_ba_download_intrinsics.restype = C.c_int
+        check(self.lib.xrsfm_ba_download_intrinsics(self._h, _dp(out)), "xrsfm_ba_download_intrinsics")
+        return out
+
+    def debug_wide(self, huber_a: float = 5.99, radius: float | None = None) -> dict:
+        """bal9 contexts: scaled linearisation (and, with a radius, the reduced-system step) in caller order."""
+        p = self.problem
+        out = dict(r=np.zeros((p.n_obs, 2)), Jc=np.zeros((p.n_obs, 2, 9)), Jp=np.zeros((p.n_obs, 2, 3)), Hcc_diag=np.zeros((p.n_cams, 9)),
+                   gc=np.zeros((p.n_cams, 9)))
+        y = np.zeros((p.n_cams, 9)) if radius is not None else None
+        cost = C.c_double(0)
+        self.lib.xrsfm_ba_debug_wide.argtypes = [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double)] + [_c_double_p] * 6
+        self.lib.xrsfm_ba_debug_wide.restype = C.c_int
+        check(self.lib.xrsfm_ba_debug_wide(self._h, huber_a, float(radius or 1.0), C.byref(cost), _dp(out["r"]), _dp(out["Jc"]), _dp(out["Jp"]),
+                                          _dp(out["Hcc_diag"]), _dp(out["gc"]), _dp(y)), "xrsfm_ba_debug_wide")
+        out["cost"] = cost.value
+        if y is not None:
+            out["y"] = y
+        return out
 
     def debug_backsub(self) -> dict:
         """After debug_cholesky_solve: one k_backsub launch; per-item partials and the candidate state in PACKED order."""

@@ -30,6 +30,7 @@ struct CholDev {
     const int* cam_off;   // [n_cams] first scalar row of the camera's 6x6 diagonal block (tile-aligned groups)
     const int* one_k;     // [T] identity list 0..T-1 (right-looking path: kernels read their panel from a list)
     const int* tile_rows; // [T] leading rows of the tile that hold cameras (the rest is identity padding)
+    int cw, cpt;          // unknowns per camera and cameras per tile: 6 / 10, or 9 / 7 in bal9 mode (ba_wide.h)
 };
 
 typedef double v4d __attribute__((ext_vector_type(4)));
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(256) void k_tile_fill(CholDev c, Dev d, const int* 
 // the solution back in camera order
 __global__ void k_sol_gather(CholDev c, double* __restrict__ out, int n_cams) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_cams * 6) out[i] = c.x[c.cam_off[i / 6] + i % 6];
+    if (i < n_cams * c.cw) out[i] = c.x[c.cam_off[i / c.cw] + i % c.cw];
 }
 
 // ---- small helpers for the in-register 16x16 diagonal-block factorisation
@@ -1474,8 +1475,8 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
             s2 += __shfl_xor(s2, 2, kWave);
             if (part == 0) {
                 c.x[k * kNB + o] = s2;
-                const int cam = (o < 6 * kCamsPerTileDev) ? tile_cam[k * kCamsPerTileDev + o / 6] : -1;
-                if (cam >= 0) px[6 * (size_t)cam + o % 6] = s2;
+                const int cam = (o < c.cw * c.cpt) ? tile_cam[k * c.cpt + o / c.cw] : -1;
+                if (cam >= 0) px[c.cw * (size_t)cam + o % c.cw] = s2;
             }
         }
         XBA_STAMP(1, 13);
@@ -1539,8 +1540,8 @@ __global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict
     s2 += __shfl_xor(s2, 2, kWave);
     if (part == 0) {
         c.x[k * kNB + o] = s2;
-        const int cam = (o < 6 * kCamsPerTileDev) ? tile_cam[k * kCamsPerTileDev + o / 6] : -1;
-        if (cam >= 0) px[6 * (size_t)cam + o % 6] = s2;          // the solution in camera order (what k_sol_gather did)
+        const int cam = (o < c.cw * c.cpt) ? tile_cam[k * c.cpt + o / c.cw] : -1;
+        if (cam >= 0) px[c.cw * (size_t)cam + o % c.cw] = s2;    // the solution in camera order (what k_sol_gather did)
     }
 }
 

@@ -28,6 +28,7 @@ struct Proj {
     double r0, r1;        // residual (not robustified)
     double jp[6];         // d r / d Pc, 2x3 row-major (zero in the clamp case)
     double rp[3];         // M(q) * P  (= Pc - t)
+    double ji[6];         // d r / d (f, k1, k2), 2x3 row-major: extension model 5 only (bal9 mode), project<true, true>
     bool clamped;
 };
 
@@ -39,7 +40,8 @@ __device__ __forceinline__ void quat_to_mat(const double q[4], double M[9]) {
 }
 
 // Residual (and optionally d r/d Pc) for one observation.
-template <bool kJac>
+// kIntr: also d r / d (f, k1, k2) of the extension model 5 (zero for the reference's models, whose intrinsics are constant)
+template <bool kJac, bool kIntr = false>
 __device__ __forceinline__ void project(const double M[9], const double t[3], const double* __restrict__ k,
                                         int model, const double P[3], double u_obs, double v_obs, Proj& o) {
     o.rp[0] = M[0] * P[0] + M[1] * P[1] + M[2] * P[2];
@@ -49,6 +51,7 @@ __device__ __forceinline__ void project(const double M[9], const double t[3], co
     if (Z < kMinDepth) {
         o.r0 = kClampRes; o.r1 = kClampRes; o.clamped = true;
         if (kJac) { for (int i = 0; i < 6; ++i) o.jp[i] = 0.0; }
+        if (kIntr) { for (int i = 0; i < 6; ++i) o.ji[i] = 0.0; }
         return;
     }
     o.clamped = false;
@@ -72,6 +75,18 @@ __device__ __forceinline__ void project(const double M[9], const double t[3], co
             D01 = 2.0 * kk * xn * yn; D10 = D01;
         }
         break; }
+    case 5: {   // extension, not a reference model: BAL-style {f, k1, k2}, no principal point (bal9 mode)
+        fx = k[0]; fy = k[0]; cx = 0.0; cy = 0.0;
+        const double k1 = k[1], k2 = k[2];
+        const double rad = k1 * r2 + k2 * r2 * r2;
+        du = xn * rad; dv = yn * rad;
+        if (kJac) {
+            const double rad_x = 2.0 * k1 * xn + 4.0 * k2 * r2 * xn;
+            const double rad_y = 2.0 * k1 * yn + 4.0 * k2 * r2 * yn;
+            D00 = 1.0 + rad + xn * rad_x; D01 = xn * rad_y;
+            D10 = yn * rad_x; D11 = 1.0 + rad + yn * rad_y;
+        }
+        break; }
     default: {  // OPENCV
         fx = k[0]; fy = k[1]; cx = k[2]; cy = k[3];
         const double k1 = k[4], k2 = k[5], p1 = k[6], p2 = k[7];
@@ -91,6 +106,14 @@ __device__ __forceinline__ void project(const double M[9], const double t[3], co
     }
     o.r0 = fx * (xn + du) + cx - u_obs;
     o.r1 = fy * (yn + dv) + cy - v_obs;
+    if (kIntr) {
+        if (model == 5) {
+            o.ji[0] = xn + du; o.ji[1] = fx * xn * r2; o.ji[2] = fx * xn * r2 * r2;
+            o.ji[3] = yn + dv; o.ji[4] = fx * yn * r2; o.ji[5] = fx * yn * r2 * r2;
+        } else {
+            for (int i = 0; i < 6; ++i) o.ji[i] = 0.0;
+        }
+    }
     if (kJac) {
         const double A00 = fx * D00, A01 = fx * D01, A10 = fy * D10, A11 = fy * D11;
         o.jp[0] = A00 * iz; o.jp[1] = A01 * iz; o.jp[2] = -(A00 * xn + A01 * yn) * iz;

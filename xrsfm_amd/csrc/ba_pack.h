@@ -123,7 +123,13 @@ struct Packed {
     int n_var_q = 0, n_var_t = 0, n_var_p = 0;
 };
 
-inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
+// Cameras whose intrinsics block is VARIABLE (cam_const bit 2, value 4: bal9 mode — 9-wide camera blocks; the reference always
+// holds intrinsics constant, ba_solver.cc:602-606): only the extension model 5 {f, k1, k2}, one intrinsics entry per such camera.
+constexpr unsigned kCamIntrVariable = 4u;
+constexpr int kModelBal = 5;
+
+// wide (bal9 mode): no Gram tiles and no regular-tile pre-reductions — the 9-wide kernels work per observation / per pair.
+inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false) {
     if (p.n_cams < 0 || p.n_points < 0 || p.n_obs < 0 || p.n_intr < 0) return XRSFM_BA_EINVAL;
     if (p.n_obs > 0 && (!p.obs_cam || !p.obs_pt || !p.obs_uv)) return XRSFM_BA_EINVAL;
     if (p.n_cams > 0 && (!p.cam_q || !p.cam_t || !p.cam_intr)) return XRSFM_BA_EINVAL;
@@ -133,7 +139,14 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
         const int ii = p.cam_intr[c];
         if (ii < 0 || ii >= p.n_intr) return XRSFM_BA_EINVAL;
         const int m = p.intr_model[ii];
-        if (m < 0 || m > 4) return XRSFM_BA_EINVAL;
+        if (m < 0 || m > kModelBal) return XRSFM_BA_EINVAL;
+        if (p.cam_const && (p.cam_const[c] & kCamIntrVariable) && m != kModelBal) return XRSFM_BA_EINVAL;
+    }
+    if (wide) {      // a variable intrinsics entry belongs to exactly one camera
+        std::vector<int> users(p.n_intr, 0);
+        for (int c = 0; c < p.n_cams; ++c) users[p.cam_intr[c]]++;
+        for (int c = 0; c < p.n_cams; ++c)
+            if (p.cam_const && (p.cam_const[c] & kCamIntrVariable) && users[p.cam_intr[c]] != 1) return XRSFM_BA_EINVAL;
     }
     const int No = p.n_obs, Np = p.n_points, Nc = p.n_cams;
     PhaseTimer timer("pack");
@@ -404,7 +417,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
                 if (o.slot_cam[s2] != o.slot_cam[b0 + r]) { regular = false; break; }
                 if (r > 0 ? o.slot_pt[s2] != o.slot_pt[s2 - 1] : o.slot_pt[s2] == o.slot_pt[s2 - 1]) { regular = false; break; }
             }
-            if (regular && nvalid % L == 0 && nvalid >= 2 * L) o.tile_stride[t] = L;
+            if (regular && nvalid % L == 0 && nvalid >= 2 * L && !wide) o.tile_stride[t] = L;
         }
     }, 4000);
     for (size_t it = 0; it + 1 < o.items.size(); it += 2)          // long items are never regular
@@ -417,7 +430,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o) {
     {
         std::vector<char> single(o.n_tiles, 0);
         for (size_t it = 0; it + 1 < o.items.size(); it += 2)
-            if (o.items[it + 1] == 1) single[o.items[it]] = 1;
+            if (o.items[it + 1] == 1 && !wide) single[o.items[it]] = 1;
         std::vector<int> tile_cams((size_t)o.n_tiles * kGramMaxCams, -1);       // ascending distinct cameras of the Gram tiles
         pack_parallel_for(o.n_tiles, [&](long long t0, long long t1) {
             int cams[64];

@@ -14,9 +14,11 @@ namespace xba {
 
 constexpr int kPlanTile = 64;        // tile size (must equal kNB of ba_chol.h)
 constexpr int kCamsPerTile = 10;     // 10 cameras = 60 rows per tile + 4 identity padding rows
+constexpr int kCamsPerTileWide = 7;  // bal9 mode (9 unknowns per camera): 7 cameras = 63 rows per tile + 1 identity padding row
 
 struct CholPlan {
     int n = 0, n_pad = 0, T = 0, n_blocks = 0, n_pairs = 0, n_writes = 0, n_tiles_nz = 0, n_levels = 0;
+    int cam_width = 6, cams_per_tile = kCamsPerTile;     // unknowns per camera (9 in bal9 mode) and cameras per 64-row tile
     int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring, 2 reverse Cuthill-McKee (unordered
                                      // collections with viewpoint clusters: banded fill instead of a dense factor)
     long long tile_products = 0;     // 64x64x64 tile products of one factorisation (symbolic count; 2 * 64^3 flop each)
@@ -283,12 +285,14 @@ inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<
 // and then only while the n_pad^2 doubles of the tile storage stay within `max_tile_bytes`; XRSFM_BA_ETOOBIG otherwise.
 inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const PairKeys& keyed,
                            const std::vector<unsigned long long>* pattern, CholPlan& P,
-                           long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX) {
+                           long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX, int cam_width = 6) {
+    const int CW = cam_width, CPT = (cam_width == 6) ? kCamsPerTile : kCamsPerTileWide;
     const int Nc = k.n_cams, ns = k.n_slots;
     PhaseTimer timer("plan");
     P = CholPlan();
     P.spp = spp;
-    P.n = 6 * Nc;
+    P.cam_width = CW; P.cams_per_tile = CPT;
+    P.n = CW * Nc;
     P.n_pairs = spp[ns] + k.n_gt_cells;      // pair_dst: observation pairs | cells of the Gram tiles' tables
     P.n_writes = (int)keyed.size();
     std::vector<unsigned long long> blk_keys;
@@ -355,7 +359,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         std::vector<int> root;
         const int wr = std::min(w, nk);
         if (wrap) for (int c = 0; c < wr; ++c) root.push_back(keep[c]);   // closes the ring: eliminated with the top separators
-        plan_detail::dissect(wrap ? wr : 0, nk, w, 2 * kCamsPerTile, kCamsPerTile, root, keep, groups);
+        plan_detail::dissect(wrap ? wr : 0, nk, w, 2 * CPT, CPT, root, keep, groups);
         if (P.n_hubs > 0) {
             std::vector<int> hubs;
             for (int c = 0; c < Nc; ++c) if (is_hub[c]) hubs.push_back(c);
@@ -372,14 +376,16 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         // affordable far beyond `max_dense_unknowns`.  Reverse Cuthill-McKee of the camera graph; taken only if the symbolic
         // factorisation says it pays (<= 60 % of the natural order's tile products, within the work budget), from 48 tile
         // columns (480 cameras) on; random visibility (no clusters) keeps the natural order / the PCG path.
-        const int Tn = (Nc + kCamsPerTile - 1) / kCamsPerTile;
+        const int Tn = (Nc + CPT - 1) / CPT;
         const char* rcm_env = std::getenv("XRSFM_BA_RCM");
         if (Tn >= 48 && !(rcm_env && rcm_env[0] == '0')) {
             const long long budget = 12000000;              // tile products of one factorisation: 6.3e12 flop, ~0.25 s
             const std::vector<int> rcm = plan_detail::rcm_order(Nc, blk_rc, n_blocks);
-            const long long pr = plan_detail::count_tile_products(Nc, blk_rc, n_blocks, rcm, kCamsPerTile, budget);
-            const long long pn = (6LL * Nc <= max_dense_unknowns) ? plan_detail::count_tile_products(Nc, blk_rc, n_blocks, all, kCamsPerTile, budget) : -1;
-            if (pr >= 0 && (pn < 0 || pr * 10 <= pn * 6)) { all = rcm; P.ordering = 2; }
+            const long long pr = plan_detail::count_tile_products(Nc, blk_rc, n_blocks, rcm, CPT, budget);
+            const long long pn = ((long long)CW * Nc <= max_dense_unknowns) ? plan_detail::count_tile_products(Nc, blk_rc, n_blocks, all, CPT, budget) : -1;
+            // natural order not allowed (beyond the dense limit): its pattern is taken as full, Tn^3 / 6 products
+            const long long pn_eff = pn >= 0 ? pn : (long long)Tn * Tn * Tn / 6;
+            if (pr >= 0 && pr * 10 <= pn_eff * 6) { all = rcm; P.ordering = 2; }      // (random visibility: no gain -> natural order / PCG)
         }
         groups.push_back(all);
     }
@@ -387,16 +393,16 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.cam_off.assign(Nc, 0);
     int T = 0;
     for (const auto& g : groups) {
-        for (size_t q = 0; q < g.size(); ++q) P.cam_off[g[q]] = kPlanTile * (T + (int)q / kCamsPerTile) + 6 * ((int)q % kCamsPerTile);
-        const int nt = ((int)g.size() + kCamsPerTile - 1) / kCamsPerTile;
-        for (int q = 0; q < nt; ++q) P.tile_rows.push_back(6 * std::min(kCamsPerTile, (int)g.size() - q * kCamsPerTile));
+        for (size_t q = 0; q < g.size(); ++q) P.cam_off[g[q]] = kPlanTile * (T + (int)q / CPT) + CW * ((int)q % CPT);
+        const int nt = ((int)g.size() + CPT - 1) / CPT;
+        for (int q = 0; q < nt; ++q) P.tile_rows.push_back(CW * std::min(CPT, (int)g.size() - q * CPT));
         T += nt;
     }
     if (T == 0) { T = 1; P.tile_rows.push_back(0); }
     P.T = T; P.n_pad = T * kPlanTile;
-    P.tile_cam.assign((size_t)T * kCamsPerTile, -1);
-    for (int c = 0; c < Nc; ++c) P.tile_cam[(size_t)(P.cam_off[c] / kPlanTile) * kCamsPerTile + (P.cam_off[c] % kPlanTile) / 6] = c;
-    if (6LL * Nc > max_dense_unknowns &&
+    P.tile_cam.assign((size_t)T * CPT, -1);
+    for (int c = 0; c < Nc; ++c) P.tile_cam[(size_t)(P.cam_off[c] / kPlanTile) * CPT + (P.cam_off[c] % kPlanTile) / CW] = c;
+    if ((long long)CW * Nc > max_dense_unknowns &&
         (P.ordering == 0 || (unsigned long long)P.n_pad * (unsigned long long)P.n_pad * sizeof(double) > max_tile_bytes)) return XRSFM_BA_ETOOBIG;
 
     // ---- tile pattern + symbolic factorisation

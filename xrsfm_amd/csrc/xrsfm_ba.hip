@@ -31,6 +31,7 @@
 #include "ba_pack.h"
 #include "ba_plan.h"
 #include "ba_refine.h"
+#include "ba_wide.h"
 #include "pose_graph.h"
 #include "tag_refine.h"
 
@@ -150,6 +151,9 @@ struct xrsfm_ba_context {
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
     bool linearized = false;
     bool fused = true;              // fused level kernels / linearisation tail (XRSFM_BA_FUSED=0: the launch-per-phase schedule, A/B aid)
+    bool wide = false;              // bal9 mode: 9-wide camera blocks (ba_wide.h); single rank, exact solver only
+    DevW w{};
+    std::vector<int> cam_intr_host; // wide: intrinsics entry of every camera (xrsfm_ba_download_intrinsics)
     bool prep_fused = true;         // Cholesky path: damped point blocks factored inside k_schur_pairs / k_backsub, LM diagonal of the
                                     // cameras inside the tile fill: no k_point_prep launch (XRSFM_BA_PREP_FUSED=0: round-2 schedule)
     double step_radius = 0.0;       // radius of the step being assembled / solved (prepare_step)
@@ -568,12 +572,12 @@ int chol_setup(xrsfm_ba_context* c) {
         c->have_pattern = true;
     }
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
+    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes, c->wide ? kW : 6))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     timer.mark("plan");
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
     // (... or a reverse Cuthill-McKee order whose symbolic factorisation stays within the work budget of ba_plan.h: panel schedule)
-    if (6 * Nc > kCholMaxN && (!(P.use_levels || P.ordering == 2) || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
+    if (P.n > kCholMaxN && (!(P.use_levels || P.ordering == 2) || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
@@ -608,13 +612,16 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(up.flush());
     h.gplan.tab = reinterpret_cast<const int4*>(d_gplan);
     timer.mark("uploads");
-    TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * 36));
+    const size_t blk_vals = c->wide ? kWB : 36, cam_vals = c->wide ? kWS : 28;
+    TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * blk_vals));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
         double* both = nullptr;
-        TRYC(dev_alloc(c, &both, (size_t)Nc * 28 + (size_t)(P.n_blocks > 0 ? P.n_blocks : 1) * 36));
-        c->d.camS = both; h.Sblk = both + (size_t)Nc * 28;
+        TRYC(dev_alloc(c, &both, (size_t)Nc * cam_vals + (size_t)(P.n_blocks > 0 ? P.n_blocks : 1) * blk_vals));
+        if (c->wide) c->w.camS = both; else c->d.camS = both;
+        h.Sblk = both + (size_t)Nc * cam_vals;
     }
     h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
+    h.dev.cw = P.cam_width; h.dev.cpt = P.cams_per_tile;
     TRYC(dev_alloc(c, &h.dev.S, (size_t)P.n_pad * P.n_pad));
     TRYC(dev_alloc(c, &h.dev.Linv, (size_t)P.T * kNB * kNB));
     TRYC(dev_alloc(c, &h.dev.y, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)P.n_pad));
@@ -714,6 +721,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
     const int T = h.T;
+    double* px_out = c->wide ? c->w.px : d.px;        // solution in camera order, cw values per camera
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
     if ((h.use_levels || h.panel_ll) && c->fused) {
         // one launch per elimination-tree level (three on a split level: partial products, their fixed-order sum, then the
@@ -742,10 +750,10 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                 lf.fz_q = h.fz_q; lf.rest = h.fill_rest; lf.n_factor = nf;
                 if (nf + h.n_fill_rest > 0)
                     LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + h.n_fill_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
-                           (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr, lf);
+                           (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
             } else if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
-                       (const int*)h.tile_cam, with_bwd ? d.px : (double*)nullptr, lf);
+                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
         }
         if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
@@ -753,12 +761,12 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                 const int ncol = h.cols_off[k + 1] - h.cols_off[k];
                 LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
             }
-            if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.px, d.n_cams);
+            if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
             return 0;
         }
         for (int lv = h.n_levels - 2; lv >= 0; --lv) {      // (the last level: inside its k_lv_factor launch)
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
-            LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, d.px);
+            LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, px_out);
         }
         return 0;
     } else if (h.use_levels || h.panel_ll) {
@@ -807,7 +815,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
         }
     }
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * 6, 256)), dim3(256), 0, h.dev, d.px, d.n_cams);
+    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
     return 0;
 }
 
@@ -1021,7 +1029,8 @@ int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** ou
 static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out) {
     c->device = device;
     PhaseTimer timer("create");
-    int e = pack_problem(*p, c->pk);
+    for (int i = 0; i < p->n_cams && p->cam_const; ++i) c->wide = c->wide || (p->cam_const[i] & kCamIntrVariable) != 0;
+    int e = pack_problem(*p, c->pk, c->wide);
     if (e) { delete c; return e; }
     timer.mark("pack_problem");
     {
@@ -1093,6 +1102,13 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
     TRY(dev_alloc(c, &d.pcgpart, nc * 3));
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));
     TRY(dev_alloc(c, &d.st, (size_t)1));
+    if (c->wide) {      // 9-wide path: stored Jacobian blocks, wide scale / sums / solution (ba_wide.h)
+        TRY(dev_alloc(c, &c->w.Fw, ns * 18)); TRY(dev_alloc(c, &c->w.Ew, ns * 6));
+        TRY(dev_alloc(c, &c->w.scale_c, nc * kW)); TRY(dev_alloc(c, &c->w.camlin, nc * 18));
+        TRY(dev_alloc(c, &c->w.px, nc * kW + kNB));
+        TRY(dev_alloc(c, &c->w.scat, (size_t)(k.n_obs > 0 ? k.n_obs : 1) * kWS));
+        c->cam_intr_host.assign(p->cam_intr, p->cam_intr + p->n_cams);
+    }
     TRY(dev_alloc(c, &c->part2, (size_t)kTailJobs * kTailGrid));
     TRY(dev_alloc(c, &c->ticket, (size_t)32 * 9));
 #undef TRY
@@ -1183,6 +1199,144 @@ int xrsfm_ba_download(xrsfm_ba_context* c, double* cam_q, double* cam_t, double*
     return 0;
 }
 
+// bal9 mode: the same trust-region loop over the 9-wide kernels of ba_wide.h.  Plain schedule — linearise, assemble,
+// factor, back-substitute, cost of the candidate, linearise again after an accepted step — through the launch-per-phase tail.
+static int linearize_wide(xrsfm_ba_context* c, double huber_a, bool scaled_pass) {
+    Dev& d = c->d;
+    (void)scaled_pass;
+    c->gradmax_done = false; c->published = false;
+    if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k9_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, c->w, huber_a);
+    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<18>, dim3(d.n_cams), dim3(kBlock), 0, c->w.scat, d.cam_ptr, c->w.camlin, (const PcgStatus*)nullptr);
+    ReduceJobs j{};
+    const double* ins[3] = {d.part, d.part + d.n_items, d.part + 2 * (size_t)d.n_items};
+    double* outs[3] = {d.scal + S_COST, d.scal + S_XNORM2_PTS, d.scal + S_GRADMAX_PTS};
+    for (int q = 0; q < 3; ++q) { j.in[q] = ins[q]; j.n[q] = d.n_items; j.out[q] = outs[q]; j.op[q] = q == 2 ? 1 : 0; }
+    LAUNCH(c, K_SMALL, k_reduce_multi, dim3(3), dim3(kPcgThreads), 0, j);
+    return 0;
+}
+
+static int run_wide(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary* sum) {
+    Dev& d = c->d;
+    CholHost& h = c->chol;
+    hipStream_t st = c->stream;
+    int e;
+    sum->linear_solver_used = XRSFM_BA_SOLVER_CHOLESKY;
+    c->profiling = opt.profile != 0;
+    for (int i = 0; i < K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
+    c->recs.clear(); c->ev_used = 0;
+    const auto t_begin = std::chrono::steady_clock::now();
+    sum->num_residuals = 2 * c->pk.n_obs;
+    {
+        int n_var_i = 0;
+        std::vector<unsigned char> cc(d.n_cams);
+        std::vector<double> act(d.n_cams);
+        if (d.n_cams) { HIPCHK(hipMemcpy(cc.data(), d.cam_const, d.n_cams, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(act.data(), d.cam_act, sizeof(double) * d.n_cams, hipMemcpyDeviceToHost)); }
+        for (int i = 0; i < d.n_cams; ++i) n_var_i += (act[i] > 0.0 && (cc[i] & kCamIntrVariable)) ? 1 : 0;
+        sum->num_effective_params = 3 * (c->pk.n_var_q + c->pk.n_var_t + c->pk.n_var_p + n_var_i);
+    }
+    auto finish = [&](int term, int reason, double cost) {
+        sum->termination = term; sum->termination_reason = reason; sum->final_cost = cost;
+        (void)hipStreamSynchronize(st);
+        sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (c->profiling) {
+            profile_collect(c);
+            int best = 0;
+            for (int i = 1; i < K_COUNT - 1; ++i) if (c->prof_ms[i] > c->prof_ms[best]) best = i;
+            sum->dom_kernel_id = best; sum->dom_kernel_ms = c->prof_ms[best]; sum->dom_kernel_launches = c->prof_n[best];
+        }
+        c->profiling = false;
+        return XRSFM_BA_OK;
+    };
+    auto gradmax_fetch = [&](double* gmax) {
+        LAUNCH(c, K_SMALL, k9_gradmax_cams, dim3(1), dim3(kPcgThreads), 0, d, c->w, d.scal + S_GRADMAX_CAMS);
+        int e2 = fetch_scalars(c);
+        if (e2) return e2;
+        *gmax = std::fmax(c->h_scal[S_GRADMAX_PTS], c->h_scal[S_GRADMAX_CAMS]);
+        return 0;
+    };
+    // iteration 0: Jacobi scaling from the unscaled column norms, then the scaled linearisation
+    LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_cams * kW, kBlock) + 1), dim3(kBlock), 0, c->w.scale_c, 1.0, (size_t)d.n_cams * kW);
+    LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, d.scale_p, 1.0, (size_t)d.n_pts * 3);
+    if ((e = linearize_wide(c, opt.huber_a, false))) return e;
+    {
+        const long long n = std::max((long long)d.n_cams * kW, (long long)d.n_pts * 3);
+        LAUNCH(c, K_SMALL, k9_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, d, c->w);
+    }
+    if ((e = linearize_wide(c, opt.huber_a, true))) return e;
+    c->linearized = true;
+    double gmax = 0.0;
+    if ((e = gradmax_fetch(&gmax))) return e;
+    double cost = 0.5 * c->h_scal[S_COST];
+    double xnorm2_pts = c->h_scal[S_XNORM2_PTS];
+    sum->initial_cost = cost;
+    double radius = opt.initial_radius, decrease = 2.0;
+    print_progress(opt, 0, cost, 0.0, gmax, 0.0, 0.0, radius);
+    if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
+    int it = 0, invalid = 0;
+    const double max_radius = 1e16, min_radius = 1e-32, min_rel_decrease = 1e-3;
+    const int n_obs_pairs = h.n_pairs - c->pk.n_gt_cells;
+    while (true) {
+        if (it >= opt.max_iterations) return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
+        ++it;
+        sum->lm_steps_attempted++;
+        // reduced camera system: per-observation diagonal terms + per-pair blocks, fixed-order sums, tile fill, tile Cholesky
+        if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k9_pairs, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, c->w, h.slot_pair_ptr, h.pair_dst, h.scat2, radius);
+        (void)n_obs_pairs;
+        if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k9_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, c->w.scat, d.cam_ptr, c->w.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
+        if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k9_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, c->w, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, radius);
+        h.S_filled = true;
+        if ((e = chol_factor_solve(c))) return e;
+        {   // back-substitution + candidate state, cost of the candidate, the scalars of the step
+            const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cdiv(d.n_cams, kBlock);
+            if (nbi + nbc > 0) LAUNCH(c, K_BACKSUB, k9_backsub, dim3(nbi + nbc), dim3(kBlock), 0, d, c->w, nbi, radius);
+            if (d.n_items > 0) LAUNCH(c, K_COST, k_cost, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, opt.huber_a);
+            ReduceJobs j{};
+            const double* ins[5] = {d.part, d.part + 2 * (size_t)d.n_items, d.part + 3 * (size_t)d.n_items, d.campart, d.campart + d.n_cams};
+            const int ns[5] = {d.n_items, d.n_items, d.n_items, d.n_cams, d.n_cams};
+            double* outs[5] = {d.scal + S_COST_CAND, d.scal + S_MODEL, d.scal + S_STEP2_PTS, d.scal + S_STEP2_CAMS, d.scal + S_XNORM2_CAMS};
+            for (int q = 0; q < 5; ++q) { j.in[q] = ins[q]; j.n[q] = ns[q]; j.out[q] = outs[q]; j.op[q] = 0; }
+            LAUNCH(c, K_SMALL, k_reduce_multi, dim3(5), dim3(kPcgThreads), 0, j);
+            if ((e = fetch_scalars(c))) return e;
+        }
+        const double* s = c->h_scal;
+        const double model_change = s[S_MODEL];
+        const double xnorm = std::sqrt(xnorm2_pts + s[S_XNORM2_CAMS]);
+        if (!(model_change > 0.0) || !std::isfinite(model_change)) {
+            ++invalid;
+            sum->n_unsuccessful++;
+            print_progress(opt, it, cost, 0.0, gmax, 0.0, 0.0, radius);
+            if (invalid >= 5) return finish(XRSFM_BA_FAILURE, 6, cost);
+            radius /= decrease; decrease *= 2.0;
+            continue;
+        }
+        invalid = 0;
+        const double cost_cand = 0.5 * s[S_COST_CAND];
+        const double step_norm = std::sqrt(s[S_STEP2_PTS] + s[S_STEP2_CAMS]);
+        if (step_norm <= opt.parameter_tolerance * (xnorm + opt.parameter_tolerance)) return finish(XRSFM_BA_CONVERGENCE, 2, cost);
+        const double cost_change = cost - cost_cand;
+        if (std::fabs(cost_change) <= opt.function_tolerance * cost) return finish(XRSFM_BA_CONVERGENCE, 3, cost);
+        const double rel = cost_change / model_change;
+        if (rel > min_rel_decrease) {
+            std::swap(d.cam, d.cam_cand);
+            std::swap(d.P, d.P_cand);
+            if ((e = linearize_wide(c, opt.huber_a, true))) return e;
+            if ((e = gradmax_fetch(&gmax))) return e;
+            cost = 0.5 * c->h_scal[S_COST];
+            xnorm2_pts = c->h_scal[S_XNORM2_PTS];
+            radius = std::fmin(max_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
+            decrease = 2.0;
+            sum->n_successful++;
+            print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
+            if (gmax <= opt.gradient_tolerance) return finish(XRSFM_BA_CONVERGENCE, 1, cost);
+        } else {
+            radius /= decrease; decrease *= 2.0;
+            sum->n_unsuccessful++;
+            print_progress(opt, it, cost, cost_change, gmax, step_norm, rel, radius);
+            if (radius < min_radius) return finish(XRSFM_BA_CONVERGENCE, 4, cost);
+        }
+    }
+}
+
 static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_summary* sum) {
     if (!c || !optp || !sum) return XRSFM_BA_EINVAL;
     const xrsfm_ba_options opt = *optp;
@@ -1192,6 +1346,13 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
     hipStream_t st = c->stream;
     int solver = opt.linear_solver;
     int e;
+    if (c->wide) {      // bal9 mode: exact solver, one rank
+        if (solver == XRSFM_BA_SOLVER_PCG || c->multi()) {
+            fprintf(stderr, "[xrsfm_ba] variable intrinsics (9-wide camera blocks): only the exact solver on one rank is implemented\n");
+            return XRSFM_BA_EINVAL;
+        }
+        solver = XRSFM_BA_SOLVER_CHOLESKY;
+    }
     if (solver == XRSFM_BA_SOLVER_AUTO) {
         // exact tile Cholesky whenever its plan is feasible (always up to kCholMaxN unknowns; larger problems when the camera
         // graph is a band / ring), implicit-Schur PCG otherwise
@@ -1208,6 +1369,7 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
         }
         return e;
     }
+    if (c->wide) return run_wide(c, opt, sum);
     sum->linear_solver_used = solver;
     c->profiling = opt.profile != 0;
     for (int i = 0; i < K_COUNT; ++i) { c->prof_ms[i] = 0.0; c->prof_n[i] = 0; }
@@ -1328,6 +1490,7 @@ int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm
     if (e) return e;
     e = xrsfm_ba_run(c, opt, summary);
     if (!e) e = xrsfm_ba_download(c, problem->cam_q, problem->cam_t, problem->points);
+    if (!e && problem->intr_params) e = xrsfm_ba_download_intrinsics(c, problem->intr_params);      // (bal9 mode only)
     xrsfm_ba_destroy(c);
     return e;
 }
@@ -1627,7 +1790,7 @@ int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, d
 // ---------------------------------------------------------------- diagnostics
 int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scaling, double* r, double* Jc, double* Jp,
                              double* Hpp, double* gp, double* Hcc_diag, double* gc, double* cost) {
-    if (!c) return XRSFM_BA_EINVAL;
+    if (!c || c->wide) return XRSFM_BA_EINVAL;          // (bal9 contexts: xrsfm_ba_debug_wide)
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
     int e;
@@ -1683,7 +1846,84 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scalin
     return 0;
 }
 
+// bal9 mode diagnostics: linearise at the current state (Jacobi scaling from the column norms), optionally assemble and solve the
+// reduced system for one radius.  Outputs in caller order: cost, per observation r [n_obs][2], Jc [n_obs][2][9], Jp [n_obs][2][3];
+// per camera diag(Hcc) and g_c [n_cams][9]; step y [n_cams][9] (skipped if NULL).
+int xrsfm_ba_debug_wide(xrsfm_ba_context* c, double huber_a, double radius, double* cost, double* r, double* Jc, double* Jp,
+                        double* Hcc_diag, double* gc, double* y) {
+    if (!c || !c->wide) return XRSFM_BA_EINVAL;
+    HIPCHK(hipSetDevice(c->device));
+    Dev& d = c->d;
+    CholHost& h = c->chol;
+    int e;
+    LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_cams * kW, kBlock) + 1), dim3(kBlock), 0, c->w.scale_c, 1.0, (size_t)d.n_cams * kW);
+    LAUNCH(c, K_SMALL, k_fill, dim3(cdiv((long long)d.n_pts * 3, kBlock) + 1), dim3(kBlock), 0, d.scale_p, 1.0, (size_t)d.n_pts * 3);
+    if ((e = linearize_wide(c, huber_a, false))) return e;
+    {
+        const long long n = std::max((long long)d.n_cams * kW, (long long)d.n_pts * 3);
+        LAUNCH(c, K_SMALL, k9_scale_from_norms, dim3(cdiv(n, kBlock) + 1), dim3(kBlock), 0, d, c->w);
+    }
+    if ((e = linearize_wide(c, huber_a, true))) return e;
+    if ((e = fetch_scalars(c))) return e;
+    c->linearized = true;
+    if (cost) *cost = 0.5 * c->h_scal[S_COST];
+    const Packed& k = c->pk;
+    const size_t ns = (size_t)k.n_slots;
+    std::vector<double> hb;
+    auto fetch = [&](const double* dev, size_t n) -> int {
+        hb.resize(n);
+        if (n && hipMemcpy(hb.data(), dev, n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return XRSFM_BA_ENODEV;
+        return 0;
+    };
+    if (r) {
+        if ((e = fetch(d.rt, ns * 2))) return e;
+        for (size_t s2 = 0; s2 < ns; ++s2) if (k.slot_obs[s2] >= 0) { r[2 * (size_t)k.slot_obs[s2]] = hb[s2]; r[2 * (size_t)k.slot_obs[s2] + 1] = hb[ns + s2]; }
+    }
+    if (Jc) {
+        if ((e = fetch(c->w.Fw, ns * 18))) return e;
+        for (size_t s2 = 0; s2 < ns; ++s2) if (k.slot_obs[s2] >= 0) for (int q = 0; q < 18; ++q) Jc[18 * (size_t)k.slot_obs[s2] + q] = hb[q * ns + s2];
+    }
+    if (Jp) {
+        if ((e = fetch(c->w.Ew, ns * 6))) return e;
+        for (size_t s2 = 0; s2 < ns; ++s2) if (k.slot_obs[s2] >= 0) for (int q = 0; q < 6; ++q) Jp[6 * (size_t)k.slot_obs[s2] + q] = hb[q * ns + s2];
+    }
+    if (Hcc_diag || gc) {
+        if ((e = fetch(c->w.camlin, (size_t)k.n_cams * 18))) return e;
+        for (int i = 0; i < k.n_cams; ++i) for (int q = 0; q < kW; ++q) {
+            if (Hcc_diag) Hcc_diag[kW * (size_t)i + q] = hb[18 * (size_t)i + q];
+            if (gc) gc[kW * (size_t)i + q] = hb[18 * (size_t)i + kW + q];
+        }
+    }
+    if (y) {
+        if ((e = chol_setup(c))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
+        if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k9_pairs, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, c->w, h.slot_pair_ptr, h.pair_dst, h.scat2, radius);
+        if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k9_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, c->w.scat, d.cam_ptr, c->w.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
+        if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k9_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, c->w, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, radius);
+        h.S_filled = true;
+        if ((e = chol_factor_solve(c))) return e;
+        HIPCHK(hipMemcpyAsync(y, c->w.px, sizeof(double) * (size_t)k.n_cams * kW, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return 0;
+}
+
+// bal9 mode: the intrinsics {f, k1, k2} of the cameras that keep them variable, written into intr_params [n_intr][8] (rows of
+// the other entries untouched) — what xrsfm_ba_solve does for the caller's problem->intr_params.
+int xrsfm_ba_download_intrinsics(xrsfm_ba_context* c, double* intr_params) {
+    if (!c || !intr_params) return XRSFM_BA_EINVAL;
+    if (!c->wide) return XRSFM_BA_OK;
+    HIPCHK(hipSetDevice(c->device));
+    const int n = c->d.n_cams;
+    std::vector<CamRec> cams(n);
+    std::vector<unsigned char> cc(n);
+    if (n) { HIPCHK(hipMemcpy(cams.data(), c->d.cam, sizeof(CamRec) * (size_t)n, hipMemcpyDeviceToHost)); HIPCHK(hipMemcpy(cc.data(), c->d.cam_const, n, hipMemcpyDeviceToHost)); }
+    for (int i = 0; i < n; ++i)
+        if (cc[i] & kCamIntrVariable) for (int q = 0; q < 3; ++q) intr_params[8 * (size_t)c->cam_intr_host[i] + q] = cams[i].intr[q];
+    return XRSFM_BA_OK;
+}
+
 int xrsfm_ba_debug_schur_product(xrsfm_ba_context* c, double radius, const double* x, double* y, double* b) {
+    if (c && c->wide) return XRSFM_BA_EINVAL;
     if (!c || !x || !y) return XRSFM_BA_EINVAL;
     if (!c->linearized) return XRSFM_BA_ESTATE;
     HIPCHK(hipSetDevice(c->device));
@@ -1703,10 +1943,15 @@ int xrsfm_ba_debug_schur_product(xrsfm_ba_context* c, double radius, const doubl
     return 0;
 }
 
+static bool problem_is_wide(const xrsfm_ba_problem* p) {
+    for (int i = 0; i < p->n_cams && p->cam_const; ++i) if (p->cam_const[i] & kCamIntrVariable) return true;
+    return false;
+}
+
 int xrsfm_ba_debug_pack(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* slot_obs) {
     if (!p || !stats) return XRSFM_BA_EINVAL;
     Packed k;
-    const int e = pack_problem(*p, k);
+    const int e = pack_problem(*p, k, problem_is_wide(p));
     if (e) return e;
     int regular = 0, longs = 0, maxlen = 0;
     for (int t = 0; t < k.n_tiles; ++t) { regular += k.tile_stride[t] > 0; maxlen = std::max(maxlen, k.tile_maxlen[t]); }
@@ -1721,7 +1966,7 @@ int xrsfm_ba_debug_pack(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* sl
 int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* tile_ncam, uint8_t* slot_cidx, int32_t* slot_campos_g) {
     if (!p || !stats) return XRSFM_BA_EINVAL;
     Packed k;
-    int e = pack_problem(*p, k);
+    int e = pack_problem(*p, k, problem_is_wide(p));
     if (e) return e;
     std::vector<int> spp;
     PairKeys keyed;
@@ -1741,13 +1986,14 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem* p, int32_t stats[8], int32_
 int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* cam_offset) {
     if (!p || !stats) return XRSFM_BA_EINVAL;
     Packed k;
-    int e = pack_problem(*p, k);
+    const bool wide = problem_is_wide(p);
+    int e = pack_problem(*p, k, wide);
     if (e) return e;
     std::vector<int> spp;
     PairKeys keyed;
     if ((e = chol_local_keys(k, spp, keyed))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
+    if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes, wide ? kW : 6))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
     stats[6] = P.use_levels ? 1 : 0; stats[7] = P.n_tiles_nz;
     if (cam_offset) for (int i = 0; i < k.n_cams; ++i) cam_offset[i] = P.cam_off[i];
@@ -1770,7 +2016,7 @@ int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context* c, int n_pairs, const int
 }
 
 int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y, double* S_dense) {
-    if (!c || !y) return XRSFM_BA_EINVAL;
+    if (!c || !y || c->wide) return XRSFM_BA_EINVAL;
     if (!c->linearized) return XRSFM_BA_ESTATE;
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
@@ -1802,7 +2048,7 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
 
 int xrsfm_ba_debug_backsub(xrsfm_ba_context* c, double* part_model, double* part_step2, double* cand_points, double* point_step,
                            double* cand_cam_q, double* cand_cam_t) {
-    if (!c) return XRSFM_BA_EINVAL;
+    if (!c || c->wide) return XRSFM_BA_EINVAL;
     if (!c->linearized) return XRSFM_BA_ESTATE;
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;

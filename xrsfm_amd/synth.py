@@ -379,3 +379,25 @@ def make_collection(n_cams: int, n_points: int, seed: int = 0, cams_per_cluster:
 
 # BASELINE.json config 5 at its size (docs/en/benchmark.md:93,111: ~7.5k registered frames; ~10M observations estimated)
 CONFIGS["T"] = dict(n_cams=7500, n_points=1_800_000, seed=12)
+# BASELINE.json config 4 in bal9 mode (SURVEY.md section 8(d) "optional bal9 mode"): to_bal9(make_problem(**CONFIGS["L"]))
+CONFIGS["Lb9"] = CONFIGS["L"]
+
+
+def to_bal9(arr: dict, seed: int = 0) -> dict:
+    """The same geometry and observations with one intrinsics entry of the extension model 5 {f, k1, k2} per camera, kept
+    VARIABLE (cam_const bit 2 of include/xrsfm_ba.h): 9-wide camera blocks.  The principal point of the pinhole model the
+    problem was generated with is subtracted from the observations (model 5 has none); the intrinsics start 1 % / 0.01 off
+    the generating ones, so they have somewhere to go."""
+    out = dict(arr)
+    n_cams = arr["cam_q"].shape[0]
+    rng = np.random.default_rng(9000 + seed)
+    prm0 = np.asarray(arr["intr_params"], np.float64)[0]
+    f, cx, cy = prm0[0], prm0[1], prm0[2]
+    out["obs_uv"] = np.ascontiguousarray(np.asarray(arr["obs_uv"], np.float64) - np.array([cx, cy]))
+    out["cam_intr"] = np.arange(n_cams, dtype=np.int32)
+    out["intr_model"] = np.full(n_cams, 5, np.int32)
+    prm = np.zeros((n_cams, 8))
+    prm[:, 0] = f * (1 + rng.normal(0, 0.01, n_cams)); prm[:, 1] = rng.normal(0, 0.01, n_cams); prm[:, 2] = rng.normal(0, 0.01, n_cams)
+    out["intr_params"] = prm
+    out["cam_const"] = (np.asarray(arr["cam_const"], np.uint8) | 4).astype(np.uint8)
+    return out
