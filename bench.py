@@ -292,7 +292,7 @@ def mapper_bench(args):
                       "parallelism": "single GPU, one-shot xrsfm_ba_solve per call through the BASolver adapter (tests/shim)"},
            "calls": rep["classes"], "replay_wall_ms": rep["wall_ms"], "first_replay_wall_ms": r["replays"][0]["wall_ms"],
            "same_end_state_in_both_replays": r["same_end_state"],
-           "free_device_bytes_after_replay": [x["free_bytes"] for x in r["replays"]], "tracks_filtered": r["n_outlier_tracks"]}
+           "free_device_bytes_after_replay": [x["free_bytes"] for x in r["replays"]], "tracks_filtered": r["n_outlier_tracks"], "tracks_never_triangulated": r["n_never_triangulated"]}
     print(json.dumps(out), flush=True)
 
 

@@ -56,8 +56,45 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
     // of every pass over map.tracks_ by its outlier flag (FilterPoints3d would count a track without observations as filtered)
     const double th_rpe_lba = 16, th_angle_lba = 1.5, th_rpe_gba = 16, th_angle_gba = 1.5;      // incremental_mapper.h:20-23
     std::vector<char> active(in.np, 0);
-    for (auto &tr : map.tracks_) tr.outlier = true;
-    auto reset_point = [&](int tid) { for (int k = 0; k < 3; ++k) map.tracks_[tid].point3d_.data()[k] = in.P[3 * tid + k]; };
+    for (auto &tr : map.tracks_) { tr.outlier = true; tr.angle_ = -2.0; }      // -2: not in the map yet (a born track gets its angle from the filters, or -1)
+    // The map drifts away from the gauge of the input over a few hundred frames (scale and position random walk of a monocular
+    // sequence), so nothing may be initialised in INPUT coordinates once the map has moved: like the mapper, a new frame starts
+    // from a pose relative to the map (here: the input's relative motion from the previous frame applied to that frame's
+    // CURRENT pose, the stand-in for the PnP result), and a new point is placed relative to the frame that triangulates it (the
+    // input point expressed in that frame's input camera coordinates, carried to the world through the frame's CURRENT pose).
+    auto qrot = [](const double *q, const double *v, double *o) {      // unit quaternion x,y,z,w
+        const double x = q[0], y = q[1], z = q[2], w = q[3];
+        const double ux = y * v[2] - z * v[1], uy = z * v[0] - x * v[2], uz = x * v[1] - y * v[0];
+        o[0] = v[0] + 2 * (w * ux + y * uz - z * uy); o[1] = v[1] + 2 * (w * uy + z * ux - x * uz); o[2] = v[2] + 2 * (w * uz + x * uy - y * ux);
+    };
+    auto qmul = [](const double *a, const double *b, double *o) {
+        o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1]; o[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+        o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3]; o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    };
+    auto place_point = [&](int tid, int f) {
+        const double *qi = &in.q[4 * (size_t)f], *ti = &in.t[3 * (size_t)f];
+        double xc[3], d[3];
+        qrot(qi, &in.P[3 * (size_t)tid], xc);
+        auto &T = map.frames_[f].Tcw;
+        for (int k = 0; k < 3; ++k) d[k] = xc[k] + ti[k] - T.t.v[k];
+        const double qc[4] = {-T.q.c.v[0], -T.q.c.v[1], -T.q.c.v[2], T.q.c.v[3]};
+        qrot(qc, d, map.tracks_[tid].point3d_.data());
+    };
+    auto place_frame = [&](int f) {                                     // T_f = (T_f^in o (T_{f-1}^in)^-1) o T_{f-1}
+        const double *qa = &in.q[4 * (size_t)f], *ta = &in.t[3 * (size_t)f], *qb = &in.q[4 * (size_t)(f - 1)], *tb = &in.t[3 * (size_t)(f - 1)];
+        const double qbc[4] = {-qb[0], -qb[1], -qb[2], qb[3]};
+        double qrel[4], trel[3], tmp[3], qn[4];
+        qmul(qa, qbc, qrel);
+        qrot(qrel, tb, tmp);
+        for (int k = 0; k < 3; ++k) trel[k] = ta[k] - tmp[k];
+        auto &Tp = map.frames_[f - 1].Tcw;
+        auto &T = map.frames_[f].Tcw;
+        qmul(qrel, Tp.q.c.v, qn);
+        const double nn = std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        qrot(qrel, Tp.t.v, tmp);
+        for (int k = 0; k < 4; ++k) T.q.c.v[k] = qn[k] / nn;
+        for (int k = 0; k < 3; ++k) T.t.v[k] = tmp[k] + trel[k];
+    };
     auto attach = [&](int f, int feat, int tid) { map.frames_[f].track_ids_[feat] = tid; map.tracks_[tid].observations_[f] = feat; };
     auto triangulate_frame = [&](int f) {
         for (size_t i = 0; i < full[f].size(); ++i) {
@@ -69,9 +106,10 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
             if (nreg < 2) continue;
             // TriangulateFramePoint(map, frame_id, th_angle_lba) creates a point only from rays that meet at a sufficient angle
             // (forward-moving cameras: two consecutive frames rarely do): wait for more observers otherwise
+            place_point(tid, f);
             {
                 double best = 0.0;
-                const double *P = &in.P[3 * (size_t)tid];
+                const double *P = map.tracks_[tid].point3d_.data();
                 std::vector<xrsfm::vector3> cen;
                 for (auto &o : track_obs[tid]) if (map.frames_[o.first].registered) cen.push_back(map.frames_[o.first].Tcw.center());
                 for (size_t a = 0; a < cen.size(); ++a)
@@ -85,7 +123,7 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
                     }
                 if (best < 1.3 * th_angle_lba * 0.017453292519943295) continue;
             }
-            active[tid] = 1; map.tracks_[tid].outlier = false; reset_point(tid);
+            active[tid] = 1; map.tracks_[tid].outlier = false; map.tracks_[tid].angle_ = -1.0;
             for (auto &o : track_obs[tid]) if (map.frames_[o.first].registered) attach(o.first, o.second, tid);
         }
     };
@@ -113,6 +151,7 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
     for (int f = 2; f < in.nc; ++f) {
         auto &fr = map.frames_[f];
         fr.registered = true; fr.is_keyframe = true;
+        place_frame(f);
         {   // pose refinement against the map points the frame sees (RegisterImage, pnp.cc:38-71)
             std::vector<xrsfm::vector3> p3; std::vector<std::pair<int, int>> ids; std::vector<char> inl;
             for (size_t i = 0; i < full[f].size(); ++i) {
@@ -175,8 +214,10 @@ int main(int argc, char **argv) {
     fwrite(&same, 4, 1, o);
     if (!states.empty()) fwrite(states[0].data(), 8, states[0].size(), o);
     int32_t n_out = 0;            // tracks that were in the map and have been filtered (+ those no two registered frames ever saw)
-    for (auto &tr : map.tracks_) n_out += tr.outlier ? 1 : 0;
+    int32_t n_never = 0;          // of those: never triangulated (too small an angle between their observers)
+    for (size_t i = 0; i < map.tracks_.size(); ++i) { n_out += map.tracks_[i].outlier ? 1 : 0; n_never += (map.tracks_[i].outlier && map.tracks_[i].angle_ == -2.0) ? 1 : 0; }
     fwrite(&n_out, 4, 1, o);
+    fwrite(&n_never, 4, 1, o);
     for (int r = 0; r < repeats; ++r) {
         for (int c = 0; c < 4; ++c) {
             std::vector<double> v = all[r].ms[c];

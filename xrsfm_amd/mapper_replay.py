@@ -56,7 +56,7 @@ def run(arr: dict, repeats: int = 1, timeout: float = 1800.0) -> dict:
     off = 8
     cams = np.frombuffer(raw, dtype="f8", count=7 * nc, offset=off).reshape(nc, 7); off += 56 * nc
     pts = np.frombuffer(raw, dtype="f8", count=3 * npt, offset=off).reshape(npt, 3); off += 24 * npt
-    n_out = struct.unpack("i", raw[off:off + 4])[0]; off += 4
+    n_out, n_never = struct.unpack("2i", raw[off:off + 8]); off += 8
     replays = []
     for _ in range(repeats):
         rec = np.frombuffer(raw, dtype="f8", count=27, offset=off); off += 27 * 8
@@ -66,4 +66,4 @@ def run(arr: dict, repeats: int = 1, timeout: float = 1800.0) -> dict:
             classes[name] = dict(count=int(v[0]), total_ms=float(v[1]), p50=float(v[2]), p90=float(v[3]), p99=float(v[4]), max=float(v[5]))
         replays.append(dict(classes=classes, wall_ms=float(rec[24]), free_bytes=int(rec[25])))
     return dict(status=status, same_end_state=bool(same), cam_q=cams[:, :4].copy(), cam_t=cams[:, 4:].copy(), points=pts.copy(),
-                n_outlier_tracks=n_out, replays=replays, returncode=p.returncode, stderr=p.stderr[-2000:])
+                n_outlier_tracks=n_out - n_never, n_never_triangulated=n_never, replays=replays, returncode=p.returncode, stderr=p.stderr[-2000:])
