@@ -210,7 +210,13 @@ struct DevCache {
 DevCache g_cache;
 
 // stream + pinned scalar buffers are recycled too (hipStreamCreate/Destroy and hipHostMalloc/Free cost ~0.5 ms per call)
-struct HostBundle { hipStream_t stream; double* h_scal; PcgStatus* h_st; };
+// (and the second stream + fork / join events of the S assembly, created the first time a context needs them: creating and
+// destroying them per context cost 2.9 ms of a 4.1 ms LBA call in the mapper replay)
+struct HostBundle { hipStream_t stream; double* h_scal; PcgStatus* h_st; hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+static void bundle_release(const HostBundle& b) {
+    (void)hipHostFree(b.h_scal); (void)hipHostFree(b.h_st); (void)hipStreamDestroy(b.stream);
+    if (b.aux) { (void)hipStreamDestroy(b.aux); (void)hipEventDestroy(b.ev_fork); (void)hipEventDestroy(b.ev_join); }
+}
 struct BundleCache {
     std::mutex mu;
     std::map<int, std::vector<HostBundle>> free_bundles;
@@ -220,7 +226,7 @@ struct BundleCache {
             auto& v = free_bundles[dev];
             if (!v.empty()) { *b = v.back(); v.pop_back(); return true; }
         }
-        b->stream = nullptr; b->h_scal = nullptr; b->h_st = nullptr;
+        *b = HostBundle{nullptr, nullptr, nullptr};
         if (hipStreamCreate(&b->stream) != hipSuccess) return false;
         // coherent + mapped: the device publishes the LM scalars straight into this buffer (k_publish) and the host polls
         if (hipHostMalloc((void**)&b->h_scal, sizeof(double) * (S_COUNT + 2), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
@@ -234,7 +240,7 @@ struct BundleCache {
     void put(int dev, const HostBundle& b) {
         std::lock_guard<std::mutex> g(mu);
         auto& v = free_bundles[dev];
-        if (v.size() >= 8) { (void)hipHostFree(b.h_scal); (void)hipHostFree(b.h_st); (void)hipStreamDestroy(b.stream); return; }
+        if (v.size() >= 8) { bundle_release(b); return; }
         v.push_back(b);
     }
 };
@@ -648,10 +654,13 @@ int chol_setup(xrsfm_ba_context* c) {
             done_for[c->device] = 1;
         }
     }
-    if (h.n_pairs_other > 0 && !h.aux) {
+    if (h.n_pairs_other > 0 && !h.aux) {              // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
         if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
-                      hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) { (void)hipStreamDestroy(h.aux); h.aux = nullptr; }
+                      hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) {
+            if (h.ev_fork) (void)hipEventDestroy(h.ev_fork);
+            (void)hipStreamDestroy(h.aux); h.aux = nullptr; h.ev_fork = h.ev_join = nullptr;
+        }
     }
     timer.mark("allocations + attributes");
     h.ready = true;
@@ -972,11 +981,11 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    if (c->chol.aux) { (void)hipStreamSynchronize(c->chol.aux); (void)hipStreamDestroy(c->chol.aux); (void)hipEventDestroy(c->chol.ev_fork); (void)hipEventDestroy(c->chol.ev_join); }
+    if (c->chol.aux) (void)hipStreamSynchronize(c->chol.aux);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
-    if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st});
+    if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st, c->chol.aux, c->chol.ev_fork, c->chol.ev_join});
     // What is left is host memory.  A large context holds ~0.5 KB per observation in vectors whose release (munmap: page-table
     // teardown) takes ~10 ms per million observations: ONE reaper thread does it, the caller (one BA call of a mapper) goes on.
     // The thread is joined when the library is unloaded (g_reaper's destructor: dlclose / process exit), so no library code
@@ -1037,6 +1046,7 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         HostBundle hb;
         if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
         c->stream = hb.stream; c->h_scal = hb.h_scal; c->h_st = hb.h_st;
+        c->chol.aux = hb.aux; c->chol.ev_fork = hb.ev_fork; c->chol.ev_join = hb.ev_join;
         c->seq = 0;
         *reinterpret_cast<unsigned long long*>(c->h_scal + S_COUNT) = 0;
         void* dp = nullptr;
@@ -1485,13 +1495,26 @@ int xrsfm_ba_profile_entry(xrsfm_ba_context* c, int index, const char** name, do
 
 int xrsfm_ba_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* problem, xrsfm_ba_summary* summary) {
     if (!opt || !problem || !summary) return XRSFM_BA_EINVAL;
+    // XRSFM_BA_TRACE_CALLS=1: one stderr line per call (sizes, phases, LM steps) — how a mapper run spends its BA time
+    static const bool trace = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
     xrsfm_ba_context* c = nullptr;
     int e = xrsfm_ba_create(problem, 0, &c);
     if (e) return e;
+    const auto t1 = clk::now();
     e = xrsfm_ba_run(c, opt, summary);
+    const auto t2 = clk::now();
     if (!e) e = xrsfm_ba_download(c, problem->cam_q, problem->cam_t, problem->points);
     if (!e && problem->intr_params) e = xrsfm_ba_download_intrinsics(c, problem->intr_params);      // (bal9 mode only)
+    const auto t3 = clk::now();
     xrsfm_ba_destroy(c);
+    if (trace) {
+        auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[xrsfm_ba_solve] cams %d points %d obs %d | create %.3f run %.3f download %.3f destroy %.3f ms | LM %d+%d solver %d rc %d\n",
+                     problem->n_cams, problem->n_points, problem->n_obs, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, clk::now()),
+                     summary->n_successful, summary->n_unsuccessful, summary->linear_solver_used, e);
+    }
     return e;
 }
 
