@@ -10,7 +10,7 @@ from oracle import ba_cpu, ba_oracle as bo
 from tests import helpers as H
 
 GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
-OTHER = {"track_filter.npz", "tag_refine.npz", "pose_graph.npz", "lba_selection.npz"}   # fixtures of other rows, tested elsewhere
+OTHER = {"track_filter.npz", "tag_refine.npz", "pose_graph.npz", "lba_selection.npz", "wide_bal9.npz"}   # fixtures of other rows, tested elsewhere
 GOLD = sorted(p for p in glob.glob(os.path.join(GOLD_DIR, "*.npz")) if os.path.basename(p) not in OTHER and not os.path.basename(p).startswith("ceres_"))
 CERES = sorted(glob.glob(os.path.join(GOLD_DIR, "ceres_*.npz")))          # real Ceres runs (bench/make_ceres_golden.py); none committed yet
 
@@ -155,3 +155,16 @@ def test_oracle_against_real_ceres_runs():
         assert (s.n_successful, s.n_unsuccessful) == (int(z["n_successful"]), int(z["n_unsuccessful"])), path
         assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(float(z["final_cost"]) / n_res)) < 1e-6
         assert np.abs(pr.cam_q - z["out_cam_q"]).max() < 1e-5 and np.abs(pr.cam_t - z["out_cam_t"]).max() < 1e-5
+
+
+def test_numpy_oracle_reproduces_the_bal9_golden():
+    """tests/golden/wide_bal9.npz (make_golden_bal9.py): 9-wide camera blocks, intrinsics {f, k1, k2} of model 5 variable."""
+    z, arr, opt = _load(os.path.join(GOLD_DIR, "wide_bal9.npz"))
+    pr = H.to_oracle(arr)
+    cost0, rt, Fc, Ep = bo.evaluate(pr, pr.cam_q, pr.cam_t, pr.points)
+    assert Fc.shape[1:] == (2, 9) and abs(cost0 - float(z["init_cost"])) <= 1e-12 * cost0
+    assert H.rel_err(rt, z["init_r"]) < 1e-12 and H.rel_err(Fc, z["init_Jc"]) < 1e-12 and H.rel_err(Ep, z["init_Jp"]) < 1e-12
+    s = bo.solve(pr, bo.Options(**opt))
+    assert (s.n_successful, s.n_unsuccessful) == (int(z["n_successful"]), int(z["n_unsuccessful"]))
+    assert abs(s.final_cost - float(z["final_cost"])) <= 1e-9 * s.final_cost
+    assert np.abs(pr.cam_q - z["out_cam_q"]).max() < 1e-8 and np.abs(pr.intr_params - z["out_intr"]).max() < 1e-6

@@ -118,6 +118,8 @@ def test_large_unordered_problem_is_refused_before_the_symbolic_factorisation(li
     ("unordered", 95, 5, {"XRSFM_BA_PANEL_MACRO": "1"}),                              # odd / even numbers of tile columns
     ("unordered", 230, 5, {"XRSFM_BA_PANEL_MACRO": "1", "XRSFM_BA_PANEL_COLS": "6"}),
     ("unordered", 60, 12, {}),
+    ("unordered", 150, 5, {"XRSFM_BA_LOOKAHEAD": "0"}),                               # the round-2 panel schedule (no second stream)
+    ("unordered", 150, 5, {"XRSFM_BA_LOOKAHEAD": "0", "XRSFM_BA_PANEL_MACRO": "1"}),
     ("sequential", 130, 4, {}), ("sequential", 257, 3, {}), ("sequential", 400, 4, {}), ("sequential", 560, 4, {}),   # level schedules
 ])
 def test_schedule_covers_the_factorisation(monkeypatch, mode, n_cams, k_obs, env):
@@ -133,8 +135,10 @@ def test_schedule_covers_the_factorisation(monkeypatch, mode, n_cams, k_obs, env
     assert plan["tiles"] <= 96                      # the check covers plans of up to 96 tile columns
     if mode == "unordered":
         assert plan["level_schedule"] == 0 and plan["levels"] == plan["tiles"]
+        # a pure chain of >= 8 columns takes the look-ahead form of the panel schedule: partial products cover j < k - 2 only
+        assert plan["lookahead"] == (0 if env.get("XRSFM_BA_LOOKAHEAD") == "0" or plan["tiles"] < 8 else 1)
     else:
-        assert plan["level_schedule"] == 1
+        assert plan["level_schedule"] == 1 and plan["lookahead"] == 0
 
 
 def test_clustered_collection_takes_the_rcm_order():

@@ -431,6 +431,8 @@ def debug_chol_plan(problem: ProblemArrays) -> dict:
     check(load().xrsfm_ba_debug_chol_plan(C.byref(cs), stats.ctypes.data_as(_c_int32_p), off.ctypes.data_as(_c_int32_p)), "xrsfm_ba_debug_chol_plan")
     keys = ("tiles", "levels", "ordering", "hubs", "band", "blocks", "level_schedule", "tiles_nz")
     out = dict(zip(keys, (int(v) for v in stats)))
+    out["lookahead"] = (out["level_schedule"] >> 1) & 1      # panel schedule with partial products on a second stream (ba_plan.h)
+    out["level_schedule"] &= 1
     out["cam_offset"] = off[:problem.n_cams].copy()
     return out
 

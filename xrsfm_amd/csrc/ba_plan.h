@@ -24,6 +24,11 @@ struct CholPlan {
     long long tile_products = 0;     // 64x64x64 tile products of one factorisation (symbolic count; 2 * 64^3 flop each)
     int n_hubs = 0, band = 0;
     bool use_levels = false, panel_ll = false;
+    // look-ahead panel schedule (panel schedule of a pure chain: one column per level): the contributions j < k - 2 of column k
+    // reach it through partial products + their fixed-order sum, launched on a second stream as soon as column k - 3 is
+    // factored — while columns k - 2 and k - 1 are being factored —, and the fused factor kernel adds j = k - 2, k - 1 itself:
+    // the per-column chain update -> sum -> factor (72 us at config T) becomes factor alone
+    bool lookahead = false;
     // k_schur_pairs is launched once per LDS class: items whose staged operand fits 10 KB (16 workgroups per CU) and the rest
     size_t pairs_shm = 0, pairs_shm_big = 0;
     std::vector<int> pairs_items;    // Gram tiles of the small class | Gram tiles of the big class (tile indices) | other items (item indices)
@@ -472,7 +477,17 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.fz_off.assign(n_levels + 1, 0); P.fz_dptr.assign(1, 0);
     std::vector<int> level_cols(n_levels, 0), level_first(n_levels, -1);
     for (int kk = 0; kk < T; ++kk) { if (level_cols[level[kk]]++ == 0) level_first[level[kk]] = kk; }
-    std::vector<int> first_j(T, 0);          // contributions below first_j[k] reach column k through a macro-tile launch
+    // look-ahead needs level == column (the dependencies of the two streams are stated per column) and the fused kernels
+    bool lookahead = panel_ll && n_levels == T && T >= 8;
+    if (const char* fl = std::getenv("XRSFM_BA_LOOKAHEAD")) lookahead = lookahead && fl[0] != '0';
+    if (const char* fl = std::getenv("XRSFM_BA_FUSED")) lookahead = lookahead && fl[0] != '0';
+    P.lookahead = lookahead;
+    constexpr int kLookDepth = 2;             // columns the fused factor kernel adds itself
+    // contributions below first_j[k] reach column k through partial products (macro-tile launch, or — look-ahead — chunks of a
+    // split level too), those from first_j[k] on inside the fused factor kernel
+    std::vector<int> first_j(T, 0);
+    std::vector<char> later_of_panel(T, 0);   // second (third, ...) column of a macro panel: no partial launch of its own
+    if (lookahead) for (int kk = 0; kk < T; ++kk) first_j[kk] = std::max(0, kk - kLookDepth);
     const int macro_chunks = 512;
     // macro tiles pay off from ~100 tile columns (config U, 45 columns: 25.7 ms without, 28.1 ms with); developer switches
     bool macro_on = T >= 96;
@@ -485,7 +500,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     auto dense_panel = [&](int lv) {
         if (!panel_ll || !macro_on || level_cols[lv] != 1) return 0;
         const int k0 = level_first[lv];
-        if (k0 < 2 || first_j[k0] != 0) return 0;
+        if (k0 < (lookahead ? 2 + 2 * kLookDepth : 2) || later_of_panel[k0]) return 0;
         for (int i = k0; i < T; ++i)
             for (int j = 0; j < k0; ++j) if (!nz[(size_t)i * T + j]) return 0;
         int np = 0;
@@ -503,13 +518,19 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         fz_ents.clear();
         const int panel_cols = dense_panel(lv);
         const bool macro = panel_cols > 0;
-        for (int q = 1; q < panel_cols; ++q) first_j[level_first[lv] + q] = level_first[lv];
+        // partial products of a macro panel cover j < jhi for every column of the panel
+        const int jhi = macro ? (lookahead ? level_first[lv] - kLookDepth : level_first[lv]) : 0;
+        for (int q = lookahead ? 0 : 1; q < panel_cols; ++q) { first_j[level_first[lv] + q] = jhi; if (q > 0) later_of_panel[level_first[lv] + q] = 1; }
         for (int kk = 0; kk < T; ++kk) {
             if (level[kk] != lv) continue;
             for (int i = kk; i < T; ++i) {
                 if (!nz[(size_t)i * T + kk]) continue;
                 if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
                 std::vector<int> contrib;
+                if (lookahead) {        // the list of the partial products: j < first_j (none for the columns of a macro panel)
+                    if (!macro && !later_of_panel[kk])
+                        for (int j = 0; j < first_j[kk]; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
+                } else
                 for (int j = first_j[kk]; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
                 fz_ents.push_back({i, kk});
                 if (contrib.empty()) continue;
@@ -525,8 +546,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         const int nt = g1 - g0, nc = nt > 0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0;
         // (panel schedule: every level with lists worth cutting is split, into chunks of >= kPanelMinChunk products so that the
         //  partial tile a chunk writes stays a small part of its traffic, and into <= ~kPanelChunks chunks per level)
-        const bool second = level_cols[lv] == 1 && first_j[level_first[lv]] > 0;      // second column of a macro pair: one contribution left
-        const bool split = !macro && !second && (panel_ll ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt));
+        const bool second = level_cols[lv] == 1 && later_of_panel[level_first[lv]];    // second column of a macro pair: one contribution left
+        const bool split = !macro && !second && (lookahead ? nc > 0 : (panel_ll ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt)));
         if (macro) {
             // every macro target's j range is cut into chunks of >= panel_min_chunk steps, ~macro_chunks chunks per level (about two
             // rounds of resident workgroups: measured faster than one round of equal shares, whose partial-tile stores all
@@ -538,15 +559,15 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             for (int cp = 0; cp < ncp; ++cp)
                 for (int i0 = K0 + 2 * cp; i0 < T; i0 += 2) tg.push_back({i0, (i0 + 1 < T) ? i0 + 1 : -1, K0 + 2 * cp, K0 + 2 * cp + 1});
             const int nm = (int)tg.size();
-            const int cs = std::max(panel_min_chunk, (int)(((long long)nm * K0 + macro_chunks - 1) / macro_chunks));
+            const int cs = std::max(panel_min_chunk, (int)(((long long)nm * jhi + macro_chunks - 1) / macro_chunks));
             std::vector<int> pieces(nm, 0);       // partial slots per macro target
             struct Ent { int m, q0, q1, piece; };
             std::vector<Ent> ents;
             std::vector<int> wg_first;
             for (int m = 0; m < nm; ++m)
-                for (int q = 0; q < K0; q += cs) {
+                for (int q = 0; q < jhi; q += cs) {
                     wg_first.push_back((int)ents.size());
-                    ents.push_back({m, q, std::min(K0, q + cs), pieces[m]++});
+                    ents.push_back({m, q, std::min(jhi, q + cs), pieces[m]++});
                 }
             const int W = (int)ents.size();
             wg_first.push_back((int)ents.size());
@@ -587,7 +608,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         }
         for (const FzEnt& e : fz_ents) {        // work list of the fused level kernel
             P.fz_tile.push_back(e.i); P.fz_tile.push_back(e.k);
-            if (!split && !macro)
+            if (lookahead || (!split && !macro))
                 for (int j = first_j[e.k]; j < e.k; ++j)
                     if (nz[(size_t)e.k * T + j]) P.fz_dj.push_back((e.i == e.k || nz[(size_t)e.i * T + j]) ? j : ~j);
             P.fz_dptr.push_back((int)P.fz_dj.size());

@@ -109,6 +109,8 @@ struct CholHost {
     std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
     // level schedule (elimination-tree levels of the tile pattern; left-looking updates)
     bool use_levels = false, panel_ll = false;
+    bool lookahead = false;                       // look-ahead panel schedule (ba_plan.h): partial products on the second stream
+    hipEvent_t la_ev[16] = {nullptr};             // rings of 8: "column s factored" (main -> second stream), "column k updated" (back)
     int n_levels = 0;
     int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr, *lv_trsm = nullptr;
     int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
@@ -212,10 +214,14 @@ DevCache g_cache;
 // stream + pinned scalar buffers are recycled too (hipStreamCreate/Destroy and hipHostMalloc/Free cost ~0.5 ms per call)
 // (and the second stream + fork / join events of the S assembly, created the first time a context needs them: creating and
 // destroying them per context cost 2.9 ms of a 4.1 ms LBA call in the mapper replay)
-struct HostBundle { hipStream_t stream; double* h_scal; PcgStatus* h_st; hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
+struct HostBundle {
+    hipStream_t stream; double* h_scal; PcgStatus* h_st; hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t la_ev[16] = {nullptr};             // look-ahead panel schedule (chol_factor_solve)
+};
 static void bundle_release(const HostBundle& b) {
     (void)hipHostFree(b.h_scal); (void)hipHostFree(b.h_st); (void)hipStreamDestroy(b.stream);
     if (b.aux) { (void)hipStreamDestroy(b.aux); (void)hipEventDestroy(b.ev_fork); (void)hipEventDestroy(b.ev_join); }
+    for (hipEvent_t e : b.la_ev) if (e) (void)hipEventDestroy(e);
 }
 struct BundleCache {
     std::mutex mu;
@@ -340,21 +346,24 @@ int allreduce(xrsfm_ba_context* c, double* buf, size_t n, int op) {
 
 // Launch wrapper: in profile mode every launch is bracketed by HIP events on the library's stream.
 struct Timed {
-    xrsfm_ba_context* c; int kid; int tag; size_t e0 = 0; bool on;
-    Timed(xrsfm_ba_context* c_, int kid_, int tag_ = -1) : c(c_), kid(kid_), tag(tag_), on(c_->profiling) {
+    xrsfm_ba_context* c; int kid; int tag; size_t e0 = 0; bool on; hipStream_t st;
+    Timed(xrsfm_ba_context* c_, int kid_, int tag_ = -1, hipStream_t st_ = nullptr) : c(c_), kid(kid_), tag(tag_), on(c_->profiling), st(st_ ? st_ : c_->stream) {
         if (!on) return;
         while (c->ev_pool.size() < c->ev_used + 2) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) { on = false; return; } c->ev_pool.push_back(e); }
         e0 = c->ev_used; c->ev_used += 2;
-        (void)hipEventRecord(c->ev_pool[e0], c->stream);
+        (void)hipEventRecord(c->ev_pool[e0], st);
     }
     ~Timed() {
         if (!on) return;
-        (void)hipEventRecord(c->ev_pool[e0 + 1], c->stream);
+        (void)hipEventRecord(c->ev_pool[e0 + 1], st);
         c->recs.push_back({kid, e0, tag});
     }
 };
 #define LAUNCH(ctx, kid, kern, grid, block, shmem, ...)                                  \
     do { Timed t_((ctx), (kid)); hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__); } while (0)
+// ... on another stream of the context (the events that time it are recorded on that stream)
+#define LAUNCH_ON(ctx, stream_, kid, kern, grid, block, shmem, ...)                      \
+    do { Timed t_((ctx), (kid), -1, (stream_)); hipLaunchKernelGGL(kern, grid, block, shmem, (stream_), __VA_ARGS__); } while (0)
 
 // resolve recorded event pairs (stream must be idle); records tagged with a PCG iteration index are only
 // counted if the iteration really ran (launches after `done` are no-ops)
@@ -585,7 +594,7 @@ int chol_setup(xrsfm_ba_context* c) {
     // (... or a reverse Cuthill-McKee order whose symbolic factorisation stays within the work budget of ba_plan.h: panel schedule)
     if (P.n > kCholMaxN && (!(P.use_levels || P.ordering == 2) || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
-    h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
+    h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.lookahead = P.lookahead; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
@@ -654,7 +663,7 @@ int chol_setup(xrsfm_ba_context* c) {
             done_for[c->device] = 1;
         }
     }
-    if (h.n_pairs_other > 0 && !h.aux) {              // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
+    if ((h.n_pairs_other > 0 || h.lookahead) && !h.aux) {      // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
         if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) {
@@ -662,6 +671,12 @@ int chol_setup(xrsfm_ba_context* c) {
             (void)hipStreamDestroy(h.aux); h.aux = nullptr; h.ev_fork = h.ev_join = nullptr;
         }
     }
+    if (h.lookahead && h.aux && !h.la_ev[0]) {
+        bool ok = true;
+        for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&h.la_ev[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { for (hipEvent_t& e : h.la_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; } }
+    }
+    if (h.lookahead && (!h.aux || !h.la_ev[0])) return XRSFM_BA_ENODEV;      // (the plan's lists need the two-stream schedule)
     timer.mark("allocations + attributes");
     h.ready = true;
     return 0;
@@ -732,6 +747,55 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     const int T = h.T;
     double* px_out = c->wide ? c->w.px : d.px;        // solution in camera order, cw values per camera
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
+    if (h.lookahead && c->fused) {
+        // Look-ahead panel schedule (ba_plan.h): level = column.  Main stream: the fused factor kernel of column s, which adds
+        // the contributions of columns s-2 and s-1 itself.  Second stream: the partial products of column s+3 over the columns
+        // <= s (and their fixed-order sum into the tiles of column s+3), started as soon as column s is factored and done, as a
+        // rule, long before column s+3 is due.  Two event rings carry "column s factored" one way and "column k updated" back;
+        // every dependency is stated, so the result does not depend on how far the second stream runs ahead.
+        constexpr int kLook = 3, kRing = 8;
+        auto partials = [&](int lv) {
+            return lv < h.n_levels && ((h.mp_off[lv + 1] - h.mp_off[lv] - 1 > 0) || (h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv] > 0));
+        };
+        for (int s = 0; s < h.n_levels; ++s) {
+            if (partials(s)) HIPCHK(hipStreamWaitEvent(c->stream, h.la_ev[8 + s % kRing], 0));
+            const int nf = h.fz_off[s + 1] - h.fz_off[s];
+            const bool with_bwd = T == 1;
+            LvFill lf{};
+            if (s == 0 && !h.S_filled) {
+                lf.d = d; lf.f = FillLists{h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, c->step_prep ? c->step_radius : 0.0};
+                lf.fz_q = h.fz_q; lf.rest = h.fill_rest; lf.n_factor = nf;
+                if (nf + h.n_fill_rest > 0)
+                    LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + h.n_fill_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
+                           (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
+            } else if (nf > 0)
+                LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[s], h.fz_dptr + h.fz_off[s], h.fz_dj,
+                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
+            const int lv = s + kLook;
+            if (partials(lv)) {
+                HIPCHK(hipEventRecord(h.la_ev[s % kRing], c->stream));
+                HIPCHK(hipStreamWaitEvent(h.aux, h.la_ev[s % kRing], 0));
+                const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
+                const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
+                if (nmc > 0)
+                    LAUNCH_ON(c, h.aux, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
+                else
+                    LAUNCH_ON(c, h.aux, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
+                              h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
+                if (nrt > 0)
+                    LAUNCH_ON(c, h.aux, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
+                              h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
+                HIPCHK(hipEventRecord(h.la_ev[8 + lv % kRing], h.aux));
+            }
+        }
+        if (T == 1) return 0;
+        for (int k = T - 1; k >= 0; --k) {
+            const int ncol = h.cols_off[k + 1] - h.cols_off[k];
+            LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
+        }
+        if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
+        return 0;
+    }
     if ((h.use_levels || h.panel_ll) && c->fused) {
         // one launch per elimination-tree level (three on a split level: partial products, their fixed-order sum, then the
         // same fused kernel with empty lists), then one per level backwards
@@ -985,7 +1049,11 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
-    if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st, c->chol.aux, c->chol.ev_fork, c->chol.ev_join});
+    if (c->stream) {
+        HostBundle hb{c->stream, c->h_scal, c->h_st, c->chol.aux, c->chol.ev_fork, c->chol.ev_join};
+        for (int i = 0; i < 16; ++i) hb.la_ev[i] = c->chol.la_ev[i];
+        g_bundles.put(c->device, hb);
+    }
     // What is left is host memory.  A large context holds ~0.5 KB per observation in vectors whose release (munmap: page-table
     // teardown) takes ~10 ms per million observations: ONE reaper thread does it, the caller (one BA call of a mapper) goes on.
     // The thread is joined when the library is unloaded (g_reaper's destructor: dlclose / process exit), so no library code
@@ -1047,6 +1115,7 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
         c->stream = hb.stream; c->h_scal = hb.h_scal; c->h_st = hb.h_st;
         c->chol.aux = hb.aux; c->chol.ev_fork = hb.ev_fork; c->chol.ev_join = hb.ev_join;
+        for (int i = 0; i < 16; ++i) c->chol.la_ev[i] = hb.la_ev[i];
         c->seq = 0;
         *reinterpret_cast<unsigned long long*>(c->h_scal + S_COUNT) = 0;
         void* dp = nullptr;
@@ -2018,7 +2087,7 @@ int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     CholPlan P;
     if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes, wide ? kW : 6))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
-    stats[6] = P.use_levels ? 1 : 0; stats[7] = P.n_tiles_nz;
+    stats[6] = (P.use_levels ? 1 : 0) | (P.lookahead ? 2 : 0); stats[7] = P.n_tiles_nz;
     if (cam_offset) for (int i = 0; i < k.n_cams; ++i) cam_offset[i] = P.cam_off[i];
     return 0;
 }
