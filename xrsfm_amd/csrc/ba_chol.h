@@ -1016,19 +1016,19 @@ __device__ __forceinline__ void half_abt_mfma(const double* __restrict__ As, con
     }
 }
 
-__global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr,
-                                                        const int* __restrict__ cj, double* __restrict__ Wp) {
+__device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
+                                                    const int* __restrict__ cj, double* __restrict__ Wp) {
     __shared__ __attribute__((aligned(16))) double As[kNB * kLdH];
     __shared__ __attribute__((aligned(16))) double Bs[kNB * kLdH];
     __shared__ double yv[kNB];
-    const int i = tgt[2 * blockIdx.x], k = tgt[2 * blockIdx.x + 1];
+    const int i = tgt[2 * bx], k = tgt[2 * bx + 1];
     const bool diag = (i == k);
     v4d acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int q0 = qr[2 * blockIdx.x], q1 = qr[2 * blockIdx.x + 1];
+    const int q0 = qr[2 * bx], q1 = qr[2 * bx + 1];
     const int t = threadIdx.x, o = t >> 2, part = t & 3;
     double sv = 0.0;
     v2d ra[4], rb[4];
@@ -1058,7 +1058,7 @@ __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __
         }
         half_abt_mfma(As, Bs, acc);
     }
-    double* out = Wp + (size_t)blockIdx.x * kPartStride;
+    double* out = Wp + (size_t)bx * kPartStride;
     {
         const int lane = t & 63, wave = t >> 6;
         const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
@@ -1077,6 +1077,10 @@ __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __
         sv += __shfl_xor(sv, 2, kWave);
         if (part == 0) out[kNB * kNB + o] = sv;
     }
+}
+__global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr,
+                                                        const int* __restrict__ cj, double* __restrict__ Wp) {
+    ll_update_part_body(c, blockIdx.x, tgt, qr, cj, Wp);
 }
 
 // Dense part of a panel schedule: 128x128 macro tile = rows (i0,i1) x columns (k0,k1), contributions j in [q0,q1): every
@@ -1219,19 +1223,23 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, s
 }
 
 // grid (targets, 16): 256 tile elements per workgroup
-__global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* __restrict__ rt, const int* __restrict__ rp,
-                                                          const double* __restrict__ Wp) {
-    const int i = rt[2 * blockIdx.x], k = rt[2 * blockIdx.x + 1];
-    const int p0 = rp[2 * blockIdx.x], p1 = rp[2 * blockIdx.x + 1];
+__device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const int bx, const int by, const int* __restrict__ rt,
+                                                      const int* __restrict__ rp, const double* __restrict__ Wp) {
+    const int i = rt[2 * bx], k = rt[2 * bx + 1];
+    const int p0 = rp[2 * bx], p1 = rp[2 * bx + 1];
     {
-        const int e = blockIdx.y * 256 + threadIdx.x;
+        const int e = by * 256 + threadIdx.x;
         const double s = sum_strided(Wp + (size_t)p0 * kPartStride + e, kPartStride, p1 - p0);
         c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] -= s;
     }
-    if (i == k && blockIdx.y == 0 && threadIdx.x < kNB) {
+    if (i == k && by == 0 && threadIdx.x < kNB) {
         const double s = sum_strided(Wp + (size_t)p0 * kPartStride + kNB * kNB + threadIdx.x, kPartStride, p1 - p0);
         c.rhs[k * kNB + threadIdx.x] -= s;
     }
+}
+__global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* __restrict__ rt, const int* __restrict__ rp,
+                                                          const double* __restrict__ Wp) {
+    ll_update_reduce_body(c, blockIdx.x, blockIdx.y, rt, rp, Wp);
 }
 
 // A_ik <- A_ik Linv_k^T for the (i,k) pairs of one level
@@ -1323,9 +1331,9 @@ __global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict
 // system — LBA-sized calls — has no fill launch at all); workgroups >= n_factor compose the tiles of the other columns.
 struct LvFill { Dev d; FillLists f; const int* fz_q; const int* rest; int n_factor; };
 template <bool FILL>
-__global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
-                                                   const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
-                                                   LvFill lf) {
+__device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, const int* __restrict__ tiles, const int* __restrict__ dptr,
+                                               const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
+                                               const LvFill& lf) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Xs[kNB][kLdT];      // off-diagonal workgroup: A_ik - update, parked here while the pivot tile is factored (it used
@@ -1334,7 +1342,6 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
                                           // instructions per column update; 109 KB of LDS = one workgroup per CU, the grid has <= 1 per CU anyway)
     __shared__ double Tb[3][16][17];
     __shared__ double yv[kNB], fv[kNB];
-    const int b = blockIdx.x;
     if (FILL && b >= lf.n_factor) {        // a tile of a later column: compose and store (k_tile_fill)
         const int q = lf.rest[b - lf.n_factor];
         const int ti = lf.f.tiles[2 * q], tj = lf.f.tiles[2 * q + 1];
@@ -1495,6 +1502,43 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
         for (int n2 = 0; n2 < 2; ++n2)
 #pragma unroll
             for (int g = 0; g < 4; ++g) Sik[(size_t)(r0 + 16 * m + lk + 4 * g) * ld + c0 + 16 * n2 + li] = acc[m][n2][g];
+}
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
+                                                   const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
+                                                   LvFill lf) {
+    lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf);
+}
+
+// Look-ahead panel schedule (ba_plan.h: lookahead; level = column): ONE launch per column s.  Workgroups [0, n_factor): the
+// fused factor kernel of column s (its lists hold the contributions of columns s-2 and s-1, everything older has been
+// subtracted in place); then 16 per target: the fixed-order sum of the partial products of column s+1 into its tiles (written
+// by the previous launch); the rest: the partial products of column s+2 over the columns < s (one chunk each).  The three
+// parts touch disjoint data (columns s / s+1 / the partial buffer of the other parity), so the kernel boundary is the only
+// synchronisation: the per-column chain update -> sum -> factor of the plain panel schedule becomes factor alone, with the
+// other two riding on the CUs the factor kernel leaves idle.  The factor workgroups come first: they are the critical path
+// and are dispatched first.  144 KB of LDS: one workgroup per CU.
+//   Measured and not adopted (round 3): the same schedule on two streams — every event record / wait on the main stream cost
+//   a 12-14 us bubble between dependent kernels (49 us per column at config U against 56 without look-ahead; this kernel: 39);
+//   a 75 KB variant for two workgroups per CU (chunk operands overlaid on the factor tiles, the off-diagonal tile parked in
+//   its own global storage, accumulators started from the negated tile to stay below 256 registers) — no gain at config T
+//   (the column is bound by the factor workgroups, not by the chunks), slower at U and on the level schedule of L.
+struct SlotArgs {
+    const int* fz_tile; const int* fz_dptr; int n_factor;                    // column s (pointers already offset to the level)
+    const int* sp_rt; const int* sp_rp; int n_reduce; const double* Wr;      // column s+1: targets, partial ranges, their buffer
+    const int* sp_tgt; const int* sp_q; int n_part; double* Wp;              // column s+2: chunks and their buffer
+};
+__global__ __launch_bounds__(256) void k_panel_slot(CholDev c, SlotArgs a, const int* __restrict__ dj, const int* __restrict__ cj,
+                                                    const int* __restrict__ tile_cam) {
+    const int b = blockIdx.x;
+    if (b < a.n_factor) {
+        lv_factor_body<false>(c, b, a.fz_tile, a.fz_dptr, dj, tile_cam, nullptr, LvFill{});
+    } else if (b < a.n_factor + 16 * a.n_reduce) {
+        const int r = b - a.n_factor;
+        ll_update_reduce_body(c, r >> 4, r & 15, a.sp_rt, a.sp_rp, a.Wr);
+    } else {
+        ll_update_part_body(c, b - a.n_factor - 16 * a.n_reduce, a.sp_tgt, a.sp_q, cj, a.Wp);
+    }
 }
 
 // Backward substitution, one level per launch: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i).  Every term of the sum

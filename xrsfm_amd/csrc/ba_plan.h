@@ -25,9 +25,9 @@ struct CholPlan {
     int n_hubs = 0, band = 0;
     bool use_levels = false, panel_ll = false;
     // look-ahead panel schedule (panel schedule of a pure chain: one column per level): the contributions j < k - 2 of column k
-    // reach it through partial products + their fixed-order sum, launched on a second stream as soon as column k - 3 is
-    // factored — while columns k - 2 and k - 1 are being factored —, and the fused factor kernel adds j = k - 2, k - 1 itself:
-    // the per-column chain update -> sum -> factor (72 us at config T) becomes factor alone
+    // reach it through partial products (formed in the launch that factors column k - 2) + their fixed-order sum (in the launch
+    // of column k - 1), and the fused factor kernel adds j = k - 2, k - 1 itself: one launch per column (k_panel_slot,
+    // ba_chol.h) instead of the chain update -> sum -> factor (72 us per column at config T)
     bool lookahead = false;
     // k_schur_pairs is launched once per LDS class: items whose staged operand fits 10 KB (16 workgroups per CU) and the rest
     size_t pairs_shm = 0, pairs_shm_big = 0;
@@ -478,8 +478,11 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     std::vector<int> level_cols(n_levels, 0), level_first(n_levels, -1);
     for (int kk = 0; kk < T; ++kk) { if (level_cols[level[kk]]++ == 0) level_first[level[kk]] = kk; }
     // look-ahead needs level == column (the dependencies of the two streams are stated per column) and the fused kernels
-    bool lookahead = panel_ll && n_levels == T && T >= 8;
-    if (const char* fl = std::getenv("XRSFM_BA_LOOKAHEAD")) lookahead = lookahead && fl[0] != '0';
+    // ... and pays where a column's update is short of work for the whole chip (config T: ~1600 tile products per column, U: ~340);
+    // a dense factor of >= 96 columns (config D: ~6700 per column) keeps the macro-tile panels, whose launches need the CUs to
+    // themselves (two 74 KB workgroups per CU; the one-launch-per-column kernel holds 144 KB of LDS per workgroup)
+    bool lookahead = panel_ll && n_levels == T && T >= 8 && (T < 96 || P.tile_products <= (long long)4096 * T);
+    if (const char* fl = std::getenv("XRSFM_BA_LOOKAHEAD")) lookahead = panel_ll && n_levels == T && T >= 8 && fl[0] != '0';
     if (const char* fl = std::getenv("XRSFM_BA_FUSED")) lookahead = lookahead && fl[0] != '0';
     P.lookahead = lookahead;
     constexpr int kLookDepth = 2;             // columns the fused factor kernel adds itself
@@ -492,6 +495,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     // macro tiles pay off from ~100 tile columns (config U, 45 columns: 25.7 ms without, 28.1 ms with); developer switches
     bool macro_on = T >= 96;
     if (const char* fl = std::getenv("XRSFM_BA_PANEL_MACRO")) macro_on = fl[0] == '1';
+    if (lookahead) macro_on = false;        // (k_panel_slot carries chunks of split levels only)
     // (wider panels were measured on config D: 4 / 8 columns leave the update time where it is and lengthen the lists of the
     //  fused factor kernel: 237 -> 250 / 266 ms)
     const int panel_cols_max = std::getenv("XRSFM_BA_PANEL_COLS") ? std::atoi(std::getenv("XRSFM_BA_PANEL_COLS")) : 2;

@@ -109,8 +109,7 @@ struct CholHost {
     std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
     // level schedule (elimination-tree levels of the tile pattern; left-looking updates)
     bool use_levels = false, panel_ll = false;
-    bool lookahead = false;                       // look-ahead panel schedule (ba_plan.h): partial products on the second stream
-    hipEvent_t la_ev[16] = {nullptr};             // rings of 8: "column s factored" (main -> second stream), "column k updated" (back)
+    bool lookahead = false;                       // look-ahead panel schedule (ba_plan.h): one launch per column (k_panel_slot)
     int n_levels = 0;
     int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr, *lv_trsm = nullptr;
     int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
@@ -118,7 +117,7 @@ struct CholHost {
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off, mp_off;
     int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
-    double* sp_work = nullptr;
+    double* sp_work = nullptr; int sp_max_chunks = 0;
     int *fz_tile = nullptr, *fz_dptr = nullptr, *fz_dj = nullptr, *tile_cam = nullptr;   // fused level kernel (ba_plan.h)
     int *fz_q = nullptr, *fill_rest = nullptr; int n_fill_rest = 0;    // tile fill inside the first level's launch
     bool S_filled = false;                                   // chol_assemble ran k_tile_fill (else the first level composes its tiles)
@@ -214,14 +213,10 @@ DevCache g_cache;
 // stream + pinned scalar buffers are recycled too (hipStreamCreate/Destroy and hipHostMalloc/Free cost ~0.5 ms per call)
 // (and the second stream + fork / join events of the S assembly, created the first time a context needs them: creating and
 // destroying them per context cost 2.9 ms of a 4.1 ms LBA call in the mapper replay)
-struct HostBundle {
-    hipStream_t stream; double* h_scal; PcgStatus* h_st; hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipEvent_t la_ev[16] = {nullptr};             // look-ahead panel schedule (chol_factor_solve)
-};
+struct HostBundle { hipStream_t stream; double* h_scal; PcgStatus* h_st; hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr; };
 static void bundle_release(const HostBundle& b) {
     (void)hipHostFree(b.h_scal); (void)hipHostFree(b.h_st); (void)hipStreamDestroy(b.stream);
     if (b.aux) { (void)hipStreamDestroy(b.aux); (void)hipEventDestroy(b.ev_fork); (void)hipEventDestroy(b.ev_join); }
-    for (hipEvent_t e : b.la_ev) if (e) (void)hipEventDestroy(e);
 }
 struct BundleCache {
     std::mutex mu;
@@ -622,7 +617,8 @@ int chol_setup(xrsfm_ba_context* c) {
     const std::vector<int> gplan_tab = gram_store_plan(h.gplan.off);      // must outlive up.flush()
     int* d_gplan = nullptr;
     up.add(&d_gplan, gplan_tab);
-    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride));
+    h.sp_max_chunks = P.sp_max_chunks;
+    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
     up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
     TRYC(up.flush());
     h.gplan.tab = reinterpret_cast<const int4*>(d_gplan);
@@ -663,7 +659,7 @@ int chol_setup(xrsfm_ba_context* c) {
             done_for[c->device] = 1;
         }
     }
-    if ((h.n_pairs_other > 0 || h.lookahead) && !h.aux) {      // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
+    if (h.n_pairs_other > 0 && !h.aux) {              // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
         if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) {
@@ -671,12 +667,6 @@ int chol_setup(xrsfm_ba_context* c) {
             (void)hipStreamDestroy(h.aux); h.aux = nullptr; h.ev_fork = h.ev_join = nullptr;
         }
     }
-    if (h.lookahead && h.aux && !h.la_ev[0]) {
-        bool ok = true;
-        for (int i = 0; i < 16 && ok; ++i) ok = hipEventCreateWithFlags(&h.la_ev[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { for (hipEvent_t& e : h.la_ev) { if (e) (void)hipEventDestroy(e); e = nullptr; } }
-    }
-    if (h.lookahead && (!h.aux || !h.la_ev[0])) return XRSFM_BA_ENODEV;      // (the plan's lists need the two-stream schedule)
     timer.mark("allocations + attributes");
     h.ready = true;
     return 0;
@@ -748,47 +738,33 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     double* px_out = c->wide ? c->w.px : d.px;        // solution in camera order, cw values per camera
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
     if (h.lookahead && c->fused) {
-        // Look-ahead panel schedule (ba_plan.h): level = column.  Main stream: the fused factor kernel of column s, which adds
-        // the contributions of columns s-2 and s-1 itself.  Second stream: the partial products of column s+3 over the columns
-        // <= s (and their fixed-order sum into the tiles of column s+3), started as soon as column s is factored and done, as a
-        // rule, long before column s+3 is due.  Two event rings carry "column s factored" one way and "column k updated" back;
-        // every dependency is stated, so the result does not depend on how far the second stream runs ahead.
-        constexpr int kLook = 3, kRing = 8;
-        auto partials = [&](int lv) {
-            return lv < h.n_levels && ((h.mp_off[lv + 1] - h.mp_off[lv] - 1 > 0) || (h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv] > 0));
-        };
-        for (int s = 0; s < h.n_levels; ++s) {
-            if (partials(s)) HIPCHK(hipStreamWaitEvent(c->stream, h.la_ev[8 + s % kRing], 0));
-            const int nf = h.fz_off[s + 1] - h.fz_off[s];
-            const bool with_bwd = T == 1;
-            LvFill lf{};
-            if (s == 0 && !h.S_filled) {
+        // Look-ahead panel schedule (ba_plan.h, k_panel_slot): level = column, one launch per column s = factor of column s (which
+        // adds columns s-2, s-1 itself) | fixed-order sum of the partial products of column s+1 | partial products of column s+2
+        // over the columns < s.  The partial buffers alternate with the parity of the column they belong to.
+        auto chunks = [&](int lv) { return lv < h.n_levels ? h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv] : 0; };
+        auto targets = [&](int lv) { return lv < h.n_levels ? h.sp_rt_off[lv + 1] - h.sp_rt_off[lv] : 0; };
+        double* const Wbuf[2] = {h.sp_work, h.sp_work + (size_t)std::max(1, h.sp_max_chunks) * kPartStride};
+        for (int s2 = 0; s2 < h.n_levels; ++s2) {
+            const int nf = h.fz_off[s2 + 1] - h.fz_off[s2];
+            if (s2 == 0 && !h.S_filled) {      // (nothing else can run yet: the tiles of every column are composed here)
+                LvFill lf{};
                 lf.d = d; lf.f = FillLists{h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, c->step_prep ? c->step_radius : 0.0};
                 lf.fz_q = h.fz_q; lf.rest = h.fill_rest; lf.n_factor = nf;
                 if (nf + h.n_fill_rest > 0)
                     LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + h.n_fill_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
-                           (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
-            } else if (nf > 0)
-                LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[s], h.fz_dptr + h.fz_off[s], h.fz_dj,
-                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
-            const int lv = s + kLook;
-            if (partials(lv)) {
-                HIPCHK(hipEventRecord(h.la_ev[s % kRing], c->stream));
-                HIPCHK(hipStreamWaitEvent(h.aux, h.la_ev[s % kRing], 0));
-                const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
-                const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
-                if (nmc > 0)
-                    LAUNCH_ON(c, h.aux, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
-                else
-                    LAUNCH_ON(c, h.aux, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
-                              h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-                if (nrt > 0)
-                    LAUNCH_ON(c, h.aux, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
-                              h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
-                HIPCHK(hipEventRecord(h.la_ev[8 + lv % kRing], h.aux));
+                           (const int*)h.tile_cam, (double*)nullptr, lf);
+                continue;
             }
+            SlotArgs a{};
+            a.fz_tile = h.fz_tile + 2 * (size_t)h.fz_off[s2]; a.fz_dptr = h.fz_dptr + h.fz_off[s2]; a.n_factor = nf;
+            const int lr = s2 + 1, lp = s2 + 2;
+            a.n_reduce = targets(lr);
+            if (a.n_reduce > 0) { a.sp_rt = h.sp_rt + 2 * (size_t)h.sp_rt_off[lr]; a.sp_rp = h.sp_rp + 2 * (size_t)h.sp_rt_off[lr]; a.Wr = Wbuf[lr & 1]; }
+            a.n_part = chunks(lp);
+            if (a.n_part > 0) { a.sp_tgt = h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lp]; a.sp_q = h.sp_q + 2 * (size_t)h.sp_chunk_off[lp]; a.Wp = Wbuf[lp & 1]; }
+            const int nwg = a.n_factor + 16 * a.n_reduce + a.n_part;
+            if (nwg > 0) LAUNCH(c, K_POTRF, k_panel_slot, dim3(nwg), dim3(256), 0, h.dev, a, (const int*)h.fz_dj, (const int*)h.lv_cj, (const int*)h.tile_cam);
         }
-        if (T == 1) return 0;
         for (int k = T - 1; k >= 0; --k) {
             const int ncol = h.cols_off[k + 1] - h.cols_off[k];
             LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
@@ -1049,11 +1025,7 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
-    if (c->stream) {
-        HostBundle hb{c->stream, c->h_scal, c->h_st, c->chol.aux, c->chol.ev_fork, c->chol.ev_join};
-        for (int i = 0; i < 16; ++i) hb.la_ev[i] = c->chol.la_ev[i];
-        g_bundles.put(c->device, hb);
-    }
+    if (c->stream) g_bundles.put(c->device, HostBundle{c->stream, c->h_scal, c->h_st, c->chol.aux, c->chol.ev_fork, c->chol.ev_join});
     // What is left is host memory.  A large context holds ~0.5 KB per observation in vectors whose release (munmap: page-table
     // teardown) takes ~10 ms per million observations: ONE reaper thread does it, the caller (one BA call of a mapper) goes on.
     // The thread is joined when the library is unloaded (g_reaper's destructor: dlclose / process exit), so no library code
@@ -1115,7 +1087,6 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
         c->stream = hb.stream; c->h_scal = hb.h_scal; c->h_st = hb.h_st;
         c->chol.aux = hb.aux; c->chol.ev_fork = hb.ev_fork; c->chol.ev_join = hb.ev_join;
-        for (int i = 0; i < 16; ++i) c->chol.la_ev[i] = hb.la_ev[i];
         c->seq = 0;
         *reinterpret_cast<unsigned long long*>(c->h_scal + S_COUNT) = 0;
         void* dp = nullptr;
