@@ -1344,10 +1344,12 @@ __global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict
 // (what k_tile_fill does: one launch and a global round trip of every level-0 tile less per LM iteration; a single-tile
 // system — LBA-sized calls — has no fill launch at all); workgroups >= n_factor compose the tiles of the other columns.
 struct LvFill { Dev d; FillLists f; const int* fz_q; const int* rest; int n_factor; };
+// late / Ql (look-ahead schedule, else nullptr): per entry the partial slots of (k,k) and (i,k) whose tiles the accumulators start
+// from (the contribution of column k-2, formed by the previous launch), -1 none.
 template <bool FILL>
 __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, const int* __restrict__ tiles, const int* __restrict__ dptr,
                                                const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
-                                               const LvFill& lf) {
+                                               const LvFill& lf, const int* __restrict__ late = nullptr, const double* __restrict__ Ql = nullptr) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Xs[kNB][kLdT];      // off-diagonal workgroup: A_ik - update, parked here while the pivot tile is factored (it used
@@ -1408,8 +1410,27 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
                 akk[m][n2][g] = 0.0; aik[m][n2][g] = 0.0;
             }
     }
+    const int late_kk = (!FILL && late) ? late[2 * b] : -1, late_ik = (!FILL && late) ? late[2 * b + 1] : -1;
+    if (late_kk >= 0) {            // (requested with the assembled tiles: no round trip of its own)
+        const double* Q = Ql + (size_t)late_kk * kPartStride;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) akk[m][n2][g] = Q[(r0 + 16 * m + lk + 4 * g) * kNB + c0 + 16 * n2 + li];
+    }
+    if (late_ik >= 0) {
+        const double* Q = Ql + (size_t)late_ik * kPartStride;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) aik[m][n2][g] = Q[(r0 + 16 * m + lk + 4 * g) * kNB + c0 + 16 * n2 + li];
+    }
     double fsum = 0.0;              // (diagonal workgroup) this thread's share of sum_j L_kj y_j, row o
-    if (t < kNB) fv[t] = 0.0;
+    if (t < kNB) fv[t] = (diag && late_kk >= 0) ? Ql[(size_t)late_kk * kPartStride + kNB * kNB + t] : 0.0;
     if (!FILL) {
         double* As = &A[0][0]; double* Bs = &Li[0][0];
         const int qa = dptr[b], qb = dptr[b + 1];
@@ -1442,7 +1463,7 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
         if (diag) {
             fsum += __shfl_xor(fsum, 1, kWave);
             fsum += __shfl_xor(fsum, 2, kWave);
-            if (part == 0) fv[o] = fsum;
+            if (part == 0) fv[o] += fsum;
         }
     }
     XBA_STAMP(1, 1);
@@ -1525,9 +1546,11 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
 }
 
 // Look-ahead panel schedule (ba_plan.h: lookahead; level = column): ONE launch per column s.  Workgroups [0, n_factor): the
-// fused factor kernel of column s (its lists hold the contributions of columns s-2 and s-1, everything older has been
+// fused factor kernel of column s (its list holds the contribution of column s-1, everything older than s-2 has been
 // subtracted in place); then 16 per target: the fixed-order sum of the partial products of column s+1 into its tiles (written
-// by the previous launch); the rest: the partial products of column s+2 over the columns < s (one chunk each).  The three
+// by the previous launch); one per tile of column s+1: its "late partial", the contribution of column s-1, which the next
+// launch's factor workgroups start their accumulators from (one product instead of two on the critical path of a column);
+// the rest: the partial products of column s+2 over the columns < s (one chunk each).  The
 // parts touch disjoint data (columns s / s+1 / the partial buffer of the other parity), so the kernel boundary is the only
 // synchronisation: the per-column chain update -> sum -> factor of the plain panel schedule becomes factor alone, with the
 // other two riding on the CUs the factor kernel leaves idle.  The factor workgroups come first: they are the critical path
@@ -1538,20 +1561,24 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
 //   its own global storage, accumulators started from the negated tile to stay below 256 registers) — no gain at config T
 //   (the column is bound by the factor workgroups, not by the chunks), slower at U and on the level schedule of L.
 struct SlotArgs {
-    const int* fz_tile; const int* fz_dptr; int n_factor;                    // column s (pointers already offset to the level)
+    const int* fz_tile; const int* fz_dptr; const int* fz_late; const double* Ql; int n_factor;   // column s (pointers offset to the level)
     const int* sp_rt; const int* sp_rp; int n_reduce; const double* Wr;      // column s+1: targets, partial ranges, their buffer
+    const int* md_tgt; const int* md_q; int n_late; double* Wq;              // column s+1: late partials (the contribution of column s-1)
     const int* sp_tgt; const int* sp_q; int n_part; double* Wp;              // column s+2: chunks and their buffer
 };
 __global__ __launch_bounds__(256) void k_panel_slot(CholDev c, SlotArgs a, const int* __restrict__ dj, const int* __restrict__ cj,
-                                                    const int* __restrict__ tile_cam) {
+                                                    const int* __restrict__ mcj, const int* __restrict__ tile_cam) {
     const int b = blockIdx.x;
     if (b < a.n_factor) {
-        lv_factor_body<false>(c, b, a.fz_tile, a.fz_dptr, dj, tile_cam, nullptr, LvFill{});
+        lv_factor_body<false>(c, b, a.fz_tile, a.fz_dptr, dj, tile_cam, nullptr, LvFill{}, a.fz_late, a.Ql);
     } else if (b < a.n_factor + 16 * a.n_reduce) {
         const int r = b - a.n_factor;
         ll_update_reduce_body(c, r >> 4, r & 15, a.sp_rt, a.sp_rp, a.Wr);
+    } else if (b < a.n_factor + 16 * a.n_reduce + a.n_late) {
+        // (before the chunks of column s+2: the next launch's factor workgroups start from these)
+        ll_update_part_body(c, b - a.n_factor - 16 * a.n_reduce, a.md_tgt, a.md_q, mcj, a.Wq);
     } else {
-        ll_update_part_body(c, b - a.n_factor - 16 * a.n_reduce, a.sp_tgt, a.sp_q, cj, a.Wp);
+        ll_update_part_body(c, b - a.n_factor - 16 * a.n_reduce - a.n_late, a.sp_tgt, a.sp_q, cj, a.Wp);
     }
 }
 

@@ -62,6 +62,11 @@ struct CholPlan {
     //                 (it then also contributes to tile (i,k)), ~j otherwise;
     //   split level:  empty lists (k_ll_update_part + k_ll_update_reduce have updated the tiles and the right-hand side in place).
     std::vector<int> fz_tile, fz_dptr, fz_dj, fz_off;
+    // look-ahead schedule: the contribution of column k - 2 to column k is formed in the launch of column k - 1 — one single-product
+    // chunk per tile (md_tgt: (i,k); md_q: its entry in md_cj), written to partial slot = its index within the level — and the
+    // factor kernel of column k starts its accumulators from it: fz_late, per fused-kernel entry the slot of (k,k) and of (i,k), -1 none
+    std::vector<int> md_tgt, md_q, md_cj, md_off, fz_late;      // (md_q indexes md_cj: the CSR over lv_cj must stay contiguous)
+    int md_max = 0;
     std::vector<int> fz_q;              // per fused-kernel entry: index in tiles_nz of (k,k) and of (i,k) (fill lists tf_ptr / tf_ent)
     std::vector<int> fill_rest;         // tiles_nz indices of the tiles whose column is not in level 0
     std::vector<int> tile_cam;          // [T][kCamsPerTile] camera in slot q of tile t, -1 = none (backward kernel: candidate cameras)
@@ -475,6 +480,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
     P.mp_off.assign(n_levels + 1, 0);
     P.fz_off.assign(n_levels + 1, 0); P.fz_dptr.assign(1, 0);
+    P.md_off.assign(1, 0);
     std::vector<int> level_cols(n_levels, 0), level_first(n_levels, -1);
     for (int kk = 0; kk < T; ++kk) { if (level_cols[level[kk]]++ == 0) level_first[level[kk]] = kk; }
     // look-ahead needs level == column (the dependencies of the two streams are stated per column) and the fused kernels
@@ -485,7 +491,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     if (const char* fl = std::getenv("XRSFM_BA_LOOKAHEAD")) lookahead = panel_ll && n_levels == T && T >= 8 && fl[0] != '0';
     if (const char* fl = std::getenv("XRSFM_BA_FUSED")) lookahead = lookahead && fl[0] != '0';
     P.lookahead = lookahead;
-    constexpr int kLookDepth = 2;             // columns the fused factor kernel adds itself
+    constexpr int kLookDepth = 1;             // columns the fused factor kernel adds itself (k - 1); k - 2 arrives as one late partial per tile
     // contributions below first_j[k] reach column k through partial products (macro-tile launch, or — look-ahead — chunks of a
     // split level too), those from first_j[k] on inside the fused factor kernel
     std::vector<int> first_j(T, 0);
@@ -531,9 +537,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 if (!nz[(size_t)i * T + kk]) continue;
                 if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
                 std::vector<int> contrib;
-                if (lookahead) {        // the list of the partial products: j < first_j (none for the columns of a macro panel)
-                    if (!macro && !later_of_panel[kk])
-                        for (int j = 0; j < first_j[kk]; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
+                if (lookahead) {        // the list of the partial products that are summed in place: j < k - 2
+                    for (int j = 0; j < kk - 2; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
                 } else
                 for (int j = first_j[kk]; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
                 fz_ents.push_back({i, kk});
@@ -610,6 +615,23 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             }
             P.sp_max_chunks = std::max(P.sp_max_chunks, np);
         }
+        if (lookahead) {
+            // late partials: column k - 2 (the pivot tile's first, so that every workgroup of the column finds its slot at once)
+            const int kk = level_first[lv];
+            const int m0 = (int)P.md_tgt.size() / 2;
+            std::vector<int> slot_of(T, -1);
+            if (kk >= 2 && nz[(size_t)kk * T + kk - 2])
+                for (int i = kk; i < T; ++i)
+                    if (nz[(size_t)i * T + kk] && nz[(size_t)i * T + kk - 2]) {
+                        slot_of[i] = (int)P.md_tgt.size() / 2 - m0;
+                        P.md_tgt.push_back(i); P.md_tgt.push_back(kk);
+                        P.md_q.push_back((int)P.md_cj.size()); P.md_q.push_back((int)P.md_cj.size() + 1);
+                        P.md_cj.push_back(kk - 2);
+                    }
+            P.md_max = std::max(P.md_max, (int)P.md_tgt.size() / 2 - m0);
+            for (const FzEnt& e : fz_ents) { P.fz_late.push_back(slot_of[e.k]); P.fz_late.push_back(e.i == e.k ? -1 : slot_of[e.i]); }
+        }
+        P.md_off.push_back((int)P.md_tgt.size() / 2);
         for (const FzEnt& e : fz_ents) {        // work list of the fused level kernel
             P.fz_tile.push_back(e.i); P.fz_tile.push_back(e.k);
             if (lookahead || (!split && !macro))
@@ -665,6 +687,22 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (size_t e = 0; e < P.sp_tgt.size() / 2; ++e) {
             const int i = P.sp_tgt[2 * e], k2 = P.sp_tgt[2 * e + 1];
             for (int q = P.sp_q[2 * e]; q < P.sp_q[2 * e + 1]; ++q) { U(i, k2, P.lv_cj[q])++; if (i == k2) fwd[(size_t)k2 * T + P.lv_cj[q]]++; }
+        }
+        for (size_t e = 0; e < P.md_tgt.size() / 2; ++e) {
+            const int i = P.md_tgt[2 * e], k2 = P.md_tgt[2 * e + 1];
+            for (int q = P.md_q[2 * e]; q < P.md_q[2 * e + 1]; ++q) { U(i, k2, P.md_cj[q])++; if (i == k2) fwd[(size_t)k2 * T + P.md_cj[q]]++; }
+        }
+        if (P.lookahead) {        // every fused-kernel entry reads the late partials that were written for its two tiles, and only those
+            for (int lv = 0; lv < n_levels; ++lv)
+                for (int e = P.fz_off[lv]; e < P.fz_off[lv + 1]; ++e)
+                    for (int w = 0; w < 2; ++w) {
+                        const int sl = P.fz_late[2 * (size_t)e + w];
+                        const int ti = w ? P.fz_tile[2 * (size_t)e] : P.fz_tile[2 * (size_t)e + 1], tk = P.fz_tile[2 * (size_t)e + 1];
+                        bool want = tk >= 2 && nz[(size_t)tk * T + tk - 2] && nz[(size_t)ti * T + tk - 2] && !(w == 1 && ti == tk);
+                        if ((sl >= 0) != want) return kErrPlanCheck;
+                        if (sl >= 0 && (sl >= P.md_off[lv + 1] - P.md_off[lv] || P.md_tgt[2 * (size_t)(P.md_off[lv] + sl)] != ti ||
+                                        P.md_tgt[2 * (size_t)(P.md_off[lv] + sl) + 1] != tk)) return kErrPlanCheck;
+                    }
         }
         for (size_t e = 0; e < P.fz_tile.size() / 2; ++e) {
             const int i = P.fz_tile[2 * e], k2 = P.fz_tile[2 * e + 1];

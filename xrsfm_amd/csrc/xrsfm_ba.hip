@@ -119,6 +119,8 @@ struct CholHost {
     int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
     double* sp_work = nullptr; int sp_max_chunks = 0;
     int *fz_tile = nullptr, *fz_dptr = nullptr, *fz_dj = nullptr, *tile_cam = nullptr;   // fused level kernel (ba_plan.h)
+    int *md_tgt = nullptr, *md_q = nullptr, *md_cj = nullptr, *fz_late = nullptr;        // look-ahead schedule: late partials (ba_plan.h)
+    std::vector<int> md_off; int md_max = 0; double* md_work = nullptr;
     int *fz_q = nullptr, *fill_rest = nullptr; int n_fill_rest = 0;    // tile fill inside the first level's launch
     bool S_filled = false;                                   // chol_assemble ran k_tile_fill (else the first level composes its tiles)
     std::vector<int> fz_off;
@@ -610,6 +612,8 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
     up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
     up.add(&h.fz_q, P.fz_q); up.add(&h.fill_rest, P.fill_rest); h.n_fill_rest = (int)P.fill_rest.size();
+    up.add(&h.md_tgt, P.md_tgt); up.add(&h.md_q, P.md_q); up.add(&h.md_cj, P.md_cj); up.add(&h.fz_late, P.fz_late);
+    h.md_off = P.md_off; h.md_max = P.md_max;
     up.add(&h.tile_cam, P.tile_cam);
     const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
     up.add(&h.zero2, two_zeros);
@@ -619,6 +623,7 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&d_gplan, gplan_tab);
     h.sp_max_chunks = P.sp_max_chunks;
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
+    if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
     up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
     TRYC(up.flush());
     h.gplan.tab = reinterpret_cast<const int4*>(d_gplan);
@@ -738,14 +743,26 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     double* px_out = c->wide ? c->w.px : d.px;        // solution in camera order, cw values per camera
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
     if (h.lookahead && c->fused) {
-        // Look-ahead panel schedule (ba_plan.h, k_panel_slot): level = column, one launch per column s = factor of column s (which
-        // adds columns s-2, s-1 itself) | fixed-order sum of the partial products of column s+1 | partial products of column s+2
-        // over the columns < s.  The partial buffers alternate with the parity of the column they belong to.
+        // Look-ahead panel schedule (ba_plan.h, k_panel_slot): level = column, one launch per column s =
+        //   factor of column s (starts from the late partials of column s-2, adds column s-1 itself)
+        //   | fixed-order sum of the partial products of column s+1 into its tiles   | late partials of column s+1 (column s-1)
+        //   | partial products of column s+2 over the columns < s.
+        // The partial buffers alternate with the parity of the column they belong to.
         auto chunks = [&](int lv) { return lv < h.n_levels ? h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv] : 0; };
         auto targets = [&](int lv) { return lv < h.n_levels ? h.sp_rt_off[lv + 1] - h.sp_rt_off[lv] : 0; };
+        auto lates = [&](int lv) { return lv < h.n_levels ? h.md_off[lv + 1] - h.md_off[lv] : 0; };
         double* const Wbuf[2] = {h.sp_work, h.sp_work + (size_t)std::max(1, h.sp_max_chunks) * kPartStride};
+        double* const Qbuf[2] = {h.md_work, h.md_work + (size_t)std::max(1, h.md_max) * kPartStride};
         for (int s2 = 0; s2 < h.n_levels; ++s2) {
             const int nf = h.fz_off[s2 + 1] - h.fz_off[s2];
+            SlotArgs a{};
+            const int lr = s2 + 1, lp = s2 + 2;
+            a.n_reduce = targets(lr);
+            if (a.n_reduce > 0) { a.sp_rt = h.sp_rt + 2 * (size_t)h.sp_rt_off[lr]; a.sp_rp = h.sp_rp + 2 * (size_t)h.sp_rt_off[lr]; a.Wr = Wbuf[lr & 1]; }
+            a.n_part = chunks(lp);
+            if (a.n_part > 0) { a.sp_tgt = h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lp]; a.sp_q = h.sp_q + 2 * (size_t)h.sp_chunk_off[lp]; a.Wp = Wbuf[lp & 1]; }
+            a.n_late = lates(lr);
+            if (a.n_late > 0) { a.md_tgt = h.md_tgt + 2 * (size_t)h.md_off[lr]; a.md_q = h.md_q + 2 * (size_t)h.md_off[lr]; a.Wq = Qbuf[lr & 1]; }
             if (s2 == 0 && !h.S_filled) {      // (nothing else can run yet: the tiles of every column are composed here)
                 LvFill lf{};
                 lf.d = d; lf.f = FillLists{h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, c->step_prep ? c->step_radius : 0.0};
@@ -753,17 +770,13 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                 if (nf + h.n_fill_rest > 0)
                     LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + h.n_fill_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
                            (const int*)h.tile_cam, (double*)nullptr, lf);
+                if (a.n_reduce + a.n_part + a.n_late > 0) return XRSFM_BA_EINTERNAL;      // columns 1 and 2 have nothing older than column 0
                 continue;
             }
-            SlotArgs a{};
             a.fz_tile = h.fz_tile + 2 * (size_t)h.fz_off[s2]; a.fz_dptr = h.fz_dptr + h.fz_off[s2]; a.n_factor = nf;
-            const int lr = s2 + 1, lp = s2 + 2;
-            a.n_reduce = targets(lr);
-            if (a.n_reduce > 0) { a.sp_rt = h.sp_rt + 2 * (size_t)h.sp_rt_off[lr]; a.sp_rp = h.sp_rp + 2 * (size_t)h.sp_rt_off[lr]; a.Wr = Wbuf[lr & 1]; }
-            a.n_part = chunks(lp);
-            if (a.n_part > 0) { a.sp_tgt = h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lp]; a.sp_q = h.sp_q + 2 * (size_t)h.sp_chunk_off[lp]; a.Wp = Wbuf[lp & 1]; }
-            const int nwg = a.n_factor + 16 * a.n_reduce + a.n_part;
-            if (nwg > 0) LAUNCH(c, K_POTRF, k_panel_slot, dim3(nwg), dim3(256), 0, h.dev, a, (const int*)h.fz_dj, (const int*)h.lv_cj, (const int*)h.tile_cam);
+            a.fz_late = h.fz_late + 2 * (size_t)h.fz_off[s2]; a.Ql = Qbuf[s2 & 1];
+            const int nwg = a.n_factor + 16 * a.n_reduce + a.n_late + a.n_part;
+            if (nwg > 0) LAUNCH(c, K_POTRF, k_panel_slot, dim3(nwg), dim3(256), 0, h.dev, a, (const int*)h.fz_dj, (const int*)h.lv_cj, (const int*)h.md_cj, (const int*)h.tile_cam);
         }
         for (int k = T - 1; k >= 0; --k) {
             const int ncol = h.cols_off[k + 1] - h.cols_off[k];
