@@ -1045,32 +1045,44 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
     const int q0 = qr[2 * bx], q1 = qr[2 * bx + 1];
     const int t = threadIdx.x, o = t >> 2, part = t & 3;
     double sv = 0.0;
-    v2d ra[4], rb[4];
+    // The operands of four half-product steps are in flight: a step's matrix instructions (~0.2 us) cannot hide the 1-2 us of the
+    // next step's loads, and a chunk of the panel schedules is a serial walk of 8 or more steps (measured at config T: 5.5 us
+    // per product with the loads one step ahead).  Same products in the same order.
+    constexpr int kAhead = 4;
+    v2d ra[kAhead][4], rb[kAhead][4];
     const double* rowA = c.S + (size_t)(i * kNB) * c.n_pad;
     const double* rowB = c.S + (size_t)(k * kNB) * c.n_pad;
-    {
-        const int j = cj[q0];
-        load_half_regs(ra, rowA + j * kNB, c.n_pad);
-        load_half_regs(rb, rowB + j * kNB, c.n_pad);
-    }
     const int ns = 2 * (q1 - q0);
-    for (int s = 0; s < ns; ++s) {
-        const int kh = s & 1;
-        __syncthreads();                       // the previous half product no longer reads LDS
-        store_half_lds(As, ra);
-        store_half_lds(Bs, rb);
-        if (diag && kh == 0 && t < kNB) yv[t] = c.y[cj[q0 + (s >> 1)] * kNB + t];
-        __syncthreads();
-        if (s + 1 < ns) {
-            const int col = cj[q0 + ((s + 1) >> 1)] * kNB + ((s + 1) & 1) * 32;
-            load_half_regs(ra, rowA + col, c.n_pad);
-            load_half_regs(rb, rowB + col, c.n_pad);
-        }
-        if (diag) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) sv += As[o * kLdH + part * 8 + m] * yv[kh * 32 + part * 8 + m];
+    for (int u = 0; u < kAhead; ++u)
+        if (u < ns) {
+            const int col = cj[q0 + (u >> 1)] * kNB + (u & 1) * 32;
+            load_half_regs(ra[u], rowA + col, c.n_pad);
+            load_half_regs(rb[u], rowB + col, c.n_pad);
         }
-        half_abt_mfma(As, Bs, acc);
+    for (int s0 = 0; s0 < ns; s0 += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; ++u) {
+            const int s = s0 + u;
+            if (s < ns) {                              // (uniform)
+                const int kh = s & 1;
+                __syncthreads();                       // the previous half product no longer reads LDS
+                store_half_lds(As, ra[u]);
+                store_half_lds(Bs, rb[u]);
+                if (diag && kh == 0 && t < kNB) yv[t] = c.y[cj[q0 + (s >> 1)] * kNB + t];
+                __syncthreads();
+                if (s + kAhead < ns) {
+                    const int col = cj[q0 + ((s + kAhead) >> 1)] * kNB + ((s + kAhead) & 1) * 32;
+                    load_half_regs(ra[u], rowA + col, c.n_pad);
+                    load_half_regs(rb[u], rowB + col, c.n_pad);
+                }
+                if (diag) {
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) sv += As[o * kLdH + part * 8 + m] * yv[kh * 32 + part * 8 + m];
+                }
+                half_abt_mfma(As, Bs, acc);
+            }
+        }
     }
     double* out = Wp + (size_t)bx * kPartStride;
     {
@@ -1237,12 +1249,16 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, s
 }
 
 // grid (targets, 16): 256 tile elements per workgroup
+// EPT tile elements per thread: 16 / EPT workgroups per target (standalone launch: 1 — short lists, as many CUs as possible; inside
+// k_panel_slot, whose workgroups hold a CU each: 4)
+template <int EPT>
 __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const int bx, const int by, const int* __restrict__ rt,
                                                       const int* __restrict__ rp, const double* __restrict__ Wp) {
     const int i = rt[2 * bx], k = rt[2 * bx + 1];
     const int p0 = rp[2 * bx], p1 = rp[2 * bx + 1];
-    {
-        const int e = by * 256 + threadIdx.x;
+#pragma unroll
+    for (int u = 0; u < EPT; ++u) {
+        const int e = (by * EPT + u) * 256 + threadIdx.x;
         const double s = sum_strided(Wp + (size_t)p0 * kPartStride + e, kPartStride, p1 - p0);
         c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] -= s;
     }
@@ -1253,7 +1269,7 @@ __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const in
 }
 __global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* __restrict__ rt, const int* __restrict__ rp,
                                                           const double* __restrict__ Wp) {
-    ll_update_reduce_body(c, blockIdx.x, blockIdx.y, rt, rp, Wp);
+    ll_update_reduce_body<1>(c, blockIdx.x, blockIdx.y, rt, rp, Wp);
 }
 
 // A_ik <- A_ik Linv_k^T for the (i,k) pairs of one level
@@ -1568,17 +1584,17 @@ struct SlotArgs {
 };
 __global__ __launch_bounds__(256) void k_panel_slot(CholDev c, SlotArgs a, const int* __restrict__ dj, const int* __restrict__ cj,
                                                     const int* __restrict__ mcj, const int* __restrict__ tile_cam) {
+    // order: the factor workgroups (critical path), the late partials (the next launch starts from them), the chunks (long), the sums (short)
     const int b = blockIdx.x;
     if (b < a.n_factor) {
         lv_factor_body<false>(c, b, a.fz_tile, a.fz_dptr, dj, tile_cam, nullptr, LvFill{}, a.fz_late, a.Ql);
-    } else if (b < a.n_factor + 16 * a.n_reduce) {
-        const int r = b - a.n_factor;
-        ll_update_reduce_body(c, r >> 4, r & 15, a.sp_rt, a.sp_rp, a.Wr);
-    } else if (b < a.n_factor + 16 * a.n_reduce + a.n_late) {
-        // (before the chunks of column s+2: the next launch's factor workgroups start from these)
-        ll_update_part_body(c, b - a.n_factor - 16 * a.n_reduce, a.md_tgt, a.md_q, mcj, a.Wq);
+    } else if (b < a.n_factor + a.n_late) {
+        ll_update_part_body(c, b - a.n_factor, a.md_tgt, a.md_q, mcj, a.Wq);
+    } else if (b < a.n_factor + a.n_late + a.n_part) {
+        ll_update_part_body(c, b - a.n_factor - a.n_late, a.sp_tgt, a.sp_q, cj, a.Wp);
     } else {
-        ll_update_part_body(c, b - a.n_factor - 16 * a.n_reduce - a.n_late, a.sp_tgt, a.sp_q, cj, a.Wp);
+        const int r = b - a.n_factor - a.n_late - a.n_part;
+        ll_update_reduce_body<4>(c, r >> 2, r & 3, a.sp_rt, a.sp_rp, a.Wr);
     }
 }
 
