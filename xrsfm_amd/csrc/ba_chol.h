@@ -1018,11 +1018,14 @@ __device__ __forceinline__ void half_abt_mfma(const double* __restrict__ As, con
     }
 }
 
+// lds: 4 * kNB * kLdH doubles (two buffers of the two half-tile operands), 16-byte aligned; yv: 2 * kNB — LDS of the calling kernel.
+// The operands of four half-product steps are in flight in registers and the LDS image is double-buffered: the stores of step
+// s+1 and the loads of step s+5 are issued ahead of the matrix instructions of step s, one barrier per step — with one
+// workgroup per CU (k_panel_slot) nothing else hides a step's staging behind its 32 matrix instructions (measured at a quarter
+// of config T with a single buffer and the loads one step ahead: 5.5 us per product against 1.7 us of matrix instructions).
+// Same products in the same order.
 __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
-                                                    const int* __restrict__ cj, double* __restrict__ Wp) {
-    __shared__ __attribute__((aligned(16))) double As[kNB * kLdH];
-    __shared__ __attribute__((aligned(16))) double Bs[kNB * kLdH];
-    __shared__ double yv[kNB];
+                                                    const int* __restrict__ cj, double* __restrict__ Wp, double* lds, double* yv) {
     const int i = tgt[2 * bx], k = tgt[2 * bx + 1];
     const bool diag = (i == k);
     v4d acc[2][2];
@@ -1033,9 +1036,6 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
     const int q0 = qr[2 * bx], q1 = qr[2 * bx + 1];
     const int t = threadIdx.x, o = t >> 2, part = t & 3;
     double sv = 0.0;
-    // The operands of four half-product steps are in flight: a step's matrix instructions (~0.2 us) cannot hide the 1-2 us of the
-    // next step's loads, and a chunk of the panel schedules is a serial walk of 8 or more steps (measured at config T: 5.5 us
-    // per product with the loads one step ahead).  Same products in the same order.
     constexpr int kAhead = 4;
     v2d ra[kAhead][4], rb[kAhead][4];
     const double* rowA = c.S + (size_t)(i * kNB) * c.n_pad;
@@ -1048,27 +1048,46 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
             load_half_regs(ra[u], rowA + col, c.n_pad);
             load_half_regs(rb[u], rowB + col, c.n_pad);
         }
+    double yreg = (diag && t < kNB) ? c.y[cj[q0] * kNB + t] : 0.0;      // y_j of the product that starts at an even step
+    // prologue: step 0 into buffer 0
+    store_half_lds(lds, ra[0]);
+    store_half_lds(lds + kNB * kLdH, rb[0]);
+    if (diag && t < kNB) yv[t] = yreg;
+    if (kAhead < ns) {
+        const int col = cj[q0 + (kAhead >> 1)] * kNB + (kAhead & 1) * 32;
+        load_half_regs(ra[0], rowA + col, c.n_pad);
+        load_half_regs(rb[0], rowB + col, c.n_pad);
+    }
+    if (diag && 2 < ns && t < kNB) yreg = c.y[cj[q0 + 1] * kNB + t];
+    __syncthreads();
     for (int s0 = 0; s0 < ns; s0 += kAhead) {
 #pragma unroll
         for (int u = 0; u < kAhead; ++u) {
             const int s = s0 + u;
             if (s < ns) {                              // (uniform)
-                const int kh = s & 1;
-                __syncthreads();                       // the previous half product no longer reads LDS
-                store_half_lds(As, ra[u]);
-                store_half_lds(Bs, rb[u]);
-                if (diag && kh == 0 && t < kNB) yv[t] = c.y[cj[q0 + (s >> 1)] * kNB + t];
-                __syncthreads();
-                if (s + kAhead < ns) {
-                    const int col = cj[q0 + ((s + kAhead) >> 1)] * kNB + ((s + kAhead) & 1) * 32;
-                    load_half_regs(ra[u], rowA + col, c.n_pad);
-                    load_half_regs(rb[u], rowB + col, c.n_pad);
+                const int kh = s & 1, buf = s & 1;
+                double* As = lds + (size_t)buf * 2 * kNB * kLdH;
+                double* Bs = As + kNB * kLdH;
+                if (s + 1 < ns) {                      // operands of step s+1: registers -> the other buffer (free since the barrier)
+                    const int un = (u + 1) % kAhead;      // (a constant once the loop over u is unrolled)
+                    double* An = lds + (size_t)(buf ^ 1) * 2 * kNB * kLdH;
+                    store_half_lds(An, ra[un]);
+                    store_half_lds(An + kNB * kLdH, rb[un]);
+                    if (diag && ((s + 1) & 1) == 0 && t < kNB) yv[(((s + 1) >> 1) & 1) * kNB + t] = yreg;
+                    if (s + 1 + kAhead < ns) {         // ... and the registers refilled with step s+1+kAhead
+                        const int col = cj[q0 + ((s + 1 + kAhead) >> 1)] * kNB + ((s + 1 + kAhead) & 1) * 32;
+                        load_half_regs(ra[un], rowA + col, c.n_pad);
+                        load_half_regs(rb[un], rowB + col, c.n_pad);
+                    }
+                    if (diag && ((s + 1) & 1) == 0 && s + 3 < ns && t < kNB) yreg = c.y[cj[q0 + ((s + 3) >> 1)] * kNB + t];
                 }
                 if (diag) {
+                    const double* yq = yv + ((s >> 1) & 1) * kNB;
 #pragma unroll
-                    for (int m = 0; m < 8; ++m) sv += As[o * kLdH + part * 8 + m] * yv[kh * 32 + part * 8 + m];
+                    for (int m = 0; m < 8; ++m) sv += As[o * kLdH + part * 8 + m] * yq[kh * 32 + part * 8 + m];
                 }
                 half_abt_mfma(As, Bs, acc);
+                __syncthreads();                       // buffer `buf` is free for step s+2, buffer buf^1 is complete
             }
         }
     }
@@ -1094,7 +1113,9 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
 }
 __global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr,
                                                         const int* __restrict__ cj, double* __restrict__ Wp) {
-    ll_update_part_body(c, blockIdx.x, tgt, qr, cj, Wp);
+    __shared__ __attribute__((aligned(16))) double lds[4 * kNB * kLdH];
+    __shared__ double yv[2 * kNB];
+    ll_update_part_body(c, blockIdx.x, tgt, qr, cj, Wp, lds, yv);
 }
 
 // Dense part of a panel schedule: 128x128 macro tile = rows (i0,i1) x columns (k0,k1), contributions j in [q0,q1): every
@@ -1238,7 +1259,7 @@ __device__ __forceinline__ double sum_strided(const double* __restrict__ base, s
 
 // grid (targets, 16): 256 tile elements per workgroup
 // EPT tile elements per thread: 16 / EPT workgroups per target (standalone launch: 1 — short lists, as many CUs as possible; inside
-// k_panel_slot, whose workgroups hold a CU each: 4)
+// k_panel_slot, whose workgroups hold a CU each: 16 = one workgroup per target)
 template <int EPT>
 __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const int bx, const int by, const int* __restrict__ rt,
                                                       const int* __restrict__ rp, const double* __restrict__ Wp) {
@@ -1353,15 +1374,12 @@ struct LvFill { Dev d; FillLists f; const int* fz_q; const int* rest; int n_fact
 template <bool FILL>
 __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, const int* __restrict__ tiles, const int* __restrict__ dptr,
                                                const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
-                                               const LvFill& lf, const int* __restrict__ late = nullptr, const double* __restrict__ Ql = nullptr) {
-    __shared__ double A[kNB][kLdT];
-    __shared__ double Li[kNB][kLdT];
-    __shared__ double Xs[kNB][kLdT];      // off-diagonal workgroup: A_ik - update, parked here while the pivot tile is factored (it used
-                                          // to stay in 64 registers across potrf_lds: with them the in-register 16x16 factorisation
-                                          // ran out of architectural VGPRs and copied every broadcast value through AGPRs — 4 of its 8
-                                          // instructions per column update; 109 KB of LDS = one workgroup per CU, the grid has <= 1 per CU anyway)
-    __shared__ double Tb[3][16][17];
-    __shared__ double yv[kNB], fv[kNB];
+                                               const LvFill& lf, double (*A)[kLdT], double (*Li)[kLdT], double (*Xs)[kLdT], double (*Tb)[16][17],
+                                               double* yv, double* fv, const int* __restrict__ late = nullptr, const double* __restrict__ Ql = nullptr) {
+    // LDS of the calling kernel: A, Li, Xs [kNB][kLdT], Tb [3][16][17], yv, fv [kNB].  Xs: off-diagonal workgroup: A_ik - update, parked
+    // there while the pivot tile is factored (it used to stay in 64 registers across potrf_lds: with them the in-register 16x16
+    // factorisation ran out of architectural VGPRs and copied every broadcast value through AGPRs — 4 of its 8 instructions per column
+    // update; 109 KB of LDS = one workgroup per CU, the grid of a level has <= 1 per CU anyway)
     if (FILL && b >= lf.n_factor) {        // a tile of a later column: compose and store (k_tile_fill)
         const int q = lf.rest[b - lf.n_factor];
         const int ti = lf.f.tiles[2 * q], tj = lf.f.tiles[2 * q + 1];
@@ -1546,7 +1564,12 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
                                                    const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
                                                    LvFill lf) {
-    lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf);
+    __shared__ double A[kNB][kLdT];
+    __shared__ double Li[kNB][kLdT];
+    __shared__ double Xs[kNB][kLdT];
+    __shared__ double Tb[3][16][17];
+    __shared__ double yv[kNB], fv[kNB];
+    lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf, A, Li, Xs, Tb, yv, fv);
 }
 
 // Look-ahead panel schedule (ba_plan.h: lookahead; level = column): ONE launch per column s.  Workgroups [0, n_factor): the
@@ -1558,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restr
 // parts touch disjoint data (columns s / s+1 / the partial buffer of the other parity), so the kernel boundary is the only
 // synchronisation: the per-column chain update -> sum -> factor of the plain panel schedule becomes factor alone, with the
 // other two riding on the CUs the factor kernel leaves idle.  The factor workgroups come first: they are the critical path
-// and are dispatched first.  144 KB of LDS: one workgroup per CU.
+// and are dispatched first.  109 KB of LDS (the chunks overlay the factor tiles): one workgroup per CU.
 //   Measured and not adopted (round 3): the same schedule on two streams — every event record / wait on the main stream cost
 //   a 12-14 us bubble between dependent kernels (49 us per column at config U against 56 without look-ahead; this kernel: 39);
 //   a 75 KB variant for two workgroups per CU (chunk operands overlaid on the factor tiles, the off-diagonal tile parked in
@@ -1573,16 +1596,19 @@ struct SlotArgs {
 __global__ __launch_bounds__(256) void k_panel_slot(CholDev c, SlotArgs a, const int* __restrict__ dj, const int* __restrict__ cj,
                                                     const int* __restrict__ mcj, const int* __restrict__ tile_cam) {
     // order: the factor workgroups (critical path), the late partials (the next launch starts from them), the chunks (long), the sums (short)
+    __shared__ __attribute__((aligned(16))) double T3[3][kNB][kLdT];      // A | Li | Xs of the factor workgroups; the chunks' operand buffers overlay them
+    __shared__ double Tb[3][16][17];
+    __shared__ double yv[2 * kNB], fv[kNB];
+    static_assert(4 * kNB * kLdH <= 3 * kNB * kLdT, "the chunk operands fit the factor tiles");
     const int b = blockIdx.x;
     if (b < a.n_factor) {
-        lv_factor_body<false>(c, b, a.fz_tile, a.fz_dptr, dj, tile_cam, nullptr, LvFill{}, a.fz_late, a.Ql);
+        lv_factor_body<false>(c, b, a.fz_tile, a.fz_dptr, dj, tile_cam, nullptr, LvFill{}, T3[0], T3[1], T3[2], Tb, yv, fv, a.fz_late, a.Ql);
     } else if (b < a.n_factor + a.n_late) {
-        ll_update_part_body(c, b - a.n_factor, a.md_tgt, a.md_q, mcj, a.Wq);
+        ll_update_part_body(c, b - a.n_factor, a.md_tgt, a.md_q, mcj, a.Wq, &T3[0][0][0], yv);
     } else if (b < a.n_factor + a.n_late + a.n_part) {
-        ll_update_part_body(c, b - a.n_factor - a.n_late, a.sp_tgt, a.sp_q, cj, a.Wp);
+        ll_update_part_body(c, b - a.n_factor - a.n_late, a.sp_tgt, a.sp_q, cj, a.Wp, &T3[0][0][0], yv);
     } else {
-        const int r = b - a.n_factor - a.n_late - a.n_part;
-        ll_update_reduce_body<4>(c, r >> 2, r & 3, a.sp_rt, a.sp_rp, a.Wr);
+        ll_update_reduce_body<16>(c, b - a.n_factor - a.n_late - a.n_part, 0, a.sp_rt, a.sp_rp, a.Wr);
     }
 }
 

@@ -602,6 +602,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             P.sp_max_chunks = std::max(P.sp_max_chunks, base[nm]);
         }
         if (split) {
+            // (look-ahead schedule: chunks of ~60 products — one round of k_panel_slot's workgroups per column — were measured at a
+            //  quarter of config T: 100-196 us per column instead of 45; a chunk is a serial walk, short ones in several rounds win)
             const int cs = panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks) : std::max(1, (nc + 511) / 512);
             int np = 0;
             for (int g = g0; g < g1; ++g) {

@@ -775,7 +775,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             }
             a.fz_tile = h.fz_tile + 2 * (size_t)h.fz_off[s2]; a.fz_dptr = h.fz_dptr + h.fz_off[s2]; a.n_factor = nf;
             a.fz_late = h.fz_late + 2 * (size_t)h.fz_off[s2]; a.Ql = Qbuf[s2 & 1];
-            const int nwg = a.n_factor + 4 * a.n_reduce + a.n_late + a.n_part;
+            const int nwg = a.n_factor + a.n_reduce + a.n_late + a.n_part;
             if (nwg > 0) LAUNCH(c, K_POTRF, k_panel_slot, dim3(nwg), dim3(256), 0, h.dev, a, (const int*)h.fz_dj, (const int*)h.lv_cj, (const int*)h.md_cj, (const int*)h.tile_cam);
         }
         for (int k = T - 1; k >= 0; --k) {
