@@ -1265,11 +1265,34 @@ __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const in
                                                       const int* __restrict__ rp, const double* __restrict__ Wp) {
     const int i = rt[2 * bx], k = rt[2 * bx + 1];
     const int p0 = rp[2 * bx], p1 = rp[2 * bx + 1];
-#pragma unroll
-    for (int u = 0; u < EPT; ++u) {
-        const int e = (by * EPT + u) * 256 + threadIdx.x;
+    if (EPT == 1) {
+        const int e = by * 256 + threadIdx.x;
         const double s = sum_strided(Wp + (size_t)p0 * kPartStride + e, kPartStride, p1 - p0);
         c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] -= s;
+    } else {
+        // the thread's EPT elements advance together: EPT (x2) loads in flight per partial instead of EPT serial sums
+        double s[EPT], a0[EPT];
+        const double* W = Wp + (size_t)p0 * kPartStride + (size_t)by * EPT * 256 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) { s[u] = 0.0; a0[u] = c.S[(size_t)(i * kNB + (((by * EPT + u) * 256 + threadIdx.x) >> 6)) * c.n_pad + k * kNB + (threadIdx.x & 63)]; }
+        int p = p0;
+        for (; p + 2 <= p1; p += 2) {
+            double v0[EPT], v1[EPT];
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) { v0[u] = W[(size_t)u * 256]; v1[u] = W[kPartStride + (size_t)u * 256]; }
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) { s[u] += v0[u]; s[u] += v1[u]; }
+            W += 2 * kPartStride;
+        }
+        if (p < p1) {
+#pragma unroll
+            for (int u = 0; u < EPT; ++u) s[u] += W[(size_t)u * 256];
+        }
+#pragma unroll
+        for (int u = 0; u < EPT; ++u) {
+            const int e = (by * EPT + u) * 256 + threadIdx.x;
+            c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] = a0[u] - s[u];
+        }
     }
     if (i == k && by == 0 && threadIdx.x < kNB) {
         const double s = sum_strided(Wp + (size_t)p0 * kPartStride + kNB * kNB + threadIdx.x, kPartStride, p1 - p0);
