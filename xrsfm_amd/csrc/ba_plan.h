@@ -604,7 +604,11 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         if (split) {
             // (look-ahead schedule: chunks of ~60 products — one round of k_panel_slot's workgroups per column — were measured at a
             //  quarter of config T: 100-196 us per column instead of 45; a chunk is a serial walk, short ones in several rounds win)
-            const int cs = panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks) : std::max(1, (nc + 511) / 512);
+            // (look-ahead schedule, chunks of 4 / 6 / 8 / 12 / 16 products at a quarter of config T: 41 / 39 / 44 / 41 / 50 ms per four
+            //  factorisations — the chunks are bound by their operand traffic, 64 KB per product, not by their number)
+            const int la_chunk = std::getenv("XRSFM_BA_LA_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_LA_CHUNK"))) : 6;
+            const int cs = lookahead ? std::max(la_chunk, (nc + panel_chunks - 1) / panel_chunks)
+                         : panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks) : std::max(1, (nc + 511) / 512);
             int np = 0;
             for (int g = g0; g < g1; ++g) {
                 const int p0 = np;
