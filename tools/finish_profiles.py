@@ -42,6 +42,7 @@ def main():
                           ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter"),
                           ("T", "BASELINE config 5 at its size: 7500 photos in viewpoint clusters / 1.8M points / 8.1M observations, shuffled ids; exact path in the reverse Cuthill-McKee order; no CPU leg"),
                           ("T_pcg", "the same through the implicit-Schur PCG (the only path at this size until round 2)"),
+                          ("Lb9", "config 4 in bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks (k9_* kernels, not tuned); no CPU leg: the C restatement is 6-wide"),
                           ("M", "mapper-shaped replay through the BASolver adapter: a different metric (wall time of the BA calls of a 300-frame incremental reconstruction)")):
             if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
                 continue
@@ -72,7 +73,7 @@ def main():
                     "k_lv_factor = pivot factorisation + triangular solve of one tile column, k_bwd = backward substitution.\n\n" + rd("kernel_stats_table_D.md"))
             if os.path.exists(os.path.join(src, "mfma_rate.txt")):
                 f.write("\n## Sustained rate of v_mfma_f64_16x16x4_f64 with nothing else in the loop (tools/bench_mfma.hip)\n\n```\n" + rd("mfma_rate.txt") + "```\n")
-    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt"):
+    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt", "mapper_trace.txt"):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
     print("profiles written for", tag)

@@ -34,6 +34,8 @@ python bench.py --config D --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/ben
 python bench.py --config T --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_T.err | tail -1 > $OUT/bench_T.json
 python bench.py --config T --steps 1 --warmup 0 --no-cpu --no-extras --solver pcg 2> $OUT/bench_T_pcg.err | tail -1 > $OUT/bench_T_pcg.json
 python bench.py --config M 2> $OUT/bench_M.err | tail -1 > $OUT/bench_M.json
+python bench.py --config Lb9 --steps 3 --warmup 1 --no-extras 2> $OUT/bench_Lb9.err | tail -1 > $OUT/bench_Lb9.json
+python tools/mapper_trace.py $OUT/mapper_trace.txt > /dev/null 2>&1
 # 5. the dense reduced solve (config D): per-kernel table, and the sustained FP64 matrix-core rate of the instruction it uses
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsD -o stats -- python $ROOT/bench.py --config D --no-cpu --no-extras --steps 1 --warmup 1 > $OUT/statsD_bench.log 2>&1; \
   python $ROOT/tools/rocprof_summary.py $(find $OUT/statsD -name "*.db" | head -1) $OUT/kernel_stats_table_D.md > /dev/null; rm -rf $OUT/statsD )
