@@ -49,7 +49,19 @@ def main():
         t = sharded / n + repl + gaps + comm
         out[n] = t
         print(f"| {n} | {sharded / n:.0f} | {repl:.0f} | {gaps:.0f} | {comm:.0f} | {t:.0f} | {out[1] / t:.2f} |")
-    print(json.dumps({"t_iter_us": out, "speedup_8": out[1] / out[8]}))
+    # weak scaling (bench.py --scaling weak: N config-sized point shards over the same cameras): the sharded kernels keep their
+    # one-GPU time, the job does N times the work
+    print()
+    print("weak scaling (N x the points over the same cameras):")
+    print("| GPUs | t_iter us | throughput vs 1 GPU |")
+    print("|---:|---:|---:|")
+    weak = {}
+    for n in (1, 2, 4, 8):
+        comm = 0.0 if n == 1 else args.collectives * args.alpha_us + 2.0 * (n - 1) / n * args.bytes / (args.beta_gbs * 1e3)
+        t = sharded + repl + gaps + comm
+        weak[n] = n * out[1] / t
+        print(f"| {n} | {t:.0f} | {weak[n]:.2f} |")
+    print(json.dumps({"t_iter_us": out, "speedup_8": out[1] / out[8], "weak_throughput_8": weak[8]}))
 
 
 if __name__ == "__main__":
