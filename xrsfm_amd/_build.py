@@ -31,7 +31,6 @@ VARIANTS = {
     # (with contraction the compiler is free to fuse differently when the initialisers differ: observed, 1e-10 relative)
     "poison": ["-DXBA_POISON", "-ffp-contract=off"],
     "strict": ["-ffp-contract=off"],
-    "storeplan": ["-DXBA_STORE_PLAN"],           # A/B: Gram epilogue through a host-built store plan (measured slower)
     "backsub_w5": ["-DXBA_BACKSUB_WAVES=5"],    # k_backsub register-allocated for 5 waves per SIMD (round-2 finding xi)
 }
 

@@ -51,34 +51,12 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 //  * long tracks: lane loops over all later observations of its track.
 constexpr int kRedLd = 15;      // row stride (doubles) of the LDS reduction buffer of k_schur_pairs: 64 x 15 x 8 B
 
-// Store plan of the Gram product's epilogue.  Which accumulator element (product p of the NI(NI+1)/2, register g of 4) of
-// which lane belongs to which camera pair (ra < rb) and where inside its 6x6 block depends on the camera count C of the
-// tile and the lane alone: computed on the host once (gram_store_plan), one int per element = (ra * C + rb) << 6 | (6 i + j),
-// -1 for elements that belong to no block (diagonal blocks, rows / columns beyond 6 C, the upper triangle).  The kernel
-// reads its 4 ints per product with one 16-byte load instead of two divisions by 6, three range tests and the index
-// arithmetic per element (266 integer VALU + ~150 SALU instructions per tile before, profiles/r02_L_instruction_mix.md).
-// Layout: for C = 2..10 a block of NP x 64 int4 (product-major, lane-minor: one coalesced load per product).
-struct GramPlan { const int4* tab; int off[kGramMaxCams + 1]; };      // off[C]: first int4 of C's block
-
-inline std::vector<int> gram_store_plan(int (&off)[kGramMaxCams + 1]) {
-    std::vector<int> tab;
-    for (int C = 0; C <= kGramMaxCams; ++C) {
-        off[C] = (int)tab.size() / 4;
-        if (C < 2) continue;
-        const int R = 6 * C, NI = (R + 15) / 16;
-        for (int I = 0; I < NI; ++I)
-            for (int J = 0; J <= I; ++J)
-                for (int lane = 0; lane < 64; ++lane) {
-                    const int li = lane & 15, lk = lane >> 4;
-                    const int col = 16 * J + li, ra = col / 6, j = col - 6 * ra;
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = 16 * I + lk + 4 * g, rb = row / 6, i = row - 6 * rb;
-                        tab.push_back((row < R && col < R && rb > ra) ? (((ra * C + rb) << 6) | (6 * i + j)) : -1);
-                    }
-                }
-    }
-    return tab;
-}
+// Destination table of a Gram tile in LDS: kGramTabLd x kGramTabLd ints, entry [ra][rb] = block id of the camera pair (ra < rb,
+// both < C, the pair occurs in the tile), -1 otherwise.  The fixed row stride makes an accumulator element's table offset a
+// function of the lane and of compile-time indices only, and folds "row < R && col < R && rb > ra" into the one test dst >= 0.
+// (A host-built "store plan" — one int per accumulator element — was measured in round 3 and removed again: 107.6-111.4 us per
+//  launch at config L against 103.6 for index arithmetic; its loads are one more dependent round trip at the end of every tile.)
+constexpr int kGramTabLd = kGramMaxCams + 1;      // rows 60..63 of the last operand tile map to "camera 10": always -1
 
 // UPPER = false: hc = lower factor {c00 c10 c20 c11 c21 c22} stored by k_point_prep;  UPPER = true: hc = upper factor
 // {c00 c01 c02 c11 c12 c22} of point_factor() (formed in the kernel).  Either way hc hc^T = Hinv and V = W hc.
@@ -128,7 +106,7 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
 template <int NI>
 __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int Cp, int C, const int* __restrict__ dtab,
                                           double* __restrict__ scat2, int lane, const double (&V)[18], bool valid, int t, int cidx,
-                                          int T, int Th, int passes, bool dense, const int4* __restrict__ plan) {
+                                          int T, int Th, int passes, bool dense) {
     static_assert(NI >= 1 && NI <= 4, "a Gram tile has at most 10 cameras = 60 operand rows (ba_pack.h: kGramMaxCams)");
     const int li = lane & 15, lk = lane >> 4;
     v4d acc[NI * (NI + 1) / 2];
@@ -174,44 +152,27 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         __builtin_amdgcn_wave_barrier();
     }
     XBA_STAMP(0, 7);
-#ifdef XBA_STORE_PLAN
-    // (A/B build -DXBA_STORE_PLAN, measured and not adopted: 107.6-111.4 us per launch at config L against 103.6 us for the index
-    //  arithmetic below — the 16-byte plan loads are one more dependent memory round trip at the end of every tile)
-    // blocks (camera rb > camera ra) to their destinations, by the store plan of the tile's camera count
-    const int4* pl = plan + lane;
+    // blocks (camera rb > camera ra) to their destinations: dtab[ra][rb] (fixed stride), -1 = nothing to store
+    (void)C; (void)R;
+    int tcol[NI], jcol[NI];
 #pragma unroll
-    for (int p = 0; p < NI * (NI + 1) / 2; ++p) {
-        const int4 e4 = pl[p * kWave];
-        const int e[4] = {e4.x, e4.y, e4.z, e4.w};
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            if (e[g] >= 0) {
-                const int dst = dtab[e[g] >> 6];
-                if (dst >= 0) scat2[36 * (size_t)dst + (e[g] & 63)] = acc[p][g];
-            }
-    }
-#else
-    // blocks (camera rb > camera ra) to their destinations (dtab: [C][C], -1 = the pair never occurs in the tile)
-    (void)plan;
+    for (int J = 0; J < NI; ++J) { const int col = 16 * J + li; const int ra = col / 6; tcol[J] = ra * kGramTabLd; jcol[J] = col - 6 * ra; }
     int p = 0;
 #pragma unroll
-    for (int I = 0; I < NI; ++I)
+    for (int I = 0; I < NI; ++I) {
+        int trow[4], irow[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { const int row = 16 * I + lk + 4 * g; const int rb = row / 6; trow[g] = rb; irow[g] = 6 * (row - 6 * rb); }
 #pragma unroll
         for (int J = 0; J <= I; ++J) {
-            const int col = 16 * J + li;
-            const int ra = col / 6, j = col - 6 * ra;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int row = 16 * I + lk + 4 * g;
-                const int rb = row / 6, i = row - 6 * rb;
-                if (row < R && col < R && rb > ra) {
-                    const int dst = dtab[ra * C + rb];
-                    if (dst >= 0) scat2[36 * (size_t)dst + 6 * i + j] = acc[p][g];
-                }
+                const int dst = dtab[tcol[J] + trow[g]];
+                if (dst >= 0) scat2[36 * (size_t)dst + irow[g] + jcol[J]] = acc[p][g];
             }
             ++p;
         }
-#endif
+    }
 }
 
 // GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
@@ -226,7 +187,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 template <bool GRAM, bool PREP, int NIK>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu((GRAM && NIK < 4) ? 4 : (GRAM ? 3 : 2), (GRAM && NIK < 4) ? 4 : 3)))      // no instantiation may spill (tests/test_capi_cpu.py)
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
-                   int n_obs_pairs, double* __restrict__ scat2, double radius, GramPlan gplan) {
+                   int n_obs_pairs, double* __restrict__ scat2, double radius) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     XBA_STAMP(0, 0);
@@ -239,12 +200,14 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
         // (Gram tile) the destination table of its camera pairs and the lane's entry in the camera-major scatter buffer are
         // requested before anything else: two dependent loads whose latency then hides behind the operand loads and the
         // diagonal terms instead of sitting in front of the Gram stage
-        int dt0 = -1, dt1 = -1;
+        int dt0 = -1, dt1 = -1;         // entries lane and lane + 64 of the kGramTabLd x kGramTabLd table
         if (GRAM) {
             const int C0 = d.tile_ncam[it.first_tile];
             const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[it.first_tile];
-            if (lane < C0 * C0) dt0 = src[lane];
-            if (lane + kWave < C0 * C0) dt1 = src[lane + kWave];
+            const int a0 = lane / kGramTabLd, b0 = lane - kGramTabLd * a0;
+            const int a1 = (lane + kWave) / kGramTabLd, b1 = lane + kWave - kGramTabLd * a1;
+            if (b0 > a0 && b0 < C0) dt0 = src[a0 * C0 + b0];
+            if (b1 > a1 && b1 < C0 && a1 < kGramTabLd) dt1 = src[a1 * C0 + b1];
         }
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int cp = d.slot_campos_g[s.slot];
@@ -294,6 +257,28 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                     for (int k = 0; k < 14; ++k) red[lane * kRedLd + k] = o28[14 * h + k];
                     __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0)
                     __builtin_amdgcn_wave_barrier();
+                    // tracks of 2, 3 or 4 observations in a full tile (what most of a map consists of): one round, compile-time
+                    // strides — LDS reads with immediate offsets, no loop control (−1 VALU and −3 SALU per term)
+                    if ((L == 4 && T == 16) || (L == 2 && T == 32) || (L == 3 && T == 21)) {
+                        const bool on = lane < 14 * L;
+                        const int r = on ? lane / 14 : 0, k = lane - 14 * r;
+                        const int cpr = __shfl(cp, r, kWave);
+                        if (on) {
+                            const double* src = red + r * kRedLd + k;
+                            double sum = 0.0;
+                            if (L == 4) {
+#pragma unroll
+                                for (int t = 0; t < 16; ++t) sum += src[t * 4 * kRedLd];
+                            } else if (L == 2) {
+#pragma unroll
+                                for (int t = 0; t < 32; ++t) sum += src[t * 2 * kRedLd];
+                            } else {
+#pragma unroll
+                                for (int t = 0; t < 21; ++t) sum += src[t * 3 * kRedLd];
+                            }
+                            d.scat[28 * (size_t)cpr + 14 * h + k] = sum;
+                        }
+                    } else
                     for (int q0 = 0; q0 < 14 * L; q0 += kWave) {                 // uniform trip count: the shuffle below reads lanes
                         const int q = q0 + lane;                                 // that a per-lane loop bound would already have retired
                         const bool on = q < 14 * L;                              // (L = 14, 19, ...: the last round's source lane)
@@ -367,12 +352,12 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             const int Th = (T + passes - 1) / passes;
             const int R = 6 * C, Rp = (R + 15) & ~15, Cp = ((3 * Th + 3) & ~3) + 2;
             double* Vst = smem;                                             // only the R rows that hold data are staged
-            int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [C][C] destination of block (cb > ca) at [ca][cb], -1 none
-            if (lane < C * C) dtab[lane] = dt0;
-            if (lane + kWave < C * C) dtab[lane + kWave] = dt1;
+            int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [kGramTabLd][kGramTabLd] destination of block (cb > ca) at [ca][cb], -1 none
+            dtab[lane] = dt0;
+            if (lane + kWave < kGramTabLd * kGramTabLd) dtab[lane + kWave] = dt1;
             const bool dense = nvalid == T * C;
             (void)Rp;
-            gram_tile<(NIK > 0 ? NIK : 1)>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense, gplan.tab + gplan.off[C]);
+            gram_tile<(NIK > 0 ? NIK : 1)>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
             XBA_STAMP(0, 8);
             return;
         }

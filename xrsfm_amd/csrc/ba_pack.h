@@ -29,11 +29,12 @@ constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly
 __host__ __device__
 #endif
 inline int gram_lds_need(int C, int T, int* passes) {
-    const int one = 6 * C * ((((3 * T + 3) & ~3)) + 2) * 8 + C * C * 4;
+    constexpr int tab = (kGramMaxCams + 1) * (kGramMaxCams + 1) * 4;      // destination table with a fixed row stride (ba_chol.h: kGramTabLd)
+    const int one = 6 * C * ((((3 * T + 3) & ~3)) + 2) * 8 + tab;
     if (one <= kGramSmallLds) { *passes = 1; return one; }
     const int Th = (T + 1) / 2;
     *passes = 2;
-    return 6 * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + C * C * 4;
+    return 6 * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + tab;
 }
 
 // Host-side helper: run fn(begin, end) over [0, n) on up to 8 threads (16 for the largest loops) (large problems only; the packing of config L is ~100 ms

@@ -101,7 +101,6 @@ struct CholHost {
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
     int* pairs_items = nullptr; int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
-    GramPlan gplan{};                             // store plan of the Gram epilogue (ba_chol.h)
     int gram_n[8] = {0}; size_t gram_shm[8] = {0};   // Gram tiles / dynamic LDS per launch bucket (ba_plan.h)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // the non-Gram items run concurrently
     // right-looking schedule (dense patterns): one panel after the other
@@ -618,15 +617,11 @@ int chol_setup(xrsfm_ba_context* c) {
     const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
     up.add(&h.zero2, two_zeros);
     up.add(&h.pairs_items, P.pairs_items);
-    const std::vector<int> gplan_tab = gram_store_plan(h.gplan.off);      // must outlive up.flush()
-    int* d_gplan = nullptr;
-    up.add(&d_gplan, gplan_tab);
     h.sp_max_chunks = P.sp_max_chunks;
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
     if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
     up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
     TRYC(up.flush());
-    h.gplan.tab = reinterpret_cast<const int4*>(d_gplan);
     timer.mark("uploads");
     const size_t blk_vals = c->wide ? kWB : 36, cam_vals = c->wide ? kWS : 28;
     TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * blk_vals));
@@ -649,7 +644,7 @@ int chol_setup(xrsfm_ba_context* c) {
         static std::vector<char> done_for(64, 0);
         std::lock_guard<std::mutex> g(mu);
         if (c->device < 64 && !done_for[c->device]) {
-            const int pairs_max = kGramMaxLds + kGramMaxCams * kGramMaxCams * (int)sizeof(int);
+            const int pairs_max = kGramMaxLds + kGramTabLd * kGramTabLd * (int)sizeof(int);
             (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
             (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
@@ -691,13 +686,13 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         const double radius = c->step_radius;
         auto launch_other = [&](hipStream_t st) {
             const int* items = h.pairs_items + h.n_pairs_small + h.n_pairs_big;
-            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
-            else hipLaunchKernelGGL((k_schur_pairs<false, false, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+            else hipLaunchKernelGGL((k_schur_pairs<false, false, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
         };
         auto launch_gram = [&](auto ni, int n, size_t shm, const int* items) {
             constexpr int NI = decltype(ni)::value;
-            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
-            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, h.gplan);
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
         };
         if (fork) {
             HIPCHK(hipEventRecord(h.ev_fork, c->stream));
