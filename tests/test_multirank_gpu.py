@@ -49,10 +49,27 @@ def _worker(rank, world, port, arr, solver, opt_kw, out_prefix):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", [1, 0], ids=["cholesky", "pcg"])
-@pytest.mark.parametrize("mode,world", [("sequential", 2), ("unordered", 2), ("sequential", 3), ("ragged", 2)])
+@pytest.mark.parametrize("mode,world", [("sequential", 2), ("unordered", 2), ("sequential", 3), ("ragged", 2),
+                                        ("unordered-panels", 2), ("clustered", 2)])
 def test_ranks_equal_one_rank(lib, tmp_path, solver, mode, world):
-    from xrsfm_amd import capi
-    arr = H.make(24, 1500, 8, seed=140, dropout=0.35) if mode == "ragged" else H.make(24, 1500, 4, seed=140, mode=mode)
+    """(round 3) "unordered-panels": 130 cameras with random visibility = 13 tile columns: the look-ahead panel schedule
+    (k_panel_slot) on every rank over the union block pattern; "clustered": a small photo collection with viewpoint clusters in
+    the reverse Cuthill-McKee order (every rank must derive the same order from the all-reduced pattern)."""
+    from xrsfm_amd import capi, synth
+    if mode == "ragged":
+        arr = H.make(24, 1500, 8, seed=140, dropout=0.35)
+    elif mode == "unordered-panels":
+        arr = H.make(130, 4000, 5, seed=141, mode="unordered")
+    elif mode == "clustered":
+        d = synth.make_collection(n_cams=600, n_points=30000, seed=5, cams_per_cluster=60)
+        arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    else:
+        arr = H.make(24, 1500, 4, seed=140, mode=mode)
+    if solver == 0 and mode in ("unordered-panels", "clustered"):
+        pytest.skip("the larger cases are about the exact path's schedules")
+    if mode in ("unordered-panels", "clustered"):
+        plan = capi.debug_chol_plan(H.to_product(arr))
+        assert plan["lookahead"] == 1 and (mode != "clustered" or plan["ordering"] == 2), plan
     opt_kw = dict(max_iterations=8)
     ref = H.to_product(arr)
     s1 = capi.solve(ref, capi.default_options(linear_solver=solver, **opt_kw))
@@ -71,7 +88,7 @@ def test_ranks_equal_one_rank(lib, tmp_path, solver, mode, world):
     n_p = arr["points"].shape[0]
     # (ragged tracks leave points seen by two neighbouring frames only: their depth amplifies the 1e-9 differences of the
     # cameras by five orders of magnitude, at no difference in cost)
-    ptol = 1e-2 if mode == "ragged" else 1e-5
+    ptol = 1e-2 if mode == "ragged" else (1e-4 if mode == "clustered" else 1e-5)
     for r in range(world):
         assert np.abs(z[r]["P"] - ref.points[np.arange(n_p) % world == r]).max() < ptol
 
