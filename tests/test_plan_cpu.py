@@ -159,3 +159,24 @@ def test_clustered_collection_takes_the_rcm_order():
     assert np.median(spread) < 450                                   # a landmark has ~150 cameras, its neighbours 300 more
     u = H.make(500, 20000, 5, seed=5, mode="unordered")
     assert capi.debug_chol_plan(H.to_product(u))["ordering"] == 0
+
+
+def test_pair_keys_of_a_large_collection_are_sorted_in_parallel():
+    """Above 2 M pair keys the key list is radix-sorted on up to 16 threads (ba_plan.h: chol_local_keys; config T has 61.8 M keys).
+    The number of distinct camera pairs the plan reports must be the number an independent count over the tracks gives."""
+    from xrsfm_amd import synth
+    d = synth.make_collection(n_cams=1200, n_points=150000, seed=3)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    order = np.lexsort((arr["obs_cam"], arr["obs_pt"]))
+    cam, pt = arr["obs_cam"][order].astype(np.int64), arr["obs_pt"][order]
+    ptr = np.searchsorted(pt, np.arange(arr["points"].shape[0] + 1))
+    n_pairs = int(sum((ptr[j + 1] - ptr[j]) * (ptr[j + 1] - ptr[j] - 1) // 2 for j in range(len(ptr) - 1)))
+    assert n_pairs > 2_000_000                       # the parallel path
+    keys = set()
+    for j in range(len(ptr) - 1):
+        c = cam[ptr[j]:ptr[j + 1]]
+        if len(c) > 1:
+            a, b = np.triu_indices(len(c), 1)
+            keys.update((c[b] * 1200 + c[a]).tolist())
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["blocks"] == len(keys)
