@@ -72,7 +72,11 @@ struct CholPlan {
     std::vector<int> tile_cam;          // [T][kCamsPerTile] camera in slot q of tile t, -1 = none (backward kernel: candidate cameras)
 };
 
-typedef std::vector<std::pair<unsigned long long, int>> PairKeys;   // ((cam_b << 32) | cam_a, pair index), sorted
+struct PairKey {                 // ((cam_b << 32) | cam_a, pair index); trivially constructible: the lists below are never zero-filled
+    unsigned long long first; int second;
+    bool operator<(const PairKey& o) const { return first != o.first ? first < o.first : second < o.second; }
+};
+typedef RawVec<PairKey> PairKeys;   // sorted by (key, index)
 
 // A track with two observations in the same camera (the reference guards against it, pnp.cc:84, but the map format allows it;
 // Ceres simply adds both residuals): its camera pair (a,a) is a diagonal block, which the pair-block assembly does not
@@ -95,29 +99,51 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
     const int nch = (int)cut.size() - 1;
     spp.resize((size_t)ns + 1);
     spp[0] = 0;
-    std::vector<long long> total(nch, 0);
+    std::vector<long long> total(nch, 0), nkeys(nch, 0);
     pack_parallel_chunks(cut, [&](int t, long long s0, long long s1) {
         int run = 0;
         if (s1 < ns && k.slot_cam[s1] >= 0)
             for (long long s = s1 + 1; s < ns && k.slot_cam[s] >= 0 && k.slot_pt[s] == k.slot_pt[s1]; ++s) ++run;
-        long long sum = 0;
+        long long sum = 0, keys = 0;
         for (long long s = s1 - 1; s >= s0; --s) {
             if (k.slot_cam[s] < 0) run = 0;
             else run = (s + 1 < ns && k.slot_cam[s + 1] >= 0 && k.slot_pt[s + 1] == k.slot_pt[s]) ? run + 1 : 0;
             spp[s + 1] = run;
             sum += run;
+            if (k.tile_ncam[s / 64] <= 0) keys += run;       // (a Gram tile writes per camera pair of the tile, below)
         }
-        total[t] = sum;
+        total[t] = sum; nkeys[t] = keys;
     });
-    std::vector<long long> base(nch + 1, 0);
-    for (int t = 0; t < nch; ++t) base[t + 1] = base[t] + total[t];
+    std::vector<long long> base(nch + 1, 0), kbase(nch + 1, 0);
+    for (int t = 0; t < nch; ++t) { base[t + 1] = base[t] + total[t]; kbase[t + 1] = kbase[t] + nkeys[t]; }
     if (base[nch] > INT32_MAX) return XRSFM_BA_EINVAL;
     const int n_obs_pairs = (int)base[nch];
-    std::vector<PairKeys> local(nch);
+    // Gram tiles: one key per co-visible camera pair of the tile (counted first, so that every piece writes its keys in place:
+    // an unordered collection with long tracks has tens of millions of keys, and neither per-piece lists nor a zero-filled
+    // result are affordable — config T: 61.8 M keys, 1 GB)
+    const std::vector<long long> tcut = pack_cuts(k.n_tiles, 8000, 1);
+    const int ntc = (int)tcut.size() - 1;
+    std::vector<long long> gkeys(ntc, 0);
+    pack_parallel_chunks(tcut, [&](int t, long long t0, long long t1) {
+        long long n = 0;
+        for (long long tile = t0; tile < t1; ++tile) {
+            const int C = k.tile_ncam[tile];
+            if (C <= 0) continue;
+            const unsigned char* cell = k.gt_cell.data() + k.tile_gt_off[tile];
+            for (int a = 0; a < C; ++a)
+                for (int b = a + 1; b < C; ++b) n += cell[a * C + b] != 0;
+        }
+        gkeys[t] = n;
+    });
+    std::vector<long long> gbase(ntc + 1, kbase[nch]);
+    for (int t = 0; t < ntc; ++t) gbase[t + 1] = gbase[t] + gkeys[t];
+    if (gbase[ntc] > INT32_MAX) return XRSFM_BA_EINVAL;
+    keyed.clear();
+    keyed.resize((size_t)gbase[ntc]);
     std::vector<char> bad(nch, 0);
     pack_parallel_chunks(cut, [&](int t, long long s0, long long s1) {
         int acc = (int)base[t];
-        PairKeys& out = local[t];
+        PairKey* out = keyed.data() + kbase[t];
         for (long long s = s0; s < s1; ++s) {
             const int start = acc, np = spp[s + 1];
             acc += np;
@@ -128,17 +154,14 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
             for (int dd = 1; dd <= np; ++dd) {
                 const unsigned long long cb = (unsigned)k.slot_cam[s + dd];
                 if (cb <= ca) { bad[t] = 1; return; }   // two observations of one track in the same frame
-                if (!gram) out.push_back({(cb << 32) | ca, start + dd - 1});
+                if (!gram) *out++ = PairKey{(cb << 32) | ca, start + dd - 1};
             }
         }
     });
     for (int t = 0; t < nch; ++t) if (bad[t]) return kErrDuplicateObs;
-    // Gram tiles: one key per co-visible camera pair of the tile
-    const std::vector<long long> tcut = pack_cuts(k.n_tiles, 8000, 1);
-    std::vector<PairKeys> glocal(tcut.size() - 1);
     pack_parallel_chunks(tcut, [&](int t, long long t0, long long t1) {
         int cams[64];
-        PairKeys& out = glocal[t];
+        PairKey* out = keyed.data() + gbase[t];
         for (long long tile = t0; tile < t1; ++tile) {
             const int C = k.tile_ncam[tile];
             if (C <= 0) continue;
@@ -147,25 +170,9 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
             for (int a = 0; a < C; ++a)
                 for (int b = a + 1; b < C; ++b)
                     if (cell[a * C + b])
-                        out.push_back({((unsigned long long)(unsigned)cams[b] << 32) | (unsigned)cams[a], n_obs_pairs + k.tile_gt_off[tile] + a * C + b});
+                        *out++ = PairKey{((unsigned long long)(unsigned)cams[b] << 32) | (unsigned)cams[a], n_obs_pairs + k.tile_gt_off[tile] + a * C + b};
         }
     });
-    // concatenate (pieces in parallel: an unordered collection with long tracks has tens of millions of keys)
-    std::vector<const PairKeys*> pieces;
-    for (const auto& v : local) pieces.push_back(&v);
-    for (const auto& v : glocal) pieces.push_back(&v);
-    std::vector<size_t> at(pieces.size() + 1, 0);
-    for (size_t i = 0; i < pieces.size(); ++i) at[i + 1] = at[i] + pieces[i]->size();
-    const size_t nk = at.back();
-    keyed.clear();
-    keyed.resize(nk);
-    {
-        std::vector<long long> pc(pieces.size() + 1);
-        for (size_t i = 0; i <= pieces.size(); ++i) pc[i] = (long long)i;
-        if (nk < 2000000) for (size_t i = 0; i < pieces.size(); ++i) std::copy(pieces[i]->begin(), pieces[i]->end(), keyed.begin() + at[i]);
-        else pack_parallel_chunks(pc, [&](int, long long i0, long long) { std::copy(pieces[i0]->begin(), pieces[i0]->end(), keyed.begin() + at[i0]); });
-    }
-    local.clear(); glocal.clear();
     // (key, index) order.  The entries were appended in ascending index order (pairs by slot, then the Gram cells by tile), so a
     // stable LSD radix sort over the two camera fields of the key gives it; small lists take std::sort.  Each pass runs on up to
     // 16 threads over fixed pieces of the list: per-piece histograms, offsets by (digit, piece), pieces scattered in order —
