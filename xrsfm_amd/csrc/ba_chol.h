@@ -22,7 +22,11 @@ constexpr int kCamsPerTileDev = 10;   // cameras per 64-row tile (ba_plan.h: kCa
 
 struct CholDev {
     int n, n_pad, T;
-    double* S;        // [n_pad][n_pad] row-major, lower triangle valid
+    double* S;        // tile storage of the lower triangle: dense [n_pad][n_pad] row-major (tmap == nullptr, ld = n_pad), or PACKED:
+                      // only the structurally non-zero tiles, 64 x 64 row-major each (ld = 64), tile (i,k) at S + tmap[i*T+k] * tstride
+                      // (tstride = 4096 + 64 doubles: consecutive tiles start on different channels); tiles outside the pattern map to
+                      // one shared all-zero tile, like the zero regions of the dense form
+    const int* tmap; size_t ld; size_t tstride;
     double* Linv;     // [T][64][64] inverse of the diagonal tiles of L
     double* y;        // [n_pad] forward-substituted rhs
     double* rhs;      // [n_pad] working copy of b
@@ -32,6 +36,10 @@ struct CholDev {
     const int* tile_rows; // [T] leading rows of the tile that hold cameras (the rest is identity padding)
     int cw, cpt;          // unknowns per camera and cameras per tile: 6 / 10, or 9 / 7 in bal9 mode (ba_wide.h)
 };
+
+__device__ __forceinline__ double* tile_ptr(const CholDev& c, int i, int k) {
+    return c.tmap ? c.S + (size_t)c.tmap[i * c.T + k] * c.tstride : c.S + (size_t)(i * kNB) * c.ld + k * kNB;
+}
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -479,10 +487,10 @@ __global__ __launch_bounds__(256) void k_tile_fill(CholDev c, Dev d, const int* 
     const int ti = tiles[2 * q], tj = tiles[2 * q + 1];
     const int t = threadIdx.x;
     compose_tile<kNB + 1>(c, d, f, q, A, rl);
-    double* base = c.S + (size_t)(ti * kNB) * c.n_pad + tj * kNB;
+    double* base = tile_ptr(c, ti, tj);
     for (int e = t; e < kNB * kNB; e += 256) {
         const int r = e >> 6, col = e & 63;
-        base[(size_t)r * c.n_pad + col] = A[r * (kNB + 1) + col];
+        base[(size_t)r * c.ld + col] = A[r * (kNB + 1) + col];
     }
     if (ti == tj && t < kNB) c.rhs[ti * kNB + t] = rl[t];
 }
@@ -693,11 +701,11 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
     __shared__ double Li[kNB][kLdT];
     __shared__ double Tb[3][16][17];
     const int t = threadIdx.x;
-    double* base = c.S + (size_t)(k * kNB) * c.n_pad + k * kNB;
+    double* base = tile_ptr(c, k, k);
 #pragma unroll
     for (int it = 0; it < 8; ++it) {           // 2048 double2 of the tile, 8 per thread; the upper triangle is masked to 0
         const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
-        const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * c.n_pad + col);
+        const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * c.ld + col);
         A[r][col] = (col <= r) ? v.x : 0.0;
         A[r][col + 1] = (col + 1 <= r) ? v.y : 0.0;
         Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
@@ -710,7 +718,7 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
     for (int it = 0; it < 8; ++it) {
         const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
         reinterpret_cast<double2*>(lo)[e] = make_double2((col <= r) ? Li[r][col] : 0.0, (col + 1 <= r) ? Li[r][col + 1] : 0.0);
-        double* dst = base + (size_t)r * c.n_pad + col;
+        double* dst = base + (size_t)r * c.ld + col;
         if (col + 1 <= r) *reinterpret_cast<double2*>(dst) = make_double2(A[r][col], A[r][col + 1]);
         else if (col <= r) dst[0] = A[r][col];
     }
@@ -723,7 +731,7 @@ __global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict_
             __syncthreads();
             if (t < kNB) v[t] = c.y[j * kNB + t];
             __syncthreads();
-            const double* M = c.S + (size_t)(k * kNB + o) * c.n_pad + j * kNB + part * 16;
+            const double* M = tile_ptr(c, k, j) + (size_t)o * c.ld + part * 16;
             double sacc = 0.0;
 #pragma unroll
             for (int m = 0; m < 16; ++m) sacc += M[m] * v[part * 16 + m];
@@ -808,8 +816,8 @@ __global__ __launch_bounds__(256) void k_trsm(CholDev c, int k, const int* __res
     __shared__ double vr[kNB], yk[kNB], tmp[kNB];
     double* As = smem; double* Bs = smem + kNB * kLdT;
     const int i = rows[blockIdx.x];
-    double* Ag = c.S + (size_t)(i * kNB) * c.n_pad + k * kNB;
-    load_tile_lds(As, Ag, c.n_pad);
+    double* Ag = tile_ptr(c, i, k);
+    load_tile_lds(As, Ag, c.ld);
     load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
     if (threadIdx.x < kNB) vr[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
     __syncthreads();
@@ -830,7 +838,7 @@ __global__ __launch_bounds__(256) void k_trsm(CholDev c, int k, const int* __res
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Ag[(size_t)r * c.n_pad + col] = acc[m][n2][g];
+                Ag[(size_t)r * c.ld + col] = acc[m][n2][g];
                 As[r * kLdT + col] = acc[m][n2][g];
             }
     __syncthreads();
@@ -844,8 +852,8 @@ __global__ __launch_bounds__(256) void k_update(CholDev c, int k, const int* __r
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem; double* Bs = smem + kNB * kLdT;
     const int i = pairs[2 * blockIdx.x], j = pairs[2 * blockIdx.x + 1];
-    load_tile_lds(As, c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad);
-    load_tile_lds(Bs, c.S + (size_t)(j * kNB) * c.n_pad + k * kNB, c.n_pad);
+    load_tile_lds(As, tile_ptr(c, i, k), c.ld);
+    load_tile_lds(Bs, tile_ptr(c, j, k), c.ld);
     __syncthreads();
     v4d acc[2][2];
 #pragma unroll
@@ -853,7 +861,7 @@ __global__ __launch_bounds__(256) void k_update(CholDev c, int k, const int* __r
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
     tile_abt_mfma(As, Bs, acc);
-    double* Cg = c.S + (size_t)(i * kNB) * c.n_pad + j * kNB;
+    double* Cg = tile_ptr(c, i, j);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
 #pragma unroll
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(256) void k_update(CholDev c, int k, const int* __r
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Cg[(size_t)r * c.n_pad + col] -= acc[m][n2][g];
+                Cg[(size_t)r * c.ld + col] -= acc[m][n2][g];
             }
 }
 
@@ -880,7 +888,7 @@ __global__ __launch_bounds__(256) void k_fwd(CholDev c, int k, const int* __rest
         return;
     }
     const int i = rows[blockIdx.x - 1];
-    tile_gemv(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, yk, tmp, false, nullptr);
+    tile_gemv(tile_ptr(c, i, k), c.ld, yk, tmp, false, nullptr);
     __syncthreads();
     if (threadIdx.x < kNB) c.rhs[i * kNB + threadIdx.x] -= tmp[threadIdx.x];
 }
@@ -899,7 +907,7 @@ __global__ __launch_bounds__(256) void k_bwd(CholDev c, int k, const int* __rest
         return;
     }
     const int j = cols[blockIdx.x - 1];
-    tile_gemv(c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad, xk, tmp, true, nullptr);
+    tile_gemv(tile_ptr(c, k, j), c.ld, xk, tmp, true, nullptr);
     __syncthreads();
     if (threadIdx.x < kNB) c.y[j * kNB + threadIdx.x] -= tmp[threadIdx.x];
 }
@@ -942,8 +950,8 @@ __global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restr
     double2 ra[8], rb[8];
     if (q0 < q1) {
         const int j = cj[q0];
-        load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
-        load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+        load_tile_regs(ra, tile_ptr(c, i, j), c.ld);
+        load_tile_regs(rb, tile_ptr(c, k, j), c.ld);
     }
     for (int q = q0; q < q1; ++q) {
         __syncthreads();                       // the previous product no longer reads LDS
@@ -952,12 +960,12 @@ __global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restr
         __syncthreads();
         if (q + 1 < q1) {                      // next contribution: loads in flight during the MFMAs below
             const int j = cj[q + 1];
-            load_tile_regs(ra, c.S + (size_t)(i * kNB) * c.n_pad + j * kNB, c.n_pad);
-            load_tile_regs(rb, c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad);
+            load_tile_regs(ra, tile_ptr(c, i, j), c.ld);
+            load_tile_regs(rb, tile_ptr(c, k, j), c.ld);
         }
         tile_abt_mfma(As, Bs, acc);
     }
-    store_acc_sub(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, acc);
+    store_acc_sub(tile_ptr(c, i, k), c.ld, acc);
 }
 
 // Thin levels near the root of the elimination tree have few targets with long lists: one workgroup per CHUNK [q0,q1) of a
@@ -1023,15 +1031,13 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
     double sv = 0.0;
     constexpr int kAhead = 4;
     v2d ra[kAhead][4], rb[kAhead][4];
-    const double* rowA = c.S + (size_t)(i * kNB) * c.n_pad;
-    const double* rowB = c.S + (size_t)(k * kNB) * c.n_pad;
     const int ns = 2 * (q1 - q0);
 #pragma unroll
     for (int u = 0; u < kAhead; ++u)
         if (u < ns) {
-            const int col = cj[q0 + (u >> 1)] * kNB + (u & 1) * 32;
-            load_half_regs(ra[u], rowA + col, c.n_pad);
-            load_half_regs(rb[u], rowB + col, c.n_pad);
+            const int j = cj[q0 + (u >> 1)], col = (u & 1) * 32;
+            load_half_regs(ra[u], tile_ptr(c, i, j) + col, c.ld);
+            load_half_regs(rb[u], tile_ptr(c, k, j) + col, c.ld);
         }
     double yreg = (diag && t < kNB) ? c.y[cj[q0] * kNB + t] : 0.0;      // y_j of the product that starts at an even step
     // prologue: step 0 into buffer 0
@@ -1039,9 +1045,9 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
     store_half_lds(lds + kNB * kLdH, rb[0]);
     if (diag && t < kNB) yv[t] = yreg;
     if (kAhead < ns) {
-        const int col = cj[q0 + (kAhead >> 1)] * kNB + (kAhead & 1) * 32;
-        load_half_regs(ra[0], rowA + col, c.n_pad);
-        load_half_regs(rb[0], rowB + col, c.n_pad);
+        const int j = cj[q0 + (kAhead >> 1)], col = (kAhead & 1) * 32;
+        load_half_regs(ra[0], tile_ptr(c, i, j) + col, c.ld);
+        load_half_regs(rb[0], tile_ptr(c, k, j) + col, c.ld);
     }
     if (diag && 2 < ns && t < kNB) yreg = c.y[cj[q0 + 1] * kNB + t];
     __syncthreads();
@@ -1060,9 +1066,9 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
                     store_half_lds(An + kNB * kLdH, rb[un]);
                     if (diag && ((s + 1) & 1) == 0 && t < kNB) yv[(((s + 1) >> 1) & 1) * kNB + t] = yreg;
                     if (s + 1 + kAhead < ns) {         // ... and the registers refilled with step s+1+kAhead
-                        const int col = cj[q0 + ((s + 1 + kAhead) >> 1)] * kNB + ((s + 1 + kAhead) & 1) * 32;
-                        load_half_regs(ra[un], rowA + col, c.n_pad);
-                        load_half_regs(rb[un], rowB + col, c.n_pad);
+                        const int j = cj[q0 + ((s + 1 + kAhead) >> 1)], col = ((s + 1 + kAhead) & 1) * 32;
+                        load_half_regs(ra[un], tile_ptr(c, i, j) + col, c.ld);
+                        load_half_regs(rb[un], tile_ptr(c, k, j) + col, c.ld);
                     }
                     if (diag && ((s + 1) & 1) == 0 && s + 3 < ns && t < kNB) yreg = c.y[cj[q0 + ((s + 3) >> 1)] * kNB + t];
                 }
@@ -1144,26 +1150,25 @@ __global__ __launch_bounds__(256, 2) void k_panel2_part(CholDev c, const int* __
     for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n2 = 0; n2 < 4; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const double* row0 = c.S + (size_t)(i0 * kNB) * c.n_pad;
-    const double* row1 = c.S + (size_t)((i1 >= 0 ? i1 : i0) * kNB) * c.n_pad;
-    const double* row2 = c.S + (size_t)(k0 * kNB) * c.n_pad;
-    const double* row3 = c.S + (size_t)(k1 * kNB) * c.n_pad;
+    const int i1r = i1 >= 0 ? i1 : i0;
+    // quarter `st` (16 columns) of the operand tiles of step st: column tile q0 + st / 4
+    auto load_step = [&](int st, v2d (&g0)[2], v2d (&g1)[2], v2d (&g2)[2], v2d (&g3)[2]) {
+        const int j = q0 + (st >> 2), col = (st & 3) * 16;
+        load_quarter_regs(g0, tile_ptr(c, i0, j) + col, c.ld); load_quarter_regs(g1, tile_ptr(c, i1r, j) + col, c.ld);
+        load_quarter_regs(g2, tile_ptr(c, k0, j) + col, c.ld); load_quarter_regs(g3, tile_ptr(c, k1, j) + col, c.ld);
+    };
     const int ns = 4 * (q1 - q0);
     v2d rg0[2], rg1[2], rg2[2], rg3[2];
     double yreg = 0.0;
     // prologue: step 0 into buffer 0, step 1 into the registers
     {
-        const int col = q0 * kNB;
-        load_quarter_regs(rg0, row0 + col, c.n_pad); load_quarter_regs(rg1, row1 + col, c.n_pad);
-        load_quarter_regs(rg2, row2 + col, c.n_pad); load_quarter_regs(rg3, row3 + col, c.n_pad);
+        load_step(0, rg0, rg1, rg2, rg3);
         if (diag && t < kNB) yreg = c.y[q0 * kNB + t];
         store_quarter_lds(Rs[0][0], rg0); store_quarter_lds(Rs[0][1], rg1);
         store_quarter_lds(Cs[0][0], rg2); store_quarter_lds(Cs[0][1], rg3);
         if (diag && t < kNB) yv[0][t] = yreg;
         if (ns > 1) {
-            const int col1 = q0 * kNB + 16;
-            load_quarter_regs(rg0, row0 + col1, c.n_pad); load_quarter_regs(rg1, row1 + col1, c.n_pad);
-            load_quarter_regs(rg2, row2 + col1, c.n_pad); load_quarter_regs(rg3, row3 + col1, c.n_pad);
+            load_step(1, rg0, rg1, rg2, rg3);
         }
         __syncthreads();
     }
@@ -1176,9 +1181,7 @@ __global__ __launch_bounds__(256, 2) void k_panel2_part(CholDev c, const int* __
             if (diag && ((s + 1) & 3) == 0 && t < kNB) yv[((s + 1) >> 2) & 1][t] = yreg;
         }
         if (s + 2 < ns) {                      // operands of step s+2: global -> registers
-            const int col = (q0 + ((s + 2) >> 2)) * kNB + ((s + 2) & 3) * 16;
-            load_quarter_regs(rg0, row0 + col, c.n_pad); load_quarter_regs(rg1, row1 + col, c.n_pad);
-            load_quarter_regs(rg2, row2 + col, c.n_pad); load_quarter_regs(rg3, row3 + col, c.n_pad);
+            load_step(s + 2, rg0, rg1, rg2, rg3);
             if (diag && ((s + 2) & 3) == 0 && t < kNB) yreg = c.y[(q0 + ((s + 2) >> 2)) * kNB + t];
         }
         if (diag) {
@@ -1253,13 +1256,14 @@ __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const in
     if (EPT == 1) {
         const int e = by * 256 + threadIdx.x;
         const double s = sum_strided(Wp + (size_t)p0 * kPartStride + e, kPartStride, p1 - p0);
-        c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] -= s;
+        tile_ptr(c, i, k)[(size_t)(e >> 6) * c.ld + (e & 63)] -= s;
     } else {
         // the thread's EPT elements advance together: EPT (x2) loads in flight per partial instead of EPT serial sums
         double s[EPT], a0[EPT];
         const double* W = Wp + (size_t)p0 * kPartStride + (size_t)by * EPT * 256 + threadIdx.x;
+        double* const tik = tile_ptr(c, i, k);
 #pragma unroll
-        for (int u = 0; u < EPT; ++u) { s[u] = 0.0; a0[u] = c.S[(size_t)(i * kNB + (((by * EPT + u) * 256 + threadIdx.x) >> 6)) * c.n_pad + k * kNB + (threadIdx.x & 63)]; }
+        for (int u = 0; u < EPT; ++u) { s[u] = 0.0; a0[u] = tik[(size_t)(((by * EPT + u) * 256 + threadIdx.x) >> 6) * c.ld + (threadIdx.x & 63)]; }
         int p = p0;
         for (; p + 2 <= p1; p += 2) {
             double v0[EPT], v1[EPT];
@@ -1276,7 +1280,7 @@ __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const in
 #pragma unroll
         for (int u = 0; u < EPT; ++u) {
             const int e = (by * EPT + u) * 256 + threadIdx.x;
-            c.S[(size_t)(i * kNB + (e >> 6)) * c.n_pad + k * kNB + (e & 63)] = a0[u] - s[u];
+            tik[(size_t)(e >> 6) * c.ld + (e & 63)] = a0[u] - s[u];
         }
     }
     if (i == k && by == 0 && threadIdx.x < kNB) {
@@ -1294,8 +1298,8 @@ __global__ __launch_bounds__(256) void k_ll_trsm(CholDev c, const int* __restric
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* As = smem; double* Bs = smem + kNB * kLdT;
     const int i = pairs[2 * blockIdx.x], k = pairs[2 * blockIdx.x + 1];
-    double* Ag = c.S + (size_t)(i * kNB) * c.n_pad + k * kNB;
-    load_tile_lds(As, Ag, c.n_pad);
+    double* Ag = tile_ptr(c, i, k);
+    load_tile_lds(As, Ag, c.ld);
     load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
     __syncthreads();
     v4d acc[2][2];
@@ -1313,7 +1317,7 @@ __global__ __launch_bounds__(256) void k_ll_trsm(CholDev c, const int* __restric
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Ag[(size_t)r * c.n_pad + col] = acc[m][n2][g];
+                Ag[(size_t)r * c.ld + col] = acc[m][n2][g];
             }
 }
 
@@ -1328,7 +1332,7 @@ __global__ __launch_bounds__(256) void k_ll_fwd(CholDev c, const int* __restrict
         __syncthreads();
         if (threadIdx.x < kNB) v[threadIdx.x] = c.y[j * kNB + threadIdx.x];
         __syncthreads();
-        tile_gemv(c.S + (size_t)(k * kNB) * c.n_pad + j * kNB, c.n_pad, v, tmp, false, nullptr);
+        tile_gemv(tile_ptr(c, k, j), c.ld, v, tmp, false, nullptr);
         __syncthreads();
         if (threadIdx.x < kNB) acc[threadIdx.x] -= tmp[threadIdx.x];
     }
@@ -1349,7 +1353,7 @@ __global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict
         __syncthreads();
         if (threadIdx.x < kNB) v[threadIdx.x] = c.x[i * kNB + threadIdx.x];
         __syncthreads();
-        tile_gemv(c.S + (size_t)(i * kNB) * c.n_pad + k * kNB, c.n_pad, v, tmp, true, nullptr);
+        tile_gemv(tile_ptr(c, i, k), c.ld, v, tmp, true, nullptr);
         __syncthreads();
         if (threadIdx.x < kNB) acc[threadIdx.x] -= tmp[threadIdx.x];
     }
@@ -1392,10 +1396,10 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
         const int q = lf.rest[b - lf.n_factor];
         const int ti = lf.f.tiles[2 * q], tj = lf.f.tiles[2 * q + 1];
         compose_tile<kLdT>(c, lf.d, lf.f, q, &A[0][0], yv);
-        double* base = c.S + (size_t)(ti * kNB) * c.n_pad + tj * kNB;
+        double* base = tile_ptr(c, ti, tj);
         for (int e = threadIdx.x; e < kNB * kNB; e += 256) {
             const int r = e >> 6, col = e & 63;
-            base[(size_t)r * c.n_pad + col] = A[r][col];
+            base[(size_t)r * c.ld + col] = A[r][col];
         }
         if (ti == tj && threadIdx.x < kNB) c.rhs[ti * kNB + threadIdx.x] = yv[threadIdx.x];
         return;
@@ -1408,9 +1412,9 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
     const int li = lane & 15, lk = lane >> 4;
     const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
     const int o = t >> 2, part = t & 3;
-    const size_t ld = (size_t)c.n_pad;
-    const double* Skk = c.S + (size_t)(k * kNB) * ld + k * kNB;
-    double* Sik = c.S + (size_t)(i * kNB) * ld + k * kNB;
+    const size_t ld = c.ld;
+    const double* Skk = tile_ptr(c, k, k);
+    double* Sik = tile_ptr(c, i, k);
     // the assembled tiles, in the accumulator layout of tile_abt_mfma (requested now, used after the update phase)
     v4d skk[2][2], sik[2][2], akk[2][2], aik[2][2];
     if (FILL) {
@@ -1467,8 +1471,8 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
         double2 ra[8], rb[8];
         if (qa < qb) {
             const int jj = dj[qa]; const bool own = jj >= 0; const int j = own ? jj : ~jj;
-            load_tile_regs(rb, c.S + (size_t)(k * kNB) * ld + j * kNB, ld);
-            if (!diag && own) load_tile_regs(ra, c.S + (size_t)(i * kNB) * ld + j * kNB, ld);
+            load_tile_regs(rb, tile_ptr(c, k, j), ld);
+            if (!diag && own) load_tile_regs(ra, tile_ptr(c, i, j), ld);
         }
         for (int q = qa; q < qb; ++q) {
             const int jj = dj[q]; const bool own = jj >= 0; const int j = own ? jj : ~jj;
@@ -1479,8 +1483,8 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
             __syncthreads();
             if (q + 1 < qb) {                      // next contribution: loads in flight during the MFMAs below
                 const int jn = dj[q + 1]; const bool ownn = jn >= 0; const int j2 = ownn ? jn : ~jn;
-                load_tile_regs(rb, c.S + (size_t)(k * kNB) * ld + j2 * kNB, ld);
-                if (!diag && ownn) load_tile_regs(ra, c.S + (size_t)(i * kNB) * ld + j2 * kNB, ld);
+                load_tile_regs(rb, tile_ptr(c, k, j2), ld);
+                if (!diag && ownn) load_tile_regs(ra, tile_ptr(c, i, j2), ld);
             }
             if (diag) {
 #pragma unroll
@@ -1646,10 +1650,10 @@ __global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict
 #pragma unroll 4
         for (int e = 0; e < n; ++e) {
             const int i = ids[e];
-            const double* M = c.S + (size_t)(i * kNB + part * 16) * c.n_pad + k * kNB + o;
+            const double* M = tile_ptr(c, i, k) + (size_t)(part * 16) * c.ld + o;
             const double* xv = c.x + i * kNB + part * 16;
 #pragma unroll
-            for (int m = 0; m < 16; ++m) s += M[(size_t)m * c.n_pad] * xv[m];
+            for (int m = 0; m < 16; ++m) s += M[(size_t)m * c.ld] * xv[m];
         }
     }
     s += __shfl_xor(s, 1, kWave);

@@ -65,6 +65,7 @@ struct CholPlan {
     // look-ahead schedule: the contribution of column k - 2 to column k is formed in the launch of column k - 1 — one single-product
     // chunk per tile (md_tgt: (i,k); md_q: its entry in md_cj), written to partial slot = its index within the level — and the
     // factor kernel of column k starts its accumulators from it: fz_late, per fused-kernel entry the slot of (k,k) and of (i,k), -1 none
+    std::vector<int> tile_map;          // [T][T] packed tile storage: index of tile (i,k) in tiles_nz order, n_tiles_nz (= the shared zero tile) outside the pattern
     std::vector<int> md_tgt, md_q, md_cj, md_off, fz_late;      // (md_q indexes md_cj: the CSR over lv_cj must stay contiguous)
     int md_max = 0;
     std::vector<int> fz_q;              // per fused-kernel entry: index in tiles_nz of (k,k) and of (i,k) (fill lists tf_ptr / tf_ent)
@@ -501,6 +502,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     timer.mark("  symbolic factorisation");
     std::vector<int> tile_id((size_t)T * T, -1);
     for (int q = 0; q < P.n_tiles_nz; ++q) tile_id[(size_t)P.tiles_nz[2 * q] * T + P.tiles_nz[2 * q + 1]] = q;
+    P.tile_map.resize((size_t)T * T);
+    for (size_t e = 0; e < P.tile_map.size(); ++e) P.tile_map[e] = tile_id[e] >= 0 ? tile_id[e] : P.n_tiles_nz;
     {
         std::vector<int> cnt(P.n_tiles_nz + 1, 0);
         auto tile_of_block = [&](int b) {

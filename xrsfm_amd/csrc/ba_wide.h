@@ -312,10 +312,10 @@ __global__ __launch_bounds__(256) void k9_tile_fill(CholDev c, Dev d, DevW w, co
         }
     }
     __syncthreads();
-    double* base = c.S + (size_t)(ti * kNB) * c.n_pad + tj * kNB;
+    double* base = tile_ptr(c, ti, tj);
     for (int e = t; e < kNB * kNB; e += 256) {
         const int r = e >> 6, col = e & 63;
-        base[(size_t)r * c.n_pad + col] = A[r * LD + col];
+        base[(size_t)r * c.ld + col] = A[r * LD + col];
     }
     if (ti == tj && t < kNB) c.rhs[ti * kNB + t] = rl[t];
 }

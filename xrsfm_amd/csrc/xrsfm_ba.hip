@@ -126,6 +126,7 @@ struct CholHost {
     int* zero2 = nullptr;                                    // two zeros: an empty CSR row list
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
+    std::vector<int> tile_map_host; size_t S_doubles = 0;    // packed tile storage of S (CholDev::tmap), its size in doubles
     int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee
 };
 
@@ -588,14 +589,14 @@ int chol_setup(xrsfm_ba_context* c) {
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
     // (... or a reverse Cuthill-McKee order whose symbolic factorisation stays within the work budget of ba_plan.h: panel schedule)
-    if (P.n > kCholMaxN && (!(P.use_levels || P.ordering == 2) || (size_t)P.n_pad * P.n_pad * sizeof(double) > kCholMaxBytes)) return XRSFM_BA_ETOOBIG;
+    if (P.n > kCholMaxN && !(P.use_levels || P.ordering == 2)) return XRSFM_BA_ETOOBIG;       // (the size of the tile storage is checked where it is allocated)
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.lookahead = P.lookahead; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
     h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.mp_off = P.mp_off; h.fz_off = P.fz_off;
-    int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr;
+    int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr, *d_tmap = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     BatchUpload up(c);
     up.add(&h.slot_pair_ptr, P.spp); up.add(&h.pair_dst, P.pair_dst);
@@ -620,7 +621,7 @@ int chol_setup(xrsfm_ba_context* c) {
     h.sp_max_chunks = P.sp_max_chunks;
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
     if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
-    up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows);
+    up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows); up.add(&d_tmap, P.tile_map);
     TRYC(up.flush());
     timer.mark("uploads");
     const size_t blk_vals = c->wide ? kWB : 36, cam_vals = c->wide ? kWS : 28;
@@ -633,11 +634,19 @@ int chol_setup(xrsfm_ba_context* c) {
     }
     h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
     h.dev.cw = P.cam_width; h.dev.cpt = P.cams_per_tile;
-    TRYC(dev_alloc(c, &h.dev.S, (size_t)P.n_pad * P.n_pad));
+    // tile storage of S: packed (only the structurally non-zero tiles + one zero tile; XRSFM_BA_PACKED=0: dense n_pad x n_pad)
+    static const bool packed = [] { const char* e = std::getenv("XRSFM_BA_PACKED"); return !(e && e[0] == '0'); }();
+    h.dev.tmap = packed ? d_tmap : nullptr;
+    h.dev.ld = packed ? (size_t)kNB : (size_t)P.n_pad;
+    h.dev.tstride = (size_t)kNB * kNB + kNB;
+    h.S_doubles = packed ? ((size_t)P.n_tiles_nz + 1) * h.dev.tstride : (size_t)P.n_pad * P.n_pad;
+    if (h.S_doubles * sizeof(double) > kCholMaxBytes) return XRSFM_BA_ETOOBIG;
+    h.tile_map_host = P.tile_map;
+    TRYC(dev_alloc(c, &h.dev.S, h.S_doubles));
     TRYC(dev_alloc(c, &h.dev.Linv, (size_t)P.T * kNB * kNB));
     TRYC(dev_alloc(c, &h.dev.y, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)P.n_pad));
 #undef TRYC
-    HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * (size_t)P.n_pad * P.n_pad, c->stream));
+    HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * h.S_doubles, c->stream));
     const int shm = 2 * kNB * kLdT * (int)sizeof(double);
     {   // dynamic-LDS limits: once per device and process (each call costs a few microseconds, an LBA-sized solve has few to spare)
         static std::mutex mu;
@@ -2097,18 +2106,22 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
     if ((e = chol_assemble(c, S_dense != nullptr))) return e;      // (the fused fill of the first level is what a plain call runs)
     const CholDev& cd = c->chol.dev;
     if (S_dense) {
-        std::vector<double> h((size_t)cd.n_pad * cd.n_pad);
+        std::vector<double> h(c->chol.S_doubles);
         HIPCHK(hipStreamSynchronize(c->stream));
         HIPCHK(hipMemcpy(h.data(), cd.S, h.size() * sizeof(double), hipMemcpyDeviceToHost));
         const std::vector<int>& off = c->chol.cam_off_host;
+        const std::vector<int>& tm = c->chol.tile_map_host;
+        auto at = [&](int r, int col) -> double {      // element (r, col), r >= col, of the lower triangle in either storage form
+            if (!cd.tmap) return h[(size_t)r * cd.n_pad + col];
+            return h[(size_t)tm[(size_t)(r / kNB) * cd.T + col / kNB] * cd.tstride + (size_t)(r % kNB) * kNB + col % kNB];
+        };
         const int Nc = d.n_cams;
         for (int ca = 0; ca < Nc; ++ca)
             for (int cb = 0; cb < Nc; ++cb)
                 for (int a = 0; a < 6; ++a)
                     for (int b2 = 0; b2 < 6; ++b2) {
                         const int r = off[ca] + a, col = off[cb] + b2;
-                        const double v = (r >= col) ? h[(size_t)r * cd.n_pad + col] : h[(size_t)col * cd.n_pad + r];
-                        S_dense[(size_t)(6 * ca + a) * cd.n + 6 * cb + b2] = v;
+                        S_dense[(size_t)(6 * ca + a) * cd.n + 6 * cb + b2] = (r >= col) ? at(r, col) : at(col, r);
                     }
     }
     if ((e = chol_factor_solve(c))) return e;
