@@ -317,3 +317,29 @@ def test_mid_size_solves_match_c_restatement(lib, n_cams, n_pts, k_obs, dropout)
     again = H.to_product(arr)
     s2 = capi.solve(again, capi.default_options())
     assert s2.final_cost == s.final_cost and np.array_equal(again.cam_q, prod.cam_q) and np.array_equal(again.points, prod.points)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,n_cams,n_pts,k_obs,kw", [("sequential", 130, 4000, 4, {}), ("unordered", 150, 4000, 5, {}),
+                                                        ("sequential", 300, 6000, 8, {"dropout": 0.35})])
+def test_packed_tile_storage_equals_dense(lib, monkeypatch, mode, n_cams, n_pts, k_obs, kw):
+    """The reduced camera matrix lives in a dense n_pad x n_pad array while that is small and in PACKED form (only the
+    structurally non-zero 64x64 tiles, ba_chol.h: tile_ptr) beyond 4 GB — config T: 1.4 GB instead of 16.  Same kernels, same
+    order of operations: both forms must give bit-identical solves (level schedule, look-ahead panel schedule, split levels),
+    and the matrix read back through the debug entry must be the same."""
+    from xrsfm_amd import capi
+    arr = H.make(n_cams, n_pts, k_obs, seed=77, mode=mode, min_tri_angle_deg=1.0, **kw)
+    out = {}
+    for packed in ("0", "1"):
+        monkeypatch.setenv("XRSFM_BA_PACKED", packed)
+        ctx = capi.Context(H.to_product(arr))
+        ctx.debug_linearize(5.99, False)
+        y, S = ctx.debug_cholesky_solve(2e3, want_S=True)
+        ctx.reset()
+        s = ctx.run(capi.default_options(max_iterations=8, linear_solver=capi.SOLVER_CHOLESKY))
+        q, t, P = ctx.download()
+        ctx.close()
+        out[packed] = (y, S, s.final_cost, s.n_successful, s.n_unsuccessful, q, t, P)
+    a, b = out["0"], out["1"]
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert a[2:5] == b[2:5] and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
