@@ -65,7 +65,7 @@ def main():
             solver = 1
         if not big and not tiny:
             solver = 0 if (len(sys.argv) > 3 and sys.argv[3] == "pcg") else 1
-        for var in ("XRSFM_BA_PANEL_MACRO", "XRSFM_BA_PANEL_COLS", "XRSFM_BA_PANEL_LL"):
+        for var in ("XRSFM_BA_PANEL_MACRO", "XRSFM_BA_PANEL_COLS", "XRSFM_BA_LOOKAHEAD", "XRSFM_BA_PACKED"):
             os.environ.pop(var, None)
         mode = seed % 4
         if mode == 1:
@@ -73,7 +73,7 @@ def main():
         elif mode == 2:
             os.environ["XRSFM_BA_PANEL_MACRO"] = "1"; os.environ["XRSFM_BA_PANEL_COLS"] = "4"
         elif mode == 3:
-            os.environ["XRSFM_BA_PANEL_LL"] = "0"
+            os.environ["XRSFM_BA_LOOKAHEAD"] = "0"; os.environ["XRSFM_BA_PACKED"] = "1"      # round-2 panel schedule, packed tile storage
         ran += 1
         pr = H.to_oracle(arr)
         s_ref = bo.solve(pr, bo.Options(linear_solver="exact", max_iterations=6))

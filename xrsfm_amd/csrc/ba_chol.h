@@ -32,7 +32,6 @@ struct CholDev {
     double* rhs;      // [n_pad] working copy of b
     double* x;        // [n_pad]
     const int* cam_off;   // [n_cams] first scalar row of the camera's 6x6 diagonal block (tile-aligned groups)
-    const int* one_k;     // [T] identity list 0..T-1 (right-looking path: kernels read their panel from a list)
     const int* tile_rows; // [T] leading rows of the tile that hold cameras (the rest is identity padding)
     int cw, cpt;          // unknowns per camera and cameras per tile: 6 / 10, or 9 / 7 in bal9 mode (ba_wide.h)
 };
@@ -693,63 +692,6 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
     }
 }
 
-__global__ __launch_bounds__(256) void k_potrf(CholDev c, const int* __restrict__ klist, const int* __restrict__ rptr,
-                                               const int* __restrict__ rj) {
-    const int k = klist[blockIdx.x];
-    const int nb = (c.tile_rows[k] + 15) >> 4;       // 16-row blocks that are not pure identity padding
-    __shared__ double A[kNB][kLdT];
-    __shared__ double Li[kNB][kLdT];
-    __shared__ double Tb[3][16][17];
-    const int t = threadIdx.x;
-    double* base = tile_ptr(c, k, k);
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {           // 2048 double2 of the tile, 8 per thread; the upper triangle is masked to 0
-        const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
-        const double2 v = *reinterpret_cast<const double2*>(base + (size_t)r * c.ld + col);
-        A[r][col] = (col <= r) ? v.x : 0.0;
-        A[r][col + 1] = (col + 1 <= r) ? v.y : 0.0;
-        Li[r][col] = (r == col && r >= 16 * nb) ? 1.0 : 0.0;
-        Li[r][col + 1] = (r == col + 1 && r >= 16 * nb) ? 1.0 : 0.0;
-    }
-    __syncthreads();
-    potrf_lds(A, Li, Tb, nb);
-    double* lo = c.Linv + (size_t)k * kNB * kNB;
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
-        reinterpret_cast<double2*>(lo)[e] = make_double2((col <= r) ? Li[r][col] : 0.0, (col + 1 <= r) ? Li[r][col + 1] : 0.0);
-        double* dst = base + (size_t)r * c.ld + col;
-        if (col + 1 <= r) *reinterpret_cast<double2*>(dst) = make_double2(A[r][col], A[r][col + 1]);
-        else if (col <= r) dst[0] = A[r][col];
-    }
-    if (rptr) {     // forward substitution of this panel; Tb (3*16*17 doubles) is reused as 3 x 64 scratch
-        double* acc = &Tb[0][0][0]; double* v = acc + 64; double* tmp = acc + 128;
-        if (t < kNB) acc[t] = c.rhs[k * kNB + t];
-        const int o = t >> 2, part = t & 3;
-        for (int q = rptr[blockIdx.x]; q < rptr[blockIdx.x + 1]; ++q) {
-            const int j = rj[q];
-            __syncthreads();
-            if (t < kNB) v[t] = c.y[j * kNB + t];
-            __syncthreads();
-            const double* M = tile_ptr(c, k, j) + (size_t)o * c.ld + part * 16;
-            double sacc = 0.0;
-#pragma unroll
-            for (int m = 0; m < 16; ++m) sacc += M[m] * v[part * 16 + m];
-            sacc += __shfl_xor(sacc, 1, kWave);
-            sacc += __shfl_xor(sacc, 2, kWave);
-            if (part == 0) tmp[o] = sacc;
-            __syncthreads();
-            if (t < kNB) acc[t] -= tmp[t];
-        }
-        __syncthreads();
-        double sacc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) sacc += Li[o][part * 16 + m] * acc[part * 16 + m];
-        sacc += __shfl_xor(sacc, 1, kWave);
-        sacc += __shfl_xor(sacc, 2, kWave);
-        if (part == 0) c.y[k * kNB + o] = sacc;
-    }
-}
 
 // C(64x64) (op)= alpha * A(64x64) * B(64x64)^T on the FP64 matrix cores.  A, B row-major tiles in LDS
 // (stride kLdT).  4 waves, each a 32x32 quadrant = 2x2 MFMA 16x16 tiles, 16 k-steps of 4.
@@ -808,91 +750,6 @@ __device__ __forceinline__ void tile_gemv(const double* __restrict__ M, size_t l
     (void)red;
 }
 
-// (right-looking schedule) ... and the forward substitution of the panel rides along: with y_k = Linv_k rhs_k (k_potrf wrote
-// the same vector to c.y) every block updates its own row tile of the right-hand side, rhs_i -= L_ik y_k, from the tile it
-// has just formed — no separate forward launches.
-__global__ __launch_bounds__(256) void k_trsm(CholDev c, int k, const int* __restrict__ rows) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    __shared__ double vr[kNB], yk[kNB], tmp[kNB];
-    double* As = smem; double* Bs = smem + kNB * kLdT;
-    const int i = rows[blockIdx.x];
-    double* Ag = tile_ptr(c, i, k);
-    load_tile_lds(As, Ag, c.ld);
-    load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
-    if (threadIdx.x < kNB) vr[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
-    __syncthreads();
-    tile_gemv(Bs, kLdT, vr, yk, false, nullptr);
-    v4d acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_abt_mfma(As, Bs, acc);
-    __syncthreads();                              // all reads of As / Bs done, yk complete
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Ag[(size_t)r * c.ld + col] = acc[m][n2][g];
-                As[r * kLdT + col] = acc[m][n2][g];
-            }
-    __syncthreads();
-    tile_gemv(As, kLdT, yk, tmp, false, nullptr);
-    __syncthreads();
-    if (threadIdx.x < kNB) c.rhs[i * kNB + threadIdx.x] -= tmp[threadIdx.x];
-}
-
-// A_ij -= A_ik * A_jk^T for the tile pairs (i,j) listed in pairs[]
-__global__ __launch_bounds__(256) void k_update(CholDev c, int k, const int* __restrict__ pairs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* As = smem; double* Bs = smem + kNB * kLdT;
-    const int i = pairs[2 * blockIdx.x], j = pairs[2 * blockIdx.x + 1];
-    load_tile_lds(As, tile_ptr(c, i, k), c.ld);
-    load_tile_lds(Bs, tile_ptr(c, j, k), c.ld);
-    __syncthreads();
-    v4d acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_abt_mfma(As, Bs, acc);
-    double* Cg = tile_ptr(c, i, j);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Cg[(size_t)r * c.ld + col] -= acc[m][n2][g];
-            }
-}
-
-// 64x64 matrix-vector helpers (one workgroup of 256 threads): out = M v or M^T v, M row-major ld
-// forward substitution, panel k: y_k = Linv_k rhs_k;  rhs_i -= L_ik y_k for i in rows[]
-__global__ __launch_bounds__(256) void k_fwd(CholDev c, int k, const int* __restrict__ rows) {
-    __shared__ double v[kNB], yk[kNB], tmp[kNB];
-    if (threadIdx.x < kNB) v[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
-    __syncthreads();
-    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, v, yk, false, nullptr);
-    __syncthreads();
-    if (blockIdx.x == 0) {
-        if (threadIdx.x < kNB) c.y[k * kNB + threadIdx.x] = yk[threadIdx.x];
-        return;
-    }
-    const int i = rows[blockIdx.x - 1];
-    tile_gemv(tile_ptr(c, i, k), c.ld, yk, tmp, false, nullptr);
-    __syncthreads();
-    if (threadIdx.x < kNB) c.rhs[i * kNB + threadIdx.x] -= tmp[threadIdx.x];
-}
-
 // backward substitution, panel k: x_k = Linv_k^T y_k;  y_j -= L_kj^T x_k for j in cols[]
 __global__ __launch_bounds__(256) void k_bwd(CholDev c, int k, const int* __restrict__ cols) {
     // (requesting this workgroup's tile L_kj together with Linv_k and y_k — one memory round trip per column instead of two — was
@@ -917,56 +774,12 @@ __global__ void k_copy_pad(double* dst, const double* src, int n, int n_pad) {
     if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0;
 }
 
-// ------------------------------------------------------------ level-scheduled (left-looking) variants
-// Panels whose elimination-tree level is equal are independent; each launch below covers one level.
+// ------------------------------------------------------------ partial products of split levels / panel schedules
+// Panels whose elimination-tree level is equal are independent; each launch covers one level (or, look-ahead schedule, one column).
 // Targets never overlap inside a launch and every sum runs in list order, so the result is deterministic.
-
-__device__ __forceinline__ void store_acc_sub(double* Cg, size_t ld, const v4d (&acc)[2][2]) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Cg[(size_t)r * ld + col] -= acc[m][n2][g];
-            }
-}
-
-// Target tile (i,k):  A_ik -= sum_{j in contrib} A_ij A_kj^T.   tgt: (i,k) pairs; cptr/cj: CSR of contributing j.
-__global__ __launch_bounds__(256) void k_ll_update(CholDev c, const int* __restrict__ tgt, const int* __restrict__ cptr,
-                                                   const int* __restrict__ cj) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* As = smem; double* Bs = smem + kNB * kLdT;
-    const int i = tgt[2 * blockIdx.x], k = tgt[2 * blockIdx.x + 1];
-    v4d acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    const int q0 = cptr[blockIdx.x], q1 = cptr[blockIdx.x + 1];
-    double2 ra[8], rb[8];
-    if (q0 < q1) {
-        const int j = cj[q0];
-        load_tile_regs(ra, tile_ptr(c, i, j), c.ld);
-        load_tile_regs(rb, tile_ptr(c, k, j), c.ld);
-    }
-    for (int q = q0; q < q1; ++q) {
-        __syncthreads();                       // the previous product no longer reads LDS
-        store_tile_lds(As, ra);
-        store_tile_lds(Bs, rb);
-        __syncthreads();
-        if (q + 1 < q1) {                      // next contribution: loads in flight during the MFMAs below
-            const int j = cj[q + 1];
-            load_tile_regs(ra, tile_ptr(c, i, j), c.ld);
-            load_tile_regs(rb, tile_ptr(c, k, j), c.ld);
-        }
-        tile_abt_mfma(As, Bs, acc);
-    }
-    store_acc_sub(tile_ptr(c, i, k), c.ld, acc);
-}
+// (Round 1's right-looking kernels k_potrf / k_trsm / k_update and the launch-per-phase level kernels k_ll_update / k_ll_trsm /
+//  k_ll_fwd / k_ll_bwd, kept as A/B switches through round 2, were removed in round 3: every schedule now runs the fused
+//  factor kernel below.)
 
 // Thin levels near the root of the elimination tree have few targets with long lists: one workgroup per CHUNK [q0,q1) of a
 // target's list writes its partial sum (a full tile, + for a diagonal target (k,k) the 64 values sum_j L_kj y_j of the
@@ -1291,76 +1104,6 @@ __device__ __forceinline__ void ll_update_reduce_body(const CholDev& c, const in
 __global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* __restrict__ rt, const int* __restrict__ rp,
                                                           const double* __restrict__ Wp) {
     ll_update_reduce_body<1>(c, blockIdx.x, blockIdx.y, rt, rp, Wp);
-}
-
-// A_ik <- A_ik Linv_k^T for the (i,k) pairs of one level
-__global__ __launch_bounds__(256) void k_ll_trsm(CholDev c, const int* __restrict__ pairs) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    double* As = smem; double* Bs = smem + kNB * kLdT;
-    const int i = pairs[2 * blockIdx.x], k = pairs[2 * blockIdx.x + 1];
-    double* Ag = tile_ptr(c, i, k);
-    load_tile_lds(As, Ag, c.ld);
-    load_tile_lds(Bs, c.Linv + (size_t)k * kNB * kNB, kNB);
-    __syncthreads();
-    v4d acc[2][2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_abt_mfma(As, Bs, acc);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                Ag[(size_t)r * c.ld + col] = acc[m][n2][g];
-            }
-}
-
-// forward, one level: y_k = Linv_k (rhs_k - sum_{j in row(k)} L_kj y_j)
-__global__ __launch_bounds__(256) void k_ll_fwd(CholDev c, const int* __restrict__ klist, const int* __restrict__ rptr,
-                                                const int* __restrict__ rj) {
-    __shared__ double v[kNB], acc[kNB], tmp[kNB];
-    const int k = klist[blockIdx.x];
-    if (threadIdx.x < kNB) acc[threadIdx.x] = c.rhs[k * kNB + threadIdx.x];
-    for (int q = rptr[blockIdx.x]; q < rptr[blockIdx.x + 1]; ++q) {
-        const int j = rj[q];
-        __syncthreads();
-        if (threadIdx.x < kNB) v[threadIdx.x] = c.y[j * kNB + threadIdx.x];
-        __syncthreads();
-        tile_gemv(tile_ptr(c, k, j), c.ld, v, tmp, false, nullptr);
-        __syncthreads();
-        if (threadIdx.x < kNB) acc[threadIdx.x] -= tmp[threadIdx.x];
-    }
-    __syncthreads();
-    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, acc, tmp, false, nullptr);
-    __syncthreads();
-    if (threadIdx.x < kNB) c.y[k * kNB + threadIdx.x] = tmp[threadIdx.x];
-}
-
-// backward, one level: x_k = Linv_k^T (y_k - sum_{i in col(k)} L_ik^T x_i)
-__global__ __launch_bounds__(256) void k_ll_bwd(CholDev c, const int* __restrict__ klist, const int* __restrict__ cptr,
-                                                const int* __restrict__ ci) {
-    __shared__ double v[kNB], acc[kNB], tmp[kNB];
-    const int k = klist[blockIdx.x];
-    if (threadIdx.x < kNB) acc[threadIdx.x] = c.y[k * kNB + threadIdx.x];
-    for (int q = cptr[blockIdx.x]; q < cptr[blockIdx.x + 1]; ++q) {
-        const int i = ci[q];
-        __syncthreads();
-        if (threadIdx.x < kNB) v[threadIdx.x] = c.x[i * kNB + threadIdx.x];
-        __syncthreads();
-        tile_gemv(tile_ptr(c, i, k), c.ld, v, tmp, true, nullptr);
-        __syncthreads();
-        if (threadIdx.x < kNB) acc[threadIdx.x] -= tmp[threadIdx.x];
-    }
-    __syncthreads();
-    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, acc, tmp, true, nullptr);
-    __syncthreads();
-    if (threadIdx.x < kNB) c.x[k * kNB + threadIdx.x] = tmp[threadIdx.x];
 }
 
 // ------------------------------------------------------------ fused level kernels

@@ -35,10 +35,10 @@ struct CholPlan {
     int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
     int gram_n[8] = {0};             // Gram tiles per launch bucket 2 * (NI - 1) + (0 small | 1 big LDS class), in pairs_items order
     size_t gram_shm[8] = {0};        // dynamic LDS of each bucket's launch
-    std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, one_k, tiles_nz;
-    std::vector<int> rows_flat, pairs_flat, cols_flat, rows_off, pairs_off, cols_off;          // right-looking schedule
-    std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_trsm, lv_rptr, lv_rj, lv_bptr, lv_bi;     // level schedule
-    std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;
+    std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, tiles_nz;
+    std::vector<int> cols_flat, cols_off;                                  // per tile column its row tiles j < k (push-form backward substitution)
+    std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_bptr, lv_bi;         // level schedule
+    std::vector<int> lv_k_off, lv_tgt_off;
     // thin upper levels (few targets with long contribution lists): the lists are cut into chunks, one workgroup per
     // chunk writes a partial tile, a second launch adds the partials of a target in list order
     std::vector<int> sp_tgt, sp_q;      // per chunk: (i,k) and the [q0,q1) range in lv_cj
@@ -482,16 +482,13 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         const int ti = P.cam_off[blk_rc[2 * b]] / kPlanTile, tj = P.cam_off[blk_rc[2 * b + 1]] / kPlanTile;
         nz[(size_t)std::max(ti, tj) * T + std::min(ti, tj)] = 1;
     }
-    P.rows_off.assign(T + 1, 0); P.pairs_off.assign(T + 1, 0); P.cols_off.assign(T + 1, 0);
+    P.cols_off.assign(T + 1, 0);
     for (int kk = 0; kk < T; ++kk) {
         std::vector<int> R;
         for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) R.push_back(i);
-        for (int i : R) P.rows_flat.push_back(i);
         P.tile_products += (long long)R.size() * ((long long)R.size() + 1) / 2;
         for (size_t a = 0; a < R.size(); ++a)
-            for (size_t b2 = 0; b2 <= a; ++b2) { nz[(size_t)R[a] * T + R[b2]] = 1; P.pairs_flat.push_back(R[a]); P.pairs_flat.push_back(R[b2]); }
-        P.rows_off[kk + 1] = (int)P.rows_flat.size();
-        P.pairs_off[kk + 1] = (int)P.pairs_flat.size() / 2;
+            for (size_t b2 = 0; b2 <= a; ++b2) nz[(size_t)R[a] * T + R[b2]] = 1;
     }
     for (int kk = 0; kk < T; ++kk) {
         for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.cols_flat.push_back(j);
@@ -534,11 +531,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     // Deep trees (unordered / dense patterns: about one panel per level): "panel schedule" = left-looking updates per panel
     // (split into chunks), pivot + triangular solve per panel, push-form backward substitution
     bool panel_ll = (2 * n_levels > T);
-    if (const char* fl = std::getenv("XRSFM_BA_PANEL_LL")) panel_ll = (2 * n_levels > T) && fl[0] == '1';
     const int panel_min_chunk = 4, panel_chunks = 1024;      // (measured on config D: 512 / 768 / 1400 / 2048 chunks are 3-10 % slower)
     P.panel_ll = panel_ll;
-    P.lv_cptr.assign(1, 0); P.lv_rptr.assign(1, 0); P.lv_bptr.assign(1, 0);
-    P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0); P.lv_trsm_off.assign(n_levels + 1, 0);
+    P.lv_cptr.assign(1, 0); P.lv_bptr.assign(1, 0);
+    P.lv_k_off.assign(n_levels + 1, 0); P.lv_tgt_off.assign(n_levels + 1, 0);
     P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
     P.mp_off.assign(n_levels + 1, 0);
     P.fz_off.assign(n_levels + 1, 0); P.fz_dptr.assign(1, 0);
@@ -597,7 +593,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             if (level[kk] != lv) continue;
             for (int i = kk; i < T; ++i) {
                 if (!nz[(size_t)i * T + kk]) continue;
-                if (i > kk) { P.lv_trsm.push_back(i); P.lv_trsm.push_back(kk); }
                 std::vector<int> contrib;
                 if (lookahead) {        // the list of the partial products that are summed in place: j < k - 2
                     for (int j = 0; j < kk - 2; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
@@ -611,7 +606,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             }
         }
         P.lv_tgt_off[lv + 1] = (int)P.lv_tgt.size() / 2;
-        P.lv_trsm_off[lv + 1] = (int)P.lv_trsm.size() / 2;
         // split this level?  (few workgroups, each with a long serial list)
         const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
         const int nt = g1 - g0, nc = nt > 0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0;
@@ -714,11 +708,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int kk = 0; kk < T; ++kk) {
             if (level[kk] != lv) continue;
             P.lv_k.push_back(kk);
-            // forward: row tiles j < k (none on a split level: the diagonal target's chunks form L_kj y_j with the tile
-            // they already hold); backward: column tiles i > k   (CSR aligned with lv_k)
-            if (!split && !macro)
-                for (int j = first_j[kk]; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.lv_rj.push_back(j);
-            P.lv_rptr.push_back((int)P.lv_rj.size());
+            // backward: column tiles i > k   (CSR aligned with lv_k)
             for (int i = kk + 1; i < T; ++i) if (nz[(size_t)i * T + kk]) P.lv_bi.push_back(i);
             P.lv_bptr.push_back((int)P.lv_bi.size());
         }
@@ -824,8 +814,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 }
             }
     }
-    P.one_k.resize(T);
-    for (int t = 0; t < T; ++t) P.one_k[t] = t;
     {
         // S-assembly launches: one per (operand height NI = ceil(6 C / 16), LDS class) of the Gram tiles — the kernel is
         // instantiated per NI so that the 10 accumulators of a 10-camera tile do not shape (and spill) the register allocation

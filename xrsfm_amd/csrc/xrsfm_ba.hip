@@ -104,15 +104,15 @@ struct CholHost {
     int gram_n[8] = {0}; size_t gram_shm[8] = {0};   // Gram tiles / dynamic LDS per launch bucket (ba_plan.h)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // the non-Gram items run concurrently
     // right-looking schedule (dense patterns): one panel after the other
-    int *rows_flat = nullptr, *pairs_flat = nullptr, *cols_flat = nullptr;   // device lists
-    std::vector<int> rows_off, pairs_off, cols_off;                          // host offsets per panel (size T+1)
+    int* cols_flat = nullptr;                     // device list: per tile column its row tiles j < k (push-form backward substitution)
+    std::vector<int> cols_off;                    // host offsets per column (size T+1)
     // level schedule (elimination-tree levels of the tile pattern; left-looking updates)
     bool use_levels = false, panel_ll = false;
     bool lookahead = false;                       // look-ahead panel schedule (ba_plan.h): one launch per column (k_panel_slot)
     int n_levels = 0;
-    int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr, *lv_trsm = nullptr;
-    int *lv_rptr = nullptr, *lv_rj = nullptr, *lv_bptr = nullptr, *lv_bi = nullptr;
-    std::vector<int> lv_k_off, lv_tgt_off, lv_trsm_off;      // per level offsets (size n_levels+1)
+    int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr;
+    int *lv_bptr = nullptr, *lv_bi = nullptr;
+    std::vector<int> lv_k_off, lv_tgt_off;        // per level offsets (size n_levels+1)
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off, mp_off;
     int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
@@ -123,7 +123,6 @@ struct CholHost {
     int *fz_q = nullptr, *fill_rest = nullptr; int n_fill_rest = 0;    // tile fill inside the first level's launch
     bool S_filled = false;                                   // chol_assemble ran k_tile_fill (else the first level composes its tiles)
     std::vector<int> fz_off;
-    int* zero2 = nullptr;                                    // two zeros: an empty CSR row list
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
     std::vector<int> tile_map_host; size_t S_doubles = 0;    // packed tile storage of S (CholDev::tmap), its size in doubles
@@ -593,19 +592,17 @@ int chol_setup(xrsfm_ba_context* c) {
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.lookahead = P.lookahead; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
-    h.rows_off = P.rows_off; h.pairs_off = P.pairs_off; h.cols_off = P.cols_off;
-    h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off; h.lv_trsm_off = P.lv_trsm_off;
+    h.cols_off = P.cols_off;
+    h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.mp_off = P.mp_off; h.fz_off = P.fz_off;
-    int *d_cam_off = nullptr, *d_one_k = nullptr, *d_tile_rows = nullptr, *d_tmap = nullptr;
+    int *d_cam_off = nullptr, *d_tile_rows = nullptr, *d_tmap = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     BatchUpload up(c);
     up.add(&h.slot_pair_ptr, P.spp); up.add(&h.pair_dst, P.pair_dst);
     up.add(&h.blk_ptr, P.blk_ptr); up.add(&h.blk_rc, P.blk_rc);
-    up.add(&h.tiles_nz, P.tiles_nz); up.add(&h.rows_flat, P.rows_flat);
-    up.add(&h.pairs_flat, P.pairs_flat); up.add(&h.cols_flat, P.cols_flat);
+    up.add(&h.tiles_nz, P.tiles_nz); up.add(&h.cols_flat, P.cols_flat);
     up.add(&h.lv_k, P.lv_k); up.add(&h.lv_tgt, P.lv_tgt); up.add(&h.lv_cptr, P.lv_cptr);
-    up.add(&h.lv_cj, P.lv_cj); up.add(&h.lv_trsm, P.lv_trsm);
-    up.add(&h.lv_rptr, P.lv_rptr); up.add(&h.lv_rj, P.lv_rj);
+    up.add(&h.lv_cj, P.lv_cj);
     up.add(&h.lv_bptr, P.lv_bptr); up.add(&h.lv_bi, P.lv_bi);
     up.add(&h.sp_tgt, P.sp_tgt); up.add(&h.sp_q, P.sp_q); up.add(&h.mp_chunk, P.mp_chunk); up.add(&h.mp_wg, P.mp_wg);
     up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp);
@@ -615,13 +612,11 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.md_tgt, P.md_tgt); up.add(&h.md_q, P.md_q); up.add(&h.md_cj, P.md_cj); up.add(&h.fz_late, P.fz_late);
     h.md_off = P.md_off; h.md_max = P.md_max;
     up.add(&h.tile_cam, P.tile_cam);
-    const std::vector<int> two_zeros(2, 0);      // must outlive up.flush()
-    up.add(&h.zero2, two_zeros);
     up.add(&h.pairs_items, P.pairs_items);
     h.sp_max_chunks = P.sp_max_chunks;
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
     if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
-    up.add(&d_cam_off, P.cam_off); up.add(&d_one_k, P.one_k); up.add(&d_tile_rows, P.tile_rows); up.add(&d_tmap, P.tile_map);
+    up.add(&d_cam_off, P.cam_off); up.add(&d_tile_rows, P.tile_rows); up.add(&d_tmap, P.tile_map);
     TRYC(up.flush());
     timer.mark("uploads");
     const size_t blk_vals = c->wide ? kWB : 36, cam_vals = c->wide ? kWS : 28;
@@ -632,7 +627,7 @@ int chol_setup(xrsfm_ba_context* c) {
         if (c->wide) c->w.camS = both; else c->d.camS = both;
         h.Sblk = both + (size_t)Nc * cam_vals;
     }
-    h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.one_k = d_one_k; h.dev.tile_rows = d_tile_rows;
+    h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.tile_rows = d_tile_rows;
     h.dev.cw = P.cam_width; h.dev.cpt = P.cams_per_tile;
     // tile storage of S: dense n_pad x n_pad while that is small (<= 4 GB: one address computation less per tile; measured at L / X / D:
     // 1-3 % faster than the packed form), else packed = only the structurally non-zero tiles + one zero tile (config T: 1.4 GB
@@ -659,10 +654,6 @@ int chol_setup(xrsfm_ba_context* c) {
         std::lock_guard<std::mutex> g(mu);
         if (c->device < 64 && !done_for[c->device]) {
             const int pairs_max = kGramMaxLds + kGramTabLd * kGramTabLd * (int)sizeof(int);
-            (void)hipFuncSetAttribute((const void*)k_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-            (void)hipFuncSetAttribute((const void*)k_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-            (void)hipFuncSetAttribute((const void*)k_ll_trsm, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
-            (void)hipFuncSetAttribute((const void*)k_ll_update, hipFuncAttributeMaxDynamicSharedMemorySize, shm);
 #define XBA_PAIRS_ATTR(NI) \
             (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max); \
             (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
@@ -737,7 +728,7 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
     static const bool fill_in_level0 = [] { const char* e = std::getenv("XRSFM_BA_FILL_FUSED"); return !(e && e[0] == '0'); }();
-    h.S_filled = materialize || !fill_in_level0 || !((h.use_levels || h.panel_ll) && c->fused);
+    h.S_filled = materialize || !fill_in_level0;
     if (h.S_filled && h.n_tiles_nz > 0)
         LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc,
                c->step_prep ? c->step_radius : 0.0);
@@ -751,7 +742,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
     const int T = h.T;
     double* px_out = c->wide ? c->w.px : d.px;        // solution in camera order, cw values per camera
     const size_t shm = 2 * (size_t)kNB * kLdT * sizeof(double);
-    if (h.lookahead && c->fused) {
+    if (h.lookahead) {
         // Look-ahead panel schedule (ba_plan.h, k_panel_slot): level = column, one launch per column s =
         //   factor of column s (starts from the late partials of column s-2, adds column s-1 itself)
         //   | fixed-order sum of the partial products of column s+1 into its tiles   | late partials of column s+1 (column s-1)
@@ -794,7 +785,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
         if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
         return 0;
     }
-    if ((h.use_levels || h.panel_ll) && c->fused) {
+    if (h.use_levels || h.panel_ll) {
         // one launch per elimination-tree level (three on a split level: partial products, their fixed-order sum, then the
         // same fused kernel with empty lists), then one per level backwards
         for (int lv = 0; lv < h.n_levels; ++lv) {
@@ -840,54 +831,8 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, px_out);
         }
         return 0;
-    } else if (h.use_levels || h.panel_ll) {
-        // one launch per elimination-tree level and phase
-        for (int lv = 0; lv < h.n_levels; ++lv) {
-            const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
-            const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
-            const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
-            if (nmc > 0 || nch > 0) {      // chunks of the contribution lists in parallel, then a fixed-order sum
-                if (nmc > 0)
-                    LAUNCH(c, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
-                else
-                    LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
-                           h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-                LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
-                       h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
-            } else if (nt > 0)
-                LAUNCH(c, K_UPDATE, k_ll_update, dim3(nt), dim3(256), shm, h.dev, h.lv_tgt + 2 * (size_t)h.lv_tgt_off[lv], h.lv_cptr + h.lv_tgt_off[lv], h.lv_cj);
-            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
-            LAUNCH(c, K_POTRF, k_potrf, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_rptr + h.lv_k_off[lv], h.lv_rj);
-            const int ns = h.lv_trsm_off[lv + 1] - h.lv_trsm_off[lv];
-            if (ns > 0) LAUNCH(c, K_TRSM, k_ll_trsm, dim3(ns), dim3(256), shm, h.dev, h.lv_trsm + 2 * (size_t)h.lv_trsm_off[lv]);
-        }
-        // (the forward substitution is folded into k_potrf)
-        if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
-            for (int k = T - 1; k >= 0; --k) {
-                const int ncol = h.cols_off[k + 1] - h.cols_off[k];
-                LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
-            }
-        } else
-        for (int lv = h.n_levels - 1; lv >= 0; --lv) {
-            const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
-            LAUNCH(c, K_TRISOLVE, k_ll_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi);
-        }
-    } else {
-        for (int k = 0; k < T; ++k) {
-            LAUNCH(c, K_POTRF, k_potrf, dim3(1), dim3(256), 0, h.dev, h.dev.one_k + k, (const int*)h.zero2, (const int*)h.zero2);   // empty row list: y_k = Linv_k rhs_k
-            const int nr = h.rows_off[k + 1] - h.rows_off[k];
-            if (nr > 0) LAUNCH(c, K_TRSM, k_trsm, dim3(nr), dim3(256), shm, h.dev, k, h.rows_flat + h.rows_off[k]);
-            const int np = h.pairs_off[k + 1] - h.pairs_off[k];
-            if (np > 0) LAUNCH(c, K_UPDATE, k_update, dim3(np), dim3(256), shm, h.dev, k, h.pairs_flat + 2 * (size_t)h.pairs_off[k]);
-        }
-        // (forward substitution: folded into k_potrf / k_trsm)
-        for (int k = T - 1; k >= 0; --k) {
-            const int ncol = h.cols_off[k + 1] - h.cols_off[k];
-            LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
-        }
     }
-    if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
-    return 0;
+    return XRSFM_BA_EINTERNAL;      // (every plan has a level or a panel schedule)
 }
 
 // back-substitute, build the candidate state, evaluate its cost; scalars end up in h_scal
