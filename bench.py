@@ -471,9 +471,7 @@ def main():
         }
         if args.config == "Lb9":
             out["config"]["workload"] += "; bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks"
-            out["cpu_baseline_note"] = ("the C restatement under oracle/ is 6-wide; bal9 parity is checked against the numpy oracle "
-                                        "in tests/test_gpu_bal9.py, and no CPU time is quoted for this configuration")
-        if world == 1 and not args.no_cpu and args.config != "Lb9":
+        if world == 1 and not args.no_cpu:
             res = cpu_baseline(arr, n_cams, n_points, opt.max_iterations)
             if res is not None:
                 base, cpu_prob = res
@@ -483,7 +481,13 @@ def main():
                 base["rmse_diff_px"] = abs(base["final_rmse_px"] - out["final_rmse_px"])
                 base["max_cam_param_diff"] = float(max(np.abs(cpu_prob["cam_q"] - q).max(), np.abs(cpu_prob["cam_t"] - t).max()))
                 base["max_centre_diff_gauge_aligned"] = gauge_aligned_centre_diff(cpu_prob["cam_q"], cpu_prob["cam_t"], q, t)
-                base["parity"] = parity_block(arr, q, t, P, cpu_prob)
+                if args.config != "Lb9":
+                    base["parity"] = parity_block(arr, q, t, P, cpu_prob)
+                if args.config == "Lb9":          # the variable intrinsics {f, k1, k2} of both results
+                    gi = ctx.download_intrinsics()
+                    var = (np.asarray(arr["cam_const"]) & 4) != 0
+                    base["max_rel_focal_diff"] = float(np.abs(gi[var, 0] / cpu_prob["intr_params"][var, 0] - 1).max())
+                    base["max_distortion_diff"] = float(np.abs(gi[var, 1:3] - cpu_prob["intr_params"][var, 1:3]).max())
                 out["cpu_baseline"] = base
     ctx.close()
     if rank == 0:

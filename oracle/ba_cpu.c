@@ -7,7 +7,7 @@
  * PARITY UNPINNED against real Ceres (Ceres is not vendored under
  * /root/reference and not installed here; the reference ships no golden
  * vectors — SURVEY.md 8c).  This file is pinned to oracle/ba_oracle.py by
- * tests/test_oracle_c.py; ba_oracle.py's Jacobians are pinned to autodiff of
+ * tests/test_oracle_golden.py; ba_oracle.py's Jacobians are pinned to autodiff of
  * the reference functor.
  *
  * What it restates (same structure as Ceres' SPARSE_SCHUR path the reference
@@ -17,6 +17,10 @@
  *   LM loop                    SURVEY.md A.5/A.6 (TrustRegionMinimizer, LevenbergMarquardtStrategy)
  *   linear solve               exact Schur complement (A.7): 3x3 point blocks eliminated, reduced
  *                              camera matrix in block-envelope storage, Cholesky, back-substitution
+ *   bal9 mode (round 3)        camera blocks of width CW = 9 {rotation 3, translation 3, f, k1, k2} as soon as one camera
+ *                              keeps its intrinsics variable (cam_const bit 2, extension camera model 5; the reference
+ *                              never frees intrinsics, ba_solver.cc:602-606): the same code with CW instead of 6; pinned to
+ *                              oracle/ba_oracle.py's bal9 branch by tests/test_oracle_golden.py
  */
 #include <math.h>
 #include <stdint.h>
@@ -31,7 +35,9 @@
 
 typedef struct {
     int Nc, Np, No;
+    int CW;                     /* unknowns per camera block: 6, or 9 in bal9 mode */
     const xrsfm_ba_problem* p;
+    double *K, *K2;             /* intrinsics entries [n_intr][8]: current and candidate (only {f,k1,k2} of variable cameras move) */
     int* pt_ptr;   /* CSR by point: obs ids sorted by (point, camera) */
     int* pt_obs;
     int* cam_ptr;  /* CSR by camera */
@@ -39,10 +45,10 @@ typedef struct {
     int* rank_in_track; /* position of an obs inside its track list */
     double *q, *t, *P;          /* current state */
     double *q2, *t2, *P2;       /* candidate */
-    double *rt, *F, *E;         /* per obs: 2, 12, 6 (scaled, robustified) */
-    double *W, *WH;             /* per obs: 18, 18 */
+    double *rt, *F, *E;         /* per obs: 2, 2*CW, 6 (scaled, robustified) */
+    double *W, *WH;             /* per obs: 3*CW each */
     double *Hpp, *gp, *Hinv;    /* per point: 9 (full), 3, 9 */
-    double *Hcc, *gc;           /* per cam: 36, 6 */
+    double *Hcc, *gc;           /* per cam: CW*CW, CW */
     double *sc_c, *sc_p;
     double *yc, *yp;
     int* first;                 /* block envelope: first column block of each block row */
@@ -61,7 +67,7 @@ static void quat_to_mat(const double* q, double* M) {
 
 /* residual r[2], d r / d Pc (jp 2x3) and rp = M P; returns 1 if clamped (z < 1e-2) */
 static int project(const double* M, const double* t, const double* k, int model, const double* P, const double* uv,
-                   double* r, double* jp, double* rp, int want_jac) {
+                   double* r, double* jp, double* rp, int want_jac, double* ji) {
     rp[0] = M[0] * P[0] + M[1] * P[1] + M[2] * P[2];
     rp[1] = M[3] * P[0] + M[4] * P[1] + M[5] * P[2];
     rp[2] = M[6] * P[0] + M[7] * P[1] + M[8] * P[2];
@@ -69,6 +75,7 @@ static int project(const double* M, const double* t, const double* k, int model,
     if (Z < 1e-2) {
         r[0] = 12.0; r[1] = 12.0;
         if (want_jac) memset(jp, 0, 6 * sizeof(double));
+        if (ji) memset(ji, 0, 6 * sizeof(double));
         return 1;
     }
     const double iz = 1.0 / Z, xn = X * iz, yn = Y * iz, r2 = xn * xn + yn * yn;
@@ -82,6 +89,12 @@ static int project(const double* M, const double* t, const double* k, int model,
         const double rad = kk * r2;
         du = xn * rad; dv = yn * rad;
         D00 = 1 + rad + 2 * kk * xn * xn; D11 = 1 + rad + 2 * kk * yn * yn; D01 = 2 * kk * xn * yn; D10 = D01;
+    } else if (model == 5) {     /* extension: f (1 + k1 r2 + k2 r2^2) (x, y), no principal point */
+        fx = k[0]; fy = k[0]; cx = 0.0; cy = 0.0;
+        const double k1 = k[1], k2 = k[2], rad = k1 * r2 + k2 * r2 * r2;
+        du = xn * rad; dv = yn * rad;
+        const double rad_x = 2 * k1 * xn + 4 * k2 * r2 * xn, rad_y = 2 * k1 * yn + 4 * k2 * r2 * yn;
+        D00 = 1 + rad + xn * rad_x; D01 = xn * rad_y; D10 = yn * rad_x; D11 = 1 + rad + yn * rad_y;
     } else {
         fx = k[0]; fy = k[1]; cx = k[2]; cy = k[3];
         const double k1 = k[4], k2 = k[5], p1 = k[6], p2 = k[7];
@@ -100,6 +113,12 @@ static int project(const double* M, const double* t, const double* k, int model,
         const double A00 = fx * D00, A01 = fx * D01, A10 = fy * D10, A11 = fy * D11;
         jp[0] = A00 * iz; jp[1] = A01 * iz; jp[2] = -(A00 * xn + A01 * yn) * iz;
         jp[3] = A10 * iz; jp[4] = A11 * iz; jp[5] = -(A10 * xn + A11 * yn) * iz;
+    }
+    if (ji) {                    /* d r / d (f, k1, k2): model 5 only */
+        if (model == 5) {
+            ji[0] = xn + du; ji[1] = fx * xn * r2; ji[2] = fx * xn * r2 * r2;
+            ji[3] = yn + dv; ji[4] = fy * yn * r2; ji[5] = fy * yn * r2 * r2;
+        } else memset(ji, 0, 6 * sizeof(double));
     }
     return 0;
 }
@@ -123,35 +142,37 @@ static void quat_plus(const double* q, const double* d, double* out) {
 }
 
 /* cost (and, if want_jac, rt/F/E with the current scaling) at state (q,t,P) */
-static double evaluate(Ctx* c, const double* q, const double* t, const double* P, int want_jac) {
+static double evaluate(Ctx* c, const double* q, const double* t, const double* P, const double* K, int want_jac) {
     const xrsfm_ba_problem* p = c->p;
+    const int CW = c->CW;
     double cost = 0.0;
 #pragma omp parallel for reduction(+ : cost) schedule(static)
     for (int i = 0; i < c->No; ++i) {
         const int cam = p->obs_cam[i], pt = p->obs_pt[i];
         const int ii = p->cam_intr[cam];
-        double M[9], r[2], jp[6], rp[3];
+        double M[9], r[2], jp[6], rp[3], ji[6];
         quat_to_mat(q + 4 * (size_t)cam, M);
-        project(M, t + 3 * (size_t)cam, p->intr_params + 8 * (size_t)ii, p->intr_model[ii], P + 3 * (size_t)pt,
-                p->obs_uv + 2 * (size_t)i, r, jp, rp, want_jac);
+        project(M, t + 3 * (size_t)cam, K + 8 * (size_t)ii, p->intr_model[ii], P + 3 * (size_t)pt,
+                p->obs_uv + 2 * (size_t)i, r, jp, rp, want_jac, (want_jac && CW == 9) ? ji : NULL);
         double rho1;
         cost += huber(r[0] * r[0] + r[1] * r[1], c->huber_a, &rho1);
         if (!want_jac) continue;
         const double sw = sqrt(rho1);
         const unsigned cc = p->cam_const ? p->cam_const[cam] : 0u;
-        const double mq = (cc & 1u) ? 0.0 : sw, mt = (cc & 2u) ? 0.0 : sw;
+        const double mq = (cc & 1u) ? 0.0 : sw, mt = (cc & 2u) ? 0.0 : sw, mi = (cc & 4u) ? sw : 0.0;
         const double mp = (p->point_const && p->point_const[pt]) ? 0.0 : sw;
-        const double* sc = c->sc_c + 6 * (size_t)cam;
+        const double* sc = c->sc_c + CW * (size_t)cam;
         const double* sp = c->sc_p + 3 * (size_t)pt;
-        double* F = c->F + 12 * (size_t)i;
+        double* F = c->F + 2 * CW * (size_t)i;
         double* E = c->E + 6 * (size_t)i;
         c->rt[2 * (size_t)i] = r[0] * sw; c->rt[2 * (size_t)i + 1] = r[1] * sw;
         for (int row = 0; row < 2; ++row) {
             const double* j = jp + 3 * row;
-            F[6 * row + 0] = -2.0 * (j[1] * rp[2] - j[2] * rp[1]) * mq * sc[0];
-            F[6 * row + 1] = -2.0 * (j[2] * rp[0] - j[0] * rp[2]) * mq * sc[1];
-            F[6 * row + 2] = -2.0 * (j[0] * rp[1] - j[1] * rp[0]) * mq * sc[2];
-            F[6 * row + 3] = j[0] * mt * sc[3]; F[6 * row + 4] = j[1] * mt * sc[4]; F[6 * row + 5] = j[2] * mt * sc[5];
+            F[CW * row + 0] = -2.0 * (j[1] * rp[2] - j[2] * rp[1]) * mq * sc[0];
+            F[CW * row + 1] = -2.0 * (j[2] * rp[0] - j[0] * rp[2]) * mq * sc[1];
+            F[CW * row + 2] = -2.0 * (j[0] * rp[1] - j[1] * rp[0]) * mq * sc[2];
+            F[CW * row + 3] = j[0] * mt * sc[3]; F[CW * row + 4] = j[1] * mt * sc[4]; F[CW * row + 5] = j[2] * mt * sc[5];
+            if (CW == 9) for (int a = 0; a < 3; ++a) F[CW * row + 6 + a] = ji[3 * row + a] * mi * sc[6 + a];
             E[3 * row + 0] = (j[0] * M[0] + j[1] * M[3] + j[2] * M[6]) * mp * sp[0];
             E[3 * row + 1] = (j[0] * M[1] + j[1] * M[4] + j[2] * M[7]) * mp * sp[1];
             E[3 * row + 2] = (j[0] * M[2] + j[1] * M[5] + j[2] * M[8]) * mp * sp[2];
@@ -179,18 +200,19 @@ static void build_blocks(Ctx* c) {
     }
 #pragma omp parallel for schedule(dynamic, 4)
     for (int cam = 0; cam < c->Nc; ++cam) {
-        double H[36] = {0}, g[6] = {0};
+        const int CW = c->CW;
+        double H[81] = {0}, g[9] = {0};
         for (int k = c->cam_ptr[cam]; k < c->cam_ptr[cam + 1]; ++k) {
             const int i = c->cam_obs[k];
-            const double* F = c->F + 12 * (size_t)i;
+            const double* F = c->F + 2 * CW * (size_t)i;
             const double* r = c->rt + 2 * (size_t)i;
-            for (int a = 0; a < 6; ++a) {
-                for (int b = 0; b < 6; ++b) H[6 * a + b] += F[a] * F[b] + F[6 + a] * F[6 + b];
-                g[a] += F[a] * r[0] + F[6 + a] * r[1];
+            for (int a = 0; a < CW; ++a) {
+                for (int b = 0; b < CW; ++b) H[CW * a + b] += F[a] * F[b] + F[CW + a] * F[CW + b];
+                g[a] += F[a] * r[0] + F[CW + a] * r[1];
             }
         }
-        memcpy(c->Hcc + 36 * (size_t)cam, H, sizeof H);
-        memcpy(c->gc + 6 * (size_t)cam, g, sizeof g);
+        memcpy(c->Hcc + CW * CW * (size_t)cam, H, CW * CW * sizeof(double));
+        memcpy(c->gc + CW * (size_t)cam, g, CW * sizeof(double));
     }
 }
 
@@ -207,7 +229,7 @@ static double clampd(double v, double lo, double hi) { return v < lo ? lo : (v >
 
 /* Solve (Js^T Js + D^2) y = Js^T r by exact Schur elimination; returns 0 on success */
 static int solve_step(Ctx* c, double radius) {
-    const int Nc = c->Nc, Np = c->Np;
+    const int Nc = c->Nc, Np = c->Np, CW = c->CW;
 #pragma omp parallel for schedule(static)
     for (int j = 0; j < Np; ++j) {
         double H[9];
@@ -217,57 +239,57 @@ static int solve_step(Ctx* c, double radius) {
     }
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < c->No; ++i) {
-        const double* F = c->F + 12 * (size_t)i;
+        const double* F = c->F + 2 * CW * (size_t)i;
         const double* E = c->E + 6 * (size_t)i;
         const double* Hi = c->Hinv + 9 * (size_t)c->p->obs_pt[i];
-        double* W = c->W + 18 * (size_t)i;
-        double* WH = c->WH + 18 * (size_t)i;
-        for (int a = 0; a < 6; ++a) {
-            for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[6 + a] * E[3 + b];
+        double* W = c->W + 3 * CW * (size_t)i;
+        double* WH = c->WH + 3 * CW * (size_t)i;
+        for (int a = 0; a < CW; ++a) {
+            for (int b = 0; b < 3; ++b) W[3 * a + b] = F[a] * E[b] + F[CW + a] * E[3 + b];
             for (int b = 0; b < 3; ++b) WH[3 * a + b] = W[3 * a] * Hi[b] + W[3 * a + 1] * Hi[3 + b] + W[3 * a + 2] * Hi[6 + b];
         }
     }
     memset(c->env, 0, c->env_n * sizeof(double));
-    const int n = 6 * Nc;
+    const int n = CW * Nc;
     /* rows are owned by their camera: no write conflicts */
 #pragma omp parallel for schedule(dynamic, 4)
     for (int cam = 0; cam < Nc; ++cam) {
-        double bl[6];
-        for (int a = 0; a < 6; ++a) bl[a] = c->gc[6 * (size_t)cam + a];
-        const int fc = 6 * c->first[cam];
+        double bl[9];
+        for (int a = 0; a < CW; ++a) bl[a] = c->gc[CW * (size_t)cam + a];
+        const int fc = CW * c->first[cam];
         /* diagonal block: Hcc + D^2 */
-        for (int a = 0; a < 6; ++a) {
-            double* row = c->env + c->rowoff[6 * cam + a] - fc;
-            for (int b = 0; b <= a; ++b) row[6 * cam + b] += c->Hcc[36 * (size_t)cam + 6 * a + b];
-            row[6 * cam + a] += clampd(c->Hcc[36 * (size_t)cam + 7 * a], 1e-6, 1e32) / radius;
+        for (int a = 0; a < CW; ++a) {
+            double* row = c->env + c->rowoff[CW * cam + a] - fc;
+            for (int b = 0; b <= a; ++b) row[CW * cam + b] += c->Hcc[CW * CW * (size_t)cam + CW * a + b];
+            row[CW * cam + a] += clampd(c->Hcc[CW * CW * (size_t)cam + (CW + 1) * a], 1e-6, 1e32) / radius;
         }
         for (int k = c->cam_ptr[cam]; k < c->cam_ptr[cam + 1]; ++k) {
             const int i = c->cam_obs[k];
             const int j = c->p->obs_pt[i];
-            const double* WHi = c->WH + 18 * (size_t)i;
+            const double* WHi = c->WH + 3 * CW * (size_t)i;
             const double* g = c->gp + 3 * (size_t)j;
-            for (int a = 0; a < 6; ++a) bl[a] -= WHi[3 * a] * g[0] + WHi[3 * a + 1] * g[1] + WHi[3 * a + 2] * g[2];
+            for (int a = 0; a < CW; ++a) bl[a] -= WHi[3 * a] * g[0] + WHi[3 * a + 1] * g[1] + WHi[3 * a + 2] * g[2];
             for (int kk = c->pt_ptr[j]; kk < c->pt_ptr[j + 1]; ++kk) {
                 const int i2 = c->pt_obs[kk];
                 const int cam2 = c->p->obs_cam[i2];
                 if (cam2 > cam) continue;
-                const double* W2 = c->W + 18 * (size_t)i2;
-                for (int a = 0; a < 6; ++a) {
-                    double* row = c->env + c->rowoff[6 * cam + a] - fc;
-                    const int bmax = (cam2 == cam) ? a : 5;
+                const double* W2 = c->W + 3 * CW * (size_t)i2;
+                for (int a = 0; a < CW; ++a) {
+                    double* row = c->env + c->rowoff[CW * cam + a] - fc;
+                    const int bmax = (cam2 == cam) ? a : CW - 1;
                     for (int b = 0; b <= bmax; ++b)
-                        row[6 * cam2 + b] -= WHi[3 * a] * W2[3 * b] + WHi[3 * a + 1] * W2[3 * b + 1] + WHi[3 * a + 2] * W2[3 * b + 2];
+                        row[CW * cam2 + b] -= WHi[3 * a] * W2[3 * b] + WHi[3 * a + 1] * W2[3 * b + 1] + WHi[3 * a + 2] * W2[3 * b + 2];
                 }
             }
         }
-        for (int a = 0; a < 6; ++a) c->b[6 * (size_t)cam + a] = bl[a];
+        for (int a = 0; a < CW; ++a) c->b[CW * (size_t)cam + a] = bl[a];
     }
     /* envelope Cholesky, row by row: L[r][col] for col in [fc_r, r] */
     for (int r = 0; r < n; ++r) {
-        const int fr = 6 * c->first[r / 6];
+        const int fr = CW * c->first[r / CW];
         double* Lr = c->env + c->rowoff[r] - fr;
         for (int col = fr; col <= r; ++col) {
-            const int fcol = 6 * c->first[col / 6];
+            const int fcol = CW * c->first[col / CW];
             const double* Lc = c->env + c->rowoff[col] - fcol;
             const int k0 = fr > fcol ? fr : fcol;
             double s = Lr[col];
@@ -278,14 +300,14 @@ static int solve_step(Ctx* c, double radius) {
     }
     double* y = c->yc;
     for (int r = 0; r < n; ++r) {       /* forward: L z = b */
-        const int fr = 6 * c->first[r / 6];
+        const int fr = CW * c->first[r / CW];
         const double* Lr = c->env + c->rowoff[r] - fr;
         double s = c->b[r];
         for (int k = fr; k < r; ++k) s -= Lr[k] * y[k];
         y[r] = s / Lr[r];
     }
     for (int r = n - 1; r >= 0; --r) {  /* backward: L^T y = z (column sweep) */
-        const int fr = 6 * c->first[r / 6];
+        const int fr = CW * c->first[r / CW];
         const double* Lr = c->env + c->rowoff[r] - fr;
         y[r] /= Lr[r];
         const double v = y[r];
@@ -297,9 +319,9 @@ static int solve_step(Ctx* c, double radius) {
         double a[3] = {c->gp[3 * (size_t)j], c->gp[3 * (size_t)j + 1], c->gp[3 * (size_t)j + 2]};
         for (int k = c->pt_ptr[j]; k < c->pt_ptr[j + 1]; ++k) {
             const int i = c->pt_obs[k];
-            const double* W = c->W + 18 * (size_t)i;
-            const double* yc = c->yc + 6 * (size_t)c->p->obs_cam[i];
-            for (int m = 0; m < 6; ++m) { a[0] -= W[3 * m] * yc[m]; a[1] -= W[3 * m + 1] * yc[m]; a[2] -= W[3 * m + 2] * yc[m]; }
+            const double* W = c->W + 3 * CW * (size_t)i;
+            const double* yc = c->yc + CW * (size_t)c->p->obs_cam[i];
+            for (int m = 0; m < CW; ++m) { a[0] -= W[3 * m] * yc[m]; a[1] -= W[3 * m + 1] * yc[m]; a[2] -= W[3 * m + 2] * yc[m]; }
         }
         const double* Hi = c->Hinv + 9 * (size_t)j;
         for (int m = 0; m < 3; ++m) c->yp[3 * (size_t)j + m] = Hi[3 * m] * a[0] + Hi[3 * m + 1] * a[1] + Hi[3 * m + 2] * a[2];
@@ -339,6 +361,15 @@ int ba_cpu_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* p, CpuSummary* s
     const int Nc = c.Nc, Np = c.Np, No = c.No;
     for (int i = 0; i < No; ++i)
         if (p->obs_cam[i] < 0 || p->obs_cam[i] >= Nc || p->obs_pt[i] < 0 || p->obs_pt[i] >= Np) return -1;
+    /* bal9 mode: some camera keeps {f, k1, k2} variable (bit 2): model 5 with an intrinsics entry of its own */
+    c.CW = 6;
+    for (int k = 0; k < Nc; ++k)
+        if (p->cam_const && (p->cam_const[k] & 4u)) {
+            if (p->intr_model[p->cam_intr[k]] != 5) return -1;
+            for (int k2 = 0; k2 < Nc; ++k2) if (k2 != k && p->cam_intr[k2] == p->cam_intr[k]) return -1;
+            c.CW = 9;
+        }
+    const int CW = c.CW;
 #define ALLOC(ptr, n) do { (ptr) = calloc((n) > 0 ? (n) : 1, sizeof *(ptr)); if (!(ptr)) return -3; } while (0)
     ALLOC(c.pt_ptr, (size_t)Np + 1); ALLOC(c.pt_obs, No); ALLOC(c.cam_ptr, (size_t)Nc + 1); ALLOC(c.cam_obs, No);
     {   /* CSR by point with obs sorted by camera, CSR by camera */
@@ -369,61 +400,65 @@ int ba_cpu_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* p, CpuSummary* s
             if (cmin < c.first[cam]) c.first[cam] = cmin;
         }
     }
-    ALLOC(c.rowoff, (size_t)6 * Nc + 1);
+    ALLOC(c.rowoff, (size_t)CW * Nc + 1);
     size_t off = 0;
-    for (int r = 0; r < 6 * Nc; ++r) { c.rowoff[r] = off; off += (size_t)(r - 6 * c.first[r / 6] + 1); }
+    for (int r = 0; r < CW * Nc; ++r) { c.rowoff[r] = off; off += (size_t)(r - CW * c.first[r / CW] + 1); }
     c.env_n = off;
     ALLOC(c.env, c.env_n);
     ALLOC(c.q, (size_t)4 * Nc); ALLOC(c.t, (size_t)3 * Nc); ALLOC(c.P, (size_t)3 * Np);
     ALLOC(c.q2, (size_t)4 * Nc); ALLOC(c.t2, (size_t)3 * Nc); ALLOC(c.P2, (size_t)3 * Np);
     memcpy(c.q, p->cam_q, (size_t)4 * Nc * sizeof(double)); memcpy(c.t, p->cam_t, (size_t)3 * Nc * sizeof(double));
     memcpy(c.P, p->points, (size_t)3 * Np * sizeof(double));
-    ALLOC(c.rt, (size_t)2 * No); ALLOC(c.F, (size_t)12 * No); ALLOC(c.E, (size_t)6 * No);
-    ALLOC(c.W, (size_t)18 * No); ALLOC(c.WH, (size_t)18 * No);
+    ALLOC(c.K, (size_t)8 * p->n_intr); ALLOC(c.K2, (size_t)8 * p->n_intr);
+    memcpy(c.K, p->intr_params, (size_t)8 * p->n_intr * sizeof(double)); memcpy(c.K2, c.K, (size_t)8 * p->n_intr * sizeof(double));
+    ALLOC(c.rt, (size_t)2 * No); ALLOC(c.F, (size_t)2 * CW * No); ALLOC(c.E, (size_t)6 * No);
+    ALLOC(c.W, (size_t)3 * CW * No); ALLOC(c.WH, (size_t)3 * CW * No);
     ALLOC(c.Hpp, (size_t)9 * Np); ALLOC(c.gp, (size_t)3 * Np); ALLOC(c.Hinv, (size_t)9 * Np);
-    ALLOC(c.Hcc, (size_t)36 * Nc); ALLOC(c.gc, (size_t)6 * Nc);
-    ALLOC(c.sc_c, (size_t)6 * Nc); ALLOC(c.sc_p, (size_t)3 * Np);
-    ALLOC(c.yc, (size_t)6 * Nc); ALLOC(c.yp, (size_t)3 * Np); ALLOC(c.b, (size_t)6 * Nc);
+    ALLOC(c.Hcc, (size_t)CW * CW * Nc); ALLOC(c.gc, (size_t)CW * Nc);
+    ALLOC(c.sc_c, (size_t)CW * Nc); ALLOC(c.sc_p, (size_t)3 * Np);
+    ALLOC(c.yc, (size_t)CW * Nc); ALLOC(c.yp, (size_t)3 * Np); ALLOC(c.b, (size_t)CW * Nc);
     /* which blocks are variable */
-    unsigned char *qvar, *tvar, *pvar;
-    ALLOC(qvar, Nc); ALLOC(tvar, Nc); ALLOC(pvar, Np);
+    unsigned char *qvar, *tvar, *pvar, *ivar;
+    ALLOC(qvar, Nc); ALLOC(tvar, Nc); ALLOC(pvar, Np); ALLOC(ivar, Nc);
     for (int k = 0; k < Nc; ++k) {
         const int act = c.cam_ptr[k + 1] > c.cam_ptr[k];
         const unsigned cc = p->cam_const ? p->cam_const[k] : 0u;
-        qvar[k] = act && !(cc & 1u); tvar[k] = act && !(cc & 2u);
-        sum->num_effective_params += 3 * qvar[k] + 3 * tvar[k];
+        qvar[k] = act && !(cc & 1u); tvar[k] = act && !(cc & 2u); ivar[k] = act && (cc & 4u);
+        sum->num_effective_params += 3 * qvar[k] + 3 * tvar[k] + 3 * ivar[k];
     }
     for (int j = 0; j < Np; ++j) {
         pvar[j] = (c.pt_ptr[j + 1] > c.pt_ptr[j]) && !(p->point_const && p->point_const[j]);
         sum->num_effective_params += 3 * pvar[j];
     }
     double t0 = now_s();
-    for (int k = 0; k < 6 * Nc; ++k) c.sc_c[k] = 1.0;
+    for (int k = 0; k < CW * Nc; ++k) c.sc_c[k] = 1.0;
     for (int k = 0; k < 3 * Np; ++k) c.sc_p[k] = 1.0;
-    double cost = evaluate(&c, c.q, c.t, c.P, 1);
+    double cost = evaluate(&c, c.q, c.t, c.P, c.K, 1);
     build_blocks(&c);
-    for (int k = 0; k < Nc; ++k) for (int a = 0; a < 6; ++a) c.sc_c[6 * (size_t)k + a] = 1.0 / (1.0 + sqrt(c.Hcc[36 * (size_t)k + 7 * a]));
+    for (int k = 0; k < Nc; ++k) for (int a = 0; a < CW; ++a) c.sc_c[CW * (size_t)k + a] = 1.0 / (1.0 + sqrt(c.Hcc[CW * CW * (size_t)k + (CW + 1) * a]));
     for (int j = 0; j < Np; ++j) for (int a = 0; a < 3; ++a) c.sc_p[3 * (size_t)j + a] = 1.0 / (1.0 + sqrt(c.Hpp[9 * (size_t)j + 4 * a]));
-    cost = evaluate(&c, c.q, c.t, c.P, 1);
+    cost = evaluate(&c, c.q, c.t, c.P, c.K, 1);
     build_blocks(&c);
     sum->linearize_s += now_s() - t0;
     sum->initial_cost = cost;
-#define XNORM(qq, tt, PP, out) do { double s_ = 0; \
+#define XNORM(qq, tt, PP, KK, out) do { double s_ = 0; \
         for (int k = 0; k < Nc; ++k) { if (qvar[k]) for (int a = 0; a < 4; ++a) s_ += (qq)[4 * (size_t)k + a] * (qq)[4 * (size_t)k + a]; \
-                                        if (tvar[k]) for (int a = 0; a < 3; ++a) s_ += (tt)[3 * (size_t)k + a] * (tt)[3 * (size_t)k + a]; } \
+                                        if (tvar[k]) for (int a = 0; a < 3; ++a) s_ += (tt)[3 * (size_t)k + a] * (tt)[3 * (size_t)k + a]; \
+                                        if (ivar[k]) for (int a = 0; a < 3; ++a) s_ += (KK)[8 * (size_t)p->cam_intr[k] + a] * (KK)[8 * (size_t)p->cam_intr[k] + a]; } \
         for (int j = 0; j < Np; ++j) if (pvar[j]) for (int a = 0; a < 3; ++a) s_ += (PP)[3 * (size_t)j + a] * (PP)[3 * (size_t)j + a]; \
         (out) = sqrt(s_); } while (0)
 #define GRADMAX(out) do { double m_ = 0; \
-        for (int k = 0; k < Nc; ++k) { const double* g = c.gc + 6 * (size_t)k; const double* s = c.sc_c + 6 * (size_t)k; \
+        for (int k = 0; k < Nc; ++k) { const double* g = c.gc + CW * (size_t)k; const double* s = c.sc_c + CW * (size_t)k; \
             if (qvar[k]) { double d[3] = {-g[0] / s[0], -g[1] / s[1], -g[2] / s[2]}, qn[4]; quat_plus(c.q + 4 * (size_t)k, d, qn); \
                 for (int a = 0; a < 4; ++a) m_ = fmax(m_, fabs(c.q[4 * (size_t)k + a] - qn[a])); } \
-            if (tvar[k]) for (int a = 0; a < 3; ++a) m_ = fmax(m_, fabs(g[3 + a] / s[3 + a])); } \
+            if (tvar[k]) for (int a = 0; a < 3; ++a) m_ = fmax(m_, fabs(g[3 + a] / s[3 + a])); \
+            if (ivar[k]) for (int a = 0; a < 3; ++a) m_ = fmax(m_, fabs(g[6 + a] / s[6 + a])); } \
         for (int j = 0; j < Np; ++j) if (pvar[j]) for (int a = 0; a < 3; ++a) m_ = fmax(m_, fabs(c.gp[3 * (size_t)j + a] / c.sc_p[3 * (size_t)j + a])); \
         (out) = m_; } while (0)
     double gmax; GRADMAX(gmax);
     int term = XRSFM_BA_NO_CONVERGENCE, reason = 5;
     double radius = opt->initial_radius, decrease = 2.0, xnorm;
-    XNORM(c.q, c.t, c.P, xnorm);
+    XNORM(c.q, c.t, c.P, c.K, xnorm);
     int it = 0, invalid = 0;
     if (gmax <= opt->gradient_tolerance) { term = XRSFM_BA_CONVERGENCE; reason = 1; goto done; }
     while (1) {
@@ -436,10 +471,10 @@ int ba_cpu_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* p, CpuSummary* s
         if (!fail) {
 #pragma omp parallel for reduction(+ : model) schedule(static)
             for (int i = 0; i < No; ++i) {
-                const double* F = c.F + 12 * (size_t)i; const double* E = c.E + 6 * (size_t)i;
-                const double* yc = c.yc + 6 * (size_t)p->obs_cam[i]; const double* yp = c.yp + 3 * (size_t)p->obs_pt[i];
+                const double* F = c.F + 2 * CW * (size_t)i; const double* E = c.E + 6 * (size_t)i;
+                const double* yc = c.yc + CW * (size_t)p->obs_cam[i]; const double* yp = c.yp + 3 * (size_t)p->obs_pt[i];
                 double m0 = 0, m1 = 0;
-                for (int a = 0; a < 6; ++a) { m0 += F[a] * yc[a]; m1 += F[6 + a] * yc[a]; }
+                for (int a = 0; a < CW; ++a) { m0 += F[a] * yc[a]; m1 += F[CW + a] * yc[a]; }
                 for (int a = 0; a < 3; ++a) { m0 += E[a] * yp[a]; m1 += E[3 + a] * yp[a]; }
                 model += m0 * (c.rt[2 * (size_t)i] - 0.5 * m0) + m1 * (c.rt[2 * (size_t)i + 1] - 0.5 * m1);
             }
@@ -452,10 +487,16 @@ int ba_cpu_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* p, CpuSummary* s
         }
         invalid = 0;
         double step2 = 0.0;
+        if (CW == 9) memcpy(c.K2, c.K, (size_t)8 * p->n_intr * sizeof(double));
         for (int k = 0; k < Nc; ++k) {
-            const double* y = c.yc + 6 * (size_t)k; const double* s = c.sc_c + 6 * (size_t)k;
+            const double* y = c.yc + CW * (size_t)k; const double* s = c.sc_c + CW * (size_t)k;
             memcpy(c.q2 + 4 * (size_t)k, c.q + 4 * (size_t)k, 4 * sizeof(double));
             memcpy(c.t2 + 3 * (size_t)k, c.t + 3 * (size_t)k, 3 * sizeof(double));
+            if (ivar[k]) for (int a = 0; a < 3; ++a) {
+                const size_t m = 8 * (size_t)p->cam_intr[k] + a;
+                c.K2[m] = c.K[m] + (-y[6 + a] * s[6 + a]);
+                const double df = c.K2[m] - c.K[m]; step2 += df * df;
+            }
             if (qvar[k]) {
                 double d[3] = {-y[0] * s[0], -y[1] * s[1], -y[2] * s[2]};
                 quat_plus(c.q + 4 * (size_t)k, d, c.q2 + 4 * (size_t)k);
@@ -472,7 +513,7 @@ int ba_cpu_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* p, CpuSummary* s
             const double df = c.P2[m] - c.P[m]; step2 += df * df;
         }
         t0 = now_s();
-        const double cost2 = evaluate(&c, c.q2, c.t2, c.P2, 0);
+        const double cost2 = evaluate(&c, c.q2, c.t2, c.P2, c.K2, 0);
         sum->linearize_s += now_s() - t0;
         const double step_norm = sqrt(step2);
         if (step_norm <= opt->parameter_tolerance * (xnorm + opt->parameter_tolerance)) { term = XRSFM_BA_CONVERGENCE; reason = 2; break; }
@@ -482,9 +523,10 @@ int ba_cpu_solve(const xrsfm_ba_options* opt, xrsfm_ba_problem* p, CpuSummary* s
         if (rel > 1e-3) {
             double* tmp;
             tmp = c.q; c.q = c.q2; c.q2 = tmp; tmp = c.t; c.t = c.t2; c.t2 = tmp; tmp = c.P; c.P = c.P2; c.P2 = tmp;
-            XNORM(c.q, c.t, c.P, xnorm);
+            tmp = c.K; c.K = c.K2; c.K2 = tmp;
+            XNORM(c.q, c.t, c.P, c.K, xnorm);
             t0 = now_s();
-            cost = evaluate(&c, c.q, c.t, c.P, 1);
+            cost = evaluate(&c, c.q, c.t, c.P, c.K, 1);
             build_blocks(&c);
             sum->linearize_s += now_s() - t0;
             radius = fmin(1e16, radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3)));
@@ -502,6 +544,8 @@ done:
     sum->termination = term; sum->reason = reason; sum->final_cost = cost;
     memcpy(p->cam_q, c.q, (size_t)4 * Nc * sizeof(double)); memcpy(p->cam_t, c.t, (size_t)3 * Nc * sizeof(double));
     memcpy(p->points, c.P, (size_t)3 * Np * sizeof(double));
+    if (CW == 9) memcpy(p->intr_params, c.K, (size_t)8 * p->n_intr * sizeof(double));
+    free(c.K); free(c.K2); free(ivar);
     free(c.pt_ptr); free(c.pt_obs); free(c.cam_ptr); free(c.cam_obs); free(c.first); free(c.rowoff); free(c.env);
     free(c.q); free(c.t); free(c.P); free(c.q2); free(c.t2); free(c.P2); free(c.rt); free(c.F); free(c.E); free(c.W); free(c.WH);
     free(c.Hpp); free(c.gp); free(c.Hinv); free(c.Hcc); free(c.gc); free(c.sc_c); free(c.sc_p); free(c.yc); free(c.yp); free(c.b);

@@ -66,6 +66,6 @@ def solve(prob: dict, max_iterations=50, function_tolerance=1e-5, parameter_tole
     rc = _load().ba_cpu_solve(C.byref(o), C.byref(p), C.byref(s), threads)
     if rc != 0:
         raise RuntimeError(f"ba_cpu_solve failed: {rc}")
-    for k in ("cam_q", "cam_t", "points"):
+    for k in ("cam_q", "cam_t", "points", "intr_params"):        # intr_params: changed in bal9 mode only (variable {f, k1, k2})
         prob[k][...] = a[k].reshape(np.asarray(prob[k]).shape)
     return {f: getattr(s, f) for f, _ in s._fields_}

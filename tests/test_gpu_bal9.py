@@ -173,3 +173,30 @@ def test_bal9_fuzz(lib):
         if not ok:
             misses.append((seed, s.n_successful, s.n_unsuccessful, s_ref.n_successful, s_ref.n_unsuccessful, s.final_cost, s_ref.final_cost))
     assert n_run >= 45 and len(misses) <= 1, misses
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_cams,n_pts,k_obs,dropout", [(200, 20000, 4, 0.0), (150, 12000, 8, 0.35)])
+def test_bal9_mid_size_matches_c_restatement(lib, n_cams, n_pts, k_obs, dropout):
+    """Hundreds of tiles of 9-wide blocks — beyond what the numpy oracle solves in seconds — against the C restatement
+    (oracle/ba_cpu.c with CW = 9): same LM decisions, RMSE 1e-6 px, cameras 1e-5 (translations of a 150-200-camera chain drift
+    along the gauge: 1e-4), intrinsics 1e-6 relative / 1e-5; twice, bit-identical."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi
+    if not ba_cpu.available():
+        ba_cpu.build()
+    arr = H.make_bal9(n_cams, n_pts, k_obs, seed=2, dropout=dropout, min_tri_angle_deg=1.0)
+    cp = {k: np.array(v, copy=True) for k, v in arr.items()}
+    sc = ba_cpu.solve(cp, threads=8)
+    outs = []
+    for _ in range(2):
+        prod = H.to_product(arr)
+        s = capi.solve(prod)
+        outs.append((s.final_cost, prod.cam_q.copy(), prod.cam_t.copy(), prod.intr_params.copy()))
+    assert outs[0][0] == outs[1][0] and all(np.array_equal(a, b) for a, b in zip(outs[0][1:], outs[1][1:]))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (sc["n_successful"], sc["n_unsuccessful"])
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(sc["final_cost"] / n_res)) < 1e-6
+    assert np.abs(prod.cam_q - cp["cam_q"]).max() < 1e-6 and np.abs(prod.cam_t - cp["cam_t"]).max() < 1e-4
+    assert np.abs(prod.intr_params[:, 0] / cp["intr_params"][:, 0] - 1).max() < 1e-6
+    assert np.abs(prod.intr_params[:, 1:3] - cp["intr_params"][:, 1:3]).max() < 1e-5

@@ -168,3 +168,30 @@ def test_numpy_oracle_reproduces_the_bal9_golden():
     assert (s.n_successful, s.n_unsuccessful) == (int(z["n_successful"]), int(z["n_unsuccessful"]))
     assert abs(s.final_cost - float(z["final_cost"])) <= 1e-9 * s.final_cost
     assert np.abs(pr.cam_q - z["out_cam_q"]).max() < 1e-8 and np.abs(pr.intr_params - z["out_intr"]).max() < 1e-6
+
+
+def test_c_restatement_reproduces_the_bal9_golden_and_the_numpy_oracle():
+    """oracle/ba_cpu.c with 9-wide camera blocks (CW = 9 as soon as one camera keeps {f, k1, k2} variable): the committed golden,
+    and the numpy oracle on a ragged problem with constant blocks — same LM decisions, cost to 1e-10, intrinsics included."""
+    z, arr, opt = _load(os.path.join(GOLD_DIR, "wide_bal9.npz"))
+    prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+    s = ba_cpu.solve(prob, threads=2, **opt)
+    assert (s["n_successful"], s["n_unsuccessful"]) == (int(z["n_successful"]), int(z["n_unsuccessful"]))
+    assert abs(s["final_cost"] - float(z["final_cost"])) <= 1e-10 * float(z["final_cost"])
+    assert np.abs(prob["cam_q"] - z["out_cam_q"]).max() < 1e-8 and np.abs(prob["intr_params"] - z["out_intr"]).max() < 1e-6
+    arr = H.make_bal9(40, 2000, 6, seed=6, dropout=0.3, min_tri_angle_deg=0.5)
+    arr["point_const"] = (np.arange(2000) % 7 == 0).astype(np.uint8)
+    cc = arr["cam_const"].copy(); cc[5] &= 3; cc[9] &= 3; cc[11] |= 1; arr["cam_const"] = cc
+    pr = H.to_oracle(arr)
+    s_ref = bo.solve(pr, bo.Options(max_iterations=12))
+    prob = {k: np.array(v, copy=True) for k, v in arr.items()}
+    s = ba_cpu.solve(prob, max_iterations=12, threads=1)
+    assert (s["n_successful"], s["n_unsuccessful"]) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert s["num_effective_params"] == s_ref.num_effective_params
+    assert abs(s["final_cost"] - s_ref.final_cost) <= 1e-10 * s_ref.final_cost
+    assert np.abs(prob["cam_q"] - pr.cam_q).max() < 1e-8 and np.abs(prob["cam_t"] - pr.cam_t).max() < 1e-7
+    assert np.abs(prob["intr_params"] - pr.intr_params).max() < 1e-6
+    # shared intrinsics entry / one of the reference's models with the bit: refused
+    bad = {k: np.array(v, copy=True) for k, v in arr.items()}; bad["cam_intr"] = np.zeros(40, np.int32)
+    with pytest.raises(RuntimeError):
+        ba_cpu.solve(bad, threads=1)
