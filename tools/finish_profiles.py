@@ -42,7 +42,7 @@ def main():
                           ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter"),
                           ("T", "BASELINE config 5 at its size: 7500 photos in viewpoint clusters / 1.8M points / 8.1M observations, shuffled ids; exact path in the reverse Cuthill-McKee order; no CPU leg"),
                           ("T_pcg", "the same through the implicit-Schur PCG (the only path at this size until round 2)"),
-                          ("Lb9", "config 4 in bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks (k9_* kernels, not tuned); no CPU leg: the C restatement is 6-wide"),
+                          ("Lb9", "config 4 in bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks (k9_* kernels, not tuned); CPU leg = the C restatement with CW = 9; parity incl. the refined intrinsics in cpu_baseline"),
                           ("M", "mapper-shaped replay through the BASolver adapter: a different metric (wall time of the BA calls of a 300-frame incremental reconstruction)")):
             if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
                 continue
