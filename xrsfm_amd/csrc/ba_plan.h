@@ -323,7 +323,7 @@ inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<
 // `pattern`: union of all ranks' camera pairs (sorted, unique) or nullptr for the local pairs.
 // Limits (checked BEFORE the symbolic factorisation, whose work and memory grow with the cube of the tile count when the
 // pattern fills in): more than `max_dense_unknowns` camera unknowns are only planned when the band / ring ordering applies,
-// and then only while the n_pad^2 doubles of the tile storage stay within `max_tile_bytes`; XRSFM_BA_ETOOBIG otherwise.
+// and then only while the packed tile storage of the factor (non-zero 64x64 tiles) stays within `max_tile_bytes`; XRSFM_BA_ETOOBIG otherwise.
 inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const PairKeys& keyed,
                            const std::vector<unsigned long long>* pattern, CholPlan& P,
                            long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX, int cam_width = 6) {
@@ -472,8 +472,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.T = T; P.n_pad = T * kPlanTile;
     P.tile_cam.assign((size_t)T * CPT, -1);
     for (int c = 0; c < Nc; ++c) P.tile_cam[(size_t)(P.cam_off[c] / kPlanTile) * CPT + (P.cam_off[c] % kPlanTile) / CW] = c;
-    if ((long long)CW * Nc > max_dense_unknowns &&
-        (P.ordering == 0 || (unsigned long long)P.n_pad * (unsigned long long)P.n_pad * sizeof(double) > max_tile_bytes)) return XRSFM_BA_ETOOBIG;
+    // beyond the dense limit only with an order that keeps the factor sparse, and while the T x T tile maps stay small (4096 tile
+    // columns = 262 000 unknowns); the bytes of the packed tile storage are checked after the symbolic factorisation
+    constexpr int kPlanMaxTiles = 4096;
+    if ((long long)CW * Nc > max_dense_unknowns && (P.ordering == 0 || T > kPlanMaxTiles)) return XRSFM_BA_ETOOBIG;
 
     // ---- tile pattern + symbolic factorisation
     std::vector<char> nz((size_t)T * T, 0);
@@ -499,6 +501,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     timer.mark("  symbolic factorisation");
     std::vector<int> tile_id((size_t)T * T, -1);
     for (int q = 0; q < P.n_tiles_nz; ++q) tile_id[(size_t)P.tiles_nz[2 * q] * T + P.tiles_nz[2 * q + 1]] = q;
+    if ((long long)CW * Nc > max_dense_unknowns &&
+        ((unsigned long long)P.n_tiles_nz + 1) * (unsigned long long)(kPlanTile * kPlanTile + kPlanTile) * sizeof(double) > max_tile_bytes) return XRSFM_BA_ETOOBIG;
     P.tile_map.resize((size_t)T * T);
     for (size_t e = 0; e < P.tile_map.size(); ++e) P.tile_map[e] = tile_id[e] >= 0 ? tile_id[e] : P.n_tiles_nz;
     {
