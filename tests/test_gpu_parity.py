@@ -987,3 +987,30 @@ def test_clustered_collection_exact_path_matches_c_restatement(lib, monkeypatch)
         assert (s3.n_successful, s3.n_unsuccessful) == (s1["n_successful"], s1["n_unsuccessful"])
         assert abs(math.sqrt(s3.final_cost / n_res) - math.sqrt(s1["final_cost"] / n_res)) < 1e-6
         assert np.abs(p3.cam_q - c1["cam_q"]).max() < 1e-5 and np.abs(p3.cam_t - c1["cam_t"]).max() < 1e-5
+
+
+@pytest.mark.gpu
+def test_twenty_thousand_sequential_cameras_take_the_exact_path(lib):
+    """120 000 camera unknowns: the dense tile array of the reduced camera matrix would be 161 GB; the packed form (non-zero tiles of
+    the nested-dissection factor only, ba_chol.h: tile_ptr) is 0.24 GB, so AUTO stays on the exact Cholesky path (round 2: PCG).
+    Properties only at this size: solver used, convergence, bit-reproducibility, idempotence, and the cost of the returned state
+    re-evaluated by the oracle."""
+    from xrsfm_amd import capi, synth
+    d = synth.make_problem(n_cams=20000, n_points=400000, k_obs=4, seed=13)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["ordering"] == 1 and plan["level_schedule"] == 1 and plan["levels"] <= 10 and plan["tiles"] > 2000
+    ctx = capi.Context(H.to_product(arr))
+    s = ctx.run(capi.default_options())
+    q, t, P = ctx.download()
+    ctx.reset()
+    s2 = ctx.run(capi.default_options())
+    q2, t2, P2 = ctx.download()
+    ctx.close()
+    assert s.linear_solver_used == capi.SOLVER_CHOLESKY and s.termination == 0 and s.final_cost < 0.1 * s.initial_cost
+    assert s2.final_cost == s.final_cost and np.array_equal(q, q2) and np.array_equal(P, P2)
+    ref = H.to_oracle(dict(arr, cam_q=q, cam_t=t, points=P))
+    assert abs(bo.evaluate(ref, ref.cam_q, ref.cam_t, ref.points, want_jac=False) - s.final_cost) <= 1e-9 * s.final_cost
+    prod = H.to_product(dict(arr, cam_q=q, cam_t=t, points=P))
+    s3 = capi.solve(prod)
+    assert s3.n_successful <= 1 and np.abs(prod.cam_q - q).max() < 1e-4
