@@ -357,9 +357,7 @@ struct Timed {
 };
 #define LAUNCH(ctx, kid, kern, grid, block, shmem, ...)                                  \
     do { Timed t_((ctx), (kid)); hipLaunchKernelGGL(kern, grid, block, shmem, (ctx)->stream, __VA_ARGS__); } while (0)
-// ... on another stream of the context (the events that time it are recorded on that stream)
-#define LAUNCH_ON(ctx, stream_, kid, kern, grid, block, shmem, ...)                      \
-    do { Timed t_((ctx), (kid), -1, (stream_)); hipLaunchKernelGGL(kern, grid, block, shmem, (stream_), __VA_ARGS__); } while (0)
+
 
 // resolve recorded event pairs (stream must be idle); records tagged with a PCG iteration index are only
 // counted if the iteration really ran (launches after `done` are no-ops)
