@@ -180,3 +180,19 @@ def test_pair_keys_of_a_large_collection_are_sorted_in_parallel():
             keys.update((c[b] * 1200 + c[a]).tolist())
     plan = capi.debug_chol_plan(H.to_product(arr))
     assert plan["blocks"] == len(keys)
+
+
+def test_schedule_of_a_clustered_collection_covers_the_factorisation(monkeypatch):
+    """The self-check of the plan (XRSFM_BA_PLAN_CHECK) on the shape of BASELINE config 5 at a quarter of its size: ~190 tile
+    columns in the reverse Cuthill-McKee order, look-ahead panel schedule with sparse columns — chunks of split levels, late
+    partials (column k-2) and in-kernel lists (column k-1) must cover every product exactly once."""
+    from xrsfm_amd import synth
+    monkeypatch.setenv("XRSFM_BA_PLAN_CHECK", "1")
+    d = synth.make_collection(n_cams=1900, n_points=120000, seed=4)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert 150 <= plan["tiles"] <= 256 and plan["ordering"] == 2 and plan["lookahead"] == 1 and plan["levels"] == plan["tiles"]
+    # the same pattern through the round-2 panel schedule (no look-ahead)
+    monkeypatch.setenv("XRSFM_BA_LOOKAHEAD", "0")
+    plan0 = capi.debug_chol_plan(H.to_product(arr))
+    assert plan0["lookahead"] == 0 and plan0["tiles_nz"] == plan["tiles_nz"]

@@ -730,7 +730,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         P.fz_q[2 * e] = tile_id[(size_t)k2 * T + k2]; P.fz_q[2 * e + 1] = tile_id[(size_t)i * T + k2];
     }
     for (int q = 0; q < P.n_tiles_nz; ++q) if (level[P.tiles_nz[2 * q + 1]] != 0) P.fill_rest.push_back(q);
-    if (std::getenv("XRSFM_BA_PLAN_CHECK") && T <= 96) {
+    if (std::getenv("XRSFM_BA_PLAN_CHECK") && T <= 256) {      // (T^3 counters: 64 MB at 256 tile columns)
         // Self-check of the fused schedule (tests/test_plan_cpu.py, no GPU): every structurally non-zero tile (i,k) must receive
         // each contribution j < k with L_ij and L_kj non-zero exactly once — from a macro-tile entry, a chunk of a split level or
         // its own list in the fused factor kernel — and the forward substitution of row k each L_kj y_j exactly once.
