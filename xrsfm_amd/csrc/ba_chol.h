@@ -769,6 +769,34 @@ __global__ __launch_bounds__(256) void k_bwd(CholDev c, int k, const int* __rest
     if (threadIdx.x < kNB) c.y[j * kNB + threadIdx.x] -= tmp[threadIdx.x];
 }
 
+// ... two columns per launch: every workgroup forms x_k = Linv_k^T y_k, then y'_{k-1} = y_{k-1} - L_{k,k-1}^T x_k and
+// x_{k-1} = Linv_{k-1}^T y'_{k-1} (the same values in the same order as two launches of k_bwd), workgroup 0 stores both, workgroup
+// b > 0 pushes both into one row tile j < k-1 of the union list (ent: j, flags — bit 0 L_kj non-zero, bit 1 L_{k-1,j}).  Half the
+// launches of the push-form backward substitution of a panel schedule (9.2 us each, one per tile column, at config T).
+__global__ __launch_bounds__(256) void k_bwd2(CholDev c, int k, int link, const int* __restrict__ ent) {
+    __shared__ double v[kNB], xk[kNB], xk1[kNB], tmp[kNB], tmp2[kNB];
+    const int t = threadIdx.x;
+    if (t < kNB) v[t] = c.y[k * kNB + t];
+    __syncthreads();
+    tile_gemv(c.Linv + (size_t)k * kNB * kNB, kNB, v, xk, true, nullptr);
+    __syncthreads();
+    if (link) tile_gemv(tile_ptr(c, k, k - 1), c.ld, xk, tmp, true, nullptr);
+    __syncthreads();
+    if (t < kNB) v[t] = c.y[(k - 1) * kNB + t] - (link ? tmp[t] : 0.0);
+    __syncthreads();
+    tile_gemv(c.Linv + (size_t)(k - 1) * kNB * kNB, kNB, v, xk1, true, nullptr);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        if (t < kNB) { c.x[k * kNB + t] = xk[t]; c.x[(k - 1) * kNB + t] = xk1[t]; }
+        return;
+    }
+    const int j = ent[2 * (blockIdx.x - 1)], f = ent[2 * (blockIdx.x - 1) + 1];
+    if (f & 1) tile_gemv(tile_ptr(c, k, j), c.ld, xk, tmp, true, nullptr);
+    if (f & 2) tile_gemv(tile_ptr(c, k - 1, j), c.ld, xk1, tmp2, true, nullptr);
+    __syncthreads();
+    if (t < kNB) c.y[j * kNB + t] -= ((f & 1) ? tmp[t] : 0.0) + ((f & 2) ? tmp2[t] : 0.0);
+}
+
 __global__ void k_copy_pad(double* dst, const double* src, int n, int n_pad) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_pad) dst[i] = (i < n) ? src[i] : 0.0;

@@ -37,6 +37,9 @@ struct CholPlan {
     size_t gram_shm[8] = {0};        // dynamic LDS of each bucket's launch
     std::vector<int> spp, pair_dst, blk_ptr, blk_rc, cam_off, tile_rows, tiles_nz;
     std::vector<int> cols_flat, cols_off;                                  // per tile column its row tiles j < k (push-form backward substitution)
+    // ... two columns per launch (k_bwd2): pair p = columns (T-1-2p, T-2-2p); per pair the union of their row tiles j < the lower
+    // column as (j, flags: bit 0 = L(k,j) non-zero, bit 1 = L(k-1,j)), and whether L(k,k-1) is non-zero
+    std::vector<int> bw2_ent, bw2_off, bw2_link;
     std::vector<int> lv_k, lv_tgt, lv_cptr, lv_cj, lv_bptr, lv_bi;         // level schedule
     std::vector<int> lv_k_off, lv_tgt_off;
     // thin upper levels (few targets with long contribution lists): the lists are cut into chunks, one workgroup per
@@ -496,6 +499,15 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         for (int j = 0; j < kk; ++j) if (nz[(size_t)kk * T + j]) P.cols_flat.push_back(j);
         P.cols_off[kk + 1] = (int)P.cols_flat.size();
         for (int j = 0; j <= kk; ++j) if (nz[(size_t)kk * T + j]) { P.tiles_nz.push_back(kk); P.tiles_nz.push_back(j); }
+    }
+    P.bw2_off.assign(1, 0);
+    for (int kk = T - 1; kk >= 1; kk -= 2) {
+        for (int j = 0; j < kk - 1; ++j) {
+            const int f = (nz[(size_t)kk * T + j] ? 1 : 0) | (nz[(size_t)(kk - 1) * T + j] ? 2 : 0);
+            if (f) { P.bw2_ent.push_back(j); P.bw2_ent.push_back(f); }
+        }
+        P.bw2_off.push_back((int)P.bw2_ent.size() / 2);
+        P.bw2_link.push_back(nz[(size_t)kk * T + kk - 1] ? 1 : 0);
     }
     P.n_tiles_nz = (int)P.tiles_nz.size() / 2;
     timer.mark("  symbolic factorisation");

@@ -106,6 +106,7 @@ struct CholHost {
     // right-looking schedule (dense patterns): one panel after the other
     int* cols_flat = nullptr;                     // device list: per tile column its row tiles j < k (push-form backward substitution)
     std::vector<int> cols_off;                    // host offsets per column (size T+1)
+    int* bw2_ent = nullptr; std::vector<int> bw2_off, bw2_link;      // two columns per backward launch (ba_plan.h, k_bwd2)
     // level schedule (elimination-tree levels of the tile pattern; left-looking updates)
     bool use_levels = false, panel_ll = false;
     bool lookahead = false;                       // look-ahead panel schedule (ba_plan.h): one launch per column (k_panel_slot)
@@ -590,7 +591,7 @@ int chol_setup(xrsfm_ba_context* c) {
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.lookahead = P.lookahead; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
-    h.cols_off = P.cols_off;
+    h.cols_off = P.cols_off; h.bw2_off = P.bw2_off; h.bw2_link = P.bw2_link;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.mp_off = P.mp_off; h.fz_off = P.fz_off;
     int *d_cam_off = nullptr, *d_tile_rows = nullptr, *d_tmap = nullptr;
@@ -598,7 +599,7 @@ int chol_setup(xrsfm_ba_context* c) {
     BatchUpload up(c);
     up.add(&h.slot_pair_ptr, P.spp); up.add(&h.pair_dst, P.pair_dst);
     up.add(&h.blk_ptr, P.blk_ptr); up.add(&h.blk_rc, P.blk_rc);
-    up.add(&h.tiles_nz, P.tiles_nz); up.add(&h.cols_flat, P.cols_flat);
+    up.add(&h.tiles_nz, P.tiles_nz); up.add(&h.cols_flat, P.cols_flat); up.add(&h.bw2_ent, P.bw2_ent);
     up.add(&h.lv_k, P.lv_k); up.add(&h.lv_tgt, P.lv_tgt); up.add(&h.lv_cptr, P.lv_cptr);
     up.add(&h.lv_cj, P.lv_cj);
     up.add(&h.lv_bptr, P.lv_bptr); up.add(&h.lv_bi, P.lv_bi);
@@ -734,6 +735,23 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
 }
 
 // Factor S = L L^T and solve S x = b (S and b from chol_assemble); the solution lands in d.px
+// push-form backward substitution of a panel schedule: two tile columns per launch from the last one down (XRSFM_BA_BWD2=0: one)
+static void panel_backward(xrsfm_ba_context* c) {
+    CholHost& h = c->chol;
+    const int T = h.T;
+    static const bool pairs = [] { const char* e = std::getenv("XRSFM_BA_BWD2"); return !(e && e[0] == '0'); }();
+    int k = T - 1;
+    if (pairs)
+        for (int p = 0; k >= 1; k -= 2, ++p) {
+            const int n = h.bw2_off[p + 1] - h.bw2_off[p];
+            LAUNCH(c, K_TRISOLVE, k_bwd2, dim3(1 + n), dim3(256), 0, h.dev, k, h.bw2_link[p], (const int*)(h.bw2_ent + 2 * (size_t)h.bw2_off[p]));
+        }
+    for (; k >= 0; --k) {
+        const int ncol = h.cols_off[k + 1] - h.cols_off[k];
+        LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
+    }
+}
+
 int chol_factor_solve(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
@@ -776,10 +794,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const int nwg = a.n_factor + a.n_reduce + a.n_late + a.n_part;
             if (nwg > 0) LAUNCH(c, K_POTRF, k_panel_slot, dim3(nwg), dim3(256), 0, h.dev, a, (const int*)h.fz_dj, (const int*)h.lv_cj, (const int*)h.md_cj, (const int*)h.tile_cam);
         }
-        for (int k = T - 1; k >= 0; --k) {
-            const int ncol = h.cols_off[k + 1] - h.cols_off[k];
-            LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
-        }
+        panel_backward(c);
         if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
         return 0;
     }
@@ -817,10 +832,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
         }
         if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
-            for (int k = T - 1; k >= 0; --k) {
-                const int ncol = h.cols_off[k + 1] - h.cols_off[k];
-                LAUNCH(c, K_TRISOLVE, k_bwd, dim3(1 + ncol), dim3(256), 0, h.dev, k, h.cols_flat + h.cols_off[k]);
-            }
+            panel_backward(c);
             if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
             return 0;
         }
