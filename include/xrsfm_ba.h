@@ -143,6 +143,12 @@ int xrsfm_ba_create(const xrsfm_ba_problem *problem, int device, xrsfm_ba_contex
  * xrsfm_ba_comm_unique_id on rank 0 and distributed by the caller. */
 int xrsfm_ba_comm_unique_id(unsigned char id[128]);
 int xrsfm_ba_comm_init(xrsfm_ba_context *ctx, int n_ranks, int rank, const unsigned char id[128]);
+/* Watchdog of multi-rank contexts (environment XRSFM_BA_WATCHDOG_S = seconds, default 300 with several ranks and OFF on one
+ * rank; an explicit value applies to every context, 0 switches it off): a rank that waits that long for its device without
+ * progress — an all-reduce a peer never joined — gets XRSFM_BA_ECOMM (XRSFM_BA_ENODEV on one rank) from xrsfm_ba_run.  The
+ * context is then POISONED: run / reset / download return XRSFM_BA_ESTATE, and xrsfm_ba_destroy aborts the communicator and
+ * releases the host side only (the stream and the device buffers the stuck work may still touch are leaked on purpose, never
+ * waited for). */
 
 /* TEST HOOK: replace the RCCL all-reduce of this context by a caller-supplied one working on a HOST copy of the buffer
  * (op 0 = sum, 1 = max; return 0 on success).  Lets several ranks share ONE GPU — RCCL refuses two ranks on one device — so the
@@ -335,7 +341,9 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], 
 
 /* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
  * (0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee of an unordered collection), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
- * [6] level schedule used (else the panel schedule of deep elimination trees: dense / unordered patterns), [7] structurally
+ * [6] schedule BITS: bit 0 (value 1) = level schedule (one launch per elimination-tree level; clear = the panel schedule of
+ * deep elimination trees: dense / unordered patterns), bit 1 (value 2) = look-ahead panel schedule (one launch per tile
+ * column, k_panel_slot) — test the bits, not the value: a look-ahead plan reports 2, [7] structurally
  * non-zero tiles after fill.  cam_offset (may be NULL):
  * [n_cams] first row of each camera in the elimination order. */
 int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *cam_offset);

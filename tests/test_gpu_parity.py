@@ -214,6 +214,28 @@ def test_cholesky_reduced_system(lib, n_cams, n_pts, k_obs, mode):
 
 
 @pytest.mark.gpu
+def test_debug_backsub_needs_a_solved_step(lib):
+    """xrsfm_ba_debug_backsub reads the camera part of a step and the radius it was assembled with: without a preceding
+    xrsfm_ba_debug_cholesky_solve of the same linearisation it must refuse (XRSFM_BA_ESTATE, -5) instead of launching the
+    kernel on uninitialised point factors / a zero radius."""
+    from xrsfm_amd import capi
+    arr = H.make(6, 200, 3, seed=41)
+    ctx = capi.Context(H.to_product(arr))
+    with pytest.raises(RuntimeError, match="-5"):
+        ctx.debug_backsub()                       # not even linearised
+    ctx.debug_linearize(5.99, True)
+    with pytest.raises(RuntimeError, match="-5"):
+        ctx.debug_backsub()                       # linearised, no step solved
+    ctx.debug_cholesky_solve(1e4)
+    out = ctx.debug_backsub()
+    assert np.isfinite(out["cand_points"]).all() and np.isfinite(out["part_model"]).all()
+    ctx.debug_linearize(5.99, True)               # a new linearisation invalidates the step
+    with pytest.raises(RuntimeError, match="-5"):
+        ctx.debug_backsub()
+    ctx.close()
+
+
+@pytest.mark.gpu
 def test_regular_tiles_of_every_track_length_match_oracle(lib):
     """Every track sees every camera: regular tiles with L = n_cams cameras per track, 2 <= L <= 32 (Gram tiles up to 10 cameras,
     the per-pair path beyond; the per-camera sums over a tile's tracks take 1-7 rounds of 64 values).  Three LM iterations on

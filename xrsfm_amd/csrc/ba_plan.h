@@ -13,6 +13,7 @@
 namespace xba {
 
 constexpr int kPlanTile = 64;        // tile size (must equal kNB of ba_chol.h)
+constexpr int kPlanMaxTiles = 4096;  // tile columns a plan may have beyond the dense limit (T x T tile maps stay small: 262 000 unknowns)
 constexpr int kCamsPerTile = 10;     // 10 cameras = 60 rows per tile + 4 identity padding rows
 constexpr int kCamsPerTileWide = 7;  // bal9 mode (9 unknowns per camera): 7 cameras = 63 rows per tile + 1 identity padding row
 
@@ -451,7 +452,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         // columns (480 cameras) on; random visibility (no clusters) keeps the natural order / the PCG path.
         const int Tn = (Nc + CPT - 1) / CPT;
         const char* rcm_env = std::getenv("XRSFM_BA_RCM");
-        if (Tn >= 48 && !(rcm_env && rcm_env[0] == '0')) {
+        // (beyond kPlanMaxTiles tile columns no order is accepted below: the probe — a Tn x Tn map and an O(Tn^2) walk — is skipped,
+        //  so an oversized unordered problem is refused before any T^2 work and AUTO falls back to the PCG at once)
+        if (Tn >= 48 && Tn <= kPlanMaxTiles && !(rcm_env && rcm_env[0] == '0')) {
             const long long budget = 12000000;              // tile products of one factorisation: 6.3e12 flop, ~0.25 s
             const std::vector<int> rcm = plan_detail::rcm_order(Nc, blk_rc, n_blocks);
             const long long pr = plan_detail::count_tile_products(Nc, blk_rc, n_blocks, rcm, CPT, budget);
@@ -477,7 +480,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     for (int c = 0; c < Nc; ++c) P.tile_cam[(size_t)(P.cam_off[c] / kPlanTile) * CPT + (P.cam_off[c] % kPlanTile) / CW] = c;
     // beyond the dense limit only with an order that keeps the factor sparse, and while the T x T tile maps stay small (4096 tile
     // columns = 262 000 unknowns); the bytes of the packed tile storage are checked after the symbolic factorisation
-    constexpr int kPlanMaxTiles = 4096;
     if ((long long)CW * Nc > max_dense_unknowns && (P.ordering == 0 || T > kPlanMaxTiles)) return XRSFM_BA_ETOOBIG;
 
     // ---- tile pattern + symbolic factorisation

@@ -58,6 +58,7 @@ struct Rccl {
     int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;   // ncclUniqueId is passed by value (128 B struct)
     int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*CommDestroy)(void*) = nullptr;
+    int (*CommAbort)(void*) = nullptr;          // optional: tears a communicator down without waiting for its pending collectives
 };
 Rccl g_rccl;
 bool load_rccl() {
@@ -72,6 +73,7 @@ bool load_rccl() {
     g_rccl.CommInitRank = (int (*)(void**, int, UniqueId, int))dlsym(g_rccl.lib, "ncclCommInitRank");
     g_rccl.AllReduce = (int (*)(const void*, void*, size_t, int, int, void*, hipStream_t))dlsym(g_rccl.lib, "ncclAllReduce");
     g_rccl.CommDestroy = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommDestroy");
+    g_rccl.CommAbort = (int (*)(void*))dlsym(g_rccl.lib, "ncclCommAbort");
     return g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.AllReduce && g_rccl.CommDestroy;
 }
 constexpr int kNcclFloat64 = 8;   // ncclDouble
@@ -153,7 +155,11 @@ struct xrsfm_ba_context {
     std::vector<Rec> recs;
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
     bool linearized = false;
-    bool fused = true;              // fused level kernels / linearisation tail (XRSFM_BA_FUSED=0: the launch-per-phase schedule, A/B aid)
+    bool poisoned = false;          // the watchdog tripped: the stream may never drain — destroy must not wait for it (fetch_scalars)
+    bool fused = true;              // one-launch linearisation tail (k_lin_tail) and candidate cameras in trailing workgroups of k_backsub;
+                                    // XRSFM_BA_FUSED=0 (A/B aid, and always with several ranks for the tail): k_cam_segsum -> k_reduce_multi ->
+                                    // k_gradmax_cams -> k_publish and k_cam_update as launches of their own.  (The factorisation always runs
+                                    // the fused level / panel kernels: the launch-per-phase Cholesky kernels were removed in round 3.)
     bool wide = false;              // bal9 mode: 9-wide camera blocks (ba_wide.h); single rank, exact solver only
     DevW w{};
     std::vector<int> cam_intr_host; // wide: intrinsics entry of every camera (xrsfm_ba_download_intrinsics)
@@ -161,6 +167,7 @@ struct xrsfm_ba_context {
                                     // cameras inside the tile fill: no k_point_prep launch (XRSFM_BA_PREP_FUSED=0: round-2 schedule)
     double step_radius = 0.0;       // radius of the step being assembled / solved (prepare_step)
     bool step_prep = false;         // ... and whether its kernels form the point factors themselves
+    bool step_valid = false;        // a step of the current linearisation has been assembled and solved (xrsfm_ba_debug_backsub needs it)
     bool gradmax_done = false, published = false;    // the linearisation tail did these in its own launch
     double* part2 = nullptr; unsigned* ticket = nullptr;      // k_lin_tail
     // Second set of linearisation buffers: every LM step linearises at the CANDIDATE point right after the back-substitution
@@ -403,7 +410,10 @@ int fetch_scalars(xrsfm_ba_context* c) {
     const unsigned long long* flag = reinterpret_cast<const unsigned long long*>(c->h_scal + S_COUNT);
     // Watchdog: a collective that never completes (a rank that died, ranks that disagree on the call sequence) would otherwise
     // leave every other rank spinning here for ever.  XRSFM_BA_WATCHDOG_S (default 300 s without progress; 0 = off).
-    static const double watchdog_s = [] { const char* e = std::getenv("XRSFM_BA_WATCHDOG_S"); return e ? std::atof(e) : 300.0; }();
+    // Default: multi-rank contexts only (300 s) — on one rank nothing can deadlock, and a legitimately long wait (hipStreamQuery
+    // still returns NotReady) must not become a spurious ENODEV; an explicit XRSFM_BA_WATCHDOG_S applies to every context.
+    static const double watchdog_env = [] { const char* e = std::getenv("XRSFM_BA_WATCHDOG_S"); return e ? std::atof(e) : -1.0; }();
+    const double watchdog_s = watchdog_env >= 0.0 ? watchdog_env : (c->multi() ? 300.0 : 0.0);
     std::chrono::steady_clock::time_point t_wait{};
     bool waiting = false;
     for (unsigned spins = 0; __atomic_load_n(flag, __ATOMIC_ACQUIRE) != want; ++spins) {
@@ -416,6 +426,7 @@ int fetch_scalars(xrsfm_ba_context* c) {
             else if (watchdog_s > 0.0 && std::chrono::duration<double>(now - t_wait).count() > watchdog_s) {
                 fprintf(stderr, "[xrsfm_ba] rank %d of %d: the device has made no progress for %.0f s%s\n", c->rank, c->n_ranks, watchdog_s,
                         c->multi() ? " — an all-reduce that never completed? every rank must make the same calls in the same order (XRSFM_BA_WATCHDOG_S)" : "");
+                c->poisoned = true;        // the queued kernels / collective may never finish: xrsfm_ba_destroy will not wait for them
                 return c->multi() ? XRSFM_BA_ECOMM : XRSFM_BA_ENODEV;
             }
         }
@@ -435,6 +446,7 @@ int linearize(xrsfm_ba_context* c, double huber_a, const Dev& d, bool with_step,
     // between a linearisation and its fetch_scalars(), or a debug entry point that skips the fetch, must not make a later
     // caller skip k_gradmax_cams / k_publish and read stale scalars)
     c->gradmax_done = false; c->published = false;
+    c->step_valid = false;
     if (d.n_cams > 0 && !(flags & LIN_SKIP_CAMLIN)) LAUNCH(c, K_SMALL, k_cam_lin, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), kWavesPerBlock * kWave * 13 * sizeof(double), d, huber_a);
     if (!c->fused && d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<12>, dim3(d.n_cams), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camlin, (const PcgStatus*)nullptr);
@@ -582,7 +594,11 @@ int chol_setup(xrsfm_ba_context* c) {
         c->have_pattern = true;
     }
     CholPlan P;
-    if ((e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes, c->wide ? kW : 6))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
+    // (a host allocation that fails inside the plan — the T x T tile maps of a very large unordered problem — is reported as
+    //  ENOMEM from here, so that AUTO still falls back to the PCG instead of the C boundary turning it into a failed run)
+    try { e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes, c->wide ? kW : 6); }
+    catch (const std::bad_alloc&) { return XRSFM_BA_ENOMEM; }
+    if (e) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     timer.mark("plan");
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
@@ -997,6 +1013,15 @@ int xrsfm_ba_version(int* n_devices) {
 void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->poisoned) {
+        // The watchdog gave up on this context's stream (a collective no peer joined): waiting for it here would only move the
+        // hang.  The communicator is aborted (not destroyed: ncclCommDestroy waits for pending work), and the stream, its pinned
+        // scalar block and the device buffers the stuck kernels may still touch are deliberately leaked — nothing of them goes
+        // back to the caches.
+        if (c->comm && g_rccl.CommAbort) g_rccl.CommAbort(c->comm);
+        delete c;
+        return;
+    }
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->chol.aux) (void)hipStreamSynchronize(c->chol.aux);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
@@ -1195,16 +1220,18 @@ int xrsfm_ba_debug_comm_hook(xrsfm_ba_context* c, int n_ranks, int rank, xrsfm_b
 
 int xrsfm_ba_reset(xrsfm_ba_context* c) {
     if (!c) return XRSFM_BA_EINVAL;
+    if (c->poisoned) return XRSFM_BA_ESTATE;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpyAsync(c->d.cam, c->cam0, sizeof(CamRec) * (size_t)c->d.n_cams, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d.P, c->P0, sizeof(double) * 3 * (size_t)c->d.n_pts, hipMemcpyDeviceToDevice, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    c->linearized = false;
+    c->linearized = false; c->step_valid = false;
     return 0;
 }
 
 int xrsfm_ba_download(xrsfm_ba_context* c, double* cam_q, double* cam_t, double* points) {
     if (!c) return XRSFM_BA_EINVAL;
+    if (c->poisoned) return XRSFM_BA_ESTATE;       // (a blocking copy would wait for the stream the watchdog gave up on)
     HIPCHK(hipSetDevice(c->device));
     const Packed& k = c->pk;
     if (cam_q || cam_t) {
@@ -1366,6 +1393,7 @@ static int run_wide(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_s
 
 static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_ba_summary* sum) {
     if (!c || !optp || !sum) return XRSFM_BA_EINVAL;
+    if (c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context: only xrsfm_ba_destroy is left
     const xrsfm_ba_options opt = *optp;
     HIPCHK(hipSetDevice(c->device));
     memset(sum, 0, sizeof(*sum));
@@ -1383,7 +1411,7 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
     if (solver == XRSFM_BA_SOLVER_AUTO) {
         // exact tile Cholesky whenever its plan is feasible (always up to kCholMaxN unknowns; larger problems when the camera
         // graph is a band / ring), implicit-Schur PCG otherwise
-        e = chol_setup(c);
+        try { e = chol_setup(c); } catch (const std::bad_alloc&) { e = XRSFM_BA_ENOMEM; }     // (pair keys / plan too large for the host: PCG)
         if (e == XRSFM_BA_ETOOBIG || e == XRSFM_BA_ENOMEM || e == kErrDuplicateObs) solver = XRSFM_BA_SOLVER_PCG;
         else if (e) return e;
         else solver = XRSFM_BA_SOLVER_CHOLESKY;
@@ -2085,6 +2113,7 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
                     }
     }
     if ((e = chol_factor_solve(c))) return e;
+    c->step_valid = true;
     HIPCHK(hipMemcpyAsync(y, d.px, sizeof(double) * (size_t)cd.n, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
@@ -2093,7 +2122,9 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
 int xrsfm_ba_debug_backsub(xrsfm_ba_context* c, double* part_model, double* part_step2, double* cand_points, double* point_step,
                            double* cand_cam_q, double* cand_cam_t) {
     if (!c || c->wide) return XRSFM_BA_EINVAL;
-    if (!c->linearized) return XRSFM_BA_ESTATE;
+    // needs the camera part of a step (d.px) and the radius / point factors it was assembled with: without a preceding
+    // xrsfm_ba_debug_cholesky_solve of the SAME linearisation the kernel would read uninitialised Hinv / px (or divide by a zero radius)
+    if (!c->linearized || !c->chol.ready || !c->step_valid) return XRSFM_BA_ESTATE;
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
     const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cdiv(d.n_cams, kBlock);
