@@ -49,19 +49,10 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s sp
 
 
 def shard_problem(arr: dict, rank: int, world: int) -> dict:
-    """Points (tracks) j with j % world == rank and their observations; all cameras replicated."""
-    if world == 1:
-        return arr
-    keep_pt = (np.arange(arr["points"].shape[0]) % world) == rank
-    new_idx = np.cumsum(keep_pt) - 1
-    keep_obs = keep_pt[arr["obs_pt"]]
-    out = dict(arr)
-    out["points"] = np.ascontiguousarray(arr["points"][keep_pt])
-    out["point_const"] = np.ascontiguousarray(arr["point_const"][keep_pt])
-    out["obs_cam"] = np.ascontiguousarray(arr["obs_cam"][keep_obs])
-    out["obs_pt"] = np.ascontiguousarray(new_idx[arr["obs_pt"][keep_obs]].astype(np.int32))
-    out["obs_uv"] = np.ascontiguousarray(arr["obs_uv"][keep_obs])
-    return out
+    """The shard of `rank`: points assigned by the length-aware greedy of SURVEY.md section 8(e) (xrsfm_amd/sharding.py:
+    observations per rank within 1 % whatever the track-length distribution), their observations, all cameras replicated."""
+    from xrsfm_amd import sharding
+    return sharding.shard_problem(arr, rank, world)
 
 
 def weak_scaled_shard(cfg: dict, rank: int, world: int) -> dict:
@@ -208,6 +199,35 @@ def cpu_baseline(arr: dict, n_cams: int, n_points: int, max_iterations: int):
     return out, prob
 
 
+def parity_workload(opt):
+    """Config LP (xrsfm_amd/synth.py): BASELINE.json config 4's sizes and code path plus 1200 distant-landmark tracks over 24 hub
+    frames, which make the absolute camera parameters well determined (the plain L problem leaves 1e-3 of gauge drift along its
+    1000-frame loop, on which no two solvers — not even the C restatement with its points relabelled — agree to 1e-5).  The HIP
+    solve against the C restatement on the host cores, the LITERAL north-star bounds: |d RMSE| <= 1e-6 px, cameras <= 1e-5."""
+    from oracle import ba_cpu
+    from xrsfm_amd import capi, synth
+    if not ba_cpu.available():
+        return None
+    d = synth.make_problem(**synth.CONFIGS["LP"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    prod = capi.ProblemArrays(**{k: np.array(v, copy=True) for k, v in arr.items()})
+    t0 = time.perf_counter()
+    s = capi.solve(prod, opt)
+    t_gpu = time.perf_counter() - t0
+    cpu = {k: np.array(v, copy=True) for k, v in arr.items()}
+    threads = min(8, os.cpu_count() or 1)
+    sc = ba_cpu.solve(cpu, max_iterations=opt.max_iterations, threads=threads)
+    n_res = 2 * arr["obs_cam"].shape[0]
+    return {"workload": "LP: config 4 + 24 hub frames x 50 distant landmarks (1000 cams / 500000 points / 2000000 obs)",
+            "lm_steps_hip": [s.n_successful, s.n_unsuccessful], "lm_steps_cpu": [sc["n_successful"], sc["n_unsuccessful"]],
+            "final_rmse_px": math.sqrt(s.final_cost / n_res),
+            "rmse_diff_px": abs(math.sqrt(s.final_cost / n_res) - math.sqrt(sc["final_cost"] / n_res)),
+            "max_cam_param_diff": float(max(np.abs(cpu["cam_q"] - prod.cam_q).max(), np.abs(cpu["cam_t"] - prod.cam_t).max())),
+            "max_point_diff": float(np.abs(cpu["points"] - prod.points).max()),
+            "bounds": "north star: RMSE within 1e-6 px, camera parameters within 1e-5", "cpu_threads": threads,
+            "one_shot_hip_s": t_gpu, "cpu_s": sc["total_s"]}
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64 issues at the FP64 vector rate)
 
 
@@ -301,7 +321,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "K", "U", "X", "R", "V", "D", "L0", "T", "M", "Lb9"]))
+    ap.add_argument("--config", default="L", choices=sorted(["S", "L", "LP", "K", "U", "X", "R", "V", "D", "L0", "T", "M", "Lb9"]))
     ap.add_argument("--pcg-tol", type=float, default=None)
     ap.add_argument("--solver", default="auto", choices=["auto", "pcg", "cholesky"])
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
@@ -488,6 +508,11 @@ def main():
                     var = (np.asarray(arr["cam_const"]) & 4) != 0
                     base["max_rel_focal_diff"] = float(np.abs(gi[var, 0] / cpu_prob["intr_params"][var, 0] - 1).max())
                     base["max_distortion_diff"] = float(np.abs(gi[var, 1:3] - cpu_prob["intr_params"][var, 1:3]).max())
+                if args.config == "L":
+                    try:
+                        base["parity_workload"] = parity_workload(opt)
+                    except Exception as exc:       # a side measurement: never at the cost of the headline line
+                        base["parity_workload"] = {"error": str(exc)}
                 out["cpu_baseline"] = base
     ctx.close()
     if rank == 0:

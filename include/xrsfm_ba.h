@@ -112,7 +112,10 @@ typedef struct xrsfm_ba_summary {
     double final_cost;     /* ... at the last accepted state                           */
     int32_t num_residuals;          /* num_residuals_reduced = 2*n_obs                 */
     int32_t num_effective_params;   /* num_effective_parameters_reduced                */
-    int32_t n_successful;           /* LM steps accepted (iteration 0 not counted)     */
+    int32_t n_successful;           /* LM steps accepted.  Iteration 0 (the evaluation at the initial point) is NOT counted: a RECALLED
+                                       detail of Ceres' num_successful_steps (UNPINNED, oracle/ba_oracle.py ALT_DETAILS
+                                       "iteration_zero_counted"): if Ceres counts it, the reference's "Iterations :" line
+                                       (ba_solver.cc:22-25) reads one more than n_successful + n_unsuccessful here */
     int32_t n_unsuccessful;         /* LM steps rejected or invalid                    */
     int32_t termination;            /* XRSFM_BA_CONVERGENCE / ...                      */
     int32_t termination_reason;     /* 1 gradient, 2 parameter, 3 function tolerance, 4 min radius, 5 max iterations, 6 invalid steps */

@@ -75,6 +75,9 @@ def main():
                     matter[alt] = True
         lines.append(f"| `{alt}` — {what} | " + " | ".join(cells) + " |")
     out = "\n".join(lines)
+    out += ("\n\n`iteration_zero_counted` changes no parameter and no cost: it moves only the printed `Iterations :` line of "
+            "`PrintSolverSummary` (`ba_solver.cc:22-25`) and the numerator of the bench metric by +1 per solve (config L: 13 -> 14 "
+            "LM iterations, +7.7 % on `value`); bench.py counts LM steps only (iteration 0 not counted), the smaller number.")
     out += "\n\nDetails that move a result beyond the parity bar (steps, 1e-6 px, 1e-5 cameras) on at least one problem: " + \
            (", ".join(f"`{a}`" for a in bo.ALT_DETAILS if matter.get(a)) or "none") + \
            ".\nDetails that change nothing measurable on these problems (a real-Ceres golden of these problems could not pin them): " + \

@@ -80,7 +80,7 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
                  mode: str = "sequential", k_dist: float = 0.0, noise: float = 0.5,
                  outlier_frac: float = 0.02, perturb=(0.01, 0.05, 0.10),
                  min_tri_angle_deg: float = 2.0, dropout: float = 0.0, point_seed: int | None = None,
-                 literal_appendix_d: bool = False) -> dict:
+                 literal_appendix_d: bool = False, n_hubs: int = 0, hub_tracks: int = 0) -> dict:
     """Return a dict of flat arrays (keys = fields of ``xrsfm_ba_problem``) + ground truth.
     ``dropout`` > 0 removes each observation with that probability (at least two per point stay): ragged tracks with many
     distinct camera tuples, like a real reconstruction with missed detections.
@@ -92,6 +92,10 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
     baselines at 1000 cameras), no triangulation-angle filter, and the perturbation added to t instead of the camera centre
     (config L0: reported once in profiles/, it is a much harder problem than the headline workload)."""
     assert n_cams >= k_obs >= 1
+    # distant landmarks (config LP): the last n_far points of the problem, see below
+    n_far = n_hubs * hub_tracks if (n_hubs >= k_obs and mode == "sequential") else 0
+    assert n_far < n_points
+    n_points_total, n_points = n_points, n_points - n_far
     rng = np.random.Generator(np.random.PCG64(seed))
     rng_cam0 = rng if point_seed is None else np.random.Generator(np.random.PCG64([seed, 999983]))
     intr = (KITTI_INTR[0], KITTI_INTR[1], KITTI_INTR[2], k_dist)
@@ -175,6 +179,45 @@ def make_problem(n_cams: int, n_points: int, k_obs: int = 4, seed: int = 0,
         P_gt[todo[ok]] = pw[ok]; cams_of[todo[ok]] = cams[ok]
         todo = todo[~ok]
 
+    if n_far > 0:
+        # ``n_hubs`` / ``hub_tracks``: DISTANT LANDMARKS.  n_hubs cameras evenly spaced along the loop ("hub" frames); every
+        # window of k_obs consecutive hubs sees hub_tracks far points (0.6 .. 2.5 ring radii away: a skyline seen over an
+        # arc of the loop).  A sequential map whose tracks span 4 frames determines its global shape only through a chain of
+        # 1000 relative poses; these few long-baseline tracks tie the loop together (the weakest Gauss-Newton eigenvalue rises
+        # by orders of magnitude) WITHOUT leaving the code path of the sequential configurations: the plan treats the hub
+        # frames as the hub cameras of a band order (ba_plan.h: long-range pairs, <= max(24, N_c/16) hubs, eliminated last).
+        rng_far = np.random.Generator(np.random.PCG64([seed, 7919]))
+        hubs = (np.arange(n_hubs) * n_cams) // n_hubs
+        P_far = np.empty((n_far, 3)); cams_far = np.empty((n_far, k_obs), dtype=np.int64)
+        for g in range(n_hubs):
+            hc = hubs[(g + np.arange(k_obs)) % n_hubs]
+            got = 0
+            tries = 0
+            while got < hub_tracks:
+                tries += 1
+                if tries > 400:
+                    raise RuntimeError("synthetic generator failed to place the distant landmarks")
+                m = 4 * hub_tracks
+                cm = hc[k_obs // 2 - 1] if k_obs > 1 else hc[0]
+                depth = rng_far.uniform(0.6, 2.5, m) * radius
+                u = rng_far.uniform(0.05 * IMG_W, 0.95 * IMG_W, m); v = rng_far.uniform(0.2 * IMG_H, 0.8 * IMG_H, m)
+                pc = np.stack([(u - cx) / f * depth, (v - cy) / f * depth, depth], axis=1)
+                pw = np.einsum("ji,nj->ni", Rq[cm], pc - t_gt[cm])
+                ok = np.ones(m, bool)
+                for j in range(k_obs):
+                    qj = np.broadcast_to(q_gt[hc[j]], (m, 4)); tj = np.broadcast_to(t_gt[hc[j]], (m, 3))
+                    uvj, z = _project_simple_radial(qj, tj, pw, intr)
+                    ok &= (z > 1.0) & (uvj[:, 0] >= 0) & (uvj[:, 0] < IMG_W) & (uvj[:, 1] >= 0) & (uvj[:, 1] < IMG_H)
+                rays = pw[:, None, :] - centre[hc][None, :, :]
+                rays /= np.linalg.norm(rays, axis=2, keepdims=True)
+                ok &= np.einsum("mik,mjk->mij", rays, rays).min(axis=(1, 2)) < np.cos(np.deg2rad(max(min_tri_angle_deg, 2.0)))
+                idx = np.nonzero(ok)[0][:hub_tracks - got]
+                P_far[g * hub_tracks + got:g * hub_tracks + got + idx.size] = pw[idx]
+                cams_far[g * hub_tracks + got:g * hub_tracks + got + idx.size] = hc[None, :]
+                got += idx.size
+        P_gt = np.concatenate([P_gt, P_far]); cams_of = np.concatenate([cams_of, cams_far])
+        n_points = n_points_total
+
     # observations, frame-major order
     obs_pt = np.repeat(np.arange(n_points), k_obs)
     obs_cam = cams_of.reshape(-1)
@@ -233,6 +276,11 @@ CONFIGS = {
     # the dense limit of the exact path: 12 000 camera unknowns, unordered -> right-looking tile Cholesky of a full S
     # (the configuration the MFMA utilisation of the reduced solve is quoted on)
     "D": dict(n_cams=2000, n_points=200_000, k_obs=5, seed=9, mode="unordered"),
+    # BASELINE.json config 4 as a PARITY workload: the same sizes and the same code path as L (band
+    # order, level schedule, regular 4-camera tiles), plus 24 hub frames that share 50 distant landmarks per window of four hubs
+    # (1200 of the 500 000 tracks).  They tie the 1000-frame loop together, so that absolute camera parameters are determined to
+    # better than the north star's 1e-5 and two exact solvers can be compared on them literally (L itself: 1e-3 of gauge drift).
+    "LP": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4, n_hubs=24, hub_tracks=50),
     # BASELINE.json config 4 with SURVEY.md Appendix D read literally (radius-40 ring, no angle filter)
     "L0": dict(n_cams=1000, n_points=500_000, k_obs=4, seed=4, literal_appendix_d=True),
 }
