@@ -525,6 +525,57 @@ __device__ __forceinline__ double row_bcast(double v, int l) {
         case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v); default: return row_bcast_c<15>(v);
     }
 }
+// The same broadcast as ONE v_mov_b64_dpp (gfx90a+: 64-bit DPP moves exist for row_newbcast; the 64-bit builtin makes the
+// compiler emit it and schedule / pad it itself — an inline-asm v_mov_b64_dpp was measured slower in round 1: scheduling barrier).
+template <int L>
+__device__ __forceinline__ double row_bcast64_c(double v) {
+    const long long x = __builtin_bit_cast(long long, v);
+    const long long r = __builtin_amdgcn_update_dpp((long long)0, x, 0x150 + L, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double row_bcast64(double v, int l) {
+    switch (l) {
+        case 0: return row_bcast64_c<0>(v); case 1: return row_bcast64_c<1>(v); case 2: return row_bcast64_c<2>(v); case 3: return row_bcast64_c<3>(v);
+        case 4: return row_bcast64_c<4>(v); case 5: return row_bcast64_c<5>(v); case 6: return row_bcast64_c<6>(v); case 7: return row_bcast64_c<7>(v);
+        case 8: return row_bcast64_c<8>(v); case 9: return row_bcast64_c<9>(v); case 10: return row_bcast64_c<10>(v); case 11: return row_bcast64_c<11>(v);
+        case 12: return row_bcast64_c<12>(v); case 13: return row_bcast64_c<13>(v); case 14: return row_bcast64_c<14>(v); default: return row_bcast64_c<15>(v);
+    }
+}
+// Column update of the in-register 16x16 factorisation as v_fmac_f64 WITH the row broadcast folded in (VOP2 + DPP
+// row_newbcast: D = S0[lane CC of the row] * S1 + D): a_cc += u_{cc,jj} * (-tl), l_cc += u_{cc,jj} * (-xs) — two instructions
+// instead of two DPP moves + two FMAs.  The compiler does not fold a 64-bit DPP move into its user, hence inline asm; what it
+// does not do for an asm statement (cdna_hip_programming.md section 5.7) is done here: the DPP source (pivot column a_jj) may
+// have been written or copied by the instruction just before the statement -> two wait states (s_nop 1) open it.
+// Same products, same single rounding as fma(-tl, bcast, a): bit-identical factor.
+template <int CC>
+__device__ __forceinline__ void potrf_upd_dpp(double& a_cc, double& l_cc, double a_jj, double ntl, double nxs) {
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(a_cc), "+v"(l_cc) : "v"(a_jj), "v"(ntl), "v"(nxs), "i"(CC));
+}
+// ... the first update of a step (column jj + 1, the next pivot column) together with the broadcast of the next pivot
+// u_{jj+1,jj+1}: the freshly written a_cc is a DPP source two wait states later
+template <int CC>
+__device__ __forceinline__ double potrf_upd_dpp_pivot(double& a_cc, double& l_cc, double a_jj, double ntl, double nxs) {
+    double piv;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_mov_b64_dpp %2, %0 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0"
+                 : "+v"(a_cc), "+v"(l_cc), "=&v"(piv) : "v"(a_jj), "v"(ntl), "v"(nxs), "i"(CC));
+    return piv;
+}
+template <int JJ, int CC>
+__device__ __forceinline__ void potrf_upd_group(double (&a)[16], double (&lcol)[16], double ntl, double nxs) {
+    if constexpr (CC < 16) {
+        potrf_upd_dpp<CC>(a[CC], lcol[CC], a[JJ], ntl, nxs);
+        potrf_upd_group<JJ, CC + 4>(a, lcol, ntl, nxs);
+    }
+}
+
 // Diagonal tile: L = chol(A) and Linv = L^-1, blocked 16x16.
 //   per block column kb: (a) wave 0 factors the 16x16 diagonal block in registers (lane = row; column
 //   broadcasts are DPP row_newbcast moves, one reciprocal per column, square roots applied once at the end) and
@@ -536,6 +587,45 @@ __device__ __forceinline__ double row_bcast(double v, int l) {
 // L^-1 (Li must hold the identity on the padding rows >= 16 nb and zeros elsewhere).  Called by all 256 threads of the
 // workgroup after a barrier; ends with a barrier.
 // (a) of potrf_lds: wave-level factorisation + inverse of the 16x16 diagonal block at (b0,b0), in registers
+// One step (pivot column JJ) of the PV = 2 sweep: compile-time column indices (DPP controls are immediates), the same
+// software pipeline as the loop of the other variants — first the update of the next pivot column together with the broadcast
+// of the next pivot, its v_rcp_f64 issued at once, the two Newton steps dealt out between the four groups of column updates.
+template <int JJ>
+__device__ __forceinline__ void potrf_step_dpp(double (&a)[16], double (&lcol)[16], double (&piv)[16], double& rj) {
+    const double ntl = -(a[JJ] * rj);                  // -(u_ij / u_jj)
+    const double nxs = -(lcol[JJ] * rj);
+    double r = 0.0, un = 1.0, e = 0.0;
+    if constexpr (JJ + 1 < 16) {
+        un = potrf_upd_dpp_pivot<JJ + 1>(a[JJ + 1], lcol[JJ + 1], a[JJ], ntl, nxs);
+        piv[JJ + 1] = un;
+        r = __builtin_amdgcn_rcp(un);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    potrf_upd_group<JJ, JJ + 2>(a, lcol, ntl, nxs);
+    if constexpr (JJ + 1 < 16) e = fma(-un, r, 1.0);
+    __builtin_amdgcn_sched_barrier(0);
+    potrf_upd_group<JJ, JJ + 3>(a, lcol, ntl, nxs);
+    if constexpr (JJ + 1 < 16) r = fma(r, e, r);
+    __builtin_amdgcn_sched_barrier(0);
+    potrf_upd_group<JJ, JJ + 4>(a, lcol, ntl, nxs);
+    if constexpr (JJ + 1 < 16) e = fma(-un, r, 1.0);
+    __builtin_amdgcn_sched_barrier(0);
+    potrf_upd_group<JJ, JJ + 5>(a, lcol, ntl, nxs);
+    if constexpr (JJ + 1 < 16) r = fma(r, e, r);
+    __builtin_amdgcn_sched_barrier(0);
+    rj = r;
+    if constexpr (JJ + 1 < 16) potrf_step_dpp<JJ + 1>(a, lcol, piv, rj);
+}
+
+// PV: how a column update gets its broadcast operand — 0: two v_mov_b32_dpp (rounds 1-3), 1: one v_mov_b64_dpp (compiler-
+// scheduled builtin), 2: folded into v_fmac_f64_dpp (inline asm).  All three form the same products with the same roundings.
+#ifndef XBA_POTRF_PV
+#define XBA_POTRF_PV 2
+#endif
+#ifndef XBA_POTRF_OVL
+#define XBA_POTRF_OVL 1
+#endif
+template <int PV>
 __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kLdT], int b0, int lane) {
     const int li = lane & 15;
     // lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
@@ -558,7 +648,7 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     // values as the plain loop (fast_rsqrt spelled out): bit-identical factor.
 #define XBA_POTRF_UPD(cc)                                                \
     {                                                                    \
-        const double bv_ = row_bcast(a[jj], (cc)); /* u_{cc,jj} */       \
+        const double bv_ = (PV == 1) ? row_bcast64(a[jj], (cc)) : row_bcast(a[jj], (cc)); /* u_{cc,jj} */       \
         a[(cc)] = fma(-tl, bv_, a[(cc)]);                                \
         lcol[(cc)] = fma(-bv_, xs, lcol[(cc)]);                          \
         asm volatile("" : "+v"(lcol[(cc)]));   /* pin it here: left alone the compiler sinks every update of the inverse behind the   \
@@ -570,6 +660,8 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     double piv[16];
     piv[0] = row_bcast(a[0], 0);
     double rj = fast_rcp(piv[0]);
+    if constexpr (PV == 2) potrf_step_dpp<0>(a, lcol, piv, rj);
+    else
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < 16; ++jj) {
         const double tl = a[jj] * rj;                      // u_ij / u_jj
@@ -577,7 +669,7 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
         double r = 0.0, un = 1.0, e = 0.0;
         if (jj + 1 < 16) {
             XBA_POTRF_UPD(jj + 1)
-            un = row_bcast(a[jj + 1], jj + 1);
+            un = (PV == 1) ? row_bcast64(a[jj + 1], jj + 1) : row_bcast(a[jj + 1], jj + 1);
             piv[jj + 1] = un;
             r = __builtin_amdgcn_rcp(un);
         }
@@ -611,12 +703,35 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     }
 }
 
-__device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT], double (*Tb)[16][17], int nb) {
+// OVL: the off-diagonal blocks of Linv are formed INSIDE the block-column loop — row kb of the inverse (blocks (kb, j), j < kb:
+// one per wave 1..3) next to wave 0's in-register factorisation of diagonal block kb + 1, whose ~1-2 us the other waves would
+// otherwise spend at the barrier; everything a block needs (L_{kb,j..kb-1}: panels of earlier block columns; Linv_{j..kb-1,j}:
+// earlier rows; Linv_{kb,kb}: factored before the previous barrier) is complete by then.  The same products in the same order
+// as the three rounds after the loop (OVL = false, rounds 1-3): bit-identical inverse, three workgroup barriers and ~1.3 us less.
+template <int PV, bool OVL>
+__device__ __forceinline__ void potrf_lds_t(double (*A)[kLdT], double (*Li)[kLdT], double (*Tb)[16][17], int nb) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int li = lane & 15, lk = lane >> 4;
+    auto inv_block = [&](int i, int j) {                  // Linv_ij = -Linv_ii * sum_{kb=j}^{i-1} L_i,kb Linv_kb,j   (scratch Tb[j])
+        v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int kb = j; kb < i; ++kb)
+#pragma unroll
+            for (int k0 = 0; k0 < 16; k0 += 4)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * i + li][16 * kb + k0 + lk], Li[16 * kb + k0 + lk][16 * j + li], acc, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Tb[j][lk + 4 * g][li] = acc[g];
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's scratch block is written
+        __builtin_amdgcn_wave_barrier();
+        v4d acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k0 = 0; k0 < 16; k0 += 4)
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[16 * i + li][16 * i + k0 + lk], Tb[j][k0 + lk][li], acc2, 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Li[16 * i + lk + 4 * g][16 * j + li] = -acc2[g];
+    };
     // Look-ahead: wave 0 factors diagonal block kb+1 as soon as it has updated it, while waves 1..3 finish the rest of the
     // trailing update of step kb (they would otherwise wait at a barrier for the 2 us the in-register factorisation takes).
-    if (wave == 0) potrf_block16(A, Li, 0, lane);
+    if (wave == 0) potrf_block16<PV>(A, Li, 0, lane);
     __syncthreads();
 #pragma clang loop unroll(disable)          // (one copy of the in-register factorisation in the loop, not nb: the kernel must stay in the instruction cache)
     for (int kb = 0; kb < nb; ++kb) {
@@ -647,7 +762,7 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
                 for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * i + li] -= acc[g];
                 __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own block is written
                 __builtin_amdgcn_wave_barrier();
-                potrf_block16(A, Li, 16 * i, lane);
+                potrf_block16<PV>(A, Li, 16 * i, lane);
             }
         } else {
             int idx = 0;
@@ -662,34 +777,23 @@ __device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT],
 #pragma unroll
                     for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * j + li] -= acc[g];
                 }
+            if (OVL && wave - 1 < kb) inv_block(kb, wave - 1);     // row kb of the inverse (its operands are complete, see above)
         }
         __syncthreads();
     }
     XBA_STAMP(1, 11);
+    if (OVL) return;
     // ---- off-diagonal blocks of Linv, block diagonals dd = 1,2,3:  Linv_ij = -Linv_ii * sum_{kb=j}^{i-1} L_i,kb Linv_kb,j  (i = j + dd).
     // Block j of a diagonal belongs to wave j: two chains of 16x16x16 products on the matrix cores with the intermediate
     // passed through the wave's own LDS scratch; one workgroup barrier per diagonal.
     for (int dd = 1; dd < nb; ++dd) {
         const int j = wave, i = j + dd;
-        if (i < nb) {
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
-            for (int kb = j; kb < i; ++kb)
-#pragma unroll
-                for (int k0 = 0; k0 < 16; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * i + li][16 * kb + k0 + lk], Li[16 * kb + k0 + lk][16 * j + li], acc, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) Tb[j][lk + 4 * g][li] = acc[g];
-            __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's scratch block is written
-            __builtin_amdgcn_wave_barrier();
-            v4d acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += 4)
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(Li[16 * i + li][16 * i + k0 + lk], Tb[j][k0 + lk][li], acc2, 0, 0, 0);
-#pragma unroll
-            for (int g = 0; g < 4; ++g) Li[16 * i + lk + 4 * g][16 * j + li] = -acc2[g];
-        }
+        if (i < nb) inv_block(i, j);
         __syncthreads();
     }
+}
+__device__ __forceinline__ void potrf_lds(double (*A)[kLdT], double (*Li)[kLdT], double (*Tb)[16][17], int nb) {
+    potrf_lds_t<XBA_POTRF_PV, (XBA_POTRF_OVL != 0)>(A, Li, Tb, nb);
 }
 
 
