@@ -1,5 +1,6 @@
 """Two or three ranks of the HIP path on ONE GPU (RCCL refuses two ranks on one device, so the all-reduces go through the library's
-test transport hook + torch.distributed/gloo on host copies): points sharded by j % world, cameras replicated.  Every rank must
+test transport hook + torch.distributed/gloo on host copies): points sharded by the length-aware partition of
+xrsfm_amd/sharding.py (bench.shard_problem), cameras replicated.  Every rank must
 take the same LM decisions and end with the same cameras as the single-rank solve; the union of the ranks' points must equal
 the single-rank points.  Covers both linear solvers (the Cholesky path also needs the union block pattern)."""
 import os
@@ -89,8 +90,40 @@ def test_ranks_equal_one_rank(lib, tmp_path, solver, mode, world):
     # (ragged tracks leave points seen by two neighbouring frames only: their depth amplifies the 1e-9 differences of the
     # cameras by five orders of magnitude, at no difference in cost)
     ptol = 1e-2 if mode == "ragged" else (1e-4 if mode == "clustered" else 1e-5)
+    from xrsfm_amd import sharding
+    owner = sharding.partition_points(arr["obs_pt"], n_p, world)          # what bench.shard_problem applied on every rank
+    assert sharding.imbalance(arr["obs_pt"], owner, world) <= 0.01
     for r in range(world):
-        assert np.abs(z[r]["P"] - ref.points[np.arange(n_p) % world == r]).max() < ptol
+        assert np.abs(z[r]["P"] - ref.points[owner == r]).max() < ptol
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world,fused", [(2, "1"), (4, "0"), (8, "1"), (8, "0")])
+def test_config_s_sized_problem_on_2_4_8_ranks(lib, tmp_path, monkeypatch, world, fused):
+    """BASELINE.json config 2's size (100 cameras / 50 000 points / 200 000 observations) split over
+    2, 4 and 8 ranks that share the GPU through the transport hook, with the one-launch linearisation tail (single-rank form)
+    replaced by the multi-rank sequence either way and XRSFM_BA_FUSED = 0 / 1 for the rest: every rank takes the single-rank
+    solve's LM decisions, all ranks hold bit-identical cameras, cameras within 1e-5 and RMSE within 1e-6 px of the single-rank
+    solve, and the shards' observation counts balance within 1 %."""
+    from xrsfm_amd import capi, sharding, synth
+    monkeypatch.setenv("XRSFM_BA_FUSED", fused)
+    d = synth.make_problem(**synth.CONFIGS["S"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    opt_kw = dict(max_iterations=6)
+    ref = H.to_product(arr)
+    s1 = capi.solve(ref, capi.default_options(linear_solver=1, **opt_kw))
+    prefix = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(world, _free_port(), arr, 1, opt_kw, prefix), nprocs=world, join=True)
+    z = [np.load(f"{prefix}{r}.npz") for r in range(world)]
+    n_res = 2 * arr["obs_cam"].shape[0]
+    owner = sharding.partition_points(arr["obs_pt"], arr["points"].shape[0], world)
+    assert sharding.imbalance(arr["obs_pt"], owner, world) <= 0.01
+    for r in range(world):
+        assert tuple(z[r]["stat"]) == (s1.n_successful, s1.n_unsuccessful, s1.termination_reason)
+        assert abs(np.sqrt(z[r]["cost"][1] / n_res) - np.sqrt(s1.final_cost / n_res)) < 1e-6
+        assert np.abs(z[r]["q"] - ref.cam_q).max() < 1e-5 and np.abs(z[r]["t"] - ref.cam_t).max() < 1e-5
+        assert np.array_equal(z[0]["q"], z[r]["q"]) and np.array_equal(z[0]["t"], z[r]["t"])
+        assert np.abs(z[r]["P"] - ref.points[owner == r]).max() < 1e-5
 
 
 @pytest.mark.gpu

@@ -619,8 +619,10 @@ __device__ __forceinline__ void potrf_step_dpp(double (&a)[16], double (&lcol)[1
 
 // PV: how a column update gets its broadcast operand — 0: two v_mov_b32_dpp (rounds 1-3), 1: one v_mov_b64_dpp (compiler-
 // scheduled builtin), 2: folded into v_fmac_f64_dpp (inline asm).  All three form the same products with the same roundings.
+// Measured (tools/bench_potrf, MI355X, one 64x64 tile incl. the full inverse): PV 0 12.7 us, PV 1 11.9, PV 2 13.4 (the DPP form
+// of v_fmac_f64 issues slower than a DPP move + a plain FMA), PV 1 with OVL 10.9 — all bit-identical.  Default: PV 1 + OVL.
 #ifndef XBA_POTRF_PV
-#define XBA_POTRF_PV 2
+#define XBA_POTRF_PV 1
 #endif
 #ifndef XBA_POTRF_OVL
 #define XBA_POTRF_OVL 1
@@ -661,7 +663,56 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     piv[0] = row_bcast(a[0], 0);
     double rj = fast_rcp(piv[0]);
     if constexpr (PV == 2) potrf_step_dpp<0>(a, lcol, piv, rj);
-    else
+    else if constexpr (PV == 3) {
+        // PV 3: the broadcasts of a group of (up to four) column updates are issued one group AHEAD of the FMAs that use them.
+        // A wave issues in order: with the broadcast right in front of its two FMAs (the other variants: the register allocator
+        // even reuses ONE temporary pair for all of them) every update waits for its own DPP move; here the moves of group
+        // st + 1 travel with the FMAs of group st, whose operands were requested a group earlier.  Same operations, same values.
+#pragma clang loop unroll(full)
+        for (int jj = 0; jj < 16; ++jj) {
+            const double tl = a[jj] * rj;                      // u_ij / u_jj
+            const double xs = lcol[jj] * rj;
+            double r = 0.0, un = 1.0, e = 0.0;
+            double bq[2][4];
+#pragma clang loop unroll(full)
+            for (int u = 0; u < 4; ++u) { bq[0][u] = 0.0; bq[1][u] = 0.0; }
+#pragma clang loop unroll(full)
+            for (int u = 0; u < 4; ++u) if (jj + 2 + 4 * u < 16) bq[0][u] = row_bcast64(a[jj], jj + 2 + 4 * u);
+            if (jj + 1 < 16) {
+                const double b1 = row_bcast64(a[jj], jj + 1);
+                a[jj + 1] = fma(-tl, b1, a[jj + 1]);
+                lcol[jj + 1] = fma(-b1, xs, lcol[jj + 1]);
+                asm volatile("" : "+v"(lcol[jj + 1]));
+                un = row_bcast64(a[jj + 1], jj + 1);
+                piv[jj + 1] = un;
+                r = __builtin_amdgcn_rcp(un);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+            for (int st = 0; st < 4; ++st) {
+                if (st + 1 < 4) {
+#pragma clang loop unroll(full)
+                    for (int u = 0; u < 4; ++u) if (jj + 3 + st + 4 * u < 16) bq[(st + 1) & 1][u] = row_bcast64(a[jj], jj + 3 + st + 4 * u);
+                }
+#pragma clang loop unroll(full)
+                for (int u = 0; u < 4; ++u) {
+                    const int cc = jj + 2 + st + 4 * u;
+                    if (cc < 16) {
+                        a[cc] = fma(-tl, bq[st & 1][u], a[cc]);
+                        lcol[cc] = fma(-bq[st & 1][u], xs, lcol[cc]);
+                        asm volatile("" : "+v"(lcol[cc]));
+                    }
+                }
+                if (jj + 1 < 16) {
+                    if (st % 2 == 0) e = fma(-un, r, 1.0);
+                    else r = fma(r, e, r);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rj = r;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < 16; ++jj) {
         const double tl = a[jj] * rj;                      // u_ij / u_jj
