@@ -343,3 +343,47 @@ def test_packed_tile_storage_equals_dense(lib, monkeypatch, mode, n_cams, n_pts,
     a, b = out["0"], out["1"]
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert a[2:5] == b[2:5] and np.array_equal(a[5], b[5]) and np.array_equal(a[6], b[6]) and np.array_equal(a[7], b[7])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["band", "ragged", "closures", "bal9"])
+def test_one_launch_backward_substitution_equals_level_launches(lib, monkeypatch, case):
+    """Round 4: the backward substitution of a level schedule runs as ONE launch (k_lv_bwd_all: one workgroup per tile column,
+    the solution of a column handed to its descendants as data-tagged granules inside the launch) instead of one launch per
+    elimination-tree level.  Same sums in the same order: the solves must be BIT-identical to the per-level launches
+    (XRSFM_BA_BWD_ALL=0), on a plain band (5 levels), a ragged band (wider band, binary tree: 8+ levels), a band with hub
+    cameras (loop closures) and in bal9 mode (7 cameras x 9 rows per tile); every plan must really have several levels.
+    Repeated solves of one context reuse the granule buffer with a new epoch: also bit-identical."""
+    from xrsfm_amd import capi, synth
+    if case == "band":
+        arr = H.make(400, 20000, 4, seed=910)
+    elif case == "ragged":
+        arr = H.make(300, 20000, 8, seed=911, dropout=0.35)
+    elif case == "closures":
+        d = synth.make_problem(n_cams=500, n_points=30000, k_obs=4, seed=912, n_hubs=24, hub_tracks=10)
+        arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    else:
+        arr = synth.to_bal9(synth.make_problem(n_cams=200, n_points=12000, k_obs=4, seed=913))
+        arr = {k: arr[k] for k in capi.ProblemArrays.FIELDS}
+    if case != "bal9":
+        plan = capi.debug_chol_plan(H.to_product(arr))
+        assert plan["level_schedule"] == 1 and plan["levels"] >= 4, plan
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("XRSFM_BA_BWD_ALL", mode)
+        prod = H.to_product(arr)
+        ctx = capi.Context(prod)
+        runs = []
+        for rep in range(3 if mode == "1" else 1):
+            ctx.reset()
+            s = ctx.run(capi.default_options(max_iterations=12, linear_solver=1))
+            q, t, P = ctx.download()
+            runs.append((s.n_successful, s.n_unsuccessful, s.final_cost, q.copy(), t.copy(), P.copy()))
+        ctx.close()
+        for r in runs[1:]:
+            assert r[:3] == runs[0][:3] and all(np.array_equal(a, b) for a, b in zip(r[3:], runs[0][3:]))
+        res[mode] = runs[0]
+    assert res["1"][0] + res["1"][1] >= 3
+    assert res["1"][:3] == res["0"][:3]
+    assert all(np.array_equal(a, b) for a, b in zip(res["1"][3:], res["0"][3:]))
+

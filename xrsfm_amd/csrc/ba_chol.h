@@ -1598,6 +1598,103 @@ __global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict
     }
 }
 
+// ---- the whole backward substitution of a level schedule in ONE launch (round 4)
+// One launch per level (k_lv_bwd above) costs 8-18 us per level — a kernel boundary, three or four dependent global round trips
+// (column list -> tile addresses -> tiles -> result) and a grid of a few workgroups — for 64 values per column; a band with
+// missed detections (config R) or loop closures (config LP) has 8-9 levels: 100 us of every LM iteration.  What travels
+// between the levels is tiny (x_i: 64 doubles per column), and everything else a column needs — Linv_k^T, y_k, its tiles L_ik —
+// was written by EARLIER kernels.  So: one workgroup per column, all levels in one launch; a workgroup requests its
+// operands at once, then waits for the x_i of its ancestors, which arrive as DATA-TAGGED granules (8 bytes = {tag = epoch of
+// this launch, 32 bits of the value}; the hand-off recipe R2 of cdna_hip_programming.md Guideline 16: agent-scope relaxed
+// stores / loads of single aligned 8-byte words, the data is the flag, no fences) — a hop costs ~1-2 us instead of a launch.
+//  * order[] lists the columns by level, root side first, and a workgroup takes its entry with a ticket (atomic counter), so
+//    every workgroup only ever waits for workgroups that already run: no assumption about dispatch order or residency;
+//  * tags: epoch counts the launches of the context (never 0; the granule buffer is zeroed when it is allocated), the ticket
+//    counter is never reset (base = tickets handed out by earlier launches, modulo 2^32) — no memset per launch;
+//  * every spin is bounded: after kBwdSpinMax polls the workgroup raises *err (the host turns it into XRSFM_BA_EINTERNAL at the
+//    end of the solve) and goes on with what it has, so the launch always terminates;
+//  * columns of the LAST level (col_final) were solved inside their k_lv_factor launch: their x is read from c.x;
+//  * the sums run in the order of k_lv_bwd (list order, then row order): bit-identical solution (XRSFM_BA_BWD_ALL=0 is the A/B).
+typedef __attribute__((address_space(1))) unsigned long long xba_gu64;
+constexpr int kBwdPre = 4;                    // ancestors per round: one per wave polls, their tile values sit in registers
+constexpr unsigned kBwdSpinMax = 1u << 21;
+__global__ __launch_bounds__(256) void k_lv_bwd_all(CholDev c, const int* __restrict__ klist, const int* __restrict__ cptr, const int* __restrict__ ci,
+                                                    const int* __restrict__ tile_cam, double* __restrict__ px, const int* __restrict__ order,
+                                                    const unsigned char* __restrict__ col_final, unsigned long long* gx, unsigned* counter,
+                                                    unsigned base, unsigned epoch, unsigned* err) {
+    __shared__ double xs[kBwdPre][kNB];
+    __shared__ double acc[kNB];
+    __shared__ int s_b;
+    const int t = threadIdx.x, o = t >> 2, part = t & 3, lane = t & 63, wave = t >> 6;
+    if (t == 0) s_b = (int)(atomicAdd(counter, 1u) - base);
+    __syncthreads();
+    const int e = order[s_b];
+    const int k = klist[e];
+    const int q0 = cptr[e], q1 = cptr[e + 1];
+    const double* Lk = c.Linv + (size_t)k * kNB * kNB;
+    double lk[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) lk[m] = Lk[(part * 16 + m) * kNB + o];
+    const double yk = c.y[k * kNB + o];
+    double s = 0.0;
+    for (int qb = q0; qb < q1; qb += kBwdPre) {
+        const int n = min(kBwdPre, q1 - qb);
+        double M[kBwdPre][16];
+#pragma unroll
+        for (int u = 0; u < kBwdPre; ++u)
+            if (u < n) {
+                const double* Mp = tile_ptr(c, ci[qb + u], k) + (size_t)(part * 16) * c.ld + o;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) M[u][m] = Mp[(size_t)m * c.ld];
+            }
+        if (wave < n) {                                  // wave w fetches x of ancestor w of this round
+            const int i = ci[qb + wave];
+            double xv;
+            if (col_final[i]) xv = c.x[i * kNB + lane];
+            else {
+                xba_gu64* g = (xba_gu64*)(gx + (size_t)i * (2 * kNB) + 2 * lane);
+                unsigned long long a0 = 0, a1 = 0;
+                for (unsigned spins = 0;; ++spins) {
+                    a0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const bool ok = (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch;
+                    if (__all(ok)) break;                // (wave-uniform exit)
+                    if (spins >= kBwdSpinMax) { if (lane == 0) atomicOr(err, 1u); break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                xv = __hiloint2double((int)(unsigned)a1, (int)(unsigned)a0);
+            }
+            xs[wave][lane] = xv;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < kBwdPre; ++u)
+            if (u < n) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) s += M[u][m] * xs[u][part * 16 + m];
+            }
+        __syncthreads();                                 // xs is reused by the next round
+    }
+    s += __shfl_xor(s, 1, kWave);
+    s += __shfl_xor(s, 2, kWave);
+    if (part == 0) acc[o] = yk - s;
+    __syncthreads();
+    double s2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s2 += lk[m] * acc[part * 16 + m];
+    s2 += __shfl_xor(s2, 1, kWave);
+    s2 += __shfl_xor(s2, 2, kWave);
+    if (part == 0) {
+        xba_gu64* g = (xba_gu64*)(gx + (size_t)k * (2 * kNB) + 2 * o);
+        const unsigned long long tag = (unsigned long long)epoch << 32;
+        __hip_atomic_store(g, tag | (unsigned)__double2loint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(g + 1, tag | (unsigned)__double2hiint(s2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.x[k * kNB + o] = s2;
+        const int cam = (o < c.cw * c.cpt) ? tile_cam[k * c.cpt + o / c.cw] : -1;
+        if (cam >= 0) px[c.cw * (size_t)cam + o % c.cw] = s2;    // the solution in camera order
+    }
+}
+
 __global__ void k_zero_vec(double* p, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = 0.0;

@@ -116,6 +116,10 @@ struct CholHost {
     int *lv_k = nullptr, *lv_tgt = nullptr, *lv_cptr = nullptr, *lv_cj = nullptr;
     int *lv_bptr = nullptr, *lv_bi = nullptr;
     std::vector<int> lv_k_off, lv_tgt_off;        // per level offsets (size n_levels+1)
+    // one-launch backward substitution of a level schedule (k_lv_bwd_all): columns by level (root side first), which columns the
+    // last factor launch has solved already, the granule buffer, the ticket counter / error word, launches so far
+    int* bw_order = nullptr; unsigned char* bw_final = nullptr; unsigned long long* bw_gx = nullptr; unsigned* bw_ctr = nullptr;
+    int bw_n = 0; unsigned bw_launches = 0; bool bwd_all = false;
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off, mp_off;
     int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
@@ -660,6 +664,23 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(dev_alloc(c, &h.dev.S, h.S_doubles));
     TRYC(dev_alloc(c, &h.dev.Linv, (size_t)P.T * kNB * kNB));
     TRYC(dev_alloc(c, &h.dev.y, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.rhs, (size_t)P.n_pad)); TRYC(dev_alloc(c, &h.dev.x, (size_t)P.n_pad));
+    {   // one-launch backward substitution (level schedules with at least two levels; XRSFM_BA_BWD_ALL=0: one launch per level)
+        const char* be = std::getenv("XRSFM_BA_BWD_ALL");        // (read per context: the A/B test switches it inside one process)
+        const bool on = !(be && be[0] == '0');
+        h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2;
+        if (h.bwd_all) {
+            std::vector<int> order;
+            std::vector<unsigned char> fin(P.T, 0);
+            for (int lv = P.n_levels - 2; lv >= 0; --lv)
+                for (int e2 = P.lv_k_off[lv]; e2 < P.lv_k_off[lv + 1]; ++e2) order.push_back(e2);
+            for (int e2 = P.lv_k_off[P.n_levels - 1]; e2 < P.lv_k_off[P.n_levels]; ++e2) fin[P.lv_k[e2]] = 1;
+            h.bw_n = (int)order.size(); h.bw_launches = 0;
+            TRYC(dev_upload(c, &h.bw_order, order)); TRYC(dev_upload(c, &h.bw_final, fin));
+            TRYC(dev_alloc(c, &h.bw_gx, (size_t)P.T * 2 * kNB)); TRYC(dev_alloc(c, &h.bw_ctr, (size_t)2));
+            HIPCHK(hipMemsetAsync(h.bw_gx, 0, sizeof(unsigned long long) * (size_t)P.T * 2 * kNB, c->stream));      // tag 0 = never written
+            HIPCHK(hipMemsetAsync(h.bw_ctr, 0, sizeof(unsigned) * 2, c->stream));                                   // [0] tickets, [1] error word
+        }
+    }
 #undef TRYC
     HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * h.S_doubles, c->stream));
     const int shm = 2 * kNB * kLdT * (int)sizeof(double);
@@ -852,6 +873,14 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
             return 0;
         }
+        if (h.bwd_all && h.bw_n > 0) {
+            // all remaining levels in one launch: x travels between the workgroups of the launch as tagged granules (ba_chol.h)
+            const unsigned base = h.bw_launches * (unsigned)h.bw_n;       // tickets handed out so far (unsigned wrap-around is fine)
+            const unsigned epoch = ++h.bw_launches;
+            LAUNCH(c, K_TRISOLVE, k_lv_bwd_all, dim3(h.bw_n), dim3(256), 0, h.dev, (const int*)h.lv_k, (const int*)h.lv_bptr, (const int*)h.lv_bi,
+                   (const int*)h.tile_cam, px_out, (const int*)h.bw_order, (const unsigned char*)h.bw_final, h.bw_gx, h.bw_ctr, base, epoch, h.bw_ctr + 1);
+            return 0;
+        }
         for (int lv = h.n_levels - 2; lv >= 0; --lv) {      // (the last level: inside its k_lv_factor launch)
             const int nk = h.lv_k_off[lv + 1] - h.lv_k_off[lv];
             LAUNCH(c, K_TRISOLVE, k_lv_bwd, dim3(nk), dim3(256), 0, h.dev, h.lv_k + h.lv_k_off[lv], h.lv_bptr + h.lv_k_off[lv], h.lv_bi, h.tile_cam, px_out);
@@ -917,6 +946,21 @@ int finish_step(xrsfm_ba_context* c, double huber_a, bool speculate) {
     int e = allreduce(c, d.scal + S_MODEL, 3, kNcclSum);   // MODEL, STEP2_PTS, COST_CAND adjacent
     if (e) return e;
     return fetch_scalars(c);
+}
+
+// k_lv_bwd_all bounds its spins and raises a device word when one gives up (a granule that never arrived): checked once per
+// solve, after the stream has drained (level schedules with >= 2 levels only: never an LBA-sized call).
+int bwd_all_status(xrsfm_ba_context* c) {
+    CholHost& h = c->chol;
+    if (!h.bwd_all || h.bw_launches == 0 || !h.bw_ctr) return 0;
+    unsigned ev = 0;
+    if (hipMemcpy(&ev, h.bw_ctr + 1, sizeof(unsigned), hipMemcpyDeviceToHost) != hipSuccess) return XRSFM_BA_ENODEV;
+    if (ev) {
+        fprintf(stderr, "[xrsfm_ba] backward substitution: a hand-off between workgroups timed out (k_lv_bwd_all); rerun with XRSFM_BA_BWD_ALL=0\n");
+        (void)hipMemset(h.bw_ctr + 1, 0, sizeof(unsigned));
+        return XRSFM_BA_EINTERNAL;
+    }
+    return 0;
 }
 
 void print_progress(const xrsfm_ba_options& o, int it, double cost, double change, double gmax, double step, double rho, double radius) {
@@ -1292,6 +1336,7 @@ static int run_wide(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_s
         sum->termination = term; sum->termination_reason = reason; sum->final_cost = cost;
         (void)hipStreamSynchronize(st);
         sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (int be = bwd_all_status(c)) return be;
         if (c->profiling) {
             profile_collect(c);
             int best = 0;
@@ -1436,6 +1481,7 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
         sum->termination = term; sum->termination_reason = reason; sum->final_cost = cost;
         (void)hipStreamSynchronize(st);
         sum->total_time_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+        if (int be = bwd_all_status(c)) return be;
         if (c->profiling) {
             profile_collect(c);
             int best = 0;
