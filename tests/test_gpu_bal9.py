@@ -54,6 +54,45 @@ def test_bal9_linearisation_and_step_match_oracle(lib, name):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k_cams", [2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("ragged", [False, True])
+def test_bal9_gram_tiles_of_every_camera_count(lib, k_cams, ragged):
+    """Round 4 (k9_pairs_gram): the S assembly of 9-wide blocks through Gram tiles.  Every camera count a tile can have —
+    C = 2..7 cameras = 18..63 operand rows = all four operand heights NI, dense tracks (every track sees every camera) and
+    ragged ones (missed detections: zero-filled operand, per-camera sums over a subset of the lanes) — plus C = 8, which must
+    take the per-pair path: the step of the FIRST linearisation against the oracle's exact solve, and three LM iterations
+    against the oracle (same decisions, cost, cameras, intrinsics)."""
+    from xrsfm_amd import capi
+    kw = dict(mode="unordered", min_tri_angle_deg=0.5)
+    n_cams = k_cams + (3 if ragged else 0)
+    if ragged:
+        kw["dropout"] = 0.3
+    arr = H.make_bal9(n_cams, 260, min(k_cams + (2 if ragged else 0), n_cams), seed=300 + 10 * k_cams + int(ragged), **kw)
+    g = capi.debug_pack_gram(H.to_product(arr))
+    if not ragged:
+        assert (g["gram_tiles"] > 0) == (k_cams <= 7) and (k_cams > 7 or g["max_cams"] == k_cams), g
+    pr = H.to_oracle(arr)
+    cost, rt, Fs, Es, lin = _scaled_lin(pr)
+    radius = 2e3
+    ctx = capi.Context(H.to_product(arr))
+    out = ctx.debug_wide(5.99, radius)
+    ctx.close()
+    Dc2 = np.clip(np.einsum("nii->ni", lin.Hcc), 1e-6, 1e32) / radius
+    Dp2 = np.clip(np.einsum("nii->ni", lin.Hpp), 1e-6, 1e32) / radius
+    yc, yp, _ = bo._solve_exact(pr, lin, Dc2, Dp2)
+    assert H.rel_err(out["y"], yc) < 1e-7
+    pr2 = H.to_oracle(arr)
+    s_ref = bo.solve(pr2, bo.Options(max_iterations=3))
+    prod = H.to_product(arr)
+    s = capi.solve(prod, capi.default_options(max_iterations=3))
+    n_res = 2 * arr["obs_cam"].shape[0]
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful)
+    assert abs(math.sqrt(s.final_cost / n_res) - math.sqrt(s_ref.final_cost / n_res)) < 1e-6
+    assert max(np.abs(prod.cam_q - pr2.cam_q).max(), np.abs(prod.cam_t - pr2.cam_t).max()) < 1e-5
+    assert np.abs(prod.intr_params[:, 0] / pr2.intr_params[:, 0] - 1).max() < 1e-6
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["seq", "ragged_consts", "unordered", "long"])
 def test_bal9_full_solve_parity(lib, name):
     from xrsfm_amd import capi

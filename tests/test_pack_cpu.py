@@ -130,14 +130,19 @@ def test_gram_tiles_and_item_classes(kind):
 
 
 def test_bal9_problems_pack_per_observation_and_plan_with_nine_rows_per_camera(lib):
-    """bal9 mode (cam_const bit 2): no Gram tiles, no regular-tile pre-reductions (the 9-wide kernels work per observation and
-    per pair), 7 cameras x 9 rows per 64-row tile in the plan; the bit is refused for the reference's camera models and for
-    shared intrinsics entries."""
+    """bal9 mode (cam_const bit 2): no regular-tile pre-reductions (the 9-wide linearisation works per observation), Gram tiles of
+    at most 7 cameras (63 operand rows: k9_pairs_gram, round 4) — a tile with more cameras takes the per-pair path —, 7 cameras x 9
+    rows per 64-row tile in the plan; the bit is refused for the reference's camera models and for shared intrinsics entries."""
     from xrsfm_amd import capi
     arr = H.make_bal9(40, 2000, 4, seed=5)
     st = capi.debug_pack(H.to_product(arr))
     g = capi.debug_pack_gram(H.to_product(arr))
-    assert st["regular_tiles"] == 0 and g["gram_tiles"] == 0 and g["items_other"] == st["items"] and st["cam_entries"] == arr["obs_cam"].shape[0]
+    assert st["regular_tiles"] == 0 and st["cam_entries"] == arr["obs_cam"].shape[0]
+    assert g["gram_tiles"] >= 0.9 * st["tiles"] and 2 <= g["max_cams"] <= 7 and g["items_small"] + g["items_big"] == g["gram_tiles"]
+    assert g["cam_entries_g"] < 0.5 * st["cam_entries"]            # one S-assembly entry per distinct camera of a Gram tile
+    wide_tracks = H.make_bal9(40, 200, 9, seed=6)                  # 9-camera tracks: more than 7 distinct cameras per tile
+    g9 = capi.debug_pack_gram(H.to_product(wide_tracks))
+    assert g9["gram_tiles"] == 0 and g9["items_other"] == g9["items"]
     plan = capi.debug_chol_plan(H.to_product(arr))
     off = plan["cam_offset"]
     assert plan["tiles"] == 6 and np.all(off % 64 % 9 == 0) and np.all(off % 64 <= 54) and len(set(off.tolist())) == 40

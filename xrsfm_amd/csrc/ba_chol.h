@@ -110,9 +110,10 @@ __device__ __forceinline__ void pairs_diag(const double* F, const double* V, con
 // K-step of 4 every lane reads ONE value per row tile — the same register is the A operand of the products in its tile row
 // and the B operand of those in its tile column (identical layouts) — and all NI(NI+1)/2 accumulators advance.  Then the
 // blocks (camera rb > camera ra) go to their destinations (dtab: [C][C], -1 = the pair never occurs in the tile).
-template <int NI>
+// CW: operand rows per camera = width of the camera blocks (6; 9 in bal9 mode, ba_wide.h: k9_pairs_gram — up to 7 cameras = 63 rows).
+template <int NI, int CW = 6>
 __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int Cp, int C, const int* __restrict__ dtab,
-                                          double* __restrict__ scat2, int lane, const double (&V)[18], bool valid, int t, int cidx,
+                                          double* __restrict__ scat2, int lane, const double (&V)[3 * CW], bool valid, int t, int cidx,
                                           int T, int Th, int passes, bool dense) {
     static_assert(NI >= 1 && NI <= 4, "a Gram tile has at most 10 cameras = 60 operand rows (ba_pack.h: kGramMaxCams)");
     const int li = lane & 15, lk = lane >> 4;
@@ -138,9 +139,9 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
         }
         if (valid && t >= t0 && t < t0 + tn) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i)
+            for (int i = 0; i < CW; ++i)
 #pragma unroll
-                for (int m = 0; m < 3; ++m) Vst[(6 * cidx + i) * Cp + 3 * (t - t0) + m] = V[3 * i + m];
+                for (int m = 0; m < 3; ++m) Vst[(CW * cidx + i) * Cp + 3 * (t - t0) + m] = V[3 * i + m];
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the staged operand (and dtab) are in LDS.  Not vmcnt: the stores
         __builtin_amdgcn_wave_barrier();               // of the diagonal terms issued just before are still in flight and stay so
@@ -163,19 +164,19 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
     (void)C; (void)R;
     int tcol[NI], jcol[NI];
 #pragma unroll
-    for (int J = 0; J < NI; ++J) { const int col = 16 * J + li; const int ra = col / 6; tcol[J] = ra * kGramTabLd; jcol[J] = col - 6 * ra; }
+    for (int J = 0; J < NI; ++J) { const int col = 16 * J + li; const int ra = col / CW; tcol[J] = ra * kGramTabLd; jcol[J] = col - CW * ra; }
     int p = 0;
 #pragma unroll
     for (int I = 0; I < NI; ++I) {
         int trow[4], irow[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) { const int row = 16 * I + lk + 4 * g; const int rb = row / 6; trow[g] = rb; irow[g] = 6 * (row - 6 * rb); }
+        for (int g = 0; g < 4; ++g) { const int row = 16 * I + lk + 4 * g; const int rb = row / CW; trow[g] = rb; irow[g] = CW * (row - CW * rb); }
 #pragma unroll
         for (int J = 0; J <= I; ++J) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int dst = dtab[tcol[J] + trow[g]];
-                if (dst >= 0) scat2[36 * (size_t)dst + irow[g] + jcol[J]] = acc[p][g];
+                if (dst >= 0) scat2[(CW * CW) * (size_t)dst + irow[g] + jcol[J]] = acc[p][g];
             }
             ++p;
         }

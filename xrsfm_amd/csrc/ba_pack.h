@@ -28,14 +28,15 @@ constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
-inline int gram_lds_need(int C, int T, int* passes) {
+inline int gram_lds_need(int C, int T, int* passes, int cw = 6) {     // cw: operand rows per camera (9 in bal9 mode, ba_wide.h)
     constexpr int tab = (kGramMaxCams + 1) * (kGramMaxCams + 1) * 4;      // destination table with a fixed row stride (ba_chol.h: kGramTabLd)
-    const int one = 6 * C * ((((3 * T + 3) & ~3)) + 2) * 8 + tab;
+    const int one = cw * C * ((((3 * T + 3) & ~3)) + 2) * 8 + tab;
     if (one <= kGramSmallLds) { *passes = 1; return one; }
     const int Th = (T + 1) / 2;
     *passes = 2;
-    return 6 * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + tab;
+    return cw * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + tab;
 }
+constexpr int kGramMaxCamsWide = 7;      // bal9 mode: 7 cameras x 9 rows = 63 operand rows
 
 // Host-side helper: run fn(begin, end) over [0, n) on up to 8 threads (16 for the largest loops) (large problems only; the packing of config L is ~100 ms
 // of single-thread work otherwise).  The pieces are disjoint, so the result does not depend on the thread count.
@@ -129,7 +130,9 @@ struct Packed {
 constexpr unsigned kCamIntrVariable = 4u;
 constexpr int kModelBal = 5;
 
-// wide (bal9 mode): no Gram tiles and no regular-tile pre-reductions — the 9-wide kernels work per observation / per pair.
+// wide (bal9 mode): no regular-tile pre-reductions (the 9-wide linearisation / back-substitution work per observation); Gram
+// tiles of up to kGramMaxCamsWide cameras (round 4: k9_pairs_gram — the S assembly of 9-wide blocks through the same Gram
+// product and per-camera pre-reduction as the 6-wide path).
 inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false) {
     if (p.n_cams < 0 || p.n_points < 0 || p.n_obs < 0 || p.n_intr < 0) return XRSFM_BA_EINVAL;
     if (p.n_obs > 0 && (!p.obs_cam || !p.obs_pt || !p.obs_uv)) return XRSFM_BA_EINVAL;
@@ -431,7 +434,8 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
     {
         std::vector<char> single(o.n_tiles, 0);
         for (size_t it = 0; it + 1 < o.items.size(); it += 2)
-            if (o.items[it + 1] == 1 && !wide) single[o.items[it]] = 1;
+            if (o.items[it + 1] == 1) single[o.items[it]] = 1;
+        const int gram_max_cams = wide ? kGramMaxCamsWide : kGramMaxCams, gram_cw = wide ? 9 : 6;
         std::vector<int> tile_cams((size_t)o.n_tiles * kGramMaxCams, -1);       // ascending distinct cameras of the Gram tiles
         pack_parallel_for(o.n_tiles, [&](long long t0, long long t1) {
             int cams[64];
@@ -447,7 +451,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
                 std::sort(cams, cams + nc);
                 const int C = (int)(std::unique(cams, cams + nc) - cams);
                 int passes = 1;
-                if (C < 2 || C > kGramMaxCams || gram_lds_need(C, ntrk, &passes) > kGramMaxLds) continue;
+                if (C < 2 || C > gram_max_cams || gram_lds_need(C, ntrk, &passes, gram_cw) > kGramMaxLds) continue;
                 o.tile_ncam[t] = C;
                 for (int q = 0; q < C; ++q) tile_cams[(size_t)t * kGramMaxCams + q] = cams[q];
                 for (int q = 0; q < 64 && o.slot_cam[b0 + q] >= 0; ++q)
@@ -478,7 +482,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
         auto lds_need = [&](int t) {
             int ntrk = 0, passes = 1;
             for (int q = 0; q < 64 && o.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || o.slot_pt[64 * t + q] != o.slot_pt[64 * t + q - 1]);
-            return (size_t)gram_lds_need(o.tile_ncam[t], ntrk, &passes);
+            return (size_t)gram_lds_need(o.tile_ncam[t], ntrk, &passes, gram_cw);
         };
         int n_big = 0;
         for (int t = 0; t < o.n_tiles; ++t) n_big += (o.tile_ncam[t] > 0 && lds_need(t) > (size_t)kGramSmallLds);

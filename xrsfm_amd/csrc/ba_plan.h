@@ -848,9 +848,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             int ntrk = 0;
             for (int q = 0; q < 64 && k.slot_cam[64 * t + q] >= 0; ++q) ntrk += (q == 0 || k.slot_pt[64 * t + q] != k.slot_pt[64 * t + q - 1]);
             int passes = 1;
-            const size_t need = std::max(base, (size_t)gram_lds_need(C, ntrk, &passes));
+            const size_t need = std::max(base, (size_t)gram_lds_need(C, ntrk, &passes, P.cam_width));
             // (Gram classes list the TILE itself: one dependent load less at the head of every workgroup)
-            const int b = 2 * ((6 * C + 15) / 16 - 1) + (need <= small_cap ? 0 : 1);
+            const int b = 2 * ((P.cam_width * C + 15) / 16 - 1) + (need <= small_cap ? 0 : 1);
             bucket[b].push_back(t);
             P.gram_shm[b] = std::max(P.gram_shm[b], need);
         }

@@ -197,12 +197,14 @@ __device__ __forceinline__ void pairs9_diag(const double* F, const double* V, co
     out[54] = 0.0; out[55] = 0.0;
 }
 
-__global__ __launch_bounds__(kBlock) void k9_pairs(Dev d, DevW w, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
-                                                  double* __restrict__ scat2, double radius) {
+// (round 4: the items that are NOT Gram tiles — tiles with more than kGramMaxCamsWide cameras, long tracks; item_list as for
+//  k_schur_pairs<false, ...>.  Their per-observation diagonal terms go to the S assembly's camera-major entries, slot_campos_g.)
+__global__ __launch_bounds__(kBlock) void k9_pairs(Dev d, DevW w, const int* __restrict__ item_list, int n_list, const int* __restrict__ slot_pair_ptr,
+                                                  const int* __restrict__ pair_dst, double* __restrict__ scat2, double radius) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (item >= d.n_items) return;
-    const Item it = d.items[item];
+    const int li_ = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (li_ >= n_list) return;
+    const Item it = d.items[item_list[li_]];
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         double V[27];
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(kBlock) void k9_pairs(Dev d, DevW w, const int* __r
             pairs9_V(F, E, cf, V);
             const double* gp = d.gp + 3 * (size_t)s.pt;
             const double g[3] = {gp[0], gp[1], gp[2]};
-            pairs9_diag(F, V, cf, g, w.scat + kWS * (size_t)d.slot_campos[s.slot]);
+            pairs9_diag(F, V, cf, g, w.scat + kWS * (size_t)d.slot_campos_g[s.slot]);
             pbase = slot_pair_ptr[s.slot];
             npair = slot_pair_ptr[s.slot + 1] - pbase;
         }
@@ -251,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void k9_pairs(Dev d, DevW w, const int* __r
         load_FE9(d, w, sa, Fa, Ea);
         pairs9_V(Fa, Ea, cf, Va);
         const double g[3] = {d.gp[3 * (size_t)pt], d.gp[3 * (size_t)pt + 1], d.gp[3 * (size_t)pt + 2]};
-        pairs9_diag(Fa, Va, cf, g, w.scat + kWS * (size_t)d.slot_campos[sa]);
+        pairs9_diag(Fa, Va, cf, g, w.scat + kWS * (size_t)d.slot_campos_g[sa]);
         const int pbase = slot_pair_ptr[sa];
         const int npair = slot_pair_ptr[sa + 1] - pbase;
         for (int dd = 1; dd <= npair; ++dd) {
@@ -265,6 +267,124 @@ __global__ __launch_bounds__(kBlock) void k9_pairs(Dev d, DevW w, const int* __r
                     out[9 * rb + ca] = Vb[3 * rb] * Va[3 * ca] + Vb[3 * rb + 1] * Va[3 * ca + 1] + Vb[3 * rb + 2] * Va[3 * ca + 2];
         }
     }
+}
+
+// Value IDX of the 56-record of pairs9_diag (45 upper-triangle entries of F^T F - V V^T, 9 of -V C^T g, 2 pad) with compile-time
+// indices, and a run of 14 of them stored to dst[0..13]: the Gram kernel forms the record in four rounds of 14 live values
+// (the whole record in registers cost 112 VGPRs: one wave per SIMD at NI = 4).
+constexpr int tri9_row(int idx) { int a = 0; while (idx >= 9 - a) { idx -= 9 - a; ++a; } return a; }
+constexpr int tri9_col(int idx) { int a = 0; while (idx >= 9 - a) { idx -= 9 - a; ++a; } return a + idx; }
+template <int IDX>
+__device__ __forceinline__ double diag9_value(const double (&F)[18], const double (&V)[27], double u0, double u1, double u2) {
+    if constexpr (IDX < 45) {
+        constexpr int a = tri9_row(IDX), c2 = tri9_col(IDX);
+        return F[a] * F[c2] + F[9 + a] * F[9 + c2] - (V[3 * a] * V[3 * c2] + V[3 * a + 1] * V[3 * c2 + 1] + V[3 * a + 2] * V[3 * c2 + 2]);
+    } else if constexpr (IDX < 54) {
+        constexpr int a = IDX - 45;
+        return -(V[3 * a] * u0 + V[3 * a + 1] * u1 + V[3 * a + 2] * u2);
+    } else return 0.0;
+}
+template <int IDX0, int K>
+__device__ __forceinline__ void diag9_store(double* dst, const double (&F)[18], const double (&V)[27], double u0, double u1, double u2) {
+    if constexpr (K < 14) {
+        dst[K] = diag9_value<IDX0 + K>(F, V, u0, u1, u2);
+        diag9_store<IDX0, K + 1>(dst, F, V, u0, u1, u2);
+    }
+}
+
+// Gram tiles in bal9 mode (round 4).  The per-pair kernel above writes one 648-byte block per
+// observation pair and 448 bytes of diagonal terms per observation, which the segmented sums read back: 2.8 GB per LM iteration
+// at config 4's size, 0.046 of the HBM roofline.  Here a tile of T tracks over C <= 7 distinct cameras stages V = W chol(Hinv)
+// as a [9C x 3T] operand in LDS and forms G = V V^T on the FP64 matrix cores (gram_tile<NI, 9> of ba_chol.h: every camera-pair
+// block of the tile already summed over its tracks, written once), and the 56 diagonal-block / rhs values are summed per
+// distinct camera of the tile through LDS before they are written (four rounds of 14 values): one wave = one tile, one
+// instantiation per operand height NI = ceil(9 C / 16).
+template <int NI>
+__global__ __launch_bounds__(kWave) void k9_pairs_gram(Dev d, DevW w, const int* __restrict__ tile_list, const int* __restrict__ pair_dst,
+                                                       int n_obs_pairs, double* __restrict__ scat2, double radius) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int lane = threadIdx.x;
+    const int tile = tile_list[blockIdx.x];
+    const int C = d.tile_ncam[tile];
+    int dt0 = -1, dt1 = -1;                  // entries lane and lane + 64 of the kGramTabLd x kGramTabLd destination table
+    {
+        const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[tile];
+        const int a0 = lane / kGramTabLd, b0 = lane - kGramTabLd * a0;
+        const int a1 = (lane + kWave) / kGramTabLd, b1 = lane + kWave - kGramTabLd * a1;
+        if (b0 > a0 && b0 < C) dt0 = src[a0 * C + b0];
+        if (b1 > a1 && b1 < C && a1 < kGramTabLd) dt1 = src[a1 * C + b1];
+    }
+    const SlotCtx s = load_slot(d, tile, lane);
+    const int cp = d.slot_campos_g[s.slot];
+    const int cidx_raw = (int)d.slot_cidx[s.slot];
+    double V[27], F[18], u0 = 0.0, u1 = 0.0, u2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) V[k] = 0.0;
+#pragma unroll
+    for (int k = 0; k < 18; ++k) F[k] = 0.0;
+    if (s.valid) {
+        double E[6], cf[6];
+        load_FE9(d, w, s.slot, F, E);
+        const double* hp = d.Hpp + 6 * (size_t)s.pt;
+        const double h[6] = {hp[0], hp[1], hp[2], hp[3], hp[4], hp[5]};
+        const double* gp = d.gp + 3 * (size_t)s.pt;
+        const double g[3] = {gp[0], gp[1], gp[2]};
+        point_factor(h, radius, cf);
+        pairs9_V(F, E, cf, V);
+        u0 = cf[0] * g[0]; u1 = cf[1] * g[0] + cf[3] * g[1]; u2 = cf[2] * g[0] + cf[4] * g[1] + cf[5] * g[2];      // C^T g
+    }
+
+    {   // per distinct camera of the tile: the lane that owns (camera c, value k) adds the entries of the lanes whose observation
+        // is in camera c, in lane order; the first of them holds the camera's entry in the scatter buffer
+        const int cidx = s.valid ? cidx_raw : -1;
+        double* red = smem;                                         // [64][kRedLd]
+        const int nq = 14 * C;                                      // <= 98: two rounds of 64 lanes
+        unsigned long long m0 = 0, m1 = 0;
+        for (int cc = 0; cc < C; ++cc) {
+            const unsigned long long m = __ballot(cidx == cc);
+            if (lane / 14 == cc) m0 = m;
+            if ((lane + 64) / 14 == cc) m1 = m;
+        }
+        auto round = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            diag9_store<14 * h, 0>(red + lane * kRedLd, F, V, u0, u1, u2);      // 14 values of the 56-record, formed where they are needed
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int rd = 0; rd < 2; ++rd) {
+                const int q = lane + 64 * rd;
+                unsigned long long m = rd == 0 ? m0 : m1;
+                const bool on = q < nq;
+                const int k = q % 14;
+                const int first = on ? __ffsll((long long)m) - 1 : 0;
+                const int cpr = __shfl(cp, first, kWave);
+                if (on) {
+                    double sum = 0.0;
+                    while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * kRedLd + k]; m &= m - 1; }
+                    w.scat[kWS * (size_t)cpr + 14 * h + k] = sum;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+        };
+        round(std::integral_constant<int, 0>{}); round(std::integral_constant<int, 1>{});
+        round(std::integral_constant<int, 2>{}); round(std::integral_constant<int, 3>{});
+    }
+    const unsigned long long headmask = __ballot(s.head);
+    const int T = __popcll(headmask);
+    const int nvalid = __popcll(__ballot(s.valid));
+    const int t = __popcll(headmask & ((2ull << lane) - 1ull)) - 1;        // rank of the lane's track in the tile
+    const int cidx = s.valid ? cidx_raw : 0;
+    int passes = 1;
+    (void)gram_lds_need(C, T, &passes, kW);
+    const int Th = (T + passes - 1) / passes;
+    const int R = kW * C, Cp = ((3 * Th + 3) & ~3) + 2;
+    double* Vst = smem;
+    int* dtab = reinterpret_cast<int*>(smem + R * Cp);
+    dtab[lane] = dt0;
+    if (lane + kWave < kGramTabLd * kGramTabLd) dtab[lane + kWave] = dt1;
+    const bool dense = nvalid == T * C;
+    gram_tile<NI, kW>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
 }
 
 // workgroups [0, n_cams): the 56 diagonal-block / rhs values of a camera; [n_cams, n_cams + n_blocks): the 81 values of a block

@@ -697,6 +697,10 @@ int chol_setup(xrsfm_ba_context* c) {
 #undef XBA_PAIRS_ATTR
             (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
             (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<1>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<2>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<3>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<4>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
             done_for[c->device] = 1;
         }
     }
@@ -1313,6 +1317,37 @@ static int linearize_wide(xrsfm_ba_context* c, double huber_a, bool scaled_pass)
     return 0;
 }
 
+// S assembly in bal9 mode: Gram tiles per (operand height, LDS class) bucket (k9_pairs_gram), every other item through the
+// per-pair kernel, then the fixed-order sums over the S assembly's camera-major entries (cam_ptr_g) and the tile fill.
+static int assemble_wide(xrsfm_ba_context* c, double radius) {
+    Dev& d = c->d;
+    CholHost& h = c->chol;
+    const int n_obs_pairs = h.n_pairs - c->pk.n_gt_cells;
+    {
+        Timed t_(c, K_SCHUR_PAIRS);
+        const int* items = h.pairs_items;
+        for (int b = 0; b < 8; ++b) {
+            const int n = h.gram_n[b];
+            if (n > 0) {
+                switch (b >> 1) {
+                    case 0: hipLaunchKernelGGL(k9_pairs_gram<1>, dim3(n), dim3(kWave), h.gram_shm[b], c->stream, d, c->w, items, (const int*)h.pair_dst, n_obs_pairs, h.scat2, radius); break;
+                    case 1: hipLaunchKernelGGL(k9_pairs_gram<2>, dim3(n), dim3(kWave), h.gram_shm[b], c->stream, d, c->w, items, (const int*)h.pair_dst, n_obs_pairs, h.scat2, radius); break;
+                    case 2: hipLaunchKernelGGL(k9_pairs_gram<3>, dim3(n), dim3(kWave), h.gram_shm[b], c->stream, d, c->w, items, (const int*)h.pair_dst, n_obs_pairs, h.scat2, radius); break;
+                    default: hipLaunchKernelGGL(k9_pairs_gram<4>, dim3(n), dim3(kWave), h.gram_shm[b], c->stream, d, c->w, items, (const int*)h.pair_dst, n_obs_pairs, h.scat2, radius); break;
+                }
+            }
+            items += n;
+        }
+        if (h.n_pairs_other > 0)
+            hipLaunchKernelGGL(k9_pairs, dim3(cdiv(h.n_pairs_other, kWavesPerBlock)), dim3(kBlock), 0, c->stream, d, c->w, items, h.n_pairs_other,
+                               (const int*)h.slot_pair_ptr, (const int*)h.pair_dst, h.scat2, radius);
+    }
+    if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k9_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, c->w.scat, d.cam_ptr_g, c->w.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
+    if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k9_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, c->w, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, radius);
+    h.S_filled = true;
+    return 0;
+}
+
 static int run_wide(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary* sum) {
     Dev& d = c->d;
     CholHost& h = c->chol;
@@ -1379,11 +1414,8 @@ static int run_wide(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_s
         ++it;
         sum->lm_steps_attempted++;
         // reduced camera system: per-observation diagonal terms + per-pair blocks, fixed-order sums, tile fill, tile Cholesky
-        if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k9_pairs, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, c->w, h.slot_pair_ptr, h.pair_dst, h.scat2, radius);
         (void)n_obs_pairs;
-        if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k9_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, c->w.scat, d.cam_ptr, c->w.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
-        if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k9_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, c->w, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, radius);
-        h.S_filled = true;
+        if ((e = assemble_wide(c, radius))) return e;
         if ((e = chol_factor_solve(c))) return e;
         {   // back-substitution + candidate state, cost of the candidate, the scalars of the step
             const int nbi = cdiv(d.n_items, kWavesPerBlock), nbc = cdiv(d.n_cams, kBlock);
@@ -2010,10 +2042,7 @@ int xrsfm_ba_debug_wide(xrsfm_ba_context* c, double huber_a, double radius, doub
     }
     if (y) {
         if ((e = chol_setup(c))) return e == kErrDuplicateObs ? XRSFM_BA_EINVAL : e;
-        if (d.n_items > 0) LAUNCH(c, K_SCHUR_PAIRS, k9_pairs, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, c->w, h.slot_pair_ptr, h.pair_dst, h.scat2, radius);
-        if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k9_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, c->w.scat, d.cam_ptr, c->w.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
-        if (h.n_tiles_nz > 0) LAUNCH(c, K_DENSE_FILL, k9_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, c->w, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, radius);
-        h.S_filled = true;
+        if ((e = assemble_wide(c, radius))) return e;
         if ((e = chol_factor_solve(c))) return e;
         HIPCHK(hipMemcpyAsync(y, c->w.px, sizeof(double) * (size_t)k.n_cams * kW, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
