@@ -35,8 +35,62 @@ __device__ __forceinline__ void load_FE9(const Dev& d, const DevW& w, int slot, 
     for (int k = 0; k < 6; ++k) E[k] = w.Ew[k * ns + slot];
 }
 
+// Per-camera sums over the lanes of a Gram tile through the wave's LDS (red: [64][kRedLd]): NV <= 14 values per lane go in,
+// one lane per (distinct camera c of the tile, value k) adds the entries of the lanes whose observation is in camera c — in lane
+// order, whatever the path — and stores the sum at out[stride * entry(c) + off + k], entry(c) = the camera-major entry held by
+// the camera's first lane (cp).  dense (every track sees every camera: lane = track * C + camera index): a strided walk;
+// otherwise the lane masks of the cameras (cam_mask[r]: mask of the camera that lane + 64 r serves) and a find-first-set walk.
+// Called by all 64 lanes; ends with the wave's LDS reads complete (the buffer may be reused).
+template <int NV>
+__device__ __forceinline__ void tile_camera_sums(double* red, const double (&v)[NV], int lane, int C, int T, bool dense,
+                                                 const unsigned long long (&cam_mask)[2], int cp, double* __restrict__ out, int stride, int off) {
+    static_assert(NV <= 14 && NV * kGramMaxCamsWide <= 2 * kWave, "two lane rounds cover every (camera, value) of a tile");
+#pragma unroll
+    for (int k = 0; k < NV; ++k) red[lane * kRedLd + k] = v[k];
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const int nq = NV * C;
+#pragma unroll
+    for (int rd = 0; rd < 2; ++rd) {
+        if (rd * kWave < nq) {                             // (uniform)
+        const int q = lane + kWave * rd;
+        const bool on = q < nq;
+        const int cc = on ? q / NV : 0, k = q - NV * cc;
+        unsigned long long m = rd == 0 ? cam_mask[0] : cam_mask[1];
+        const int first = dense ? cc : (on ? __ffsll((long long)m) - 1 : 0);
+        const int cpr = __shfl(cp, first, kWave);
+        if (on) {
+            double sum = 0.0;
+            if (dense) {
+                const double* src = red + cc * kRedLd + k;
+                for (int t = 0; t < T; ++t) sum += src[t * C * kRedLd];
+            } else {
+                while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * kRedLd + k]; m &= m - 1; }
+            }
+            out[(size_t)stride * cpr + off + k] = sum;
+        }
+        }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+}
+// the lane masks tile_camera_sums needs: cam_mask[r] = lanes of the camera that (value slot) lane + 64 r belongs to
+template <int NV>
+__device__ __forceinline__ void tile_camera_masks(int cidx, int lane, int C, unsigned long long (&cam_mask)[2]) {
+    cam_mask[0] = 0; cam_mask[1] = 0;
+    for (int cc = 0; cc < C; ++cc) {
+        const unsigned long long m = __ballot(cidx == cc);
+        if (lane / NV == cc) cam_mask[0] = m;
+        if ((lane + kWave) / NV == cc) cam_mask[1] = m;
+    }
+}
+
 // ---------------------------------------------------------------- linearise
+// (round 4) Gram tiles (ba_pack.h: tile_ncam > 0) sum the 18 camera-side values of their observations per distinct camera of
+// the tile through LDS and write ONE entry per camera (slot_campos_g / cam_ptr_g, the entries of the S assembly) instead of one
+// per observation: 144 bytes per observation less to write, and the fixed-order sum that follows reads a sixteenth.
 __global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double huber_a) {
+    __shared__ double red_all[kWavesPerBlock][kWave * kRedLd];
     const int lane = threadIdx.x & (kWave - 1);
     const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
     if (item >= d.n_items) return;
@@ -51,6 +105,7 @@ __global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double hub
         const int maxlen = d.tile_maxlen[it.first_tile + tl];
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double spk[3] = {1.0, 1.0, 1.0};
+        double cs0[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, cs1[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (s.valid) {
             const CamRec& c = d.cam[s.cam];
             const double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
@@ -98,12 +153,30 @@ __global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double hub
             v[0] = E[0] * E[0] + E[3] * E[3]; v[1] = E[0] * E[1] + E[3] * E[4]; v[2] = E[0] * E[2] + E[3] * E[5];
             v[3] = E[1] * E[1] + E[4] * E[4]; v[4] = E[1] * E[2] + E[4] * E[5]; v[5] = E[2] * E[2] + E[5] * E[5];
             v[6] = E[0] * r0 + E[3] * r1; v[7] = E[1] * r0 + E[4] * r1; v[8] = E[2] * r0 + E[5] * r1;
-            // camera side: diag(F^T F) and F^T r of this observation -> the camera-major scatter buffer
-            double* out = w.scat + 18 * (size_t)d.slot_campos[s.slot];
+            // camera side: diag(F^T F) and F^T r of this observation -> the camera-major scatter buffer (below)
 #pragma unroll
-            for (int k = 0; k < 9; ++k) { out[k] = F[k] * F[k] + F[9 + k] * F[9 + k]; out[9 + k] = F[k] * r0 + F[9 + k] * r1; }
+            for (int k = 0; k < 9; ++k) { cs0[k] = F[k] * F[k] + F[9 + k] * F[9 + k]; cs1[k] = F[k] * r0 + F[9 + k] * r1; }
             if (s.head && (!is_long || tl == 0) && !pt_fixed) xn2 += Pw[0] * Pw[0] + Pw[1] * Pw[1] + Pw[2] * Pw[2];
             if (is_long && lane == 0 && tl == 0) long_pt = s.pt;
+        }
+        {
+            const int Cg = is_long ? 0 : d.tile_ncam[it.first_tile + tl];
+            const int cpg = d.slot_campos_g[s.slot];
+            if (Cg > 0) {
+                const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
+                const unsigned long long hm = __ballot(s.head);
+                const int T = __popcll(hm);
+                const bool dense = __popcll(__ballot(s.valid)) == T * Cg;
+                unsigned long long cam_mask[2];
+                tile_camera_masks<9>(cidx, lane, Cg, cam_mask);
+                double* red = red_all[threadIdx.x >> 6];
+                tile_camera_sums<9>(red, cs0, lane, Cg, T, dense, cam_mask, cpg, w.scat, 18, 0);
+                tile_camera_sums<9>(red, cs1, lane, Cg, T, dense, cam_mask, cpg, w.scat, 18, 9);
+            } else if (s.valid) {
+                double* out = w.scat + 18 * (size_t)cpg;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) { out[k] = cs0[k]; out[9 + k] = cs1[k]; }
+            }
         }
         seg_reduce<9>(v, s.pt, lane, is_long ? kWave : maxlen);
         if (!is_long) {
@@ -334,45 +407,23 @@ __global__ __launch_bounds__(kWave) void k9_pairs_gram(Dev d, DevW w, const int*
         u0 = cf[0] * g[0]; u1 = cf[1] * g[0] + cf[3] * g[1]; u2 = cf[2] * g[0] + cf[4] * g[1] + cf[5] * g[2];      // C^T g
     }
 
-    {   // per distinct camera of the tile: the lane that owns (camera c, value k) adds the entries of the lanes whose observation
-        // is in camera c, in lane order; the first of them holds the camera's entry in the scatter buffer
-        const int cidx = s.valid ? cidx_raw : -1;
+    const unsigned long long headmask = __ballot(s.head);
+    const int T = __popcll(headmask);
+    const int nvalid = __popcll(__ballot(s.valid));
+    const bool dense = nvalid == T * C;
+    {   // the 56 diagonal-block / rhs values, summed per distinct camera of the tile (tile_camera_sums), four rounds of 14
+        unsigned long long cam_mask[2];
+        tile_camera_masks<14>(s.valid ? cidx_raw : -1, lane, C, cam_mask);
         double* red = smem;                                         // [64][kRedLd]
-        const int nq = 14 * C;                                      // <= 98: two rounds of 64 lanes
-        unsigned long long m0 = 0, m1 = 0;
-        for (int cc = 0; cc < C; ++cc) {
-            const unsigned long long m = __ballot(cidx == cc);
-            if (lane / 14 == cc) m0 = m;
-            if ((lane + 64) / 14 == cc) m1 = m;
-        }
         auto round = [&](auto hc) {
             constexpr int h = decltype(hc)::value;
-            diag9_store<14 * h, 0>(red + lane * kRedLd, F, V, u0, u1, u2);      // 14 values of the 56-record, formed where they are needed
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int rd = 0; rd < 2; ++rd) {
-                const int q = lane + 64 * rd;
-                unsigned long long m = rd == 0 ? m0 : m1;
-                const bool on = q < nq;
-                const int k = q % 14;
-                const int first = on ? __ffsll((long long)m) - 1 : 0;
-                const int cpr = __shfl(cp, first, kWave);
-                if (on) {
-                    double sum = 0.0;
-                    while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * kRedLd + k]; m &= m - 1; }
-                    w.scat[kWS * (size_t)cpr + 14 * h + k] = sum;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
+            double v14[14];
+            diag9_store<14 * h, 0>(v14, F, V, u0, u1, u2);          // formed where they are needed: 14 live values, not 56
+            tile_camera_sums<14>(red, v14, lane, C, T, dense, cam_mask, cp, w.scat, kWS, 14 * h);
         };
         round(std::integral_constant<int, 0>{}); round(std::integral_constant<int, 1>{});
         round(std::integral_constant<int, 2>{}); round(std::integral_constant<int, 3>{});
     }
-    const unsigned long long headmask = __ballot(s.head);
-    const int T = __popcll(headmask);
-    const int nvalid = __popcll(__ballot(s.valid));
     const int t = __popcll(headmask & ((2ull << lane) - 1ull)) - 1;        // rank of the lane's track in the tile
     const int cidx = s.valid ? cidx_raw : 0;
     int passes = 1;
@@ -383,7 +434,6 @@ __global__ __launch_bounds__(kWave) void k9_pairs_gram(Dev d, DevW w, const int*
     int* dtab = reinterpret_cast<int*>(smem + R * Cp);
     dtab[lane] = dt0;
     if (lane + kWave < kGramTabLd * kGramTabLd) dtab[lane + kWave] = dt1;
-    const bool dense = nvalid == T * C;
     gram_tile<NI, kW>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
 }
 

@@ -1308,7 +1308,7 @@ static int linearize_wide(xrsfm_ba_context* c, double huber_a, bool scaled_pass)
     (void)scaled_pass;
     c->gradmax_done = false; c->published = false;
     if (d.n_items > 0) LAUNCH(c, K_LINEARIZE, k9_linearize, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, d, c->w, huber_a);
-    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<18>, dim3(d.n_cams), dim3(kBlock), 0, c->w.scat, d.cam_ptr, c->w.camlin, (const PcgStatus*)nullptr);
+    if (d.n_cams > 0) LAUNCH(c, K_CAM_SEGSUM, k_cam_segsum<18>, dim3(d.n_cams), dim3(kBlock), 0, c->w.scat, d.cam_ptr_g, c->w.camlin, (const PcgStatus*)nullptr);
     ReduceJobs j{};
     const double* ins[3] = {d.part, d.part + d.n_items, d.part + 2 * (size_t)d.n_items};
     double* outs[3] = {d.scal + S_COST, d.scal + S_XNORM2_PTS, d.scal + S_GRADMAX_PTS};
