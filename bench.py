@@ -228,6 +228,67 @@ def parity_workload(opt):
             "one_shot_hip_s": t_gpu, "cpu_s": sc["total_s"]}
 
 
+def self_profile(config: str, solver: str):
+    """rocprofv3 passes launched BY THIS RUN: the per-kernel duration table (--kernel-trace --stats) and
+    the HBM traffic per launch (FETCH_SIZE and WRITE_SIZE in passes of their own — counters only + kernel trace — corrected as
+    /opt/skills/guides/MI355X_MICROARCH.md prescribes and tools/pmc_summary.py documents: FETCH_SIZE x 2 for these 8-byte-per-lane
+    streams, WRITE_SIZE x 1; both counters are KiB per dispatch) of a short child run of the same configuration.  None when
+    rocprofv3 is not on PATH, in a child, or when a pass fails (the caller then falls back to the committed profiles/ JSON)."""
+    import re
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    if os.environ.get("XRSFM_BENCH_CHILD") == "1" or os.environ.get("XRSFM_BENCH_SELFPROF") == "0":
+        return None
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None
+    env = dict(os.environ, XRSFM_BENCH_CHILD="1", TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--config", config, "--solver", solver, "--no-cpu", "--no-extras", "--steps", "1", "--warmup", "1"]
+
+    def one_pass(extra):
+        d = tempfile.mkdtemp(prefix="xba_prof_", dir="/tmp")
+        try:
+            r = subprocess.run([rp, *extra, "-d", d, "-o", "p", "--", *child], cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None
+            cur = sqlite3.connect(dbs[0]).cursor()
+            sym_cols = [c[1] for c in cur.execute("pragma table_info(rocpd_info_kernel_symbol)")]
+            name_col = "display_name" if "display_name" in sym_cols else ("kernel_name" if "kernel_name" in sym_cols else sym_cols[1])
+            clean = lambda n: re.sub(r"\(.*", "", n).replace("void ", "").replace("xba::", "")     # noqa: E731
+            if "--pmc" in extra:
+                q = (f"select s.{name_col}, count(*), avg(p.value) from rocpd_pmc_event p join rocpd_kernel_dispatch d on p.event_id = d.event_id "
+                     "join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by 1")
+                return {clean(n): (c, a) for n, c, a in cur.execute(q)}
+            q = (f"select s.{name_col}, count(*), avg(d.end - d.start) from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s "
+                 "on d.kernel_id = s.id group by 1")
+            return {clean(n): (c, a) for n, c, a in cur.execute(q)}
+        except Exception:
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+
+    stats = one_pass(["--kernel-trace", "--stats"])
+    if stats is None:
+        return None
+    out = {"source": "rocprofv3 passes launched by this bench.py run (child: --steps 1 --warmup 1 --no-cpu --no-extras)",
+           "kernel_avg_us": {k: round(a / 1e3, 3) for k, (c, a) in stats.items() if not k.startswith("__amd")},
+           "kernel_calls": {k: c for k, (c, a) in stats.items() if not k.startswith("__amd")}}
+    fetch = one_pass(["--pmc", "FETCH_SIZE", "--kernel-trace"])
+    write = one_pass(["--pmc", "WRITE_SIZE", "--kernel-trace"])
+    if fetch is not None and write is not None:
+        traffic = {}
+        for k in set(fetch) | set(write):
+            b = 2.0 * fetch.get(k, (0, 0.0))[1] * 1024 + write.get(k, (0, 0.0))[1] * 1024
+            if b >= 5e4:
+                traffic[k] = int(round(b))
+        out["traffic_bytes_per_launch"] = traffic
+        out["traffic_correction"] = "FETCH_SIZE x 2 (gfx950: 128-byte requests of 8-byte-per-lane streams tallied at 64), WRITE_SIZE x 1; KiB per dispatch"
+    return out
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (datasheet; v_mfma_f64_16x16x4_f64 issues at the FP64 vector rate)
 
 
@@ -427,7 +488,18 @@ def main():
         traffic = None
         traffic_source = None
         pmc = os.path.join(ROOT, "profiles", f"pmc_traffic_{args.config}.json")
-        if world == 1 and os.path.exists(pmc):      # separate rocprofv3 --pmc passes (tools/pmc_summary.py), bytes per launch
+        prof = None
+        if world == 1 and rank == 0 and not args.no_extras:
+            try:
+                prof = self_profile(args.config, args.solver)
+            except Exception:
+                prof = None
+        if prof is not None and prof.get("traffic_bytes_per_launch"):
+            table = prof["traffic_bytes_per_launch"]
+            hits = [v for k, v in table.items() if k == dom or k.startswith(dom + "<")]
+            traffic = sum(hits) if hits else None
+            traffic_source = prof["source"] + "; " + prof["traffic_correction"]
+        elif world == 1 and os.path.exists(pmc):      # separate rocprofv3 --pmc passes (tools/pmc_summary.py), bytes per launch
             table = json.load(open(pmc))          # template instantiations of one kernel (k_schur_pairs<true|false>) make up one pass
             hits = [v for k, v in table.items() if k == dom or k.startswith(dom + "<")]
             traffic = sum(hits) if hits else None
@@ -444,7 +516,20 @@ def main():
             b_k = algorithmic_bytes(k, prob.n_obs, prob.n_points, n_cams, count_offdiag_blocks(local), width)
             per_kernel[k] = {"avg_launch_us": ms_k * 1e3 / n_k, "launches": n_k, "algorithmic_bytes_per_launch": b_k,
                              "frac": b_k / (ms_k * 1e-3 / n_k) / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and os.path.exists(pmc):
+        if prof is not None:
+            # what rocprofv3 saw in the child run of this job: average duration per kernel (must agree with the HIP-event figures
+            # above) and, when the counter passes ran, HBM bytes per launch of every kernel
+            roofline["rocprofv3"] = prof
+            hits = [v for k, v in prof["kernel_avg_us"].items() if k == dom or k.startswith(dom + "<")]
+            calls = [prof["kernel_calls"][k] for k in prof["kernel_avg_us"] if k == dom or k.startswith(dom + "<")]
+            if hits:       # per pass over the items = sum over the launches of the pass (one per Gram bucket)
+                n_pass = max(1, min(calls))
+                roofline["rocprofv3_avg_launch_us"] = sum(h * c for h, c in zip(hits, calls)) / n_pass
+            if prof.get("traffic_bytes_per_launch"):
+                for k, rec in per_kernel.items():
+                    th = [v for kk, v in prof["traffic_bytes_per_launch"].items() if kk == k or kk.startswith(k + "<")]
+                    rec["traffic"] = sum(th) if th else None
+        elif world == 1 and os.path.exists(pmc):
             # the whole per-kernel PMC table (bytes per launch, FETCH_SIZE + WRITE_SIZE passes of an earlier run), and the measured
             # traffic next to the algorithmic bytes of every streaming kernel: `traffic` above is the dominant kernel's entry only
             table = json.load(open(pmc))

@@ -135,7 +135,8 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
                 Vst[row * Cp + cc] = 0.0;
             }
         } else {
-            for (int e = lane; e < R * Cp; e += kWave) Vst[e] = 0.0;           // LDS operations of one wave complete in order
+            // LDS operations of one wave complete in order; 16-byte stores (Cp is even and the operand 16-byte aligned)
+            for (int e = lane; e < (R * Cp) / 2; e += kWave) reinterpret_cast<double2*>(Vst)[e] = make_double2(0.0, 0.0);
         }
         if (valid && t >= t0 && t < t0 + tn) {
 #pragma unroll
@@ -306,33 +307,51 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 // Gram tile with ragged tracks: the same through LDS, per DISTINCT camera of the tile: the lane that owns
                 // (camera c, value k) adds the entries of the lanes whose observation is in camera c, in lane order; the
                 // first of them holds the camera's entry in the scatter buffer.
+                // (round 4) The lanes deposit their values SORTED BY CAMERA — position = (lanes of earlier cameras) + (earlier lanes
+                // of the same camera), from the ballot masks — so that the lane of (camera c, value k) walks a contiguous run of
+                // count_c entries with a counted loop (independent LDS reads) instead of peeling a lane mask bit by bit (a dependent
+                // ffs / read / clear chain per term: 26 % of the wave's life on config R).  Same terms in the same (lane) order.
                 const int cidx = s.valid ? cidx_raw : -1;
                 double* red = smem;
                 const int nq = 14 * Cg;
-                unsigned long long m0 = 0, m1 = 0, m2 = 0;                  // lane masks of the cameras of q = lane, lane+64, lane+128
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int mypos = kWave - 1;                                      // (lanes without an observation park their zeros in the last row)
+                int pk0 = 0, pk1 = 0, pk2 = 0;          // run start | length << 8 | first lane << 16 of the camera of q = lane, + 64, + 128
+                int run = 0;
                 for (int cc = 0; cc < Cg; ++cc) {
                     const unsigned long long m = __ballot(cidx == cc);
-                    if (lane / 14 == cc) m0 = m;
-                    if ((lane + 64) / 14 == cc) m1 = m;
-                    if ((lane + 128) / 14 == cc) m2 = m;
+                    const int cnt = __popcll(m);
+                    const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);      // (wave-uniform)
+                    if (cidx == cc) mypos = run + __popcll(m & lt);
+                    if (lane / 14 == cc) pk0 = pk;
+                    if ((lane + 64) / 14 == cc) pk1 = pk;
+                    if ((lane + 128) / 14 == cc) pk2 = pk;
+                    run += cnt;
                 }
+                // (run < 64 whenever a lane has no observation, so row 63 — where those lanes park their dead values — is in no camera's run)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
 #pragma unroll
-                    for (int k = 0; k < 14; ++k) red[lane * kRedLd + k] = o28[14 * h + k];
+                    for (int k = 0; k < 14; ++k) red[mypos * kRedLd + k] = o28[14 * h + k];
                     __builtin_amdgcn_s_waitcnt(0xc07f);
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int rd = 0; rd < 3; ++rd) {
                         const int q = lane + 64 * rd;
-                        unsigned long long m = rd == 0 ? m0 : (rd == 1 ? m1 : m2);
+                        const int pk = rd == 0 ? pk0 : (rd == 1 ? pk1 : pk2);
+                        const int st = pk & 255, n = (pk >> 8) & 255, first = pk >> 16;
                         const bool on = q < nq;
                         const int k = q % 14;
-                        const int first = on ? __ffsll((long long)m) - 1 : 0;
-                        const int cpr = __shfl(cp, first, kWave);
+                        const int cpr = __shfl(cp, on ? first : 0, kWave);
                         if (on) {
+                            const double* src = red + st * kRedLd + k;
                             double sum = 0.0;
-                            while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * kRedLd + k]; m &= m - 1; }
+                            int j = 0;
+                            for (; j + 4 <= n; j += 4) {
+                                const double a0 = src[j * kRedLd], a1 = src[(j + 1) * kRedLd], a2 = src[(j + 2) * kRedLd], a3 = src[(j + 3) * kRedLd];
+                                sum += a0; sum += a1; sum += a2; sum += a3;
+                            }
+                            for (; j < n; ++j) sum += src[j * kRedLd];
                             d.scat[28 * (size_t)cpr + 14 * h + k] = sum;
                         }
                     }

@@ -338,28 +338,40 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
             } else if (Cg > 0) {
                 extern __shared__ __attribute__((aligned(16))) double lin_smem[];
                 double* red = lin_smem + (threadIdx.x >> 6) * (kWave * 13);          // this wave's [64][13]
+                // (round 4: values deposited sorted by camera — position = lanes of earlier cameras + earlier lanes of the own one — so
+                //  that a reducer lane walks a contiguous run with a counted loop instead of peeling a lane mask: k_schur_pairs, ba_chol.h)
                 const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
-                unsigned long long m0 = 0, m1 = 0;                                   // lane masks of the cameras of q = lane, lane + 64
+                const unsigned long long lt = (1ull << lane) - 1ull;
+                int mypos = kWave - 1, pk0 = 0, pk1 = 0, run = 0;                    // pk: run start | length << 8 | first lane << 16
                 for (int cc = 0; cc < Cg; ++cc) {
                     const unsigned long long m = __ballot(cidx == cc);
-                    if (lane / 12 == cc) m0 = m;
-                    if ((lane + 64) / 12 == cc) m1 = m;
+                    const int cnt = __popcll(m);
+                    const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);
+                    if (cidx == cc) mypos = run + __popcll(m & lt);
+                    if (lane / 12 == cc) pk0 = pk;
+                    if ((lane + 64) / 12 == cc) pk1 = pk;
+                    run += cnt;
                 }
 #pragma unroll
-                for (int k = 0; k < 12; ++k) red[lane * 13 + k] = cs[k];
+                for (int k = 0; k < 12; ++k) red[mypos * 13 + k] = cs[k];            // (lanes without an observation: row 63, in no run)
                 __builtin_amdgcn_s_waitcnt(0xc07f);
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int rd = 0; rd < 2; ++rd) {
                     const int q = lane + 64 * rd;
-                    unsigned long long m = rd == 0 ? m0 : m1;
+                    const int pk = rd == 0 ? pk0 : pk1;
                     const bool on = q < 12 * Cg;
-                    const int first = on ? __ffsll((long long)m) - 1 : 0;
-                    const int cpr = __shfl(cp, first, kWave);
+                    const int cpr = __shfl(cp, on ? (pk >> 16) : 0, kWave);
                     if (on) {
-                        const int k = q % 12;
+                        const int k = q % 12, n = (pk >> 8) & 255;
+                        const double* src = red + (pk & 255) * 13 + k;
                         double sum = 0.0;
-                        while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * 13 + k]; m &= m - 1; }
+                        int j = 0;
+                        for (; j + 4 <= n; j += 4) {
+                            const double a0 = src[j * 13], a1 = src[(j + 1) * 13], a2 = src[(j + 2) * 13], a3 = src[(j + 3) * 13];
+                            sum += a0; sum += a1; sum += a2; sum += a3;
+                        }
+                        for (; j < n; ++j) sum += src[j * 13];
                         d.scat[12 * (size_t)cpr + k] = sum;
                     }
                 }

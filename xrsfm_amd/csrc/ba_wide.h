@@ -35,53 +35,60 @@ __device__ __forceinline__ void load_FE9(const Dev& d, const DevW& w, int slot, 
     for (int k = 0; k < 6; ++k) E[k] = w.Ew[k * ns + slot];
 }
 
-// Per-camera sums over the lanes of a Gram tile through the wave's LDS (red: [64][kRedLd]): NV <= 14 values per lane go in,
-// one lane per (distinct camera c of the tile, value k) adds the entries of the lanes whose observation is in camera c — in lane
-// order, whatever the path — and stores the sum at out[stride * entry(c) + off + k], entry(c) = the camera-major entry held by
-// the camera's first lane (cp).  dense (every track sees every camera: lane = track * C + camera index): a strided walk;
-// otherwise the lane masks of the cameras (cam_mask[r]: mask of the camera that lane + 64 r serves) and a find-first-set walk.
+// Per-camera sums over the lanes of a Gram tile through the wave's LDS (red: [64][kRedLd]): NV <= 14 values per lane go in —
+// deposited SORTED BY CAMERA (tile_camera_runs) — and one lane per (distinct camera c of the tile, value k) adds the contiguous
+// run of camera c, i.e. the entries of the lanes whose observation is in camera c in lane order, and stores the sum at
+// out[stride * entry(c) + off + k], entry(c) = the camera-major entry held by the camera's first lane (cp).
 // Called by all 64 lanes; ends with the wave's LDS reads complete (the buffer may be reused).
 template <int NV>
-__device__ __forceinline__ void tile_camera_sums(double* red, const double (&v)[NV], int lane, int C, int T, bool dense,
-                                                 const unsigned long long (&cam_mask)[2], int cp, double* __restrict__ out, int stride, int off) {
+__device__ __forceinline__ void tile_camera_sums(double* red, const double (&v)[NV], int lane, int C, int mypos,
+                                                 const int (&run_pk)[2], int cp, double* __restrict__ out, int stride, int off) {
     static_assert(NV <= 14 && NV * kGramMaxCamsWide <= 2 * kWave, "two lane rounds cover every (camera, value) of a tile");
 #pragma unroll
-    for (int k = 0; k < NV; ++k) red[lane * kRedLd + k] = v[k];
+    for (int k = 0; k < NV; ++k) red[mypos * kRedLd + k] = v[k];
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     const int nq = NV * C;
 #pragma unroll
     for (int rd = 0; rd < 2; ++rd) {
         if (rd * kWave < nq) {                             // (uniform)
-        const int q = lane + kWave * rd;
-        const bool on = q < nq;
-        const int cc = on ? q / NV : 0, k = q - NV * cc;
-        unsigned long long m = rd == 0 ? cam_mask[0] : cam_mask[1];
-        const int first = dense ? cc : (on ? __ffsll((long long)m) - 1 : 0);
-        const int cpr = __shfl(cp, first, kWave);
-        if (on) {
-            double sum = 0.0;
-            if (dense) {
-                const double* src = red + cc * kRedLd + k;
-                for (int t = 0; t < T; ++t) sum += src[t * C * kRedLd];
-            } else {
-                while (m) { const int l = __ffsll((long long)m) - 1; sum += red[l * kRedLd + k]; m &= m - 1; }
+            const int q = lane + kWave * rd;
+            const bool on = q < nq;
+            const int pk = rd == 0 ? run_pk[0] : run_pk[1];
+            const int cpr = __shfl(cp, on ? (pk >> 16) : 0, kWave);
+            if (on) {
+                const int k = q % NV, n = (pk >> 8) & 255;
+                const double* src = red + (pk & 255) * kRedLd + k;
+                double sum = 0.0;
+                int j = 0;
+                for (; j + 4 <= n; j += 4) {
+                    const double a0 = src[j * kRedLd], a1 = src[(j + 1) * kRedLd], a2 = src[(j + 2) * kRedLd], a3 = src[(j + 3) * kRedLd];
+                    sum += a0; sum += a1; sum += a2; sum += a3;
+                }
+                for (; j < n; ++j) sum += src[j * kRedLd];
+                out[(size_t)stride * cpr + off + k] = sum;
             }
-            out[(size_t)stride * cpr + off + k] = sum;
-        }
         }
     }
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
 }
-// the lane masks tile_camera_sums needs: cam_mask[r] = lanes of the camera that (value slot) lane + 64 r belongs to
+// What tile_camera_sums needs: the lane's position in the camera-sorted order (lanes of earlier cameras + earlier lanes of the
+// own camera; a lane without an observation parks in row 63, which is in no run) and, for the (camera, value) slots lane and
+// lane + 64, the camera's run: start | length << 8 | first lane << 16.
 template <int NV>
-__device__ __forceinline__ void tile_camera_masks(int cidx, int lane, int C, unsigned long long (&cam_mask)[2]) {
-    cam_mask[0] = 0; cam_mask[1] = 0;
+__device__ __forceinline__ void tile_camera_runs(int cidx, int lane, int C, int& mypos, int (&run_pk)[2]) {
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    mypos = kWave - 1; run_pk[0] = 0; run_pk[1] = 0;
+    int run = 0;
     for (int cc = 0; cc < C; ++cc) {
         const unsigned long long m = __ballot(cidx == cc);
-        if (lane / NV == cc) cam_mask[0] = m;
-        if ((lane + kWave) / NV == cc) cam_mask[1] = m;
+        const int cnt = __popcll(m);
+        const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);
+        if (cidx == cc) mypos = run + __popcll(m & lt);
+        if (lane / NV == cc) run_pk[0] = pk;
+        if ((lane + kWave) / NV == cc) run_pk[1] = pk;
+        run += cnt;
     }
 }
 
@@ -164,14 +171,11 @@ __global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double hub
             const int cpg = d.slot_campos_g[s.slot];
             if (Cg > 0) {
                 const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
-                const unsigned long long hm = __ballot(s.head);
-                const int T = __popcll(hm);
-                const bool dense = __popcll(__ballot(s.valid)) == T * Cg;
-                unsigned long long cam_mask[2];
-                tile_camera_masks<9>(cidx, lane, Cg, cam_mask);
+                int mypos, run_pk[2];
+                tile_camera_runs<9>(cidx, lane, Cg, mypos, run_pk);
                 double* red = red_all[threadIdx.x >> 6];
-                tile_camera_sums<9>(red, cs0, lane, Cg, T, dense, cam_mask, cpg, w.scat, 18, 0);
-                tile_camera_sums<9>(red, cs1, lane, Cg, T, dense, cam_mask, cpg, w.scat, 18, 9);
+                tile_camera_sums<9>(red, cs0, lane, Cg, mypos, run_pk, cpg, w.scat, 18, 0);
+                tile_camera_sums<9>(red, cs1, lane, Cg, mypos, run_pk, cpg, w.scat, 18, 9);
             } else if (s.valid) {
                 double* out = w.scat + 18 * (size_t)cpg;
 #pragma unroll
@@ -412,14 +416,14 @@ __global__ __launch_bounds__(kWave) void k9_pairs_gram(Dev d, DevW w, const int*
     const int nvalid = __popcll(__ballot(s.valid));
     const bool dense = nvalid == T * C;
     {   // the 56 diagonal-block / rhs values, summed per distinct camera of the tile (tile_camera_sums), four rounds of 14
-        unsigned long long cam_mask[2];
-        tile_camera_masks<14>(s.valid ? cidx_raw : -1, lane, C, cam_mask);
+        int mypos, run_pk[2];
+        tile_camera_runs<14>(s.valid ? cidx_raw : -1, lane, C, mypos, run_pk);
         double* red = smem;                                         // [64][kRedLd]
         auto round = [&](auto hc) {
             constexpr int h = decltype(hc)::value;
             double v14[14];
             diag9_store<14 * h, 0>(v14, F, V, u0, u1, u2);          // formed where they are needed: 14 live values, not 56
-            tile_camera_sums<14>(red, v14, lane, C, T, dense, cam_mask, cp, w.scat, kWS, 14 * h);
+            tile_camera_sums<14>(red, v14, lane, C, mypos, run_pk, cp, w.scat, kWS, 14 * h);
         };
         round(std::integral_constant<int, 0>{}); round(std::integral_constant<int, 1>{});
         round(std::integral_constant<int, 2>{}); round(std::integral_constant<int, 3>{});
