@@ -82,7 +82,7 @@ template <typename T> using RawVec = std::vector<T, RawAlloc<T>>;
 // that hands every piece its index: for two-pass algorithms (count, then place) that need the same partition twice.
 inline std::vector<long long> pack_cuts(long long n, long long min_n, long long align) {
     const unsigned hw = std::thread::hardware_concurrency();
-    const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(8u, hw);
+    const int nt = (n < min_n || hw < 2) ? 1 : (int)std::min<unsigned>(n >= 4 * min_n ? 16u : 8u, hw);      // (the result never depends on the piece count)
     std::vector<long long> cut(nt + 1);
     for (int t = 0; t <= nt; ++t) cut[t] = (t == nt) ? n : (n * t / nt) / align * align;
     return cut;
@@ -213,6 +213,10 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
             }
         }
     });
+    // cameras of every track in track order (one sequential array: the tuple keys, the tuple comparisons and the slot fill read it
+    // instead of chasing obs_cam through the CSR, three dependent random reads per element)
+    RawVec<int> tcam(No);
+    pack_parallel_for(No, [&](long long i0, long long i1) { for (long long i = i0; i < i1; ++i) tcam[i] = p.obs_cam[csr[i]]; }, 200000);
     mark("per-track camera sort");
     // active points: short tracks sorted by their camera tuple (tracks seeing the same cameras become neighbours:
     // locality of the camera gathers, and whole tiles that share one tuple can be pre-reduced in the wave),
@@ -225,7 +229,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
         const int la = cnt[a + 1], lb = cnt[b + 1];
         const int n = std::min(la, lb);
         for (int k = 0; k < n; ++k) {
-            const int ca = p.obs_cam[csr[ptr[a] + k]], cb = p.obs_cam[csr[ptr[b] + k]];
+            const int ca = tcam[ptr[a] + k], cb = tcam[ptr[b] + k];
             if (ca != cb) return ca < cb;
         }
         return la < lb;
@@ -247,12 +251,13 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
                 const int len = cnt[j + 1];
                 unsigned long long key = (len > 64) ? (1ull << 63) : 0ull;
                 for (int q = 0; q < kcams; ++q) {
-                    const unsigned long long c = (q < len) ? (unsigned long long)p.obs_cam[csr[ptr[j] + q]] + 1ull : 0ull;
+                    const unsigned long long c = (q < len) ? (unsigned long long)tcam[ptr[j] + q] + 1ull : 0ull;
                     key |= c << (kbits * (kcams - 1 - q));
                 }
                 ki[n] = {key, j};
             }
         });
+        mark("  tuple: keys");
         auto full_less = [&](int a, int b) {
             const bool la = cnt[a + 1] > 64, lb = cnt[b + 1] > 64;
             if (la != lb) return lb;
@@ -263,6 +268,60 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
         } else {
             // (key, idx) order.  Large inputs: ki is in ascending idx order, so a stable LSD radix sort over the key fields
             // yields it; one pass per camera field (kbits wide) and a last one for the long-track flag
+            int fbits0 = 1;                                           // bits of a field value (camera id + 1 <= Nc)
+            while (fbits0 < kbits && (1ll << fbits0) <= (long long)Nc) ++fbits0;
+            int ibits = 1;
+            while ((1ll << ibits) < (long long)Np) ++ibits;
+            if (ki.size() >= 2048 && kcams * fbits0 + 1 + ibits <= 64) {
+                // (round 4) Key and point index share ONE 64-bit word: [long-track flag | kcams camera fields of fbits0 bits | index], so the
+                // stable LSD radix sort moves 8-byte records instead of 16-byte ones and only over the bits that are in use — config 4:
+                // 4 x 10 + 1 key bits, 19 index bits; the same order as the 16-byte sort (equal keys keep ascending index).
+                const int kshift = ibits;
+                RawVec<unsigned long long> pk(ki.size()), tmp8(ki.size());
+                pack_parallel_for((long long)ki.size(), [&](long long n0, long long n1) {
+                    for (long long n = n0; n < n1; ++n) {
+                        const unsigned long long key = ki[n].key;
+                        unsigned long long c = 0;
+                        for (int q = 0; q < kcams; ++q) c |= ((key >> (kbits * (kcams - 1 - q))) & ((1ull << kbits) - 1ull)) << (fbits0 * (kcams - 1 - q));
+                        c |= (key >> 63) << (kcams * fbits0);
+                        pk[n] = (c << kshift) | (unsigned long long)(unsigned)ki[n].idx;
+                    }
+                });
+                const std::vector<long long> cut = pack_cuts((long long)pk.size(), 100000, 1);
+                const int nch = (int)cut.size() - 1;
+                std::vector<std::vector<unsigned>> hist(nch);
+                const int total_bits = kcams * fbits0 + 1;
+                for (int done = 0; done < total_bits; done += 11) {
+                    const int bits = std::min(11, total_bits - done), shift = kshift + done;
+                    const size_t nb = (size_t)1 << bits;
+                    const unsigned long long mask = nb - 1;
+                    pack_parallel_chunks(cut, [&](int t, long long n0, long long n1) {
+                        hist[t].assign(nb, 0u);
+                        for (long long n = n0; n < n1; ++n) hist[t][(pk[n] >> shift) & mask]++;
+                    });
+                    unsigned run = 0;
+                    bool one_bucket = false;
+                    for (size_t b2 = 0; b2 < nb; ++b2) {
+                        unsigned in_bucket = 0;
+                        for (int t = 0; t < nch; ++t) { const unsigned v = hist[t][b2]; hist[t][b2] = run; run += v; in_bucket += v; }
+                        one_bucket |= in_bucket == pk.size();
+                    }
+                    if (one_bucket) continue;
+                    pack_parallel_chunks(cut, [&](int t, long long n0, long long n1) {
+                        for (long long n = n0; n < n1; ++n) tmp8[hist[t][(pk[n] >> shift) & mask]++] = pk[n];
+                    });
+                    pk.swap(tmp8);
+                }
+                const unsigned long long imask = (1ull << ibits) - 1ull;
+                pack_parallel_for((long long)ki.size(), [&](long long n0, long long n1) {
+                    for (long long n = n0; n < n1; ++n) {
+                        const unsigned long long c = pk[n] >> kshift;
+                        unsigned long long key = (c >> (kcams * fbits0)) << 63;
+                        for (int q = 0; q < kcams; ++q) key |= ((c >> (fbits0 * (kcams - 1 - q))) & ((1ull << fbits0) - 1ull)) << (kbits * (kcams - 1 - q));
+                        ki[n] = {key, (int)(pk[n] & imask)};
+                    }
+                });
+            } else
             if (ki.size() < 2048) {                      // tiny calls: the bucket arrays would cost more than the sort
                 std::sort(ki.begin(), ki.end(), [](const KI& a, const KI& b) { return a.key != b.key ? a.key < b.key : a.idx < b.idx; });
             } else {
@@ -299,6 +358,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
                     for (int done = 0; done < fbits; done += 11) pass(kbits * (kcams - 1 - q) + done, std::min(11, fbits - done));
                 pass(63, 1);
             }
+            mark("  tuple: radix");
             sort_keys.resize(ki.size()); key_cams = kcams;
             pack_parallel_for((long long)ki.size(), [&](long long n0, long long n1) {
                 for (long long n = n0; n < n1; ++n) { order[n] = ki[n].idx; sort_keys[n] = ki[n].key; }
@@ -386,7 +446,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
             const long long s0 = trk_start[pj];
             for (int q = 0; q < len; ++q) {
                 const int i = obs_b[q];
-                o.slot_cam[s0 + q] = p.obs_cam[i]; o.slot_pt[s0 + q] = (int)pj; o.slot_obs[s0 + q] = i;
+                o.slot_cam[s0 + q] = tcam[ptr[j] + q]; o.slot_pt[s0 + q] = (int)pj; o.slot_obs[s0 + q] = i;
                 o.slot_u[s0 + q] = p.obs_uv[2 * (size_t)i]; o.slot_v[s0 + q] = p.obs_uv[2 * (size_t)i + 1];
             }
             // padding up to the next track (or the end): owned by this track's thread as well
@@ -542,8 +602,7 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
     o.n_cam_entries_g = o.cam_ptr_g[Nc];
     mark("camera-major maps");
     std::vector<char> cam_seen(Nc, 0);
-    for (int s2 = 0; s2 < o.n_slots; ++s2)
-        if (o.slot_cam[s2] >= 0) cam_seen[o.slot_cam[s2]] = 1;
+    for (int c = 0; c < Nc; ++c) cam_seen[c] = o.cam_ptr[c + 1] > o.cam_ptr[c];      // (every observed camera owns at least one camera-major entry)
     // effective parameter count (num_effective_parameters_reduced)
     o.n_var_q = o.n_var_t = o.n_var_p = 0;
     for (int c = 0; c < Nc; ++c) {
@@ -552,8 +611,12 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
         if (!(cc & XRSFM_BA_CONST_Q)) o.n_var_q++;
         if (!(cc & XRSFM_BA_CONST_T)) o.n_var_t++;
     }
-    for (int pj = 0; pj < o.n_pts; ++pj)
-        if (!o.pt_const[pj]) o.n_var_p++;
+    {
+        const std::vector<long long> pc = pack_cuts(o.n_pts, 200000, 1);
+        std::vector<int> part((int)pc.size() - 1, 0);
+        pack_parallel_chunks(pc, [&](int t, long long p0, long long p1) { int n = 0; for (long long pj = p0; pj < p1; ++pj) n += !o.pt_const[pj]; part[t] = n; });
+        for (int v : part) o.n_var_p += v;
+    }
     mark("counts");
     return XRSFM_BA_OK;
 }
