@@ -351,6 +351,11 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], 
  * [n_cams] first row of each camera in the elimination order. */
 int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *cam_offset);
 
+/* TEST ENTRY: device-side packing (large problems: xrsfm_ba_create sorts and lays out the observations on the GPU) against the host
+ * packing it replaces: packs `problem` both ways and compares every array.  Returns 0 with *field = 0 when they are identical,
+ * *field > 0 = the first array that differs (see xrsfm_ba.hip), *field = -100 when the device path declines the problem. */
+int xrsfm_ba_debug_device_pack_check(const xrsfm_ba_problem *problem, int32_t *field, int32_t *index);
+
 /* Multi-GPU emulation for tests: supply the union of all ranks' off-diagonal camera pairs (row > col) before the first
  * Cholesky solve, exactly what xrsfm_ba_run obtains with an all-reduce when n_ranks > 1. */
 int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context *ctx, int n_pairs, const int32_t *row_col);

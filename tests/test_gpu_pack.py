@@ -1,0 +1,79 @@
+"""Device-side packing (xrsfm_amd/csrc/ba_pack_dev.h: the sorts and gathers of xrsfm_ba_create on the GPU for large problems) against
+the host packing it replaces (ba_pack.h, the specification: tests/test_pack_cpu.py): every packed array must be IDENTICAL,
+element for element — slots, tiles, Gram tables, camera-major positions, point order — on every track structure the packing
+distinguishes, and a solve of a device-packed context must equal the solve of the host-packed one bit for bit."""
+import numpy as np
+import pytest
+
+from tests import helpers as H
+
+
+def _cases():
+    from xrsfm_amd import capi, synth
+    out = {}
+    out["regular"] = H.make(60, 3000, 4, seed=11)                                   # groups of equal tuples start on tile boundaries
+    out["ragged"] = H.make(60, 3000, 8, seed=12, dropout=0.35)                      # thousands of distinct tuples, Gram tiles
+    out["wide_tiles"] = H.make(40, 60, 30, seed=13, mode="unordered")               # 30-camera tracks: no Gram tiles
+    out["pairs"] = H.make(30, 2500, 2, seed=14)                                     # 2-camera tracks: 32 tracks per tile
+    out["mixed_lengths"] = H.make(50, 2000, 9, seed=15, dropout=0.5)                # lengths 2..9: tuples longer than one sort key
+    out["unordered"] = H.make(130, 4000, 5, seed=141, mode="unordered")
+    b = H.make(40, 1500, 6, seed=16, dropout=0.3)
+    b["point_const"] = (np.arange(1500) % 7 == 0).astype(np.uint8)
+    cc = b["cam_const"].copy(); cc[5] |= 1; cc[9] |= 2; b["cam_const"] = cc
+    out["constants"] = b
+    d = synth.make_collection(n_cams=600, n_points=30000, seed=5, cams_per_cluster=60, max_track=60)
+    out["collection"] = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    # points without observations and a shuffled observation list (the reference's order is frame-major, ours must not matter)
+    e = H.make(24, 1200, 4, seed=17)
+    rng = np.random.default_rng(3)
+    keep = rng.random(e["obs_cam"].shape[0]) > 0.15
+    perm = rng.permutation(int(keep.sum()))
+    for f in ("obs_cam", "obs_pt", "obs_uv"):
+        e[f] = np.ascontiguousarray(e[f][keep][perm])
+    out["shuffled_with_gaps"] = e
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["regular", "ragged", "wide_tiles", "pairs", "mixed_lengths", "unordered", "constants", "collection", "shuffled_with_gaps"])
+def test_device_packing_equals_host_packing(lib, name):
+    from xrsfm_amd import capi
+    arr = _cases()[name]
+    field, index = capi.debug_device_pack_check(H.to_product(arr))
+    assert (field, index) == (0, -1), f"first difference: array {field} at element {index}"
+
+
+@pytest.mark.gpu
+def test_device_packing_declines_long_tracks_and_bal9(lib):
+    from xrsfm_amd import capi
+    long_tracks = H.make(72, 60, 68, seed=8, mode="unordered", min_tri_angle_deg=0.5)       # tracks of 68 observations
+    assert capi.debug_device_pack_check(H.to_product(long_tracks))[0] == -100
+    assert capi.debug_device_pack_check(H.to_product(H.make_bal9(12, 600, 4, seed=5)))[0] == -100
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["regular", "ragged", "collection"])
+def test_solve_of_a_device_packed_context_equals_the_host_packed_one(lib, monkeypatch, name):
+    """The same arrays in, the same kernels: bit-identical solves (exact solver; the Cholesky plan reads the downloaded copies)."""
+    from xrsfm_amd import capi
+    arr = _cases()[name]
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("XRSFM_BA_DEVICE_PACK", mode)
+        prod = H.to_product(arr)
+        s = capi.solve(prod, capi.default_options(max_iterations=8))
+        res[mode] = (s.n_successful, s.n_unsuccessful, s.final_cost, prod.cam_q.copy(), prod.cam_t.copy(), prod.points.copy())
+    assert res["1"][:3] == res["0"][:3]
+    assert all(np.array_equal(a, b) for a, b in zip(res["1"][3:], res["0"][3:]))
+
+
+@pytest.mark.gpu
+def test_device_packing_at_config_4_size(lib):
+    """BASELINE.json config 4 (2 M observations): identical arrays, and the size the path exists for."""
+    from xrsfm_amd import capi, synth
+    d = synth.make_problem(**synth.CONFIGS["L"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    assert capi.debug_device_pack_check(H.to_product(arr)) == (0, -1)
+    d = synth.make_problem(**synth.CONFIGS["R"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    assert capi.debug_device_pack_check(H.to_product(arr)) == (0, -1)

@@ -89,6 +89,7 @@ EXPORTS = [
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
     "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
     "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce", "xrsfm_ba_debug_backsub", "xrsfm_ba_device_memory", "xrsfm_ba_download_intrinsics", "xrsfm_ba_debug_wide",
+    "xrsfm_ba_debug_device_pack_check",
 ]
 
 SOLVER_PCG, SOLVER_CHOLESKY, SOLVER_AUTO = 0, 1, 2
@@ -421,6 +422,18 @@ def debug_pack(problem: ProblemArrays) -> dict:
     out = dict(zip(keys, (int(v) for v in stats)))
     out["slot_obs"] = slot_obs[:out["slots"]].copy()
     return out
+
+
+def debug_device_pack_check(problem: ProblemArrays) -> tuple:
+    """Device-side packing (large problems) against the host packing: (field, index) of the first difference, (0, -1) when every
+    array is identical, (-100, -1) when the device path declines the problem.  Needs a GPU."""
+    lib = load()
+    lib.xrsfm_ba_debug_device_pack_check.argtypes = [C.POINTER(CProblem), _c_int32_p, _c_int32_p]
+    lib.xrsfm_ba_debug_device_pack_check.restype = C.c_int
+    f = np.zeros(1, np.int32); i = np.zeros(1, np.int32)
+    cs = problem.c_struct()
+    check(lib.xrsfm_ba_debug_device_pack_check(C.byref(cs), f.ctypes.data_as(_c_int32_p), i.ctypes.data_as(_c_int32_p)), "xrsfm_ba_debug_device_pack_check")
+    return int(f[0]), int(i[0])
 
 
 def debug_chol_plan(problem: ProblemArrays) -> dict:

@@ -133,7 +133,8 @@ constexpr int kModelBal = 5;
 // wide (bal9 mode): no regular-tile pre-reductions (the 9-wide linearisation / back-substitution work per observation); Gram
 // tiles of up to kGramMaxCamsWide cameras (round 4: k9_pairs_gram — the S assembly of 9-wide blocks through the same Gram
 // product and per-camera pre-reduction as the 6-wide path).
-inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false) {
+// argument checks of a problem (everything but the observation indices, which the packing checks as it reads them)
+inline int pack_validate(const xrsfm_ba_problem& p, bool wide) {
     if (p.n_cams < 0 || p.n_points < 0 || p.n_obs < 0 || p.n_intr < 0) return XRSFM_BA_EINVAL;
     if (p.n_obs > 0 && (!p.obs_cam || !p.obs_pt || !p.obs_uv)) return XRSFM_BA_EINVAL;
     if (p.n_cams > 0 && (!p.cam_q || !p.cam_t || !p.cam_intr)) return XRSFM_BA_EINVAL;
@@ -152,6 +153,11 @@ inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false)
         for (int c = 0; c < p.n_cams; ++c)
             if (p.cam_const && (p.cam_const[c] & kCamIntrVariable) && users[p.cam_intr[c]] != 1) return XRSFM_BA_EINVAL;
     }
+    return XRSFM_BA_OK;
+}
+
+inline int pack_problem(const xrsfm_ba_problem& p, Packed& o, bool wide = false) {
+    if (int ev = pack_validate(p, wide)) return ev;
     const int No = p.n_obs, Np = p.n_points, Nc = p.n_cams;
     PhaseTimer timer("pack");
     auto mark = [&](const char* what) { timer.mark(what); };

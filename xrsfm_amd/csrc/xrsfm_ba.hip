@@ -32,6 +32,7 @@
 #include "ba_plan.h"
 #include "ba_refine.h"
 #include "ba_wide.h"
+#include "ba_pack_dev.h"
 #include "pose_graph.h"
 #include "tag_refine.h"
 
@@ -158,6 +159,10 @@ struct xrsfm_ba_context {
     struct Rec { int kid; size_t e0; int tag; };
     std::vector<Rec> recs;
     double prof_ms[K_COUNT] = {0}; int prof_n[K_COUNT] = {0};
+    // device-side packing (ba_pack_dev.h): the slot / tile arrays exist on the device only; the host copies the Cholesky plan and
+    // the debug entry points read (Packed::slot_cam, ...) are downloaded on first use (ensure_host_pack)
+    bool dev_packed = false; int host_pack_level = 2;       // 0 nothing downloaded, 1 what the plan reads, 2 everything (host packing: always 2)
+    int* dpk_slot_obs = nullptr; unsigned char* dpk_gt_cell = nullptr;
     bool linearized = false;
     bool poisoned = false;          // the watchdog tripped: the stream may never drain — destroy must not wait for it (fetch_scalars)
     bool fused = true;              // one-launch linearisation tail (k_lin_tail) and candidate cameras in trailing workgroups of k_backsub;
@@ -565,10 +570,38 @@ int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary
     return 0;
 }
 
+// Host copies of the packed arrays of a device-packed context (ba_pack_dev.h): level 1 = what the Cholesky plan reads (slot_cam,
+// slot_pt, slot_cidx, tile_ncam, tile_gt_off, gt_cell), level 2 = everything but the observations' u, v (debug entry points).
+int ensure_host_pack(xrsfm_ba_context* c, int level) {
+    if (!c->dev_packed || c->host_pack_level >= level) return 0;
+    Packed& k = c->pk;
+    const Dev& d = c->d;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t ns = (size_t)k.n_slots, nt = (size_t)k.n_tiles;
+    auto get = [&](auto& vec, const void* src, size_t n) -> int {
+        vec.resize(n);
+        if (n && hipMemcpy(vec.data(), src, n * sizeof(vec[0]), hipMemcpyDeviceToHost) != hipSuccess) return XRSFM_BA_ENODEV;
+        return 0;
+    };
+    int e = 0;
+    if (c->host_pack_level < 1) {
+        if ((e = get(k.slot_cam, d.slot_cam, ns)) || (e = get(k.slot_pt, d.slot_pt, ns)) || (e = get(k.slot_cidx, d.slot_cidx, ns)) ||
+            (e = get(k.tile_ncam, d.tile_ncam, nt)) || (e = get(k.tile_gt_off, d.tile_gt_off, nt)) || (e = get(k.gt_cell, c->dpk_gt_cell, (size_t)k.n_gt_cells))) return e;
+        c->host_pack_level = 1;
+    }
+    if (level >= 2) {
+        if ((e = get(k.slot_obs, c->dpk_slot_obs, ns)) || (e = get(k.slot_campos, d.slot_campos, ns)) || (e = get(k.slot_campos_g, d.slot_campos_g, ns)) ||
+            (e = get(k.tile_stride, d.tile_stride, nt)) || (e = get(k.tile_maxlen, d.tile_maxlen, nt))) return e;
+        c->host_pack_level = 2;
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------- Cholesky path: structures
 int chol_setup(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     if (h.ready) return 0;
+    if (int eh = ensure_host_pack(c, 1)) return eh;
     const Packed& k = c->pk;
     const int Nc = k.n_cams;
     std::vector<int> spp;
@@ -1108,6 +1141,7 @@ int xrsfm_ba_device_memory(int device, uint64_t* free_bytes, uint64_t* total_byt
 }
 
 static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* c, xrsfm_ba_context** out);
+static thread_local int g_force_device_pack = -1;       // xrsfm_ba_debug_device_pack_check: 1 = device packing whatever the size
 
 int xrsfm_ba_create(const xrsfm_ba_problem* p, int device, xrsfm_ba_context** out) {
     if (!p || !out) return XRSFM_BA_EINVAL;
@@ -1129,9 +1163,8 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
     c->device = device;
     PhaseTimer timer("create");
     for (int i = 0; i < p->n_cams && p->cam_const; ++i) c->wide = c->wide || (p->cam_const[i] & kCamIntrVariable) != 0;
-    int e = pack_problem(*p, c->pk, c->wide);
+    int e = pack_validate(*p, c->wide);
     if (e) { delete c; return e; }
-    timer.mark("pack_problem");
     {
         HostBundle hb;
         if (hipSetDevice(device) != hipSuccess || !g_bundles.get(device, &hb)) { delete c; return XRSFM_BA_ENODEV; }
@@ -1142,8 +1175,33 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         void* dp = nullptr;
         c->h_scal_dev = (hipHostGetDevicePointer(&dp, c->h_scal, 0) == hipSuccess) ? static_cast<double*>(dp) : nullptr;
     }
-    const Packed& k = c->pk;
     Dev& d = c->d;
+    // Packing: on the device for problems large enough to pay for its launches and round trips (ba_pack_dev.h: the same arrays as the
+    // host's, element for element), on the host otherwise — small calls (LBA: a few thousand observations, 0.2 ms of host packing),
+    // bal9 mode, tracks longer than 64 observations, 65 535 cameras or more.  XRSFM_BA_DEVICE_PACK=0 / 1: never / whenever possible.
+    devpack::Result dres;
+    {
+        const char* dpe = std::getenv("XRSFM_BA_DEVICE_PACK");
+        const bool allowed = !c->wide && p->n_cams < 65535 && p->n_obs > 0 && p->n_points > 0;
+        const bool want = g_force_device_pack >= 0 ? g_force_device_pack == 1 : (dpe ? dpe[0] != '0' : p->n_obs >= 150000);
+        if (allowed && want) {
+            std::vector<std::pair<void*, size_t>> scratch;
+            auto keep = [&](size_t bytes) -> void* { unsigned char* q = nullptr; return dev_alloc(c, &q, bytes) ? nullptr : (void*)q; };
+            auto scr = [&](size_t bytes) -> void* { size_t cls = 0; void* q = g_cache.get(c->device, bytes, &cls); if (q) scratch.push_back({q, cls}); return q; };
+            e = devpack::device_pack(*p, c->stream, keep, scr, c->pk, dres);
+            (void)hipStreamSynchronize(c->stream);
+            for (auto& b : scratch) g_cache.put(c->device, b.first, b.second);
+            if (e == 0) { c->dev_packed = true; c->host_pack_level = 0; c->dpk_slot_obs = dres.slot_obs; c->dpk_gt_cell = dres.gt_cell; }
+            else if (e != 1) { xrsfm_ba_destroy(c); return e; }
+            else { c->pk = Packed(); }                    // (a track longer than 64 observations: the host path packs it)
+        }
+    }
+    if (!c->dev_packed) {
+        e = pack_problem(*p, c->pk, c->wide);
+        if (e) { xrsfm_ba_destroy(c); return e; }
+    }
+    timer.mark("pack_problem");
+    const Packed& k = c->pk;
     c->n_points_caller = p->n_points;
     d.n_cams = k.n_cams; d.n_pts = k.n_pts; d.n_tiles = k.n_tiles; d.n_slots = k.n_slots; d.n_items = (int)k.items.size() / 2;
     std::vector<CamRec> cams(k.n_cams);
@@ -1159,7 +1217,8 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         model[i] = p->intr_model[ii];
         cconst[i] = p->cam_const ? p->cam_const[i] : 0;
     }
-    RawVec<double> P(3 * (size_t)k.n_pts);
+    RawVec<double> P(c->dev_packed ? 0 : 3 * (size_t)k.n_pts);
+    if (!c->dev_packed)
     pack_parallel_for(k.n_pts, [&](long long j0, long long j1) {
         for (long long j = j0; j < j1; ++j)
             for (int a = 0; a < 3; ++a) P[3 * (size_t)j + a] = p->points[3 * (size_t)k.pt_orig[j] + a];
@@ -1172,16 +1231,28 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         // (const members of Dev are set through a cast: the arrays are written exactly once, here)
         BatchUpload up(c);
         auto P_ = [](auto& member) { return const_cast<std::remove_const_t<std::remove_pointer_t<std::remove_reference_t<decltype(member)>>>**>(&member); };
-        up.add(P_(d.slot_cam), k.slot_cam); up.add(P_(d.slot_pt), k.slot_pt); up.add(P_(d.slot_campos), k.slot_campos);
-        up.add(P_(d.slot_u), k.slot_u); up.add(P_(d.slot_v), k.slot_v);
         up.add_raw(reinterpret_cast<void**>(const_cast<Item**>(&d.items)), k.items.data(), k.items.size() * sizeof(int));
-        up.add(P_(d.tile_stride), k.tile_stride); up.add(P_(d.tile_maxlen), k.tile_maxlen);
-        up.add(P_(d.tile_ncam), k.tile_ncam); up.add(P_(d.tile_gt_off), k.tile_gt_off); up.add(P_(d.slot_cidx), k.slot_cidx);
-        up.add(P_(d.slot_campos_g), k.slot_campos_g); up.add(P_(d.cam_ptr_g), k.cam_ptr_g);
         up.add(P_(d.cam), cams); up.add(P_(d.cam_cand), cams); up.add(&c->cam0, cams);
-        up.add(P_(d.cam_model), model); up.add(P_(d.cam_const), cconst); up.add(P_(d.cam_ptr), k.cam_ptr); up.add(P_(d.cam_act), cam_act);
-        up.add(P_(d.P), P); up.add(P_(d.P_cand), P); up.add(&c->P0, P);
-        up.add(P_(d.pt_const), k.pt_const);
+        up.add(P_(d.cam_model), model); up.add(P_(d.cam_const), cconst); up.add(P_(d.cam_act), cam_act);
+        if (c->dev_packed) {
+            d.slot_cam = dres.slot_cam; d.slot_pt = dres.slot_pt; d.slot_campos = dres.slot_campos; d.slot_u = dres.slot_u; d.slot_v = dres.slot_v;
+            d.tile_stride = dres.tile_stride; d.tile_maxlen = dres.tile_maxlen; d.tile_ncam = dres.tile_ncam; d.tile_gt_off = dres.tile_gt_off;
+            d.slot_cidx = dres.slot_cidx; d.slot_campos_g = dres.slot_campos_g; d.cam_ptr_g = dres.cam_ptr_g; d.cam_ptr = dres.cam_ptr;
+            d.P = dres.P; d.pt_const = dres.pt_const;
+            const size_t pb = sizeof(double) * 3 * (size_t)k.n_pts;
+            TRY(dev_alloc(c, &d.P_cand, 3 * (size_t)k.n_pts)); TRY(dev_alloc(c, &c->P0, 3 * (size_t)k.n_pts));
+            if (pb && (hipMemcpyAsync(d.P_cand, d.P, pb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+                       hipMemcpyAsync(c->P0, d.P, pb, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)) { xrsfm_ba_destroy(c); return XRSFM_BA_ENODEV; }
+        } else {
+            up.add(P_(d.slot_cam), k.slot_cam); up.add(P_(d.slot_pt), k.slot_pt); up.add(P_(d.slot_campos), k.slot_campos);
+            up.add(P_(d.slot_u), k.slot_u); up.add(P_(d.slot_v), k.slot_v);
+            up.add(P_(d.tile_stride), k.tile_stride); up.add(P_(d.tile_maxlen), k.tile_maxlen);
+            up.add(P_(d.tile_ncam), k.tile_ncam); up.add(P_(d.tile_gt_off), k.tile_gt_off); up.add(P_(d.slot_cidx), k.slot_cidx);
+            up.add(P_(d.slot_campos_g), k.slot_campos_g); up.add(P_(d.cam_ptr_g), k.cam_ptr_g);
+            up.add(P_(d.cam_ptr), k.cam_ptr);
+            up.add(P_(d.P), P); up.add(P_(d.P_cand), P); up.add(&c->P0, P);
+            up.add(P_(d.pt_const), k.pt_const);
+        }
         TRY(up.flush());
     }
     timer.mark("uploads");
@@ -1940,6 +2011,7 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scalin
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
     int e;
+    if ((e = ensure_host_pack(c, 2))) return e;
     if ((e = init_scaling_and_linearize(c, huber_a, use_scaling != 0))) return e;
     if ((e = fetch_scalars(c))) return e;
     if (cost) *cost = 0.5 * c->h_scal[S_COST];
@@ -2223,6 +2295,60 @@ int xrsfm_ba_debug_backsub(xrsfm_ba_context* c, double* part_model, double* part
         }
     }
     return 0;
+}
+
+// Device-side packing against the host's (ba_pack_dev.h / ba_pack.h): packs `p` both ways and compares every array.
+// *field = 0 and return 0 when they are identical; otherwise *field names the first array that differs (1 counts, 2 items,
+// 3 pt_orig, 4 slot_cam, 5 slot_pt, 6 slot_obs, 7 slot_u/v, 8 tile_maxlen, 9 tile_stride, 10 tile_ncam, 11 tile_gt_off, 12 slot_cidx,
+// 13 gt_cell, 14 slot_campos, 15 slot_campos_g, 16 cam_ptr, 17 cam_ptr_g, 18 pt_const, 19 points) and *index the first element;
+// -100: the device path declined the problem (a track longer than 64 observations, bal9 mode, ...).
+int xrsfm_ba_debug_device_pack_check(const xrsfm_ba_problem* p, int32_t* field, int32_t* index) {
+    if (!p || !field || !index) return XRSFM_BA_EINVAL;
+    *field = 0; *index = -1;
+    return no_throw([&]() -> int {
+        Packed h;
+        int e = pack_problem(*p, h, problem_is_wide(p));
+        if (e) return e;
+        xrsfm_ba_context* c = nullptr;
+        g_force_device_pack = 1;
+        e = xrsfm_ba_create(p, 0, &c);
+        g_force_device_pack = -1;
+        if (e) return e;
+        struct Guard { xrsfm_ba_context* c; ~Guard() { xrsfm_ba_destroy(c); } } guard{c};
+        if (!c->dev_packed) { *field = -100; return 0; }
+        if ((e = ensure_host_pack(c, 2))) return e;
+        const Packed& k = c->pk;
+        auto diff = [&](int f, long long i) { *field = f; *index = (int32_t)i; return 0; };
+        if (k.n_cams != h.n_cams || k.n_pts != h.n_pts || k.n_obs != h.n_obs || k.n_tiles != h.n_tiles || k.n_slots != h.n_slots ||
+            k.n_gt_cells != h.n_gt_cells || k.n_cam_entries != h.n_cam_entries || k.n_cam_entries_g != h.n_cam_entries_g ||
+            k.n_var_q != h.n_var_q || k.n_var_t != h.n_var_t || k.n_var_p != h.n_var_p) return diff(1, 0);
+        auto cmp = [&](int f, const auto& a, const auto& b) -> bool {
+            if (a.size() != b.size()) { diff(f, -2); return false; }
+            for (size_t i = 0; i < a.size(); ++i) if (a[i] != b[i]) { diff(f, (long long)i); return false; }
+            return true;
+        };
+        if (!cmp(2, k.items, h.items) || !cmp(3, k.pt_orig, h.pt_orig) || !cmp(4, k.slot_cam, h.slot_cam) || !cmp(5, k.slot_pt, h.slot_pt) ||
+            !cmp(6, k.slot_obs, h.slot_obs)) return 0;
+        {
+            const size_t ns = (size_t)k.n_slots;
+            std::vector<double> u(ns), v(ns);
+            if (ns && (hipMemcpy(u.data(), c->d.slot_u, ns * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+                       hipMemcpy(v.data(), c->d.slot_v, ns * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess)) return XRSFM_BA_ENODEV;
+            for (size_t i = 0; i < ns; ++i) if (u[i] != h.slot_u[i] || v[i] != h.slot_v[i]) return diff(7, (long long)i);
+        }
+        if (!cmp(8, k.tile_maxlen, h.tile_maxlen) || !cmp(9, k.tile_stride, h.tile_stride) || !cmp(10, k.tile_ncam, h.tile_ncam) ||
+            !cmp(11, k.tile_gt_off, h.tile_gt_off) || !cmp(12, k.slot_cidx, h.slot_cidx) || !cmp(13, k.gt_cell, h.gt_cell) ||
+            !cmp(14, k.slot_campos, h.slot_campos) || !cmp(15, k.slot_campos_g, h.slot_campos_g) || !cmp(16, k.cam_ptr, h.cam_ptr) ||
+            !cmp(17, k.cam_ptr_g, h.cam_ptr_g) || !cmp(18, k.pt_const, h.pt_const)) return 0;
+        {
+            const size_t np3 = 3 * (size_t)k.n_pts;
+            std::vector<double> P(np3);
+            if (np3 && hipMemcpy(P.data(), c->d.P, np3 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return XRSFM_BA_ENODEV;
+            for (size_t j = 0; j < (size_t)k.n_pts; ++j)
+                for (int a = 0; a < 3; ++a) if (P[3 * j + a] != p->points[3 * (size_t)h.pt_orig[j] + a]) return diff(19, (long long)j);
+        }
+        return 0;
+    });
 }
 
 #ifdef XBA_TIMELINE
