@@ -52,19 +52,21 @@ def test_device_packing_declines_long_tracks_and_bal9(lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["regular", "ragged", "collection"])
+@pytest.mark.parametrize("name", ["regular", "ragged", "collection", "wide_tiles", "mixed_lengths", "unordered", "constants", "shuffled_with_gaps"])
 def test_solve_of_a_device_packed_context_equals_the_host_packed_one(lib, monkeypatch, name):
     """The same arrays in, the same kernels: bit-identical solves (exact solver; the Cholesky plan reads the downloaded copies)."""
     from xrsfm_amd import capi
     arr = _cases()[name]
     res = {}
-    for mode in ("1", "0"):
+    for mode, keys in (("1", "1"), ("1", "0"), ("0", "1")):      # device packing + device pair keys | + host keys (downloaded arrays) | host packing
         monkeypatch.setenv("XRSFM_BA_DEVICE_PACK", mode)
+        monkeypatch.setenv("XRSFM_BA_DEVICE_KEYS", keys)
         prod = H.to_product(arr)
-        s = capi.solve(prod, capi.default_options(max_iterations=8))
-        res[mode] = (s.n_successful, s.n_unsuccessful, s.final_cost, prod.cam_q.copy(), prod.cam_t.copy(), prod.points.copy())
-    assert res["1"][:3] == res["0"][:3]
-    assert all(np.array_equal(a, b) for a, b in zip(res["1"][3:], res["0"][3:]))
+        s = capi.solve(prod, capi.default_options(max_iterations=8, linear_solver=1))
+        res[mode + keys] = (s.n_successful, s.n_unsuccessful, s.final_cost, prod.cam_q.copy(), prod.cam_t.copy(), prod.points.copy())
+    for other in ("10", "01"):
+        assert res["11"][:3] == res[other][:3], other
+        assert all(np.array_equal(a, b) for a, b in zip(res["11"][3:], res[other][3:])), other
 
 
 @pytest.mark.gpu

@@ -491,5 +491,235 @@ inline int device_pack(const xrsfm_ba_problem& p, hipStream_t st, Keep&& keep, S
     return XRSFM_BA_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Pair keys of the Cholesky path on the device (ba_plan.h: chol_local_keys + the "blocks + destinations" part of the plan):
+// slot_pair_ptr, the sorted (block key, writer index) list -> blocks (row, column camera), blk_ptr, pair_dst, and the launch
+// buckets of the S assembly (pairs_items).  The host plan then only needs the block list (a few thousand pairs).
+// Single rank, local pattern; every tile is a single-tile item (device-packed contexts have no long tracks).
+
+// per slot: pairs that start at it (later slots of the same track); duplicate-camera check; per-tile key counts
+__global__ __launch_bounds__(256) void k_pair_counts(const int* __restrict__ slot_cam, const int* __restrict__ slot_pt, const int* __restrict__ tile_ncam,
+                                                     const int* __restrict__ tile_gt_off, const unsigned char* __restrict__ gt_cell, int n_tiles,
+                                                     int* __restrict__ cnt, int* __restrict__ nk_slot, int* __restrict__ nk_tile, unsigned* __restrict__ status) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int s = 64 * t + lane;
+    const int cam = slot_cam[s], pt = slot_pt[s];
+    const bool valid = cam >= 0;
+    const int next_pt = __shfl_down(pt, 1, 64), next_cam = __shfl_down(cam, 1, 64);
+    const bool last = !valid || lane == 63 || next_cam < 0 || next_pt != pt;          // last slot of its track
+    if (valid && !last && next_cam <= cam) atomicOr(status, 4u);                        // two observations of one track in the same frame
+    const unsigned long long lm = __ballot(last && valid);
+    // slots until the end of the own track: position of the first "last" flag at or after this lane
+    const unsigned long long from = lm >> lane;
+    const int run = (valid && from) ? __ffsll((long long)from) - 1 : 0;
+    cnt[s] = run;
+    const int C = tile_ncam[t];
+    nk_slot[s] = (C > 0) ? 0 : run;
+    int cells = 0;
+    if (C > 0) {
+        const unsigned char* cell = gt_cell + tile_gt_off[t];
+        for (int e = lane; e < C * C; e += 64) { const int a = e / C, b = e - a * C; if (b > a && cell[e]) ++cells; }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cells += __shfl_xor(cells, off, 64);
+    }
+    if (lane == 0) nk_tile[t] = cells;
+}
+__global__ __launch_bounds__(256) void k_pair_keys(const int* __restrict__ slot_cam, const unsigned char* __restrict__ slot_cidx, const int* __restrict__ tile_ncam,
+                                                   const int* __restrict__ tile_gt_off, const unsigned char* __restrict__ gt_cell, int n_tiles,
+                                                   const int* __restrict__ cnt, const int* __restrict__ spp, const int* __restrict__ koff, const int* __restrict__ goff,
+                                                   int k1_total, int n_obs_pairs, int cshift, unsigned long long* __restrict__ key, int* __restrict__ val) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int s = 64 * t + lane;
+    const int cam = slot_cam[s];
+    const int C = tile_ncam[t];
+    if (C <= 0) {
+        const int n = cnt[s];
+        for (int dd = 1; dd <= n; ++dd) {
+            const int cb = slot_cam[s + dd];
+            key[koff[s] + dd - 1] = ((unsigned long long)(unsigned)cb << cshift) | (unsigned)cam;
+            val[koff[s] + dd - 1] = spp[s] + dd - 1;
+        }
+        return;
+    }
+    // ascending distinct cameras of the tile: cams[cidx] = camera
+    __shared__ int cams_s[4][16];
+    int* cams = cams_s[threadIdx.x >> 6];
+    if (cam >= 0) cams[slot_cidx[s]] = cam;           // (equal values from every lane of a camera)
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    const unsigned char* cell = gt_cell + tile_gt_off[t];
+    int base = k1_total + goff[t];
+    for (int e0 = 0; e0 < C * C; e0 += 64) {
+        const int e = e0 + lane;
+        const int a = e / C, b = e - a * C;
+        const bool on = e < C * C && b > a && cell[e];
+        const unsigned long long m = __ballot(on);
+        if (on) {
+            const int r = base + __popcll(m & ((1ull << lane) - 1ull));
+            key[r] = ((unsigned long long)(unsigned)cams[b] << cshift) | (unsigned)cams[a];
+            val[r] = n_obs_pairs + tile_gt_off[t] + e;
+        }
+        base += __popcll(m);
+    }
+}
+__global__ void k_key_heads(const unsigned long long* __restrict__ key, int n, int* __restrict__ head) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) head[i] = (i == 0 || key[i] != key[i - 1]) ? 1 : 0;
+}
+__global__ void k_blocks(const unsigned long long* __restrict__ key, const int* __restrict__ val, const int* __restrict__ head, const int* __restrict__ bid_incl,
+                         int n, int cshift, int* __restrict__ blk_ptr, int* __restrict__ blk_rc, int* __restrict__ pair_dst) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) { blk_ptr[n > 0 ? bid_incl[n - 1] : 0] = n; return; }
+    pair_dst[val[i]] = i;
+    if (head[i]) {
+        const int b = bid_incl[i] - 1;
+        blk_ptr[b] = i;
+        blk_rc[2 * b] = (int)(key[i] >> cshift); blk_rc[2 * b + 1] = (int)(key[i] & ((1ull << cshift) - 1ull));
+    }
+}
+// launch bucket of every tile (ba_plan.h: 2 * (NI - 1) + LDS class for a Gram tile, 8 = per-pair path) + per-bucket LDS need
+__global__ __launch_bounds__(256) void k_buckets(const int* __restrict__ slot_cam, const int* __restrict__ slot_pt, const int* __restrict__ tile_ncam, int n_tiles,
+                                                 int cw, unsigned* __restrict__ bkey, int* __restrict__ bcount, int* __restrict__ bshm) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int s = 64 * t + lane;
+    const int cam = slot_cam[s], pt = slot_pt[s];
+    const int prev = __shfl_up(pt, 1, 64);
+    const int ntrk = __popcll(__ballot(cam >= 0 && (lane == 0 || prev != pt)));
+    if (lane != 0) return;
+    const int C = tile_ncam[t];
+    int b = 8;
+    if (C > 0) {
+        int passes = 1;
+        const int base = 64 * 15 * 8;
+        const int need = max(base, gram_lds_need(C, ntrk, &passes, cw));
+        b = 2 * ((cw * C + 15) / 16 - 1) + (need <= kGramSmallLds ? 0 : 1);
+        atomicMax(bshm + b, need);
+    }
+    bkey[t] = (unsigned)b;
+    atomicAdd(bcount + b, 1);
+}
+
+struct KeysResult {
+    int *spp = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr, *pairs_items = nullptr;     // device (kept)
+    int n_pairs = 0, n_writes = 0, n_blocks = 0;
+    std::vector<int> blk_rc_host;
+    int gram_n[8] = {0}, n_other = 0; size_t gram_shm[8] = {0};
+    bool duplicate = false;
+};
+
+template <typename Keep, typename Scratch>
+inline int device_keys(const Packed& o, const int* slot_cam, const int* slot_pt, const unsigned char* slot_cidx, const int* tile_ncam, const int* tile_gt_off,
+                       const unsigned char* gt_cell, hipStream_t st, Keep&& keep, Scratch&& scratch_alloc, KeysResult& K) {
+    typedef unsigned long long u64;
+    const int ns = o.n_slots, nt = o.n_tiles, Nc = o.n_cams;
+    PhaseTimer timer("devkeys");
+    auto tmp = [&](size_t bytes) -> void* { return scratch_alloc(bytes ? bytes : 8); };
+    auto alloc = [&](size_t bytes) -> void* { return keep(bytes ? bytes : 8); };
+    void* d_tmp = nullptr; size_t tb = 0;
+    auto need_tmp = [&](size_t bytes) -> bool { if (bytes <= tb) return true; d_tmp = tmp(bytes); tb = d_tmp ? bytes : 0; return d_tmp != nullptr; };
+    auto sort64 = [&](u64* kin, u64* kout, int* vin, int* vout, size_t n, unsigned bits) -> int {
+        size_t q = 0;
+        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    };
+    auto sort32 = [&](unsigned* kin, unsigned* kout, int* vin, int* vout, size_t n, unsigned bits) -> int {
+        size_t q = 0;
+        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    };
+    auto scan_incl = [&](int* in, int* out, size_t n) -> int {
+        size_t q = 0;
+        if (rocprim::inclusive_scan(nullptr, q, in, out, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::inclusive_scan(d_tmp, t, in, out, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    };
+    auto scan_excl = [&](int* in, int* out, size_t n) -> int {
+        size_t q = 0;
+        if (rocprim::exclusive_scan(nullptr, q, in, out, 0, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::exclusive_scan(d_tmp, t, in, out, 0, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    };
+    int e = 0;
+#define XBA_TMP(T, name, n) T* name = static_cast<T*>(tmp(sizeof(T) * (size_t)(n))); if (!name) return XRSFM_BA_ENOMEM
+#define XBA_KEEP(T, name, n) name = static_cast<T*>(alloc(sizeof(T) * (size_t)((n) > 0 ? (n) : 1))); if (!name) return XRSFM_BA_ENOMEM
+#define XBA_DO(x) do { if ((e = (x))) return e; } while (0)
+    int cshift = 1; while ((1ll << cshift) < (long long)Nc) ++cshift;
+    const int nbw = (nt + 3) / 4;
+    XBA_TMP(unsigned, d_status, 4);
+    XBA_DP_HIP(hipMemsetAsync(d_status, 0, 16, st));
+    XBA_TMP(int, cnt, ns + 2); XBA_TMP(int, nk_slot, ns + 2); XBA_TMP(int, nk_tile, nt + 2); XBA_TMP(int, koff, ns + 2); XBA_TMP(int, goff, nt + 2);
+    XBA_KEEP(int, K.spp, ns + 1);
+    XBA_DP_HIP(hipMemsetAsync(cnt + ns, 0, sizeof(int) * 2, st)); XBA_DP_HIP(hipMemsetAsync(nk_slot + ns, 0, sizeof(int) * 2, st));
+    XBA_DP_HIP(hipMemsetAsync(nk_tile + nt, 0, sizeof(int) * 2, st));
+    if (nt > 0) hipLaunchKernelGGL(k_pair_counts, dim3(nbw), dim3(kThreads), 0, st, slot_cam, slot_pt, tile_ncam, tile_gt_off, gt_cell, nt, cnt, nk_slot, nk_tile, d_status);
+    XBA_DO(scan_excl(cnt, K.spp, (size_t)ns + 1));              // spp[ns] = number of observation pairs
+    XBA_DO(scan_excl(nk_slot, koff, (size_t)ns + 1));
+    XBA_DO(scan_excl(nk_tile, goff, (size_t)nt + 1));
+    int totals[3] = {0, 0, 0};
+    unsigned status[4] = {0, 0, 0, 0};
+    XBA_DP_HIP(hipMemcpyAsync(&totals[0], K.spp + ns, sizeof(int), hipMemcpyDeviceToHost, st));
+    XBA_DP_HIP(hipMemcpyAsync(&totals[1], koff + ns, sizeof(int), hipMemcpyDeviceToHost, st));
+    XBA_DP_HIP(hipMemcpyAsync(&totals[2], goff + nt, sizeof(int), hipMemcpyDeviceToHost, st));
+    XBA_DP_HIP(hipMemcpyAsync(status, d_status, 16, hipMemcpyDeviceToHost, st));
+    XBA_DP_HIP(hipStreamSynchronize(st));
+    if (status[0] & 4u) { K.duplicate = true; return 0; }
+    const int n_obs_pairs = totals[0], k1 = totals[1], nw = totals[1] + totals[2];
+    if ((long long)n_obs_pairs + o.n_gt_cells > INT32_MAX) return XRSFM_BA_EINVAL;
+    K.n_pairs = n_obs_pairs + o.n_gt_cells; K.n_writes = nw;
+    XBA_TMP(u64, key_a, nw + 1); XBA_TMP(u64, key_b, nw + 1); XBA_TMP(int, val_a, nw + 1); XBA_TMP(int, val_b, nw + 1);
+    XBA_TMP(int, head, nw + 1); XBA_TMP(int, bid, nw + 1);
+    if (nt > 0) hipLaunchKernelGGL(k_pair_keys, dim3(nbw), dim3(kThreads), 0, st, slot_cam, slot_cidx, tile_ncam, tile_gt_off, gt_cell, nt, cnt, K.spp, koff, goff, k1,
+                                   n_obs_pairs, cshift, key_a, val_a);
+    int n_blocks = 0;
+    if (nw > 0) {
+        XBA_DO(sort64(key_a, key_b, val_a, val_b, (size_t)nw, (unsigned)(2 * cshift)));
+        hipLaunchKernelGGL(k_key_heads, dim3((nw + kThreads - 1) / kThreads), dim3(kThreads), 0, st, key_b, nw, head);
+        XBA_DO(scan_incl(head, bid, (size_t)nw));
+        XBA_DP_HIP(hipMemcpyAsync(&n_blocks, bid + (nw - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+        XBA_DP_HIP(hipStreamSynchronize(st));
+    }
+    K.n_blocks = n_blocks;
+    XBA_KEEP(int, K.pair_dst, K.n_pairs); XBA_KEEP(int, K.blk_ptr, n_blocks + 1); XBA_KEEP(int, K.blk_rc, 2 * n_blocks);
+    if (K.n_pairs > 0) XBA_DP_HIP(hipMemsetAsync(K.pair_dst, 0xff, sizeof(int) * (size_t)K.n_pairs, st));
+    hipLaunchKernelGGL(k_blocks, dim3((nw + 1 + kThreads - 1) / kThreads), dim3(kThreads), 0, st, key_b, val_b, head, bid, nw, cshift, K.blk_ptr, K.blk_rc, K.pair_dst);
+    K.blk_rc_host.resize(2 * (size_t)n_blocks);
+    if (n_blocks > 0) XBA_DP_HIP(hipMemcpyAsync(K.blk_rc_host.data(), K.blk_rc, sizeof(int) * 2 * (size_t)n_blocks, hipMemcpyDeviceToHost, st));
+    // launch buckets of the S assembly
+    XBA_TMP(unsigned, bkey, nt + 1); XBA_TMP(unsigned, bkey_s, nt + 1); XBA_TMP(int, tl_a, nt + 1); XBA_TMP(int, bcount, 32);
+    XBA_KEEP(int, K.pairs_items, nt);
+    XBA_DP_HIP(hipMemsetAsync(bcount, 0, sizeof(int) * 32, st));
+    int hb[32] = {0};
+    if (nt > 0) {
+        hipLaunchKernelGGL(k_buckets, dim3(nbw), dim3(kThreads), 0, st, slot_cam, slot_pt, tile_ncam, nt, 6, bkey, bcount, bcount + 16);
+        hipLaunchKernelGGL(k_iota, dim3((nt + kThreads - 1) / kThreads), dim3(kThreads), 0, st, tl_a, nt);
+        XBA_DO(sort32(bkey, bkey_s, tl_a, K.pairs_items, (size_t)nt, 4u));
+    }
+    XBA_DP_HIP(hipMemcpyAsync(hb, bcount, sizeof(int) * 32, hipMemcpyDeviceToHost, st));
+    XBA_DP_HIP(hipStreamSynchronize(st));
+    XBA_DP_HIP(hipGetLastError());
+    const size_t base = (size_t)64 * 15 * sizeof(double);
+    for (int b = 0; b < 8; ++b) { K.gram_n[b] = hb[b]; K.gram_shm[b] = std::max(base, (size_t)hb[16 + b]); }
+    K.n_other = hb[8];
+    timer.mark("pair keys + blocks + buckets");
+#undef XBA_TMP
+#undef XBA_KEEP
+#undef XBA_DO
+    return XRSFM_BA_OK;
+}
+
 }  // namespace devpack
 }  // namespace xba

@@ -328,19 +328,32 @@ inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<
 // Limits (checked BEFORE the symbolic factorisation, whose work and memory grow with the cube of the tile count when the
 // pattern fills in): more than `max_dense_unknowns` camera unknowns are only planned when the band / ring ordering applies,
 // and then only while the packed tile storage of the factor (non-zero 64x64 tiles) stays within `max_tile_bytes`; XRSFM_BA_ETOOBIG otherwise.
+// What the device-side key generation (ba_pack_dev.h: device_keys) hands to the plan instead of the key list: the blocks, the
+// sizes, and the launch buckets of the S assembly; slot_pair_ptr / pair_dst / blk_ptr / pairs_items stay on the device.
+struct PlanPrebuilt {
+    int n_pairs = 0, n_writes = 0;
+    std::vector<int> blk_rc;
+    int gram_n[8] = {0}, n_other = 0; size_t gram_shm[8] = {0};
+};
+
 inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const PairKeys& keyed,
                            const std::vector<unsigned long long>* pattern, CholPlan& P,
-                           long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX, int cam_width = 6) {
+                           long long max_dense_unknowns = INT64_MAX, unsigned long long max_tile_bytes = UINT64_MAX, int cam_width = 6,
+                           const PlanPrebuilt* pre = nullptr) {
     const int CW = cam_width, CPT = (cam_width == 6) ? kCamsPerTile : kCamsPerTileWide;
     const int Nc = k.n_cams, ns = k.n_slots;
     PhaseTimer timer("plan");
     P = CholPlan();
-    P.spp = spp;
+    if (!pre) P.spp = spp;
     P.cam_width = CW; P.cams_per_tile = CPT;
     P.n = CW * Nc;
-    P.n_pairs = spp[ns] + k.n_gt_cells;      // pair_dst: observation pairs | cells of the Gram tiles' tables
-    P.n_writes = (int)keyed.size();
+    P.n_pairs = pre ? pre->n_pairs : spp[ns] + k.n_gt_cells;      // pair_dst: observation pairs | cells of the Gram tiles' tables
+    P.n_writes = pre ? pre->n_writes : (int)keyed.size();
     std::vector<unsigned long long> blk_keys;
+    if (pre) {
+        if (pattern) return XRSFM_BA_EINTERNAL;                  // (device keys are local-pattern only)
+        P.blk_rc = pre->blk_rc;
+    } else {
     if (pattern) blk_keys = *pattern;
     else if (P.n_writes < 2000000)
         for (int i = 0; i < P.n_writes; ++i)
@@ -385,7 +398,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         if (i != P.n_writes) return XRSFM_BA_EINVAL;    // a local pair that is missing from the supplied pattern
         P.blk_ptr.push_back(P.n_writes);
     }
-    const int n_blocks = P.n_blocks = (int)P.blk_ptr.size() - 1;
+    }
+    const int n_blocks = P.n_blocks = pre ? (int)P.blk_rc.size() / 2 : (int)P.blk_ptr.size() - 1;
     const std::vector<int>& blk_rc = P.blk_rc;
     timer.mark("  blocks + destinations");
 
@@ -832,7 +846,16 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 }
             }
     }
-    {
+    if (pre) {
+        const size_t base = (size_t)64 * 15 * sizeof(double);
+        P.n_pairs_small = 0; P.n_pairs_big = 0; P.pairs_shm = base; P.pairs_shm_big = base;
+        for (int b = 0; b < 8; ++b) {
+            P.gram_n[b] = pre->gram_n[b]; P.gram_shm[b] = pre->gram_shm[b];
+            ((b & 1) ? P.n_pairs_big : P.n_pairs_small) += P.gram_n[b];
+            ((b & 1) ? P.pairs_shm_big : P.pairs_shm) = std::max((b & 1) ? P.pairs_shm_big : P.pairs_shm, P.gram_shm[b]);
+        }
+        P.n_pairs_other = pre->n_other;
+    } else {
         // S-assembly launches: one per (operand height NI = ceil(6 C / 16), LDS class) of the Gram tiles — the kernel is
         // instantiated per NI so that the 10 accumulators of a 10-camera tile do not shape (and spill) the register allocation
         // of the 4-camera tiles everything else consists of — and one for the other items

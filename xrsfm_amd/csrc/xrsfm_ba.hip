@@ -601,14 +601,37 @@ int ensure_host_pack(xrsfm_ba_context* c, int level) {
 int chol_setup(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     if (h.ready) return 0;
-    if (int eh = ensure_host_pack(c, 1)) return eh;
     const Packed& k = c->pk;
     const int Nc = k.n_cams;
     std::vector<int> spp;
     PairKeys keyed;
     PhaseTimer timer("chol setup");
-    int e = chol_local_keys(k, spp, keyed);
-    if (e) return e;          // (kErrDuplicateObs: translated by the callers)
+    int e = 0;
+    // Device-packed context on one rank: the pair keys, blocks and destinations are generated on the device as well (ba_pack_dev.h:
+    // device_keys) — the host plan only sees the block list; XRSFM_BA_DEVICE_KEYS=0: download the packed arrays, host keys.
+    devpack::KeysResult KR;
+    PlanPrebuilt pre;
+    bool dev_keys = false;
+    {
+        const char* dk = std::getenv("XRSFM_BA_DEVICE_KEYS");
+        dev_keys = c->dev_packed && !c->wide && c->n_ranks == 1 && !c->have_pattern && !(dk && dk[0] == '0');
+    }
+    if (dev_keys) {
+        std::vector<std::pair<void*, size_t>> scratch;
+        auto keep = [&](size_t bytes) -> void* { unsigned char* q = nullptr; return dev_alloc(c, &q, bytes) ? nullptr : (void*)q; };
+        auto scr = [&](size_t bytes) -> void* { size_t cls = 0; void* q = g_cache.get(c->device, bytes, &cls); if (q) scratch.push_back({q, cls}); return q; };
+        e = devpack::device_keys(k, c->d.slot_cam, c->d.slot_pt, c->d.slot_cidx, c->d.tile_ncam, c->d.tile_gt_off, c->dpk_gt_cell, c->stream, keep, scr, KR);
+        (void)hipStreamSynchronize(c->stream);
+        for (auto& b : scratch) g_cache.put(c->device, b.first, b.second);
+        if (e) return e;
+        if (KR.duplicate) return kErrDuplicateObs;
+        pre.n_pairs = KR.n_pairs; pre.n_writes = KR.n_writes; pre.blk_rc = KR.blk_rc_host; pre.n_other = KR.n_other;
+        for (int b = 0; b < 8; ++b) { pre.gram_n[b] = KR.gram_n[b]; pre.gram_shm[b] = KR.gram_shm[b]; }
+    } else {
+        if ((e = ensure_host_pack(c, 1))) return e;
+        e = chol_local_keys(k, spp, keyed);
+        if (e) return e;          // (kErrDuplicateObs: translated by the callers)
+    }
     timer.mark("pair keys");
     // multi-GPU: every rank must hold the same blocks in the same order so that the block values can be all-reduced:
     // union of the ranks' camera pairs by an all-reduce(max) of an N_c x N_c occupancy map (once per problem)
@@ -633,7 +656,7 @@ int chol_setup(xrsfm_ba_context* c) {
     CholPlan P;
     // (a host allocation that fails inside the plan — the T x T tile maps of a very large unordered problem — is reported as
     //  ENOMEM from here, so that AUTO still falls back to the PCG instead of the C boundary turning it into a failed run)
-    try { e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes, c->wide ? kW : 6); }
+    try { e = chol_plan_build(k, spp, keyed, c->have_pattern ? &c->pattern_keys : nullptr, P, kCholMaxN, kCholMaxBytes, c->wide ? kW : 6, dev_keys ? &pre : nullptr); }
     catch (const std::bad_alloc&) { return XRSFM_BA_ENOMEM; }
     if (e) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     timer.mark("plan");
@@ -650,8 +673,8 @@ int chol_setup(xrsfm_ba_context* c) {
     int *d_cam_off = nullptr, *d_tile_rows = nullptr, *d_tmap = nullptr;
 #define TRYC(x) do { e = (x); if (e) return e; } while (0)
     BatchUpload up(c);
-    up.add(&h.slot_pair_ptr, P.spp); up.add(&h.pair_dst, P.pair_dst);
-    up.add(&h.blk_ptr, P.blk_ptr); up.add(&h.blk_rc, P.blk_rc);
+    if (dev_keys) { h.slot_pair_ptr = KR.spp; h.pair_dst = KR.pair_dst; h.blk_ptr = KR.blk_ptr; h.blk_rc = KR.blk_rc; }
+    else { up.add(&h.slot_pair_ptr, P.spp); up.add(&h.pair_dst, P.pair_dst); up.add(&h.blk_ptr, P.blk_ptr); up.add(&h.blk_rc, P.blk_rc); }
     up.add(&h.tiles_nz, P.tiles_nz); up.add(&h.cols_flat, P.cols_flat); up.add(&h.bw2_ent, P.bw2_ent);
     up.add(&h.lv_k, P.lv_k); up.add(&h.lv_tgt, P.lv_tgt); up.add(&h.lv_cptr, P.lv_cptr);
     up.add(&h.lv_cj, P.lv_cj);
@@ -664,7 +687,7 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.md_tgt, P.md_tgt); up.add(&h.md_q, P.md_q); up.add(&h.md_cj, P.md_cj); up.add(&h.fz_late, P.fz_late);
     h.md_off = P.md_off; h.md_max = P.md_max;
     up.add(&h.tile_cam, P.tile_cam);
-    up.add(&h.pairs_items, P.pairs_items);
+    if (dev_keys) h.pairs_items = KR.pairs_items; else up.add(&h.pairs_items, P.pairs_items);
     h.sp_max_chunks = P.sp_max_chunks;
     TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
     if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
