@@ -13,7 +13,10 @@
 //   G  per-tile analysis: longest track, regular tiles, Gram tiles (distinct cameras, camera index per slot, pair cells)
 //   H  camera-major positions of the writers (stable sort by camera), twice (linearisation / S assembly)
 // Taken when the problem has no track longer than 64 observations, fewer than 65 535 cameras, 6-wide camera blocks and enough
-// observations to pay for ~25 launches and three round trips (XRSFM_BA_DEVICE_PACK=0 / 1 forces host / device).
+// observations (32 768) to pay for ~25 launches and three round trips (XRSFM_BA_DEVICE_PACK=0 / 1 forces host / device).
+// Measured on MI355X (tools/pack_crossover.py, tools/pack_phases.py): config 4 (2 M observations) xrsfm_ba_create 31 -> 3.7 ms
+// (upload + observation sort 1.4, tracks + tuple sort 0.5, placement on the host 0.95, slots / tiles / camera-major 0.7), Cholesky
+// set-up 5.7 -> 1.0 ms (device_keys below); 48 k observations 1.5 -> 1.2 ms; below 30 k the host packing is faster.
 #pragma once
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
