@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -35,7 +36,15 @@ namespace {
 // Flat copy of the parameter blocks of one BA call + the way back into the Map.
 class FlatProblem {
   public:
-    explicit FlatProblem(Map &map) : map_(map) {}
+    // (round 4) Tracks and frames are addressed by their index in Map::tracks_ / Map::frames_ (map.h:116-195), so the id -> slot maps are
+    // dense tables, not hash maps: two million observations of a global BA used to cost two million hash lookups per call.
+    explicit FlatProblem(Map &map) : map_(map), track_slot_(map.tracks_.size(), -1), t_begin_(std::chrono::steady_clock::now()) {
+        size_t n_obs = 0;
+        for (const auto &f : map.frames_) if (f.registered) n_obs += f.track_ids_.size();
+        obs_cam_.reserve(n_obs); obs_pt_.reserve(n_obs); obs_uv_.reserve(2 * n_obs);
+        const size_t n_trk = std::min(n_obs, map.tracks_.size());
+        tracks_.reserve(n_trk); points_.reserve(3 * n_trk); point_const_.reserve(n_trk);
+    }
 
     // One frame = SetUp(problem, map, frame).  `lba_frame_id >= 0` selects SetUpLBA's rule for constant points.
     void AddFrame(Frame &frame, int lba_frame_id = -1) {
@@ -46,17 +55,14 @@ class FlatProblem {
             const int tid = frame.track_ids_[i];
             if (tid == -1) continue;
             ++num_mea;
-            auto it = track_slot_.find(tid);
-            int slot;
-            if (it == track_slot_.end()) {
+            int slot = track_slot_[tid];
+            if (slot < 0) {
                 slot = static_cast<int>(tracks_.size());
-                track_slot_.emplace(tid, slot);
+                track_slot_[tid] = slot;
                 tracks_.push_back(tid);
                 const double *p = map_.tracks_[tid].point3d_.data();
                 points_.insert(points_.end(), p, p + 3);
                 point_const_.push_back(0);
-            } else {
-                slot = it->second;
             }
             if (lba_frame_id >= 0) {
                 const Track &track = map_.tracks_[tid];
@@ -110,7 +116,9 @@ class FlatProblem {
         p.intr_model = intr_model_.data(); p.intr_params = intr_params_.data();
         p.points = points_.data(); p.point_const = point_const_.data();
         p.obs_cam = obs_cam_.data(); p.obs_pt = obs_pt_.data(); p.obs_uv = obs_uv_.data();
+        const auto t_packed = std::chrono::steady_clock::now();
         const int rc = xrsfm_ba_solve(&opt, &p, summary);
+        const auto t_solved = std::chrono::steady_clock::now();
         if (rc != XRSFM_BA_OK) {
             // The reference's call sites are void and never look at a status (ba_solver.cc:636-637 ignores Ceres' summary too),
             // so a persistent failure (no device, out of memory) would silently yield a reconstruction without any BA: count the
@@ -132,13 +140,21 @@ class FlatProblem {
             double *p3 = map_.tracks_[tracks_[j]].point3d_.data();
             for (int k = 0; k < 3; ++k) p3[k] = points_[3 * j + k];
         }
+        static const bool trace = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;      // the adapter's own share of a call (Map -> SoA and back)
+        if (trace) {
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[BASolver adapter] frames %zu tracks %zu obs %zu | Map -> SoA %.3f ms, xrsfm_ba_solve %.3f ms, SoA -> Map %.3f ms\n", frames_.size(),
+                         tracks_.size(), obs_cam_.size(), ms(t_begin_, t_packed), ms(t_packed, t_solved), ms(t_solved, std::chrono::steady_clock::now()));
+        }
         return rc;
     }
 
   private:
     Map &map_;
     std::vector<Frame *> frames_;
-    std::unordered_map<int, int> frame_slot_, track_slot_, intr_slot_;
+    std::unordered_map<int, int> frame_slot_, intr_slot_;      // (a handful of entries: frames of the call, camera ids)
+    std::vector<int> track_slot_;                              // Map::tracks_ index -> point slot of this call, -1 = not in it
+    std::chrono::steady_clock::time_point t_begin_;
     std::vector<int> tracks_;
     std::vector<double> cam_q_, cam_t_, intr_params_, points_, obs_uv_;
     std::vector<uint8_t> cam_const_, point_const_;
