@@ -315,7 +315,8 @@ def host_inclusive(arr: dict, opt, n_cams: int, n_points: int):
         out = {"create_ms": (t1 - t0) * 1e3, "run_ms": (t2 - t1) * 1e3, "download_ms": (t3 - t2) * 1e3, "destroy_ms": (t4 - t3) * 1e3,
                "total_ms": (t4 - t0) * 1e3, "lm_iterations": iters, "value": iters * (n_cams + n_points) / (t4 - t0),
                "unit": "cam-pts*iter/s",
-               "what": "one-shot solve on host buffers (pack + upload | Cholesky set-up + solve | download), second call of the process"}
+               "what": "one-shot solve on host buffers (upload + packing, on the device from 32k observations | Cholesky set-up + solve | download), "
+                       "second call of the process"}
         if rep == 0:
             first = out["total_ms"]
     out["first_call_ms"] = first

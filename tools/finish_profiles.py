@@ -33,7 +33,8 @@ def main():
     shutil.copy(os.path.join(src, "pmc_traffic_L.json"), os.path.join(dst, "pmc_traffic_L.json"))
     with open(os.path.join(dst, f"{tag}_bench_lines.md"), "w") as f:
         f.write(f"# Round {tag[1:]} — bench.py lines (MI355X, 1 GPU, host with {nproc} cores), `python bench.py --config C --steps 5 --warmup 2`\n")
-        for cfg, note in (("L", "default workload"), ("S", ""), ("K", "KITTI-00-sized sequential problem"),
+        for cfg, note in (("L", "default workload: `python bench.py --steps 20 --warmup 5`, incl. the rocprofv3 passes the run launches itself"), ("S", ""),
+                          ("LP", "config 4 as a parity workload: + 24 hub frames x 50 distant landmarks; literal north-star bounds in cpu_baseline"), ("K", "KITTI-00-sized sequential problem"),
                           ("X", "5000 cameras: 30 000 camera unknowns on the exact Cholesky path"),
                           ("R", "ragged tracks: windows of 8 frames, 35 % missed detections"),
                           ("U", "random visibility, dense reduced camera matrix; no CPU leg"),
@@ -42,7 +43,7 @@ def main():
                           ("L0", "config 4 with SURVEY Appendix D read literally: radius-40 ring, no triangulation-angle filter"),
                           ("T", "BASELINE config 5 at its size: 7500 photos in viewpoint clusters / 1.8M points / 8.1M observations, shuffled ids; exact path in the reverse Cuthill-McKee order; no CPU leg"),
                           ("T_pcg", "the same through the implicit-Schur PCG (the only path at this size until round 2)"),
-                          ("Lb9", "config 4 in bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks (k9_* kernels, not tuned); CPU leg = the C restatement with CW = 9; parity incl. the refined intrinsics in cpu_baseline"),
+                          ("Lb9", "config 4 in bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks (round 4: Gram tiles, k9_pairs_gram); CPU leg = the C restatement with CW = 9; parity incl. the refined intrinsics in cpu_baseline"),
                           ("M", "mapper-shaped replay through the BASolver adapter: a different metric (wall time of the BA calls of a 300-frame incremental reconstruction)")):
             if not os.path.exists(os.path.join(src, f"bench_{cfg}.json")):
                 continue
@@ -73,7 +74,11 @@ def main():
                     "k_lv_factor = pivot factorisation + triangular solve of one tile column, k_bwd = backward substitution.\n\n" + rd("kernel_stats_table_D.md"))
             if os.path.exists(os.path.join(src, "mfma_rate.txt")):
                 f.write("\n## Sustained rate of v_mfma_f64_16x16x4_f64 with nothing else in the loop (tools/bench_mfma.hip)\n\n```\n" + rd("mfma_rate.txt") + "```\n")
-    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt", "mapper_trace.txt"):
+    for cfgk, title in (("R", "config R (ragged tracks: windows of 8 frames, 35 % missed detections)"), ("Lb9", "config Lb9 (config 4 in bal9 mode)")):
+        if os.path.exists(os.path.join(src, f"kernel_stats_table_{cfgk}.md")):
+            with open(os.path.join(dst, f"{tag}_{cfgk}_kernel_stats.md"), "w") as f:
+                f.write(f"# Round {tag[1:]} — rocprofv3 kernel-trace summary, bench.py --config {cfgk} --no-cpu --no-extras --steps 2: {title}\n\n" + rd(f"kernel_stats_table_{cfgk}.md"))
+    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt", "mapper_trace.txt", "potrf.txt", "lat.txt", "pack_crossover.txt", "pack_phases.txt", "adapter_timing.txt"):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
     print("profiles written for", tag)

@@ -24,8 +24,9 @@ grep "^{\"metric\"" $OUT/stats_bench.log | tail -1 > $OUT/stats_bench_line.json
 rm -rf $OUT/stats $OUT/fetch $OUT/write
 # 4. bench lines with the CPU leg
 cd $ROOT
-for cfg in L S K X R; do
-  python bench.py --config $cfg --steps 5 --warmup 2 2> $OUT/bench_$cfg.err | tail -1 > $OUT/bench_$cfg.json
+python bench.py --config L --steps 20 --warmup 5 2> $OUT/bench_L.err | tail -1 > $OUT/bench_L.json      # (the driver's command: incl. its own rocprofv3 passes)
+for cfg in S K X R LP; do
+  XRSFM_BENCH_SELFPROF=0 python bench.py --config $cfg --steps 5 --warmup 2 2> $OUT/bench_$cfg.err | tail -1 > $OUT/bench_$cfg.json
 done
 python bench.py --config U --steps 3 --warmup 1 --no-cpu 2> $OUT/bench_U.err | tail -1 > $OUT/bench_U.json
 python bench.py --config V --steps 2 --warmup 1 --no-cpu --no-extras 2> $OUT/bench_V.err | tail -1 > $OUT/bench_V.json
@@ -40,6 +41,16 @@ python tools/mapper_trace.py $OUT/mapper_trace.txt > /dev/null 2>&1
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsD -o stats -- python $ROOT/bench.py --config D --no-cpu --no-extras --steps 1 --warmup 1 > $OUT/statsD_bench.log 2>&1; \
   python $ROOT/tools/rocprof_summary.py $(find $OUT/statsD -name "*.db" | head -1) $OUT/kernel_stats_table_D.md > /dev/null; rm -rf $OUT/statsD )
 [ -x tools/bench_mfma ] && tools/bench_mfma > $OUT/mfma_rate.txt 2>&1
+# 6. round 4: the ragged configuration's kernel table, the pivot-tile microbench, packing on host vs device, the adapter's share
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsR -o stats -- python $ROOT/bench.py --config R --no-cpu --no-extras --steps 2 > $OUT/statsR_bench.log 2>&1; \
+  python $ROOT/tools/rocprof_summary.py $(find $OUT/statsR -name "*.db" | head -1) $OUT/kernel_stats_table_R.md > /dev/null; rm -rf $OUT/statsR )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsB -o stats -- python $ROOT/bench.py --config Lb9 --no-cpu --no-extras --steps 2 > $OUT/statsB_bench.log 2>&1; \
+  python $ROOT/tools/rocprof_summary.py $(find $OUT/statsB -name "*.db" | head -1) $OUT/kernel_stats_table_Lb9.md > /dev/null; rm -rf $OUT/statsB )
+[ -x tools/bench_potrf ] && tools/bench_potrf > $OUT/potrf.txt 2>&1
+[ -x tools/bench_lat ] && tools/bench_lat > $OUT/lat.txt 2>&1
+python tools/pack_crossover.py > $OUT/pack_crossover.txt 2>&1
+XRSFM_BA_PACK_TIMING=1 python tools/pack_phases.py L 2>&1 | tail -22 > $OUT/pack_phases.txt
+python tools/adapter_timing.py L > $OUT/adapter_timing.txt 2>&1
 python tools/lba_phases.py > $OUT/lba_phases.txt 2>&1
 python tools/lba_timing.py > $OUT/lba_timing.txt 2>&1
 python __graft_entry__.py probe 2>&1 | grep "\[probe\]" > $OUT/probe.txt

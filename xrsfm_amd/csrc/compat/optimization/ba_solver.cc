@@ -22,6 +22,7 @@
 #include <iomanip>
 #include <iostream>
 #include <set>
+#include <thread>
 #include <unordered_map>
 
 #include "geometry/colmap/base/triangulation.h"
@@ -43,7 +44,7 @@ class FlatProblem {
         for (const auto &f : map.frames_) if (f.registered) n_obs += f.track_ids_.size();
         obs_cam_.reserve(n_obs); obs_pt_.reserve(n_obs); obs_uv_.reserve(2 * n_obs);
         const size_t n_trk = std::min(n_obs, map.tracks_.size());
-        tracks_.reserve(n_trk); points_.reserve(3 * n_trk); point_const_.reserve(n_trk);
+        tracks_.reserve(n_trk); point_const_.reserve(n_trk);
     }
 
     // One frame = SetUp(problem, map, frame).  `lba_frame_id >= 0` selects SetUpLBA's rule for constant points.
@@ -56,12 +57,10 @@ class FlatProblem {
             if (tid == -1) continue;
             ++num_mea;
             int slot = track_slot_[tid];
-            if (slot < 0) {
+            if (slot < 0) {                 // (the point itself is gathered later, in parallel: GatherPoints)
                 slot = static_cast<int>(tracks_.size());
                 track_slot_[tid] = slot;
                 tracks_.push_back(tid);
-                const double *p = map_.tracks_[tid].point3d_.data();
-                points_.insert(points_.end(), p, p + 3);
                 point_const_.push_back(0);
             }
             if (lba_frame_id >= 0) {
@@ -105,8 +104,31 @@ class FlatProblem {
     }
     size_t NumFrames() const { return frames_.size(); }
 
+    // Track::point3d_ of every track of the call -> points_ (and back).  A Track is ~100 bytes of an array of structs
+    // (map.h:12-27), so each of these is a cache miss: half a million of them cost 40 ms of a global BA on one thread — spread
+    // over the host's threads (the solve itself takes 15 ms at that size).
+    template <typename F> void ForTracks(F &&fn) {
+        const size_t n = tracks_.size();
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = (n < 50000 || hw < 2) ? 1 : std::min<size_t>(16, hw);
+        if (nt == 1) { fn(0, n); return; }
+        std::vector<std::thread> th;
+        for (size_t t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+        for (auto &x : th) x.join();
+    }
+    void GatherPoints() {
+        points_.resize(3 * tracks_.size());
+        ForTracks([&](size_t j0, size_t j1) {
+            for (size_t j = j0; j < j1; ++j) {
+                const double *p = map_.tracks_[tracks_[j]].point3d_.data();
+                points_[3 * j] = p[0]; points_[3 * j + 1] = p[1]; points_[3 * j + 2] = p[2];
+            }
+        });
+    }
+
     // ceres::Solve replacement; writes the result back into the Map on success.
     int Solve(const xrsfm_ba_options &opt, xrsfm_ba_summary *summary) {
+        GatherPoints();
         xrsfm_ba_problem p;
         p.n_cams = static_cast<int32_t>(frames_.size());
         p.n_points = static_cast<int32_t>(tracks_.size());
@@ -136,10 +158,12 @@ class FlatProblem {
             for (int k = 0; k < 4; ++k) q[k] = cam_q_[4 * c + k];
             for (int k = 0; k < 3; ++k) t[k] = cam_t_[3 * c + k];
         }
-        for (size_t j = 0; j < tracks_.size(); ++j) {
-            double *p3 = map_.tracks_[tracks_[j]].point3d_.data();
-            for (int k = 0; k < 3; ++k) p3[k] = points_[3 * j + k];
-        }
+        ForTracks([&](size_t j0, size_t j1) {
+            for (size_t j = j0; j < j1; ++j) {
+                double *p3 = map_.tracks_[tracks_[j]].point3d_.data();
+                for (int k = 0; k < 3; ++k) p3[k] = points_[3 * j + k];
+            }
+        });
         static const bool trace = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;      // the adapter's own share of a call (Map -> SoA and back)
         if (trace) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
