@@ -56,11 +56,13 @@ __global__ void k_track_ptr(const unsigned long long* __restrict__ key, const in
 }
 __global__ void k_track_len(const int* __restrict__ ptr, int n_trk, int n_obs, int* __restrict__ len, int* __restrict__ maxlen, unsigned* __restrict__ status) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_trk) return;
-    const int l = ((t + 1 < n_trk) ? ptr[t + 1] : n_obs) - ptr[t];
-    len[t] = l;
+    const int l = t < n_trk ? ((t + 1 < n_trk) ? ptr[t + 1] : n_obs) - ptr[t] : 0;
+    if (t < n_trk) len[t] = l;
     if (l > 64) atomicOr(status, 2u);
-    atomicMax(maxlen, l);
+    int m = l;                                   // one atomic per wave, not per track (half a million atomics on one word: 90 us)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(maxlen, m);
 }
 // sort key of camera group g (cameras 4g .. 4g+3 of the tuple, id + 1, 0 = beyond the end) of the track at sorted position r
 __global__ void k_tuple_key(const unsigned long long* __restrict__ obs_key, const int* __restrict__ ptr, const int* __restrict__ len,
@@ -591,23 +593,31 @@ __global__ __launch_bounds__(256) void k_buckets(const int* __restrict__ slot_ca
                                                  int cw, unsigned* __restrict__ bkey, int* __restrict__ bcount, int* __restrict__ bshm) {
     const int lane = threadIdx.x & 63;
     const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (t >= n_tiles) return;
-    const int s = 64 * t + lane;
+    const int s = 64 * min(t, n_tiles - 1) + lane;
     const int cam = slot_cam[s], pt = slot_pt[s];
     const int prev = __shfl_up(pt, 1, 64);
     const int ntrk = __popcll(__ballot(cam >= 0 && (lane == 0 || prev != pt)));
-    if (lane != 0) return;
-    const int C = tile_ncam[t];
-    int b = 8;
-    if (C > 0) {
-        int passes = 1;
-        const int base = 64 * 15 * 8;
-        const int need = max(base, gram_lds_need(C, ntrk, &passes, cw));
-        b = 2 * ((cw * C + 15) / 16 - 1) + (need <= kGramSmallLds ? 0 : 1);
-        atomicMax(bshm + b, need);
+    // counters privatised per workgroup (tens of thousands of atomics on one word cost 370 us at config 4)
+    __shared__ int s_cnt[9], s_shm[8];
+    if (threadIdx.x < 9) s_cnt[threadIdx.x] = 0;
+    if (threadIdx.x < 8) s_shm[threadIdx.x] = 0;
+    __syncthreads();
+    if (lane == 0 && t < n_tiles) {
+        const int C = tile_ncam[t];
+        int b = 8;
+        if (C > 0) {
+            int passes = 1;
+            const int base = 64 * 15 * 8;
+            const int need = max(base, gram_lds_need(C, ntrk, &passes, cw));
+            b = 2 * ((cw * C + 15) / 16 - 1) + (need <= kGramSmallLds ? 0 : 1);
+            atomicMax(&s_shm[b], need);
+        }
+        bkey[t] = (unsigned)b;
+        atomicAdd(&s_cnt[b], 1);
     }
-    bkey[t] = (unsigned)b;
-    atomicAdd(bcount + b, 1);
+    __syncthreads();
+    if (threadIdx.x < 9 && s_cnt[threadIdx.x] > 0) atomicAdd(bcount + threadIdx.x, s_cnt[threadIdx.x]);
+    if (threadIdx.x < 8 && s_shm[threadIdx.x] > 0) atomicMax(bshm + threadIdx.x, s_shm[threadIdx.x]);
 }
 
 struct KeysResult {

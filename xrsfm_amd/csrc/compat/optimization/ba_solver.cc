@@ -37,45 +37,18 @@ namespace {
 // Flat copy of the parameter blocks of one BA call + the way back into the Map.
 class FlatProblem {
   public:
-    // (round 4) Tracks and frames are addressed by their index in Map::tracks_ / Map::frames_ (map.h:116-195), so the id -> slot maps are
-    // dense tables, not hash maps: two million observations of a global BA used to cost two million hash lookups per call.
-    explicit FlatProblem(Map &map) : map_(map), track_slot_(map.tracks_.size(), -1), t_begin_(std::chrono::steady_clock::now()) {
-        size_t n_obs = 0;
-        for (const auto &f : map.frames_) if (f.registered) n_obs += f.track_ids_.size();
-        obs_cam_.reserve(n_obs); obs_pt_.reserve(n_obs); obs_uv_.reserve(2 * n_obs);
-        const size_t n_trk = std::min(n_obs, map.tracks_.size());
-        tracks_.reserve(n_trk); point_const_.reserve(n_trk);
-    }
+    // (round 4) Tracks and frames are addressed by their index in Map::tracks_ / Map::frames_ (map.h:116-195).  AddFrame only records
+    // the frame; the observations are laid out in one go (BuildObservations, at the start of Solve): per frame the count of tracked
+    // features, a mark per track that occurs, slots = rank of the track id among the marked ones, then every frame fills its own
+    // range of the observation arrays — each of these passes runs over the frames in parallel for a large call.  (Rounds 1-3: a
+    // hash lookup and a cache-missing Track access per observation, 52 ms of a global BA of 2 M observations on one thread.)
+    explicit FlatProblem(Map &map) : map_(map), t_begin_(std::chrono::steady_clock::now()) {}
 
     // One frame = SetUp(problem, map, frame).  `lba_frame_id >= 0` selects SetUpLBA's rule for constant points.
     void AddFrame(Frame &frame, int lba_frame_id = -1) {
         const int cam = static_cast<int>(frames_.size());
         const Camera &camera = map_.Camera(frame.camera_id);
-        int num_mea = 0;
-        for (size_t i = 0; i < frame.track_ids_.size(); ++i) {
-            const int tid = frame.track_ids_[i];
-            if (tid == -1) continue;
-            ++num_mea;
-            int slot = track_slot_[tid];
-            if (slot < 0) {                 // (the point itself is gathered later, in parallel: GatherPoints)
-                slot = static_cast<int>(tracks_.size());
-                track_slot_[tid] = slot;
-                tracks_.push_back(tid);
-                point_const_.push_back(0);
-            }
-            if (lba_frame_id >= 0) {
-                const Track &track = map_.tracks_[tid];
-                // reference rule: `angle_ > 5 || observations_.count(frame_id) == 0` (angle_ is in radians, so only
-                // the second half can fire, ba_solver.cc:380)
-                if (track.angle_ > 5 || track.observations_.count(lba_frame_id) == 0) point_const_[slot] = 1;
-            }
-            obs_cam_.push_back(cam);
-            obs_pt_.push_back(slot);
-            obs_uv_.push_back(frame.points[i](0));
-            obs_uv_.push_back(frame.points[i](1));
-        }
-        if (num_mea == 0)
-            std::cerr << (lba_frame_id >= 0 ? "LBA" : "BA") << ": NO Measurement In Frame " << frame.id << std::endl;
+        lba_frame_id_ = lba_frame_id;
         frames_.push_back(&frame);
         frame_slot_[static_cast<int>(frame.id)] = cam;
         const double *q = frame.Tcw.q.coeffs().data();   // x,y,z,w
@@ -104,18 +77,67 @@ class FlatProblem {
     }
     size_t NumFrames() const { return frames_.size(); }
 
-    // Track::point3d_ of every track of the call -> points_ (and back).  A Track is ~100 bytes of an array of structs
-    // (map.h:12-27), so each of these is a cache miss: half a million of them cost 40 ms of a global BA on one thread — spread
-    // over the host's threads (the solve itself takes 15 ms at that size).
-    template <typename F> void ForTracks(F &&fn) {
-        const size_t n = tracks_.size();
+    // run fn(begin, end) over [0, n) on up to 16 threads (large calls only)
+    template <typename F> static void ParallelFor(size_t n, size_t min_n, F &&fn) {
         const unsigned hw = std::thread::hardware_concurrency();
-        const size_t nt = (n < 50000 || hw < 2) ? 1 : std::min<size_t>(16, hw);
+        const size_t nt = (n < min_n || hw < 2) ? 1 : std::min<size_t>(16, hw);
         if (nt == 1) { fn(0, n); return; }
         std::vector<std::thread> th;
         for (size_t t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
         for (auto &x : th) x.join();
     }
+    // Observations of the recorded frames -> obs_cam / obs_pt / obs_uv, tracks_ (ascending track id), point_const_.
+    void BuildObservations() {
+        const size_t nf = frames_.size();
+        std::vector<size_t> off(nf + 1, 0);
+        size_t total_feats = 0;
+        for (size_t c = 0; c < nf; ++c) total_feats += frames_[c]->track_ids_.size();
+        const size_t par_min = total_feats >= 200000 ? 1 : (size_t)-1;       // frames in parallel only for a large call
+        std::vector<unsigned char> used(map_.tracks_.size(), 0);
+        ParallelFor(nf, par_min, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; ++c) {
+                size_t n = 0;
+                for (const int tid : frames_[c]->track_ids_)
+                    if (tid != -1) { ++n; used[tid] = 1; }              // (every writer stores the same value)
+                off[c + 1] = n;
+            }
+        });
+        for (size_t c = 0; c < nf; ++c) {
+            if (off[c + 1] == 0)
+                std::cerr << (lba_frame_id_ >= 0 ? "LBA" : "BA") << ": NO Measurement In Frame " << frames_[c]->id << std::endl;
+            off[c + 1] += off[c];
+        }
+        track_slot_.assign(map_.tracks_.size(), -1);
+        tracks_.clear();
+        for (size_t tid = 0; tid < used.size(); ++tid)
+            if (used[tid]) { track_slot_[tid] = static_cast<int>(tracks_.size()); tracks_.push_back(static_cast<int>(tid)); }
+        point_const_.assign(tracks_.size(), 0);
+        if (lba_frame_id_ >= 0)          // reference rule: `angle_ > 5 || observations_.count(frame_id) == 0` (angle_ is in radians, so only
+            for (size_t j = 0; j < tracks_.size(); ++j) {        // the second half can fire, ba_solver.cc:380)
+                const Track &track = map_.tracks_[tracks_[j]];
+                if (track.angle_ > 5 || track.observations_.count(lba_frame_id_) == 0) point_const_[j] = 1;
+            }
+        const size_t no = off[nf];
+        obs_cam_.resize(no); obs_pt_.resize(no); obs_uv_.resize(2 * no);
+        ParallelFor(nf, par_min, [&](size_t c0, size_t c1) {
+            for (size_t c = c0; c < c1; ++c) {
+                const Frame &frame = *frames_[c];
+                size_t o = off[c];
+                for (size_t i = 0; i < frame.track_ids_.size(); ++i) {
+                    const int tid = frame.track_ids_[i];
+                    if (tid == -1) continue;
+                    obs_cam_[o] = static_cast<int32_t>(c); obs_pt_[o] = track_slot_[tid];
+                    obs_uv_[2 * o] = frame.points[i](0); obs_uv_[2 * o + 1] = frame.points[i](1);
+                    ++o;
+                }
+            }
+        });
+    }
+
+    // Track::point3d_ of every track of the call -> points_ (and back).  A Track is ~100 bytes of an array of structs
+    // (map.h:12-27), so each of these is a cache miss: half a million of them cost 40 ms of a global BA on one thread — spread
+    // over the host's threads (the solve itself takes 15 ms at that size).
+    template <typename F> void ForTracks(F &&fn) { ParallelFor(tracks_.size(), 50000, fn); }
     void GatherPoints() {
         points_.resize(3 * tracks_.size());
         ForTracks([&](size_t j0, size_t j1) {
@@ -128,6 +150,7 @@ class FlatProblem {
 
     // ceres::Solve replacement; writes the result back into the Map on success.
     int Solve(const xrsfm_ba_options &opt, xrsfm_ba_summary *summary) {
+        BuildObservations();
         GatherPoints();
         xrsfm_ba_problem p;
         p.n_cams = static_cast<int32_t>(frames_.size());
@@ -178,6 +201,7 @@ class FlatProblem {
     std::vector<Frame *> frames_;
     std::unordered_map<int, int> frame_slot_, intr_slot_;      // (a handful of entries: frames of the call, camera ids)
     std::vector<int> track_slot_;                              // Map::tracks_ index -> point slot of this call, -1 = not in it
+    int lba_frame_id_ = -1;
     std::chrono::steady_clock::time_point t_begin_;
     std::vector<int> tracks_;
     std::vector<double> cam_q_, cam_t_, intr_params_, points_, obs_uv_;
