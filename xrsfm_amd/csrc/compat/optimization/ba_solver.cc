@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <iomanip>
 #include <iostream>
+#include <memory>
 #include <set>
 #include <thread>
 #include <unordered_map>
@@ -88,6 +89,14 @@ class FlatProblem {
     }
     // Observations of the recorded frames -> obs_cam / obs_pt / obs_uv, tracks_ (ascending track id), point_const_.
     void BuildObservations() {
+        static const bool trace = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;
+        auto tp = std::chrono::steady_clock::now();
+        auto lap = [&](const char *what) {
+            if (!trace) return;
+            const auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[BASolver adapter]   %-28s %.3f ms\n", what, std::chrono::duration<double, std::milli>(now - tp).count());
+            tp = now;
+        };
         const size_t nf = frames_.size();
         std::vector<size_t> off(nf + 1, 0);
         size_t total_feats = 0;
@@ -98,10 +107,11 @@ class FlatProblem {
             for (size_t c = c0; c < c1; ++c) {
                 size_t n = 0;
                 for (const int tid : frames_[c]->track_ids_)
-                    if (tid != -1) { ++n; used[tid] = 1; }              // (every writer stores the same value)
+                    if (tid != -1) { ++n; if (!used[tid]) used[tid] = 1; }      // (test first: 16 threads storing into shared lines cost 22 ms; every writer stores the same value)
                 off[c + 1] = n;
             }
         });
+        lap("count + mark tracks");
         for (size_t c = 0; c < nf; ++c) {
             if (off[c + 1] == 0)
                 std::cerr << (lba_frame_id_ >= 0 ? "LBA" : "BA") << ": NO Measurement In Frame " << frames_[c]->id << std::endl;
@@ -117,8 +127,11 @@ class FlatProblem {
                 const Track &track = map_.tracks_[tracks_[j]];
                 if (track.angle_ > 5 || track.observations_.count(lba_frame_id_) == 0) point_const_[j] = 1;
             }
+        lap("track slots");
         const size_t no = off[nf];
-        obs_cam_.resize(no); obs_pt_.resize(no); obs_uv_.resize(2 * no);
+        n_obs_ = no;            // (uninitialised storage: the pages are first touched by the threads that fill them, not zeroed by one thread first)
+        obs_cam_.reset(new int32_t[no ? no : 1]); obs_pt_.reset(new int32_t[no ? no : 1]); obs_uv_.reset(new double[no ? 2 * no : 1]);
+        lap("allocate observation arrays");
         ParallelFor(nf, par_min, [&](size_t c0, size_t c1) {
             for (size_t c = c0; c < c1; ++c) {
                 const Frame &frame = *frames_[c];
@@ -132,6 +145,7 @@ class FlatProblem {
                 }
             }
         });
+        lap("fill observation arrays");
     }
 
     // Track::point3d_ of every track of the call -> points_ (and back).  A Track is ~100 bytes of an array of structs
@@ -155,12 +169,12 @@ class FlatProblem {
         xrsfm_ba_problem p;
         p.n_cams = static_cast<int32_t>(frames_.size());
         p.n_points = static_cast<int32_t>(tracks_.size());
-        p.n_obs = static_cast<int32_t>(obs_cam_.size());
+        p.n_obs = static_cast<int32_t>(n_obs_);
         p.n_intr = static_cast<int32_t>(intr_model_.size());
         p.cam_q = cam_q_.data(); p.cam_t = cam_t_.data(); p.cam_const = cam_const_.data(); p.cam_intr = cam_intr_.data();
         p.intr_model = intr_model_.data(); p.intr_params = intr_params_.data();
         p.points = points_.data(); p.point_const = point_const_.data();
-        p.obs_cam = obs_cam_.data(); p.obs_pt = obs_pt_.data(); p.obs_uv = obs_uv_.data();
+        p.obs_cam = obs_cam_.get(); p.obs_pt = obs_pt_.get(); p.obs_uv = obs_uv_.get();
         const auto t_packed = std::chrono::steady_clock::now();
         const int rc = xrsfm_ba_solve(&opt, &p, summary);
         const auto t_solved = std::chrono::steady_clock::now();
@@ -191,7 +205,7 @@ class FlatProblem {
         if (trace) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             std::fprintf(stderr, "[BASolver adapter] frames %zu tracks %zu obs %zu | Map -> SoA %.3f ms, xrsfm_ba_solve %.3f ms, SoA -> Map %.3f ms\n", frames_.size(),
-                         tracks_.size(), obs_cam_.size(), ms(t_begin_, t_packed), ms(t_packed, t_solved), ms(t_solved, std::chrono::steady_clock::now()));
+                         tracks_.size(), n_obs_, ms(t_begin_, t_packed), ms(t_packed, t_solved), ms(t_solved, std::chrono::steady_clock::now()));
         }
         return rc;
     }
@@ -204,9 +218,12 @@ class FlatProblem {
     int lba_frame_id_ = -1;
     std::chrono::steady_clock::time_point t_begin_;
     std::vector<int> tracks_;
-    std::vector<double> cam_q_, cam_t_, intr_params_, points_, obs_uv_;
+    std::vector<double> cam_q_, cam_t_, intr_params_, points_;
     std::vector<uint8_t> cam_const_, point_const_;
-    std::vector<int32_t> cam_intr_, intr_model_, obs_cam_, obs_pt_;
+    std::vector<int32_t> cam_intr_, intr_model_;
+    std::unique_ptr<int32_t[]> obs_cam_, obs_pt_;
+    std::unique_ptr<double[]> obs_uv_;
+    size_t n_obs_ = 0;
 };
 
 xrsfm_ba_options ReferenceOptions(int max_iterations, double ftol, double ptol) {
