@@ -343,7 +343,7 @@ int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], 
                              int32_t *slot_campos_g);
 
 /* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
- * (0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee of an unordered collection), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
+ * (0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee of an unordered collection, 3 nested dissection of an unordered collection's camera graph), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
  * [6] schedule BITS: bit 0 (value 1) = level schedule (one launch per elimination-tree level; clear = the panel schedule of
  * deep elimination trees: dense / unordered patterns), bit 1 (value 2) = look-ahead panel schedule (one launch per tile
  * column, k_panel_slot) — test the bits, not the value: a look-ahead plan reports 2, [7] structurally

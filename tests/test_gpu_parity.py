@@ -1056,6 +1056,36 @@ def test_clustered_collection_exact_path_matches_c_restatement(lib, monkeypatch)
 
 
 @pytest.mark.gpu
+def test_unordered_collection_nested_dissection_matches_the_chain_order(lib, monkeypatch):
+    """2400 photos in 40 small viewpoint clusters on a ring, shuffled ids (244 tile columns): the plan dissects the camera graph
+    (ordering 3, ba_plan.h: nd_groups) and factors it on the LEVEL schedule — several tile columns per launch, every level with
+    lists split into chunks — instead of the reverse Cuthill-McKee chain on the look-ahead panel schedule (XRSFM_BA_ND=0: what
+    round 3 validated).  The elimination order must not change the solution beyond rounding: same LM decisions, same cost to
+    1e-9, cameras to 1e-7 / 1e-6; and the result is bit-reproducible."""
+    from xrsfm_amd import capi, synth
+    d = synth.make_collection(n_cams=2400, n_points=100000, seed=4, cams_per_cluster=60)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["ordering"] == 3 and plan["level_schedule"] == 1 and 2 * plan["levels"] <= plan["tiles"]
+    opt = capi.default_options(max_iterations=6)
+    prod = H.to_product(arr)
+    s = capi.solve(prod, opt)
+    again = H.to_product(arr)
+    s_again = capi.solve(again, opt)
+    assert s.linear_solver_used == capi.SOLVER_CHOLESKY
+    assert s_again.final_cost == s.final_cost and np.array_equal(prod.cam_q, again.cam_q) and np.array_equal(prod.points, again.points)
+    monkeypatch.setenv("XRSFM_BA_ND", "0")
+    plan0 = capi.debug_chol_plan(H.to_product(arr))
+    assert plan0["ordering"] == 2 and plan0["level_schedule"] == 0
+    chain = H.to_product(arr)
+    sc = capi.solve(chain, opt)
+    monkeypatch.delenv("XRSFM_BA_ND")
+    assert (s.n_successful, s.n_unsuccessful) == (sc.n_successful, sc.n_unsuccessful)
+    assert abs(s.final_cost - sc.final_cost) <= 1e-9 * sc.final_cost
+    assert np.abs(prod.cam_q - chain.cam_q).max() < 1e-7 and np.abs(prod.cam_t - chain.cam_t).max() < 1e-6
+
+
+@pytest.mark.gpu
 def test_twenty_thousand_sequential_cameras_take_the_exact_path(lib):
     """120 000 camera unknowns: the dense tile array of the reduced camera matrix would be 161 GB; the packed form (non-zero tiles of
     the nested-dissection factor only, ba_chol.h: tile_ptr) is 0.24 GB, so AUTO stays on the exact Cholesky path (round 2: PCG).

@@ -198,3 +198,26 @@ def test_schedule_of_a_clustered_collection_covers_the_factorisation(monkeypatch
     monkeypatch.setenv("XRSFM_BA_LOOKAHEAD", "0")
     plan0 = capi.debug_chol_plan(H.to_product(arr))
     assert plan0["lookahead"] == 0 and plan0["tiles_nz"] == plan["tiles_nz"]
+
+
+def test_ring_of_small_clusters_is_dissected(monkeypatch):
+    """Unordered collection, 40 viewpoint clusters of 60 photos on a ring (244 tile columns): George's nested dissection of the
+    camera graph (ordering 3) — elimination tree at most half as deep as the reverse Cuthill-McKee chain, no more tile products than
+    1.15 x the chain's, level schedule; the plan's self-check confirms that chunks + in-kernel lists cover every product once.
+    XRSFM_BA_ND=0 keeps the chain (look-ahead panel schedule); cameras of one landmark stay close in the elimination order."""
+    from xrsfm_amd import synth
+    monkeypatch.setenv("XRSFM_BA_PLAN_CHECK", "1")
+    d = synth.make_collection(n_cams=2400, n_points=100000, seed=4, cams_per_cluster=60)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, 2400)
+    assert plan["ordering"] == 3 and plan["level_schedule"] == 1 and plan["lookahead"] == 0
+    assert 2 * plan["levels"] <= plan["tiles"] <= 256
+    monkeypatch.setenv("XRSFM_BA_ND", "0")
+    chain = capi.debug_chol_plan(H.to_product(arr))
+    assert chain["ordering"] == 2 and chain["levels"] == chain["tiles"] and chain["lookahead"] == 1
+    assert plan["tiles_nz"] <= 1.15 * chain["tiles_nz"]
+    # same plan twice (the dissection is deterministic)
+    monkeypatch.delenv("XRSFM_BA_ND")
+    again = capi.debug_chol_plan(H.to_product(arr))
+    assert np.array_equal(again["cam_offset"], plan["cam_offset"])

@@ -683,7 +683,66 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     piv[0] = row_bcast(a[0], 0);
     double rj = fast_rcp(piv[0]);
     if constexpr (PV == 2) potrf_step_dpp<0>(a, lcol, piv, rj);
-    else if constexpr (PV == 3) {
+    else if constexpr (PV == 4) {
+        // PV 4 (round 4): the elimination sweep WITHOUT the inverse — one broadcast + one FMA per column update instead of one + two —
+        // and the forward substitution L X = I afterwards with its operands from LDS: the unscaled factor goes (transposed) into the
+        // diagonal block's own storage in A, which nothing else reads while wave 0 factors it and which the final stores overwrite,
+        // and every u_{r,jj} is then a broadcast read of one address (two values per ds_read_b128), no DPP move.  The updates of
+        // lcol[r] run over jj in the same order with the same operands (u_{r,jj}, xs_jj = lcol[jj] / u_jj): bit-identical inverse.
+        double rinv[16];                                   // 1 / u_jj
+#pragma clang loop unroll(full)
+        for (int jj = 0; jj < 16; ++jj) {
+            rinv[jj] = rj;
+            const double tl = a[jj] * rj;                  // u_ij / u_jj
+            double r = 0.0, un = 1.0, e = 0.0;
+            if (jj + 1 < 16) {
+                const double b1 = row_bcast64(a[jj], jj + 1);
+                a[jj + 1] = fma(-tl, b1, a[jj + 1]);
+                un = row_bcast64(a[jj + 1], jj + 1);
+                piv[jj + 1] = un;
+                r = __builtin_amdgcn_rcp(un);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma clang loop unroll(full)
+            for (int st = 0; st < 4; ++st) {
+#pragma clang loop unroll(full)
+                for (int cc = jj + 2 + st; cc < 16; cc += 4) { const double bv_ = row_bcast64(a[jj], cc); a[cc] = fma(-tl, bv_, a[cc]); }
+                if (jj + 1 < 16) {
+                    if (st % 2 == 0) e = fma(-un, r, 1.0);
+                    else r = fma(r, e, r);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rj = r;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // unscaled factor, transposed: A[b0 + jj][b0 + r] = u_{r,jj} (row r = this lane, columns jj <= r)
+        if (lane < 16) {
+#pragma unroll
+            for (int jj = 0; jj < 16; ++jj) if (jj <= lane) A[b0 + jj][b0 + lane] = a[jj];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // (the operands of step jj + 1 are requested before the FMAs of step jj; scheduling barriers keep the compiler from hoisting all
+        //  120 reads to the front: 420 registers, copies through AGPRs)
+        double ub[2][16];
+#pragma clang loop unroll(full)
+        for (int r = 1; r < 16; ++r) ub[0][r] = A[b0][b0 + r];
+#pragma clang loop unroll(full)
+        for (int jj = 0; jj < 16; ++jj) {
+            if (jj + 1 < 16) {
+#pragma clang loop unroll(full)
+                for (int r = jj + 2; r < 16; ++r) ub[(jj + 1) & 1][r] = A[b0 + jj + 1][b0 + r];
+            }
+            const double xs = lcol[jj] * rinv[jj];
+#pragma clang loop unroll(full)
+            for (int r = jj + 1; r < 16; ++r) { lcol[r] = fma(-ub[jj & 1][r], xs, lcol[r]); asm volatile("" : "+v"(lcol[r])); }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);                // the reads are done before the final stores below overwrite the block
+        __builtin_amdgcn_wave_barrier();
+    } else if constexpr (PV == 3) {
         // PV 3: the broadcasts of a group of (up to four) column updates are issued one group AHEAD of the FMAs that use them.
         // A wave issues in order: with the broadcast right in front of its two FMAs (the other variants: the register allocator
         // even reuses ONE temporary pair for all of them) every update waits for its own DPP move; here the moves of group

@@ -20,7 +20,7 @@ constexpr int kCamsPerTileWide = 7;  // bal9 mode (9 unknowns per camera): 7 cam
 struct CholPlan {
     int n = 0, n_pad = 0, T = 0, n_blocks = 0, n_pairs = 0, n_writes = 0, n_tiles_nz = 0, n_levels = 0;
     int cam_width = 6, cams_per_tile = kCamsPerTile;     // unknowns per camera (9 in bal9 mode) and cameras per 64-row tile
-    int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring, 2 reverse Cuthill-McKee (unordered
+    int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring, 3 nested dissection of an unordered camera graph, 2 reverse Cuthill-McKee (unordered
                                      // collections with viewpoint clusters: banded fill instead of a dense factor)
     long long tile_products = 0;     // 64x64x64 tile products of one factorisation (symbolic count; 2 * 64^3 flop each)
     int n_hubs = 0, band = 0;
@@ -273,6 +273,187 @@ inline std::vector<int> rcm_order(int Nc, const std::vector<int>& blk_rc, int n_
     return order;
 }
 
+// ---- nested dissection of an unordered camera graph (round 4)
+// The reverse Cuthill-McKee order of a photo collection is a CHAIN: one tile column per elimination-tree level (config 5's shape:
+// 750 dependent columns per factorisation), and on a ring of landmarks the breadth-first search runs both ways round, so the band
+// is twice as wide as the coupling.  George's automatic nested dissection instead: breadth-first levels from a pseudo-peripheral
+// camera, the level that balances the two sides best (and is small) becomes the separator — thinned to the cameras that really
+// touch the far side —, the two sides are dissected in turn, a part of <= `leaf` cameras gets its own reverse Cuthill-McKee order,
+// children first, separator last.  The parts of one depth are independent: the factorisation of the same collection has ~160
+// levels of several columns each instead of 750 of one, with no more (here: 15 % fewer) tile products.  Deterministic (ties by id).
+struct CamGraph {
+    std::vector<int> ptr, adj;                 // neighbours by ascending (degree, id)
+    int degree(int c) const { return ptr[c + 1] - ptr[c]; }
+};
+inline CamGraph cam_graph(int Nc, const std::vector<int>& blk_rc, int n_blocks) {
+    CamGraph G;
+    G.ptr.assign(Nc + 1, 0);
+    for (int b = 0; b < n_blocks; ++b) { G.ptr[blk_rc[2 * b] + 1]++; G.ptr[blk_rc[2 * b + 1] + 1]++; }
+    for (int c = 0; c < Nc; ++c) G.ptr[c + 1] += G.ptr[c];
+    G.adj.resize(G.ptr[Nc]);
+    std::vector<int> fill(G.ptr.begin(), G.ptr.end() - 1);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int r = blk_rc[2 * b], c = blk_rc[2 * b + 1];
+        G.adj[fill[r]++] = c; G.adj[fill[c]++] = r;
+    }
+    for (int c = 0; c < Nc; ++c)
+        std::sort(G.adj.begin() + G.ptr[c], G.adj.begin() + G.ptr[c + 1],
+                  [&](int a, int b) { return G.degree(a) != G.degree(b) ? G.degree(a) < G.degree(b) : a < b; });
+    return G;
+}
+struct NdState {
+    const CamGraph& G;
+    std::vector<int> label, lvl, queue;        // label: the part a camera belongs to; lvl: -1 outside a search
+    int next_label = 1;
+    int leaf;
+    std::vector<std::vector<int>>* groups;
+    NdState(const CamGraph& g, int Nc, int leaf_, std::vector<std::vector<int>>* out) : G(g), label(Nc, 0), lvl(Nc, -1), leaf(leaf_), groups(out) {}
+    // breadth-first levels over the cameras of part `id` from `root`; the visiting order stays in `queue` (lvl is NOT reset)
+    void bfs(int root, int id) {
+        queue.clear(); queue.push_back(root); lvl[root] = 0;
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const int u = queue[head];
+            for (int q = G.ptr[u]; q < G.ptr[u + 1]; ++q) { const int v = G.adj[q]; if (label[v] == id && lvl[v] < 0) { lvl[v] = lvl[u] + 1; queue.push_back(v); } }
+        }
+    }
+    void clear_levels() { for (int u : queue) lvl[u] = -1; }
+    // reverse Cuthill-McKee order of one part (its components one after the other), appended as one group
+    void rcm_part(std::vector<int> nodes, int id) {
+        std::sort(nodes.begin(), nodes.end(), [&](int a, int b) { return G.degree(a) != G.degree(b) ? G.degree(a) < G.degree(b) : a < b; });
+        std::vector<int> order; order.reserve(nodes.size());
+        for (int start : nodes) {
+            if (label[start] != id) continue;
+            int root = start, depth = -1;
+            for (int iter = 0; iter < 4; ++iter) {
+                bfs(root, id);
+                int far = queue.back(); const int d2 = lvl[far];
+                for (size_t i = queue.size(); i-- > 0 && lvl[queue[i]] == d2;)
+                    if (G.degree(queue[i]) < G.degree(far) || (G.degree(queue[i]) == G.degree(far) && queue[i] < far)) far = queue[i];
+                clear_levels();
+                if (d2 <= depth) break;
+                depth = d2; root = far;
+            }
+            bfs(root, id);
+            for (int u : queue) { order.push_back(u); label[u] = -1; }      // (ordered: leaves the part)
+            clear_levels();
+        }
+        std::reverse(order.begin(), order.end());
+        groups->push_back(order);
+    }
+    void dissect(std::vector<int> nodes, int id) {
+        if ((int)nodes.size() <= leaf) { rcm_part(std::move(nodes), id); return; }
+        std::sort(nodes.begin(), nodes.end());
+        // connected components of the part first
+        {
+            bfs(nodes[0], id);
+            if (queue.size() < nodes.size()) {
+                std::vector<std::vector<int>> comps;
+                std::vector<int> ids;
+                for (int start : nodes) {
+                    if (label[start] != id) continue;
+                    if (lvl[start] < 0) bfs(start, id);
+                    const int nid = next_label++;
+                    comps.emplace_back(queue); ids.push_back(nid);
+                    for (int u : queue) { label[u] = nid; lvl[u] = -1; }
+                }
+                for (size_t q = 0; q < comps.size(); ++q) dissect(std::move(comps[q]), ids[q]);
+                return;
+            }
+            clear_levels();
+        }
+        // pseudo-peripheral camera of the (connected) part
+        int root = nodes[0];
+        for (int u : nodes) if (G.degree(u) < G.degree(root)) root = u;
+        int depth = -1;
+        for (int iter = 0; iter < 4; ++iter) {
+            bfs(root, id);
+            int far = queue.back(); const int d2 = lvl[far];
+            for (size_t i = queue.size(); i-- > 0 && lvl[queue[i]] == d2;)
+                if (G.degree(queue[i]) < G.degree(far) || (G.degree(queue[i]) == G.degree(far) && queue[i] < far)) far = queue[i];
+            if (d2 <= depth) break;                        // (levels of `root` stay)
+            depth = d2;
+            if (iter == 3) break;
+            clear_levels();
+            root = far;
+        }
+        if (lvl[root] != 0) { clear_levels(); bfs(root, id); }
+        const int D = lvl[queue.back()];
+        if (D < 2) { clear_levels(); rcm_part(std::move(nodes), id); return; }
+        std::vector<long long> cnt(D + 1, 0);
+        for (int u : queue) cnt[lvl[u]]++;
+        long long below = cnt[0], best = -1; int lsep = 1;
+        for (int l = 1; l < D; ++l) {
+            const long long above = (long long)nodes.size() - below - cnt[l];
+            const long long score = 2 * cnt[l] + (below > above ? below - above : above - below);
+            if (best < 0 || score < best) { best = score; lsep = l; }
+            below += cnt[l];
+        }
+        std::vector<int> lo, hi, sep;
+        for (int u : queue) {
+            if (lvl[u] < lsep) lo.push_back(u);
+            else if (lvl[u] > lsep) hi.push_back(u);
+            else {
+                bool touches = false;
+                for (int q = G.ptr[u]; q < G.ptr[u + 1] && !touches; ++q) { const int v = G.adj[q]; touches = (label[v] == id && lvl[v] == lsep + 1); }
+                (touches ? sep : lo).push_back(u);
+            }
+        }
+        clear_levels();
+        const int id_lo = next_label++, id_hi = next_label++, id_sep = next_label++;
+        for (int u : lo) label[u] = id_lo;
+        for (int u : hi) label[u] = id_hi;
+        for (int u : sep) label[u] = id_sep;
+        dissect(std::move(lo), id_lo);
+        dissect(std::move(hi), id_hi);
+        rcm_part(std::move(sep), id_sep);
+    }
+};
+// groups (each starts on a tile boundary) in elimination order
+inline std::vector<std::vector<int>> nd_groups(int Nc, const std::vector<int>& blk_rc, int n_blocks, int leaf) {
+    std::vector<std::vector<int>> groups;
+    const CamGraph G = cam_graph(Nc, blk_rc, n_blocks);
+    NdState st(G, Nc, leaf, &groups);
+    std::vector<int> all(Nc);
+    for (int c = 0; c < Nc; ++c) all[c] = c;
+    if (Nc > 0) st.dissect(std::move(all), 0);
+    return groups;
+}
+// tile products and elimination-tree levels of the tile pattern for cameras laid out group by group (10 per tile, every group on a
+// tile boundary); products = -1 beyond `budget`
+inline long long count_group_products(int Nc, const std::vector<int>& blk_rc, int n_blocks, const std::vector<std::vector<int>>& groups,
+                                      int cams_per_tile, long long budget, int* n_levels) {
+    std::vector<int> tile_of(Nc, 0);
+    int T = 0;
+    for (const auto& g : groups) {
+        for (size_t q = 0; q < g.size(); ++q) tile_of[g[q]] = T + (int)q / cams_per_tile;
+        T += ((int)g.size() + cams_per_tile - 1) / cams_per_tile;
+    }
+    std::vector<char> nz((size_t)T * T, 0);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int ti = tile_of[blk_rc[2 * b]], tj = tile_of[blk_rc[2 * b + 1]];
+        nz[(size_t)std::max(ti, tj) * T + std::min(ti, tj)] = 1;
+    }
+    long long total = 0;
+    std::vector<int> R;
+    for (int k = 0; k < T; ++k) {
+        R.clear();
+        for (int i = k + 1; i < T; ++i) if (nz[(size_t)i * T + k]) R.push_back(i);
+        total += (long long)R.size() * ((long long)R.size() + 1) / 2;
+        if (total > budget) return -1;
+        for (size_t a = 0; a < R.size(); ++a)
+            for (size_t b2 = 0; b2 <= a; ++b2) nz[(size_t)R[a] * T + R[b2]] = 1;
+    }
+    std::vector<int> level(T, 0);
+    int nl = 0;
+    for (int k = 0; k < T; ++k) {
+        int lv = 0;
+        for (int j = 0; j < k; ++j) if (nz[(size_t)k * T + j] && level[j] + 1 > lv) lv = level[j] + 1;
+        level[k] = lv; nl = std::max(nl, lv + 1);
+    }
+    if (n_levels) *n_levels = nl;
+    return total;
+}
+
 // Symbolic factorisation of the 64x64 tile pattern for the cameras in `order` (10 per tile): number of tile products
 // sum_k |R_k| (|R_k| + 1) / 2 of one factorisation, or -1 as soon as it exceeds `budget`.
 inline long long count_tile_products(int Nc, const std::vector<int>& blk_rc, int n_blocks, const std::vector<int>& order, int cams_per_tile,
@@ -476,8 +657,23 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             // natural order not allowed (beyond the dense limit): its pattern is taken as full, Tn^3 / 6 products
             const long long pn_eff = pn >= 0 ? pn : (long long)Tn * Tn * Tn / 6;
             if (pr >= 0 && pr * 10 <= pn_eff * 6) { all = rcm; P.ordering = 2; }      // (random visibility: no gain -> natural order / PCG)
+            // ... and from 96 tile columns on, nested dissection of the same graph (plan_detail::nd_groups) where its elimination tree is
+            // at most half as deep as the chain and its fill no worse than 1.15 x: the level schedule then factors several columns per
+            // launch (config 5's shape: 169 levels of 759 columns, 1.02 M tile products against 1.21 M).  XRSFM_BA_ND=0: keep the chain.
+            const char* nd_env = std::getenv("XRSFM_BA_ND");
+            if (P.ordering == 2 && Tn >= 96 && !(nd_env && nd_env[0] == '0')) {
+                const int leaf = std::getenv("XRSFM_BA_ND_LEAF") ? std::max(2 * CPT, std::atoi(std::getenv("XRSFM_BA_ND_LEAF"))) : std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
+                std::vector<std::vector<int>> nd = plan_detail::nd_groups(Nc, blk_rc, n_blocks, leaf);
+                int nd_levels = 0, nd_tiles = 0;
+                for (const auto& g : nd) nd_tiles += ((int)g.size() + CPT - 1) / CPT;
+                const long long pd = plan_detail::count_group_products(Nc, blk_rc, n_blocks, nd, CPT, budget, &nd_levels);
+                if (std::getenv("XRSFM_BA_PLAN_VERBOSE"))
+                    fprintf(stderr, "[plan] reverse Cuthill-McKee: %d tile columns, %lld tile products | nested dissection (leaf %d): %zu groups, %d tile columns, %lld products, %d levels\n",
+                            Tn, pr, leaf, nd.size(), nd_tiles, pd, nd_levels);
+                if (nd_tiles <= kPlanMaxTiles && pd >= 0 && pd * 100 <= pr * 115 && 2 * nd_levels <= nd_tiles) { groups = std::move(nd); P.ordering = 3; }
+            }
         }
-        groups.push_back(all);
+        if (P.ordering != 3) groups.push_back(all);
     }
     timer.mark("  elimination order");
     P.cam_off.assign(Nc, 0);
@@ -644,7 +840,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         // (panel schedule: every level with lists worth cutting is split, into chunks of >= kPanelMinChunk products so that the
         //  partial tile a chunk writes stays a small part of its traffic, and into <= ~kPanelChunks chunks per level)
         const bool second = level_cols[lv] == 1 && later_of_panel[level_first[lv]];    // second column of a macro pair: one contribution left
-        const bool split = !macro && !second && (lookahead ? nc > 0 : (panel_ll ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt)));
+        // (nested dissection of an unordered collection: its levels hold hundreds of targets WITH long lists — every level with lists
+        //  worth cutting is split, as on the panel schedule)
+        const bool nd_lv = P.ordering == 3 && !panel_ll;
+        const bool split = !macro && !second && (lookahead ? nc > 0 : ((panel_ll || nd_lv) ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt)));
         if (macro) {
             // every macro target's j range is cut into chunks of >= panel_min_chunk steps, ~macro_chunks chunks per level (about two
             // rounds of resident workgroups: measured faster than one round of equal shares, whose partial-tile stores all
@@ -695,8 +894,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             // (look-ahead schedule, chunks of 4 / 6 / 8 / 12 / 16 products at a quarter of config T: 41 / 39 / 44 / 41 / 50 ms per four
             //  factorisations — the chunks are bound by their operand traffic, 64 KB per product, not by their number)
             const int la_chunk = std::getenv("XRSFM_BA_LA_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_LA_CHUNK"))) : 6;
+            const int nd_chunk = std::getenv("XRSFM_BA_ND_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_ND_CHUNK"))) : 6;
             const int cs = lookahead ? std::max(la_chunk, (nc + panel_chunks - 1) / panel_chunks)
-                         : panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks) : std::max(1, (nc + 511) / 512);
+                         : panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks)
+                         : nd_lv ? std::max(nd_chunk, (nc + 4095) / 4096) : std::max(1, (nc + 511) / 512);
             int np = 0;
             for (int g = g0; g < g1; ++g) {
                 const int p0 = np;
@@ -747,6 +948,17 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         P.lv_k_off[lv + 1] = (int)P.lv_k.size();
     }
     timer.mark("  level lists");
+    if (std::getenv("XRSFM_BA_PLAN_VERBOSE")) {
+        long long nc_all = 0, nc_split = 0; int n_split = 0, max_nt = 0;
+        for (int lv = 0; lv < n_levels; ++lv) {
+            const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
+            const long long nc = g1 > g0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0;
+            nc_all += nc; max_nt = std::max(max_nt, g1 - g0);
+            if (P.sp_chunk_off[lv + 1] > P.sp_chunk_off[lv]) { ++n_split; nc_split += nc; }
+        }
+        fprintf(stderr, "[plan] %d tile columns, %d levels (%d split: %lld of %lld list entries), %d chunks in all, largest level %d targets, partial buffer %d tiles, %lld tile products\n",
+                T, n_levels, n_split, nc_split, nc_all, (int)P.sp_tgt.size() / 2, max_nt, P.sp_max_chunks, P.tile_products);
+    }
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);
     // tile fill fused into the first level's factor launch (k_lv_factor<true>): every workgroup of a level-0 column composes

@@ -134,7 +134,7 @@ struct CholHost {
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
     std::vector<int> cam_off_host;
     std::vector<int> tile_map_host; size_t S_doubles = 0;    // packed tile storage of S (CholDev::tmap), its size in doubles
-    int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee
+    int ordering = 0;                                        // 0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee, 3 nested dissection of an unordered graph
 };
 
 struct xrsfm_ba_context {
@@ -663,7 +663,7 @@ int chol_setup(xrsfm_ba_context* c) {
     // dense tile storage: any pattern up to kCholMaxN unknowns; beyond that only with a shallow elimination tree (band / ring
     // ordering found) and while the n_pad^2 doubles stay within kCholMaxBytes
     // (... or a reverse Cuthill-McKee order whose symbolic factorisation stays within the work budget of ba_plan.h: panel schedule)
-    if (P.n > kCholMaxN && !(P.use_levels || P.ordering == 2)) return XRSFM_BA_ETOOBIG;       // (the size of the tile storage is checked where it is allocated)
+    if (P.n > kCholMaxN && !(P.use_levels || P.ordering >= 2)) return XRSFM_BA_ETOOBIG;       // (the size of the tile storage is checked where it is allocated)
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.lookahead = P.lookahead; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
