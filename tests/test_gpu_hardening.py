@@ -346,6 +346,45 @@ def test_packed_tile_storage_equals_dense(lib, monkeypatch, mode, n_cams, n_pts,
 
 
 @pytest.mark.gpu
+def test_blocks_from_stored_operands_equal_per_pair_blocks(lib, monkeypatch):
+    """Round 4, collections with long tracks: the camera-pair blocks of tracks that do not fit a Gram tile are formed where they
+    are summed, from the stored operands V of their two observations (k_chol_segsum_v, XRSFM_BA_PAIR_V=1; automatic from 1 M
+    per-pair blocks), instead of being written per pair by k_schur_pairs and read back.  Same products, another (fixed) order of a block's sum:
+    the reduced camera matrix, the solve and a full run must not differ beyond the order of a block's sum (S to 1e-13
+    relative, identical LM decisions, cameras to 1e-9) — on a collection whose tracks reach 80 photos (both per-pair paths: tracks
+    inside one tile and tracks longer than a tile) and with the round-2 schedule that reads the point factors from memory."""
+    from xrsfm_amd import capi, synth
+    d = synth.make_collection(n_cams=600, n_points=30000, seed=5, cams_per_cluster=60, max_track=80)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    L = np.bincount(arr["obs_pt"])
+    assert (L > 64).sum() > 20 and ((L > 10) & (L <= 64)).sum() > 500
+    for prep in (None, "0"):
+        if prep is not None:
+            monkeypatch.setenv("XRSFM_BA_PREP_FUSED", prep)
+        out = {}
+        for flag in ("0", "1"):
+            monkeypatch.setenv("XRSFM_BA_PAIR_V", flag)
+            ctx = capi.Context(H.to_product(arr))
+            ctx.debug_linearize(5.99, False)
+            y, S = ctx.debug_cholesky_solve(2e3, want_S=True)
+            ctx.reset()
+            s = ctx.run(capi.default_options(max_iterations=6, linear_solver=capi.SOLVER_CHOLESKY))
+            q, t, P = ctx.download()
+            ctx.reset()
+            s2 = ctx.run(capi.default_options(max_iterations=6, linear_solver=capi.SOLVER_CHOLESKY))
+            assert s2.final_cost == s.final_cost          # (bit-reproducible)
+            ctx.close()
+            out[flag] = (y, S, s, q, t, P)
+        a, b = out["0"], out["1"]
+        assert np.abs(a[1]).max() > 0
+        assert H.rel_err(b[1], a[1]) < 1e-13 and H.rel_err(b[0], a[0]) < 1e-9
+        assert (a[2].n_successful, a[2].n_unsuccessful) == (b[2].n_successful, b[2].n_unsuccessful)
+        assert abs(a[2].final_cost - b[2].final_cost) <= 1e-11 * a[2].final_cost
+        assert np.abs(a[3] - b[3]).max() < 1e-9 and np.abs(a[4] - b[4]).max() < 1e-9
+    monkeypatch.delenv("XRSFM_BA_PAIR_V")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["band", "ragged", "closures", "bal9"])
 def test_one_launch_backward_substitution_equals_level_launches(lib, monkeypatch, case):
     """Round 4: the backward substitution of a level schedule runs as ONE launch (k_lv_bwd_all: one workgroup per tile column,

@@ -95,8 +95,6 @@ int main() {
         run("PV1 + OVL", k_bench<1, true>, nb);
         run("PV2 (fmac_f64_dpp)", k_bench<2, false>, nb);
         run("PV2 + OVL", k_bench<2, true>, nb);
-        run("PV4 (inverse from LDS)", k_bench<4, false>, nb);
-        run("PV4 + OVL", k_bench<4, true>, nb);
         run("PV3 (bcast ahead)", k_bench<3, false>, nb);
         run("PV3 + OVL", k_bench<3, true>, nb);
     }

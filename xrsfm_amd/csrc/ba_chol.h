@@ -196,7 +196,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 template <bool GRAM, bool PREP, int NIK>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu((GRAM && NIK < 4) ? 4 : (GRAM ? 3 : 2), (GRAM && NIK < 4) ? 4 : 3)))      // no instantiation may spill (tests/test_capi_cpu.py)
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
-                   int n_obs_pairs, double* __restrict__ scat2, double radius) {
+                   int n_obs_pairs, double* __restrict__ scat2, double radius, double* __restrict__ pair_v = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     XBA_STAMP(0, 0);
@@ -389,6 +389,17 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             return;
         }
         if (GRAM) return;           // (not reached: keeps the per-pair code out of the Gram instantiation)
+        if (pair_v) {
+            // (round 4) collections with long tracks: the camera-pair blocks are not written per pair — 288 bytes each, tens of millions
+            // of them, read back by the segmented sum — but formed where they are summed (ba_kernels.h: k_chol_segsum_v) from the
+            // operands V, 144 bytes per observation, stored here
+            if (s.valid) {
+                double2* out = reinterpret_cast<double2*>(pair_v + 18 * (size_t)s.slot);
+#pragma unroll
+                for (int k = 0; k < 9; ++k) out[k] = make_double2(V[2 * k], V[2 * k + 1]);
+            }
+            return;
+        }
         if (s.valid) {
             pbase = slot_pair_ptr[s.slot];
             npair = slot_pair_ptr[s.slot + 1] - pbase;
@@ -438,6 +449,11 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             pairs_diag<PREP>(Fa, Va, hc, d.gp + 3 * (size_t)pt, o28);
             double* out = d.scat + 28 * (size_t)d.slot_campos_g[sa];
             for (int k = 0; k < 28; ++k) out[k] = o28[k];
+        }
+        if (pair_v) {
+            double2* out = reinterpret_cast<double2*>(pair_v + 18 * (size_t)sa);
+            for (int k = 0; k < 9; ++k) out[k] = make_double2(Va[2 * k], Va[2 * k + 1]);
+            continue;
         }
         const int pbase = slot_pair_ptr[sa];
         const int npair = slot_pair_ptr[sa + 1] - pbase;
@@ -641,6 +657,9 @@ __device__ __forceinline__ void potrf_step_dpp(double (&a)[16], double (&lcol)[1
 // scheduled builtin), 2: folded into v_fmac_f64_dpp (inline asm).  All three form the same products with the same roundings.
 // Measured (tools/bench_potrf, MI355X, one 64x64 tile incl. the full inverse): PV 0 12.7 us, PV 1 11.9, PV 2 13.4 (the DPP form
 // of v_fmac_f64 issues slower than a DPP move + a plain FMA), PV 1 with OVL 10.9 — all bit-identical.  Default: PV 1 + OVL.
+// (Also measured, round 4, and removed: the elimination sweep WITHOUT the inverse — one broadcast + one FMA per column update — and
+//  the forward substitution L X = I afterwards with its operands read from LDS: 15.2 us, the same instruction count issued in two
+//  dependent phases.)
 #ifndef XBA_POTRF_PV
 #define XBA_POTRF_PV 1
 #endif
@@ -683,66 +702,7 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     piv[0] = row_bcast(a[0], 0);
     double rj = fast_rcp(piv[0]);
     if constexpr (PV == 2) potrf_step_dpp<0>(a, lcol, piv, rj);
-    else if constexpr (PV == 4) {
-        // PV 4 (round 4): the elimination sweep WITHOUT the inverse — one broadcast + one FMA per column update instead of one + two —
-        // and the forward substitution L X = I afterwards with its operands from LDS: the unscaled factor goes (transposed) into the
-        // diagonal block's own storage in A, which nothing else reads while wave 0 factors it and which the final stores overwrite,
-        // and every u_{r,jj} is then a broadcast read of one address (two values per ds_read_b128), no DPP move.  The updates of
-        // lcol[r] run over jj in the same order with the same operands (u_{r,jj}, xs_jj = lcol[jj] / u_jj): bit-identical inverse.
-        double rinv[16];                                   // 1 / u_jj
-#pragma clang loop unroll(full)
-        for (int jj = 0; jj < 16; ++jj) {
-            rinv[jj] = rj;
-            const double tl = a[jj] * rj;                  // u_ij / u_jj
-            double r = 0.0, un = 1.0, e = 0.0;
-            if (jj + 1 < 16) {
-                const double b1 = row_bcast64(a[jj], jj + 1);
-                a[jj + 1] = fma(-tl, b1, a[jj + 1]);
-                un = row_bcast64(a[jj + 1], jj + 1);
-                piv[jj + 1] = un;
-                r = __builtin_amdgcn_rcp(un);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma clang loop unroll(full)
-            for (int st = 0; st < 4; ++st) {
-#pragma clang loop unroll(full)
-                for (int cc = jj + 2 + st; cc < 16; cc += 4) { const double bv_ = row_bcast64(a[jj], cc); a[cc] = fma(-tl, bv_, a[cc]); }
-                if (jj + 1 < 16) {
-                    if (st % 2 == 0) e = fma(-un, r, 1.0);
-                    else r = fma(r, e, r);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            rj = r;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        // unscaled factor, transposed: A[b0 + jj][b0 + r] = u_{r,jj} (row r = this lane, columns jj <= r)
-        if (lane < 16) {
-#pragma unroll
-            for (int jj = 0; jj < 16; ++jj) if (jj <= lane) A[b0 + jj][b0 + lane] = a[jj];
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // (the operands of step jj + 1 are requested before the FMAs of step jj; scheduling barriers keep the compiler from hoisting all
-        //  120 reads to the front: 420 registers, copies through AGPRs)
-        double ub[2][16];
-#pragma clang loop unroll(full)
-        for (int r = 1; r < 16; ++r) ub[0][r] = A[b0][b0 + r];
-#pragma clang loop unroll(full)
-        for (int jj = 0; jj < 16; ++jj) {
-            if (jj + 1 < 16) {
-#pragma clang loop unroll(full)
-                for (int r = jj + 2; r < 16; ++r) ub[(jj + 1) & 1][r] = A[b0 + jj + 1][b0 + r];
-            }
-            const double xs = lcol[jj] * rinv[jj];
-#pragma clang loop unroll(full)
-            for (int r = jj + 1; r < 16; ++r) { lcol[r] = fma(-ub[jj & 1][r], xs, lcol[r]); asm volatile("" : "+v"(lcol[r])); }
-            asm volatile("" ::: "memory");
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f);                // the reads are done before the final stores below overwrite the block
-        __builtin_amdgcn_wave_barrier();
-    } else if constexpr (PV == 3) {
+    else if constexpr (PV == 3) {
         // PV 3: the broadcasts of a group of (up to four) column updates are issued one group AHEAD of the FMAs that use them.
         // A wave issues in order: with the broadcast right in front of its two FMAs (the other variants: the register allocator
         // even reuses ONE temporary pair for all of them) every update waits for its own DPP move; here the moves of group

@@ -505,6 +505,81 @@ __global__ __launch_bounds__(kBlock) void k_chol_segsum(const double* __restrict
     else segsum_body<36>(scat2, blk_ptr, Sblk, blockIdx.x - n_cams);
 }
 
+// ---- S assembly of collections with long tracks (round 4): blocks formed where they are summed
+// A track seen by n photos contributes n (n - 1) / 2 camera-pair blocks; an unordered collection (BASELINE config 5's shape) has a
+// tail of tracks with 40-80 photos: 54 M per-pair blocks of 288 bytes, written by k_schur_pairs and read back here — 16 GB each way
+// per LM iteration, 28 % of the solve.  Instead k_schur_pairs stores the OPERAND of every such observation (V = W chol(Hinv),
+// 6 x 3, 144 bytes: pair_v) and the entry list of a block names its two observations (ent_src, filled once per problem by
+// k_pair_sources; x < 0: the entry is a Gram tile's cell in scat2, as before); the sum kernel forms every entry's 36 elements — the
+// same three products per element as the per-pair code — adds them in a fixed order and writes the block once.  The operands of a
+// block's entries are re-read from L2 (each is used by n - 1 blocks).
+__global__ __launch_bounds__(kWave) void k_pair_sources(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr,
+                                                        const int* __restrict__ pair_dst, int2* __restrict__ ent_src) {
+    const Item it = d.items[item_list[blockIdx.x]];
+    const int s_begin = it.first_tile * kWave, s_end = s_begin + it.n_tiles * kWave;
+    for (int sa = s_begin + (int)threadIdx.x; sa < s_end; sa += kWave) {
+        if (d.slot_cam[sa] < 0) continue;
+        const int pbase = slot_pair_ptr[sa], npair = slot_pair_ptr[sa + 1] - pbase;
+        for (int dd = 1; dd <= npair; ++dd) ent_src[pair_dst[pbase + dd - 1]] = make_int2(sa, sa + dd);
+    }
+}
+// One workgroup per block, one WAVE per entry stream (entries beg + w, beg + w + 4, ...): the entry's source is wave-uniform (scalar
+// load, scalar branch); lanes 0..17 / 18..35 fetch Va / Vb with one coalesced load (two runs of 144 bytes), park them in the wave's
+// LDS row, and lane k < 36 forms element k = (rb, ca) from six LDS reads; eight entries are in flight per wave.  The four per-wave
+// sums are added in wave order: deterministic.  (First version, measured at config T: thread (g, k) of seven 36-thread groups
+// loading its six operand values itself — 7 gather loads per entry and thread: 8.7 ms per launch against 3.4 ms for the plain
+// segmented sum of per-pair blocks it replaces, next to 11.8 -> 1.3 ms in k_schur_pairs.)
+constexpr int kPairVAhead = 8;       // (4: 5.7 ms per launch at config T — two dependent round trips per round, most blocks need two rounds)
+__global__ __launch_bounds__(kBlock) void k_chol_segsum_v(const double* __restrict__ scat, const int* __restrict__ cam_ptr,
+                                                          double* __restrict__ camS, int n_cams, const double* __restrict__ scat2,
+                                                          const int* __restrict__ blk_ptr, double* __restrict__ Sblk,
+                                                          const int2* __restrict__ ent_src, const double* __restrict__ pair_v) {
+    if ((int)blockIdx.x < n_cams) { segsum_body<28>(scat, cam_ptr, camS, blockIdx.x); return; }
+    constexpr int K = 36, NW = kBlock / kWave;
+    __shared__ double ops[NW][kPairVAhead][K];
+    __shared__ double part[NW][K];
+    const int b = blockIdx.x - n_cams, t = threadIdx.x, lane = t & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int beg = blk_ptr[b], end = blk_ptr[b + 1];
+    const int k = lane < K ? lane : 0, rb3 = 3 * (k / 6), ca3 = 3 * (k % 6);
+    double acc = 0.0;
+    for (int e0 = beg + wave; e0 < end; e0 += NW * kPairVAhead) {
+        int2 src[kPairVAhead];
+        double v[kPairVAhead];
+#pragma unroll
+        for (int u = 0; u < kPairVAhead; ++u) {
+            const int e = e0 + NW * u;
+            src[u] = make_int2(-1, -1); v[u] = 0.0;
+            if (e < end) {                                   // (wave-uniform)
+                src[u] = ent_src[e];
+                if (lane < K) v[u] = src[u].x < 0 ? scat2[36 * (size_t)e + lane]
+                                                  : pair_v[18 * (size_t)(lane < 18 ? src[u].x : src[u].y) + (lane < 18 ? lane : lane - 18)];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kPairVAhead; ++u) {
+            const int e = e0 + NW * u;
+            if (e >= end) break;
+            if (src[u].x < 0) { acc += v[u]; continue; }
+            double* row = ops[wave][u];
+            if (lane < K) row[lane] = v[u];
+            __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): LDS operations of one wave complete in order
+            __builtin_amdgcn_wave_barrier();
+            const double* Va = row + ca3;
+            const double* Vb = row + 18 + rb3;
+            acc += Vb[0] * Va[0] + Vb[1] * Va[1] + Vb[2] * Va[2];
+        }
+    }
+    if (lane < K) part[wave][lane] = acc;
+    __syncthreads();
+    if (t < K) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += part[w][t];
+        Sblk[(size_t)b * K + t] = s;
+    }
+}
+
 // Diagnostics only: materialise the 2x6 / 2x3 blocks (SoA over slots) the consumers rebuild on the fly.
 __global__ void k_debug_materialize(Dev d, double* __restrict__ Fs, double* __restrict__ Es) {
     const int slot = blockIdx.x * blockDim.x + threadIdx.x;

@@ -214,22 +214,40 @@ inline int chol_local_keys(const Packed& k, std::vector<int>& spp, PairKeys& key
 }
 
 namespace plan_detail {
+// camera graph: edges = the off-diagonal blocks of S
+struct CamGraph {
+    std::vector<int> ptr, adj;                 // neighbours by ascending (degree, id)
+    int degree(int c) const { return ptr[c + 1] - ptr[c]; }
+};
+inline CamGraph cam_graph(int Nc, const std::vector<int>& blk_rc, int n_blocks) {
+    CamGraph G;
+    G.ptr.assign(Nc + 1, 0);
+    for (int b = 0; b < n_blocks; ++b) { G.ptr[blk_rc[2 * b] + 1]++; G.ptr[blk_rc[2 * b + 1] + 1]++; }
+    for (int c = 0; c < Nc; ++c) G.ptr[c + 1] += G.ptr[c];
+    G.adj.resize(G.ptr[Nc]);
+    std::vector<int> raw(G.ptr[Nc]), fill(G.ptr.begin(), G.ptr.end() - 1);
+    for (int b = 0; b < n_blocks; ++b) {
+        const int r = blk_rc[2 * b], c = blk_rc[2 * b + 1];
+        raw[fill[r]++] = c; raw[fill[c]++] = r;
+    }
+    // every list by ascending (degree, id) without a comparison sort per list (millions of entries for a large collection): the
+    // cameras are visited in that order and appended to their neighbours' lists
+    std::vector<int> by_degree(Nc);
+    for (int c = 0; c < Nc; ++c) by_degree[c] = c;
+    std::sort(by_degree.begin(), by_degree.end(), [&](int a, int b) { return G.degree(a) != G.degree(b) ? G.degree(a) < G.degree(b) : a < b; });
+    fill.assign(G.ptr.begin(), G.ptr.end() - 1);
+    for (int v : by_degree)
+        for (int q = G.ptr[v]; q < G.ptr[v + 1]; ++q) G.adj[fill[raw[q]]++] = v;
+    return G;
+}
 // Reverse Cuthill-McKee order of the camera graph (edges = the off-diagonal blocks of S): breadth-first from a pseudo-peripheral
 // camera, neighbours by ascending degree, reversed; components one after the other.  Returns cameras in elimination order.
 // Deterministic (ties by camera id), O(edges log degree).
-inline std::vector<int> rcm_order(int Nc, const std::vector<int>& blk_rc, int n_blocks) {
-    std::vector<int> deg(Nc + 1, 0);
-    for (int b = 0; b < n_blocks; ++b) { deg[blk_rc[2 * b] + 1]++; deg[blk_rc[2 * b + 1] + 1]++; }
-    std::vector<int> ptr(Nc + 1, 0);
-    for (int c = 0; c < Nc; ++c) ptr[c + 1] = ptr[c] + deg[c + 1];
-    std::vector<int> adj(ptr[Nc]), fill(ptr.begin(), ptr.end() - 1);
-    for (int b = 0; b < n_blocks; ++b) {
-        const int r = blk_rc[2 * b], c = blk_rc[2 * b + 1];
-        adj[fill[r]++] = c; adj[fill[c]++] = r;
-    }
+inline std::vector<int> rcm_order(const CamGraph& G) {
+    const int Nc = (int)G.ptr.size() - 1;
+    const std::vector<int>& ptr = G.ptr;
+    const std::vector<int>& adj = G.adj;
     auto degree = [&](int c) { return ptr[c + 1] - ptr[c]; };
-    for (int c = 0; c < Nc; ++c)
-        std::sort(adj.begin() + ptr[c], adj.begin() + ptr[c + 1], [&](int a, int b) { return degree(a) != degree(b) ? degree(a) < degree(b) : a < b; });
     std::vector<int> order; order.reserve(Nc);
     std::vector<int> lvl(Nc, -1), queue;
     std::vector<char> done(Nc, 0);
@@ -281,26 +299,6 @@ inline std::vector<int> rcm_order(int Nc, const std::vector<int>& blk_rc, int n_
 // touch the far side —, the two sides are dissected in turn, a part of <= `leaf` cameras gets its own reverse Cuthill-McKee order,
 // children first, separator last.  The parts of one depth are independent: the factorisation of the same collection has ~160
 // levels of several columns each instead of 750 of one, with no more (here: 15 % fewer) tile products.  Deterministic (ties by id).
-struct CamGraph {
-    std::vector<int> ptr, adj;                 // neighbours by ascending (degree, id)
-    int degree(int c) const { return ptr[c + 1] - ptr[c]; }
-};
-inline CamGraph cam_graph(int Nc, const std::vector<int>& blk_rc, int n_blocks) {
-    CamGraph G;
-    G.ptr.assign(Nc + 1, 0);
-    for (int b = 0; b < n_blocks; ++b) { G.ptr[blk_rc[2 * b] + 1]++; G.ptr[blk_rc[2 * b + 1] + 1]++; }
-    for (int c = 0; c < Nc; ++c) G.ptr[c + 1] += G.ptr[c];
-    G.adj.resize(G.ptr[Nc]);
-    std::vector<int> fill(G.ptr.begin(), G.ptr.end() - 1);
-    for (int b = 0; b < n_blocks; ++b) {
-        const int r = blk_rc[2 * b], c = blk_rc[2 * b + 1];
-        G.adj[fill[r]++] = c; G.adj[fill[c]++] = r;
-    }
-    for (int c = 0; c < Nc; ++c)
-        std::sort(G.adj.begin() + G.ptr[c], G.adj.begin() + G.ptr[c + 1],
-                  [&](int a, int b) { return G.degree(a) != G.degree(b) ? G.degree(a) < G.degree(b) : a < b; });
-    return G;
-}
 struct NdState {
     const CamGraph& G;
     std::vector<int> label, lvl, queue;        // label: the part a camera belongs to; lvl: -1 outside a search
@@ -343,15 +341,19 @@ struct NdState {
     void dissect(std::vector<int> nodes, int id) {
         if ((int)nodes.size() <= leaf) { rcm_part(std::move(nodes), id); return; }
         std::sort(nodes.begin(), nodes.end());
-        // connected components of the part first
+        // connected components of the part first (the search from its camera of smallest degree doubles as the first
+        // pseudo-peripheral search below)
+        int root = nodes[0];
+        for (int u : nodes) if (G.degree(u) < G.degree(root)) root = u;
         {
-            bfs(nodes[0], id);
+            bfs(root, id);
             if (queue.size() < nodes.size()) {
+                clear_levels();
                 std::vector<std::vector<int>> comps;
                 std::vector<int> ids;
                 for (int start : nodes) {
                     if (label[start] != id) continue;
-                    if (lvl[start] < 0) bfs(start, id);
+                    bfs(start, id);
                     const int nid = next_label++;
                     comps.emplace_back(queue); ids.push_back(nid);
                     for (int u : queue) { label[u] = nid; lvl[u] = -1; }
@@ -359,20 +361,17 @@ struct NdState {
                 for (size_t q = 0; q < comps.size(); ++q) dissect(std::move(comps[q]), ids[q]);
                 return;
             }
-            clear_levels();
         }
         // pseudo-peripheral camera of the (connected) part
-        int root = nodes[0];
-        for (int u : nodes) if (G.degree(u) < G.degree(root)) root = u;
         int depth = -1;
-        for (int iter = 0; iter < 4; ++iter) {
-            bfs(root, id);
+        for (int iter = 0; iter < 3; ++iter) {
+            if (iter > 0) bfs(root, id);
             int far = queue.back(); const int d2 = lvl[far];
             for (size_t i = queue.size(); i-- > 0 && lvl[queue[i]] == d2;)
                 if (G.degree(queue[i]) < G.degree(far) || (G.degree(queue[i]) == G.degree(far) && queue[i] < far)) far = queue[i];
             if (d2 <= depth) break;                        // (levels of `root` stay)
             depth = d2;
-            if (iter == 3) break;
+            if (iter == 2) break;
             clear_levels();
             root = far;
         }
@@ -409,9 +408,9 @@ struct NdState {
     }
 };
 // groups (each starts on a tile boundary) in elimination order
-inline std::vector<std::vector<int>> nd_groups(int Nc, const std::vector<int>& blk_rc, int n_blocks, int leaf) {
+inline std::vector<std::vector<int>> nd_groups(const CamGraph& G, int leaf) {
     std::vector<std::vector<int>> groups;
-    const CamGraph G = cam_graph(Nc, blk_rc, n_blocks);
+    const int Nc = (int)G.ptr.size() - 1;
     NdState st(G, Nc, leaf, &groups);
     std::vector<int> all(Nc);
     for (int c = 0; c < Nc; ++c) all[c] = c;
@@ -651,7 +650,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         //  so an oversized unordered problem is refused before any T^2 work and AUTO falls back to the PCG at once)
         if (Tn >= 48 && Tn <= kPlanMaxTiles && !(rcm_env && rcm_env[0] == '0')) {
             const long long budget = 12000000;              // tile products of one factorisation: 6.3e12 flop, ~0.25 s
-            const std::vector<int> rcm = plan_detail::rcm_order(Nc, blk_rc, n_blocks);
+            const plan_detail::CamGraph G = plan_detail::cam_graph(Nc, blk_rc, n_blocks);
+            timer.mark("    camera graph");
+            const std::vector<int> rcm = plan_detail::rcm_order(G);
+            timer.mark("    reverse Cuthill-McKee");
             const long long pr = plan_detail::count_tile_products(Nc, blk_rc, n_blocks, rcm, CPT, budget);
             const long long pn = ((long long)CW * Nc <= max_dense_unknowns) ? plan_detail::count_tile_products(Nc, blk_rc, n_blocks, all, CPT, budget) : -1;
             // natural order not allowed (beyond the dense limit): its pattern is taken as full, Tn^3 / 6 products
@@ -663,7 +665,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             const char* nd_env = std::getenv("XRSFM_BA_ND");
             if (P.ordering == 2 && Tn >= 96 && !(nd_env && nd_env[0] == '0')) {
                 const int leaf = std::getenv("XRSFM_BA_ND_LEAF") ? std::max(2 * CPT, std::atoi(std::getenv("XRSFM_BA_ND_LEAF"))) : std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
-                std::vector<std::vector<int>> nd = plan_detail::nd_groups(Nc, blk_rc, n_blocks, leaf);
+                timer.mark("    symbolic counts");
+                std::vector<std::vector<int>> nd = plan_detail::nd_groups(G, leaf);
+                timer.mark("    nested dissection");
                 int nd_levels = 0, nd_tiles = 0;
                 for (const auto& g : nd) nd_tiles += ((int)g.size() + CPT - 1) / CPT;
                 const long long pd = plan_detail::count_group_products(Nc, blk_rc, n_blocks, nd, CPT, budget, &nd_levels);

@@ -101,6 +101,8 @@ struct CholHost {
     int n_blocks = 0, n_pairs = 0, n_tiles_nz = 0, T = 0;
     int *slot_pair_ptr = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr;
     double *scat2 = nullptr, *Sblk = nullptr;
+    bool bwd_push = false;                        // level schedule with a deep tree: backward substitution in push form (k_bwd2)
+    bool pair_from_v = false; int2* ent_src = nullptr; double* pair_v = nullptr;      // long tracks: blocks formed from stored operands (k_chol_segsum_v)
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
     int* pairs_items = nullptr; int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
@@ -702,6 +704,21 @@ int chol_setup(xrsfm_ba_context* c) {
         if (c->wide) c->w.camS = both; else c->d.camS = both;
         h.Sblk = both + (size_t)Nc * cam_vals;
     }
+    {   // collections with long tracks (>= 1 M per-pair blocks): the blocks are formed from stored operands where they are summed
+        // (ba_kernels.h: k_chol_segsum_v) instead of being written per pair and read back; XRSFM_BA_PAIR_V=0 / 1 forces one form
+        const char* pe = std::getenv("XRSFM_BA_PAIR_V");        // (read per set-up: the A/B test switches it)
+        const long long n_obs_pairs = (long long)P.n_pairs - k.n_gt_cells;
+        h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : n_obs_pairs >= 1000000);
+        if (h.pair_from_v) {
+            const size_t ne = (size_t)std::max(1, P.n_writes);
+            TRYC(dev_alloc(c, &h.ent_src, ne));
+            TRYC(dev_alloc(c, &h.pair_v, (size_t)std::max(1, k.n_slots) * 18));
+            HIPCHK(hipMemsetAsync(h.ent_src, 0xff, sizeof(int2) * ne, c->stream));
+            hipLaunchKernelGGL(k_pair_sources, dim3(h.n_pairs_other), dim3(kWave), 0, c->stream, c->d, (const int*)(h.pairs_items + h.n_pairs_small + h.n_pairs_big),
+                               (const int*)h.slot_pair_ptr, (const int*)h.pair_dst, h.ent_src);
+            HIPCHK(hipGetLastError());
+        }
+    }
     h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.tile_rows = d_tile_rows;
     h.dev.cw = P.cam_width; h.dev.cpt = P.cams_per_tile;
     // tile storage of S: dense n_pad x n_pad while that is small (<= 4 GB: one address computation less per tile; measured at L / X / D:
@@ -723,7 +740,12 @@ int chol_setup(xrsfm_ba_context* c) {
     {   // one-launch backward substitution (level schedules with at least two levels; XRSFM_BA_BWD_ALL=0: one launch per level)
         const char* be = std::getenv("XRSFM_BA_BWD_ALL");        // (read per context: the A/B test switches it inside one process)
         const bool on = !(be && be[0] == '0');
-        h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2;
+        // (shallow trees only: with the 174 levels of a dissected photo collection — 758 workgroups, most of them polling for most of the
+        //  launch — a solve took 20 ms against 1.7 ms of per-level launches; measured at config T)
+        h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2 && (P.n_levels <= 32 || (be && be[0] == '1'));
+        // ... and the pull form per level is no better there (one workgroup walks the up to 70 tiles of its column: 207 us per level):
+        // deep level schedules take the push form of the panel schedules, one workgroup per tile, two columns per launch (6.3 ms)
+        h.bwd_push = P.use_levels && !P.panel_ll && !h.bwd_all && P.n_levels > 32;
         if (h.bwd_all) {
             std::vector<int> order;
             std::vector<unsigned char> fin(P.T, 0);
@@ -787,13 +809,14 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         const double radius = c->step_radius;
         auto launch_other = [&](hipStream_t st) {
             const int* items = h.pairs_items + h.n_pairs_small + h.n_pairs_big;
-            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
-            else hipLaunchKernelGGL((k_schur_pairs<false, false, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+            double* pv = h.pair_from_v ? h.pair_v : nullptr;
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, pv);
+            else hipLaunchKernelGGL((k_schur_pairs<false, false, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, pv);
         };
         auto launch_gram = [&](auto ni, int n, size_t shm, const int* items) {
             constexpr int NI = decltype(ni)::value;
-            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
-            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius);
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
+            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
         };
         if (fork) {
             HIPCHK(hipEventRecord(h.ev_fork, c->stream));
@@ -820,7 +843,11 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         }
         if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
-    if (d.n_cams + h.n_blocks > 0) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
+    if (d.n_cams + h.n_blocks > 0) {
+        if (h.pair_from_v) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum_v, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk,
+                                  (const int2*)h.ent_src, (const double*)h.pair_v);
+        else LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
+    }
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
     static const bool fill_in_level0 = [] { const char* e = std::getenv("XRSFM_BA_FILL_FUSED"); return !(e && e[0] == '0'); }();
@@ -913,7 +940,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
             // the columns of the last level have nothing below them: their backward substitution rides in the same launch
             // (a single-tile system — LBA-sized calls — is its own last level on either schedule)
-            const bool with_bwd = (!h.panel_ll || T == 1) && lv == h.n_levels - 1;
+            const bool with_bwd = ((!h.panel_ll && !h.bwd_push) || T == 1) && lv == h.n_levels - 1;
             LvFill lf{};
             if (lv == 0 && !h.S_filled) {
                 // first level: its workgroups compose their tiles from the block values (no k_tile_fill launch, no round trip
@@ -927,7 +954,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                 LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
                        (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
         }
-        if (h.panel_ll) {       // long columns: push form, one workgroup per tile of the column
+        if (h.panel_ll || h.bwd_push) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
             panel_backward(c);
             if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
