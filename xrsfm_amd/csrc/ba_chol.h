@@ -1637,6 +1637,82 @@ __global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict
     }
 }
 
+// ---- backward substitution of a DEEP level schedule (round 4): one launch per level, the tiles of a column shared out
+// A dissected photo collection (ba_plan.h: ordering 3) has ~170 levels of a few columns with up to 70 tiles each: one workgroup per
+// column (k_lv_bwd) walks 2 MB of tiles alone — 207 us per level —, the push form of the panel schedules (k_bwd2) needs one launch
+// per two COLUMNS (380 launches, 5.4 ms), and the one-launch form above has most of its 760 workgroups polling.  Here a column's
+// list is cut into chunks of kBwdChunk tiles, one workgroup each; a chunk stores its 64 partial sums write-through and takes a
+// ticket on the column's counter, and the LAST chunk to arrive (hand-off recipe R1 of the hardware guide: payload stored
+// write-through and drained, one relaxed agent-scope arrival per workgroup, acquire fence on the reading side — nobody waits)
+// adds the partials in chunk order and forms x_k = Linv_k^T (y_k - sum): deterministic.  The counter is left at zero.
+constexpr int kBwdChunk = 4;          // (8: two dependent rounds of tile loads per workgroup, 32 us per level at config T)
+__global__ __launch_bounds__(256) void k_lv_bwd_chunk(CholDev c, const int* __restrict__ klist, const int* __restrict__ ci, const int* __restrict__ tile_cam,
+                                                      double* __restrict__ px, const int4* __restrict__ chunks, double* part_buf, unsigned* counter) {
+    __shared__ double acc[kNB];
+    __shared__ bool last;
+    const int4 ch = chunks[blockIdx.x];                  // entry of the column in klist | list range [q0, q1) | chunk index + (chunks of the column << 16)
+    const int k = klist[ch.x], q0 = ch.y, q1 = ch.z, idx = ch.w & 0xffff, nch = ch.w >> 16;
+    const int t = threadIdx.x, o = t >> 2, part = t & 3;
+    // (what only the last arrival uses is requested by everyone, up front: it would otherwise be two more dependent round trips at the end)
+    const double* Lk = c.Linv + (size_t)k * kNB * kNB;
+    double lk[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) lk[m] = Lk[(part * 16 + m) * kNB + o];
+    const double yk = (t < kNB) ? c.y[k * kNB + t] : 0.0;
+    double s = 0.0;
+    for (int qb = q0; qb < q1; qb += 4) {
+        const int n = min(4, q1 - qb);
+        double M[4][16], xv[4][16];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < n) {
+                const int i = ci[qb + u];
+                const double* Mp = tile_ptr(c, i, k) + (size_t)(part * 16) * c.ld + o;
+                const double* xp = c.x + i * kNB + part * 16;
+#pragma unroll
+                for (int m = 0; m < 16; ++m) { M[u][m] = Mp[(size_t)m * c.ld]; xv[u][m] = xp[m]; }
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (u < n) {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) s += M[u][m] * xv[u][m];
+            }
+    }
+    s += __shfl_xor(s, 1, kWave);
+    s += __shfl_xor(s, 2, kWave);
+    if (nch > 1) {
+        double* mine = part_buf + (size_t)blockIdx.x * kNB;
+        if (part == 0) __hip_atomic_store(mine + o, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t == 0) last = (__hip_atomic_fetch_add(counter + k, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)nch);
+        __syncthreads();
+        if (!last) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (t < kNB) {
+            const double* first = part_buf + (size_t)(blockIdx.x - idx) * kNB + t;      // the chunks of a column are consecutive workgroups
+            double sum = 0.0;
+            for (int j = 0; j < nch; ++j) sum += __hip_atomic_load(first + (size_t)j * kNB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc[t] = yk - sum;
+        }
+        if (t == 0) __hip_atomic_store(counter + k, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (part == 0) acc[o] = c.y[k * kNB + o] - s;
+    }
+    __syncthreads();
+    double s2 = 0.0;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) s2 += lk[m] * acc[part * 16 + m];
+    s2 += __shfl_xor(s2, 1, kWave);
+    s2 += __shfl_xor(s2, 2, kWave);
+    if (part == 0) {
+        c.x[k * kNB + o] = s2;
+        const int cam = (o < c.cw * c.cpt) ? tile_cam[k * c.cpt + o / c.cw] : -1;
+        if (cam >= 0) px[c.cw * (size_t)cam + o % c.cw] = s2;
+    }
+}
+
 // ---- the whole backward substitution of a level schedule in ONE launch (round 4)
 // One launch per level (k_lv_bwd above) costs 8-18 us per level — a kernel boundary, three or four dependent global round trips
 // (column list -> tile addresses -> tiles -> result) and a grid of a few workgroups — for 64 values per column; a band with

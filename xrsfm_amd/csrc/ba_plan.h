@@ -913,6 +913,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 P.sp_rp.push_back(p0); P.sp_rp.push_back(np);
             }
             P.sp_max_chunks = std::max(P.sp_max_chunks, np);
+            // (measured at config T and removed: the chunks of a level sorted by shared operands — column k, j range, row i — and dealt
+            //  to the XCDs in runs of 128, so that neighbours in one L2 share tiles: 176.4 ms per ten factorisations against 176.9; chunks
+            //  of 4 / 6 / 12 products: 176 / 176 / 187.  The launch is bound by the chunk kernel's own staging pipeline — 61 % of
+            //  the matrix-core cycles while a CU is busy, CUs busy 81 % of the launch — not by where its operands come from.)
         }
         if (lookahead) {
             // late partials: column k - 2 (the pivot tile's first, so that every workgroup of the column finds its slot at once)

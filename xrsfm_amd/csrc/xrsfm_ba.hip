@@ -102,6 +102,7 @@ struct CholHost {
     int *slot_pair_ptr = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr;
     double *scat2 = nullptr, *Sblk = nullptr;
     bool bwd_push = false;                        // level schedule with a deep tree: backward substitution in push form (k_bwd2)
+    bool bwd_chunk = false; int4* bc_chunks = nullptr; std::vector<int> bc_off; double* bc_part = nullptr; unsigned* bc_ctr = nullptr;   // ... or per level, columns in chunks (k_lv_bwd_chunk)
     bool pair_from_v = false; int2* ent_src = nullptr; double* pair_v = nullptr;      // long tracks: blocks formed from stored operands (k_chol_segsum_v)
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
@@ -745,7 +746,28 @@ int chol_setup(xrsfm_ba_context* c) {
         h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2 && (P.n_levels <= 32 || (be && be[0] == '1'));
         // ... and the pull form per level is no better there (one workgroup walks the up to 70 tiles of its column: 207 us per level):
         // deep level schedules take the push form of the panel schedules, one workgroup per tile, two columns per launch (6.3 ms)
-        h.bwd_push = P.use_levels && !P.panel_ll && !h.bwd_all && P.n_levels > 32;
+        // (XRSFM_BA_BWD_CHUNK=0), or — default — one launch per level with the tiles of a column shared out over workgroups (k_lv_bwd_chunk)
+        const char* bce = std::getenv("XRSFM_BA_BWD_CHUNK");
+        const bool deep = P.use_levels && !P.panel_ll && !h.bwd_all && P.n_levels > 32;
+        h.bwd_chunk = deep && !(bce && bce[0] == '0');
+        h.bwd_push = deep && !h.bwd_chunk;
+        if (h.bwd_chunk) {
+            std::vector<int4> chunks;
+            h.bc_off.assign(P.n_levels + 1, 0);
+            int max_lv = 1;
+            for (int lv = 0; lv < P.n_levels; ++lv) {
+                for (int e2 = P.lv_k_off[lv]; e2 < P.lv_k_off[lv + 1]; ++e2) {
+                    const int q0 = P.lv_bptr[e2], q1 = P.lv_bptr[e2 + 1];
+                    const int nch = std::max(1, (q1 - q0 + kBwdChunk - 1) / kBwdChunk);
+                    for (int j = 0; j < nch; ++j) chunks.push_back(make_int4(e2, q0 + j * kBwdChunk, std::min(q1, q0 + (j + 1) * kBwdChunk), j | (nch << 16)));
+                }
+                h.bc_off[lv + 1] = (int)chunks.size();
+                max_lv = std::max(max_lv, h.bc_off[lv + 1] - h.bc_off[lv]);
+            }
+            TRYC(dev_upload(c, &h.bc_chunks, chunks));
+            TRYC(dev_alloc(c, &h.bc_part, (size_t)max_lv * kNB)); TRYC(dev_alloc(c, &h.bc_ctr, (size_t)P.T));
+            HIPCHK(hipMemsetAsync(h.bc_ctr, 0, sizeof(unsigned) * (size_t)P.T, c->stream));
+        }
         if (h.bwd_all) {
             std::vector<int> order;
             std::vector<unsigned char> fin(P.T, 0);
@@ -940,7 +962,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
             // the columns of the last level have nothing below them: their backward substitution rides in the same launch
             // (a single-tile system — LBA-sized calls — is its own last level on either schedule)
-            const bool with_bwd = ((!h.panel_ll && !h.bwd_push) || T == 1) && lv == h.n_levels - 1;
+            const bool with_bwd = ((!h.panel_ll && !h.bwd_push && !h.bwd_chunk) || T == 1) && lv == h.n_levels - 1;
             LvFill lf{};
             if (lv == 0 && !h.S_filled) {
                 // first level: its workgroups compose their tiles from the block values (no k_tile_fill launch, no round trip
@@ -958,6 +980,14 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             if (T == 1) return 0;               // solved inside the factor launch
             panel_backward(c);
             if (d.n_cams > 0) LAUNCH(c, K_SMALL, k_sol_gather, dim3(cdiv((long long)d.n_cams * h.dev.cw, 256)), dim3(256), 0, h.dev, px_out, d.n_cams);
+            return 0;
+        }
+        if (h.bwd_chunk) {
+            for (int lv = h.n_levels - 1; lv >= 0; --lv) {
+                const int n = h.bc_off[lv + 1] - h.bc_off[lv];
+                if (n > 0) LAUNCH(c, K_TRISOLVE, k_lv_bwd_chunk, dim3(n), dim3(256), 0, h.dev, (const int*)h.lv_k, (const int*)h.lv_bi, (const int*)h.tile_cam, px_out,
+                                  (const int4*)(h.bc_chunks + h.bc_off[lv]), h.bc_part, h.bc_ctr);
+            }
             return 0;
         }
         if (h.bwd_all && h.bw_n > 0) {
