@@ -304,6 +304,7 @@ struct NdState {
     std::vector<int> label, lvl, queue;        // label: the part a camera belongs to; lvl: -1 outside a search
     int next_label = 1;
     int leaf;
+    int pp_iters = 4;                          // searches for the pseudo-peripheral start of a part's own order (rcm_part)
     std::vector<std::vector<int>>* groups;
     NdState(const CamGraph& g, int Nc, int leaf_, std::vector<std::vector<int>>* out) : G(g), label(Nc, 0), lvl(Nc, -1), leaf(leaf_), groups(out) {}
     // breadth-first levels over the cameras of part `id` from `root`; the visiting order stays in `queue` (lvl is NOT reset)
@@ -322,7 +323,7 @@ struct NdState {
         for (int start : nodes) {
             if (label[start] != id) continue;
             int root = start, depth = -1;
-            for (int iter = 0; iter < 4; ++iter) {
+            for (int iter = 0; iter < pp_iters; ++iter) {
                 bfs(root, id);
                 int far = queue.back(); const int d2 = lvl[far];
                 for (size_t i = queue.size(); i-- > 0 && lvl[queue[i]] == d2;)
@@ -408,10 +409,11 @@ struct NdState {
     }
 };
 // groups (each starts on a tile boundary) in elimination order
-inline std::vector<std::vector<int>> nd_groups(const CamGraph& G, int leaf) {
+inline std::vector<std::vector<int>> nd_groups(const CamGraph& G, int leaf, int pp_iters = 4) {
     std::vector<std::vector<int>> groups;
     const int Nc = (int)G.ptr.size() - 1;
     NdState st(G, Nc, leaf, &groups);
+    st.pp_iters = pp_iters;
     std::vector<int> all(Nc);
     for (int c = 0; c < Nc; ++c) all[c] = c;
     if (Nc > 0) st.dissect(std::move(all), 0);
@@ -666,11 +668,19 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             if (P.ordering == 2 && Tn >= 96 && !(nd_env && nd_env[0] == '0')) {
                 const int leaf = std::getenv("XRSFM_BA_ND_LEAF") ? std::max(2 * CPT, std::atoi(std::getenv("XRSFM_BA_ND_LEAF"))) : std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
                 timer.mark("    symbolic counts");
-                std::vector<std::vector<int>> nd = plan_detail::nd_groups(G, leaf);
-                timer.mark("    nested dissection");
+                // (the fill of a part's own order depends on which end of it the search happens to start from — 1.08 / 1.11 M tile
+                //  products at config 5's shape with 1 / 4 pseudo-peripheral searches —: both are formed, the symbolic count decides)
+                std::vector<std::vector<int>> nd = plan_detail::nd_groups(G, leaf, 4);
                 int nd_levels = 0, nd_tiles = 0;
+                long long pd = plan_detail::count_group_products(Nc, blk_rc, n_blocks, nd, CPT, budget, &nd_levels);
+                {
+                    std::vector<std::vector<int>> nd1 = plan_detail::nd_groups(G, leaf, 1);
+                    int lv1 = 0;
+                    const long long pd1 = plan_detail::count_group_products(Nc, blk_rc, n_blocks, nd1, CPT, budget, &lv1);
+                    if (pd1 >= 0 && (pd < 0 || pd1 < pd)) { nd.swap(nd1); pd = pd1; nd_levels = lv1; }
+                }
                 for (const auto& g : nd) nd_tiles += ((int)g.size() + CPT - 1) / CPT;
-                const long long pd = plan_detail::count_group_products(Nc, blk_rc, n_blocks, nd, CPT, budget, &nd_levels);
+                timer.mark("    nested dissection");
                 if (std::getenv("XRSFM_BA_PLAN_VERBOSE"))
                     fprintf(stderr, "[plan] reverse Cuthill-McKee: %d tile columns, %lld tile products | nested dissection (leaf %d): %zu groups, %d tile columns, %lld products, %d levels\n",
                             Tn, pr, leaf, nd.size(), nd_tiles, pd, nd_levels);
