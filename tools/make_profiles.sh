@@ -46,6 +46,8 @@ python tools/mapper_trace.py $OUT/mapper_trace.txt > /dev/null 2>&1
   python $ROOT/tools/rocprof_summary.py $(find $OUT/statsR -name "*.db" | head -1) $OUT/kernel_stats_table_R.md > /dev/null; rm -rf $OUT/statsR )
 ( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsB -o stats -- python $ROOT/bench.py --config Lb9 --no-cpu --no-extras --steps 2 > $OUT/statsB_bench.log 2>&1; \
   python $ROOT/tools/rocprof_summary.py $(find $OUT/statsB -name "*.db" | head -1) $OUT/kernel_stats_table_Lb9.md > /dev/null; rm -rf $OUT/statsB )
+( cd /tmp && rocprofv3 --kernel-trace --stats -d $OUT/statsT -o stats -- python $ROOT/bench.py --config T --no-cpu --no-extras --steps 1 --warmup 1 > $OUT/statsT_bench.log 2>&1; \
+  python $ROOT/tools/rocprof_summary.py $(find $OUT/statsT -name "*.db" | head -1) $OUT/kernel_stats_table_T.md > /dev/null; rm -rf $OUT/statsT )
 [ -x tools/bench_potrf ] && tools/bench_potrf > $OUT/potrf.txt 2>&1
 [ -x tools/bench_lat ] && tools/bench_lat > $OUT/lat.txt 2>&1
 python tools/pack_crossover.py > $OUT/pack_crossover.txt 2>&1

@@ -15,7 +15,7 @@ import json
 import re
 
 SHARDED = ("k_schur_pairs", "k_linearize", "k_backsub", "k_point_prep", "k_cost", "k_chol_segsum", "k_schur_prep", "k_schur_matvec", "k_cam_segsum")
-IGNORED = ("__amd_rocclr", "k_fill", "k_scale_from_norms", "k_cam_lin")       # set-up of a solve, not part of the iteration
+IGNORED = ("__amd_rocclr", "k_fill", "k_scale_from_norms", "k_cam_lin", "devpack::", "rocprim::", "k_pair_sources")       # set-up of a solve / of the problem, not part of the iteration
 
 
 def main():
