@@ -221,3 +221,34 @@ def test_ring_of_small_clusters_is_dissected(monkeypatch):
     monkeypatch.delenv("XRSFM_BA_ND")
     again = capi.debug_chol_plan(H.to_product(arr))
     assert np.array_equal(again["cam_offset"], plan["cam_offset"])
+
+
+def test_dissection_of_a_disconnected_collection(monkeypatch):
+    """Two photo collections that share nothing (two rings of 20 viewpoint clusters each, merged into one problem with interleaved
+    camera ids): the camera graph has two components.  The dissection treats the components as parts of their own; the plan must
+    cover the factorisation (self-check), keep every camera, and put no tile of one collection into a column list of the other —
+    the non-zero tile count is the sum of the two separate plans' counts up to the padding of the parts to tile boundaries."""
+    from xrsfm_amd import synth
+    monkeypatch.setenv("XRSFM_BA_PLAN_CHECK", "1")
+    a = synth.make_collection(n_cams=1200, n_points=50000, seed=7, cams_per_cluster=60)
+    b = synth.make_collection(n_cams=1200, n_points=50000, seed=8, cams_per_cluster=60)
+    na, pa = a["cam_q"].shape[0], a["points"].shape[0]
+    perm = np.random.default_rng(3).permutation(2 * na)            # new id of camera c of a: perm[c]; of b: perm[na + c]
+    inv = np.argsort(perm)
+    merged = {k: np.concatenate([a[k], b[k]])[inv] for k in ("cam_q", "cam_t", "cam_const", "cam_intr")}      # row perm[c] = camera c
+    merged.update({k: a[k] for k in ("intr_model", "intr_params")})                                         # (one shared intrinsics group)
+    merged.update({k: np.concatenate([a[k], b[k]]) for k in ("points", "point_const", "obs_uv")})
+    merged["obs_cam"] = np.concatenate([perm[a["obs_cam"]], perm[na + b["obs_cam"]]]).astype(np.int32)
+    merged["obs_pt"] = np.concatenate([a["obs_pt"], pa + b["obs_pt"]]).astype(np.int32)
+    plan = capi.debug_chol_plan(H.to_product(merged))
+    _check_layout(plan, 2 * na)
+    assert plan["ordering"] == 3 and plan["level_schedule"] == 1
+    pa_ = capi.debug_chol_plan(H.to_product({k: a[k] for k in capi.ProblemArrays.FIELDS}))
+    pb_ = capi.debug_chol_plan(H.to_product({k: b[k] for k in capi.ProblemArrays.FIELDS}))
+    assert plan["blocks"] == pa_["blocks"] + pb_["blocks"]
+    # no coupling between the collections: their elimination trees stand side by side (depth ~ the deeper one — not exactly: the part
+    # size follows the camera count and ties break by id), they are not chained (depth = the sum)
+    assert plan["levels"] <= 1.25 * max(pa_["levels"], pb_["levels"]) < pa_["levels"] + pb_["levels"]
+    off = plan["cam_offset"]
+    tiles_a, tiles_b = set((off[perm[:na]] // 64).tolist()), set((off[perm[na:]] // 64).tolist())
+    assert not (tiles_a & tiles_b)                                   # parts start on tile boundaries: no tile mixes the collections

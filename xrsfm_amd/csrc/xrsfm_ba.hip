@@ -898,6 +898,8 @@ static void panel_backward(xrsfm_ba_context* c) {
     }
 }
 
+constexpr int kFillRestApart = 4096;      // tiles outside the first level's columns from which a fill launch of their own pays (config T: 40 000)
+
 int chol_factor_solve(xrsfm_ba_context* c) {
     Dev& d = c->d;
     CholHost& h = c->chol;
@@ -969,8 +971,14 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                 // through S); trailing workgroups compose the tiles of all other columns
                 lf.d = d; lf.f = FillLists{h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc, c->step_prep ? c->step_radius : 0.0};
                 lf.fz_q = h.fz_q; lf.rest = h.fill_rest; lf.n_factor = nf;
-                if (nf + h.n_fill_rest > 0)
-                    LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + h.n_fill_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
+                // thousands of tiles outside the first level: composed by a launch of their own (several workgroups per CU)
+                const bool rest_apart = h.n_fill_rest > kFillRestApart;
+                if (rest_apart)
+                    LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_fill_rest), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc,
+                           c->step_prep ? c->step_radius : 0.0, (const int*)h.fill_rest);
+                const int n_rest = rest_apart ? 0 : h.n_fill_rest;
+                if (nf + n_rest > 0)
+                    LAUNCH(c, K_POTRF, k_lv_factor<true>, dim3(nf + n_rest), dim3(256), 0, h.dev, h.fz_tile, h.fz_dptr, h.fz_dj,
                            (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
             } else if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
