@@ -523,44 +523,43 @@ __global__ __launch_bounds__(kWave) void k_pair_sources(Dev d, const int* __rest
         for (int dd = 1; dd <= npair; ++dd) ent_src[pair_dst[pbase + dd - 1]] = make_int2(sa, sa + dd);
     }
 }
-// One workgroup per block, one WAVE per entry stream (entries beg + w, beg + w + 4, ...): the entry's source is wave-uniform (scalar
-// load, scalar branch); lanes 0..17 / 18..35 fetch Va / Vb with one coalesced load (two runs of 144 bytes), park them in the wave's
-// LDS row, and lane k < 36 forms element k = (rb, ca) from six LDS reads; eight entries are in flight per wave.  The four per-wave
-// sums are added in wave order: deterministic.  (First version, measured at config T: thread (g, k) of seven 36-thread groups
-// loading its six operand values itself — 7 gather loads per entry and thread: 8.7 ms per launch against 3.4 ms for the plain
-// segmented sum of per-pair blocks it replaces, next to 11.8 -> 1.3 ms in k_schur_pairs.)
-constexpr int kPairVAhead = 8;       // (4: 5.7 ms per launch at config T — two dependent round trips per round, most blocks need two rounds)
+// One WAVE per block (four blocks per workgroup, no workgroup barrier): the sources of the next kPairVAhead entries are fetched with one
+// load (lane u: entry e0 + u) and handed round as scalars; lanes 0..17 / 18..35 fetch Va / Vb with one coalesced load per entry (two
+// runs of 144 bytes), park them in the wave's LDS rows, and lane k < 36 forms element k = (rb, ca) from six LDS reads.  Entries
+// are added in list order: deterministic.  Measured at config T (1.65 M blocks of 33 entries on average): thread (g, k) of seven
+// 36-thread groups loading its six operand values itself: 8.7 ms per launch; one workgroup per block, a wave per entry stream,
+// 4 or 8 entries in flight: 5.6 ms whatever the order of the blocks (cluster-coherent or by shuffled id) — not the operands'
+// locality but a chain of three dependent round trips per workgroup at full occupancy; this form: four times the blocks in flight.
+constexpr int kPairVAhead = 8;
 __global__ __launch_bounds__(kBlock) void k_chol_segsum_v(const double* __restrict__ scat, const int* __restrict__ cam_ptr,
                                                           double* __restrict__ camS, int n_cams, const double* __restrict__ scat2,
-                                                          const int* __restrict__ blk_ptr, double* __restrict__ Sblk,
+                                                          const int* __restrict__ blk_ptr, double* __restrict__ Sblk, int n_blocks,
                                                           const int2* __restrict__ ent_src, const double* __restrict__ pair_v) {
     if ((int)blockIdx.x < n_cams) { segsum_body<28>(scat, cam_ptr, camS, blockIdx.x); return; }
     constexpr int K = 36, NW = kBlock / kWave;
     __shared__ double ops[NW][kPairVAhead][K];
-    __shared__ double part[NW][K];
-    const int b = blockIdx.x - n_cams, t = threadIdx.x, lane = t & (kWave - 1);
+    const int t = threadIdx.x, lane = t & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int b = ((int)blockIdx.x - n_cams) * NW + wave;
+    if (b >= n_blocks) return;
     const int beg = blk_ptr[b], end = blk_ptr[b + 1];
     const int k = lane < K ? lane : 0, rb3 = 3 * (k / 6), ca3 = 3 * (k % 6);
     double acc = 0.0;
-    for (int e0 = beg + wave; e0 < end; e0 += NW * kPairVAhead) {
-        int2 src[kPairVAhead];
+    for (int e0 = beg; e0 < end; e0 += kPairVAhead) {
+        const int2 mine = (lane < kPairVAhead && e0 + lane < end) ? ent_src[e0 + lane] : make_int2(-1, -1);
+        int sx[kPairVAhead], sy[kPairVAhead];
         double v[kPairVAhead];
 #pragma unroll
         for (int u = 0; u < kPairVAhead; ++u) {
-            const int e = e0 + NW * u;
-            src[u] = make_int2(-1, -1); v[u] = 0.0;
-            if (e < end) {                                   // (wave-uniform)
-                src[u] = ent_src[e];
-                if (lane < K) v[u] = src[u].x < 0 ? scat2[36 * (size_t)e + lane]
-                                                  : pair_v[18 * (size_t)(lane < 18 ? src[u].x : src[u].y) + (lane < 18 ? lane : lane - 18)];
-            }
+            sx[u] = __builtin_amdgcn_readlane(mine.x, u); sy[u] = __builtin_amdgcn_readlane(mine.y, u);
+            v[u] = 0.0;
+            if (e0 + u < end && lane < K)                    // (the first condition is wave-uniform)
+                v[u] = sx[u] < 0 ? scat2[36 * (size_t)(e0 + u) + lane] : pair_v[18 * (size_t)(lane < 18 ? sx[u] : sy[u]) + (lane < 18 ? lane : lane - 18)];
         }
 #pragma unroll
         for (int u = 0; u < kPairVAhead; ++u) {
-            const int e = e0 + NW * u;
-            if (e >= end) break;
-            if (src[u].x < 0) { acc += v[u]; continue; }
+            if (e0 + u >= end) break;
+            if (sx[u] < 0) { acc += v[u]; continue; }
             double* row = ops[wave][u];
             if (lane < K) row[lane] = v[u];
             __builtin_amdgcn_s_waitcnt(0xc07f);              // lgkmcnt(0): LDS operations of one wave complete in order
@@ -570,14 +569,7 @@ __global__ __launch_bounds__(kBlock) void k_chol_segsum_v(const double* __restri
             acc += Vb[0] * Va[0] + Vb[1] * Va[1] + Vb[2] * Va[2];
         }
     }
-    if (lane < K) part[wave][lane] = acc;
-    __syncthreads();
-    if (t < K) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += part[w][t];
-        Sblk[(size_t)b * K + t] = s;
-    }
+    if (lane < K) Sblk[(size_t)b * K + lane] = acc;
 }
 
 // Diagnostics only: materialise the 2x6 / 2x3 blocks (SoA over slots) the consumers rebuild on the fly.

@@ -866,8 +866,8 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
     if (d.n_cams + h.n_blocks > 0) {
-        if (h.pair_from_v) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum_v, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk,
-                                  (const int2*)h.ent_src, (const double*)h.pair_v);
+        if (h.pair_from_v) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum_v, dim3(d.n_cams + (h.n_blocks + 3) / 4), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk,
+                                  h.n_blocks, (const int2*)h.ent_src, (const double*)h.pair_v);
         else LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum, dim3(d.n_cams + h.n_blocks), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk);
     }
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
