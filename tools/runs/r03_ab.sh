@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-3 A/B of the fused schedules (run through gpurun from the repo root): bench lines per switch and configuration.
-#   gpurun -- 'bash tools/r03_ab.sh tag "L S R"'
+#   gpurun -- 'bash tools/runs/r03_ab.sh tag "L S R"'
 set -u
 TAG=${1:-ab}; CFGS=${2:-"L S R"}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}

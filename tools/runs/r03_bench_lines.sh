@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-3 developer aid (GPU box): one-line summaries of bench.py runs.   bash tools/r03_bench_lines.sh tag "L S R" [steps]
+# Round-3 developer aid (GPU box): one-line summaries of bench.py runs.   bash tools/runs/r03_bench_lines.sh tag "L S R" [steps]
 set -u
 TAG=${1:-b}; CFGS=${2:-"L S R"}; STEPS=${3:-20}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}

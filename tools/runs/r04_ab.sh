@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-4 A/B of library builds (run through gpurun from the repo root): one bench line per (build variant, configuration).
-#   gpurun -- 'bash tools/r04_ab.sh tag "L S" "default potrf00 potrf01"'
+#   gpurun -- 'bash tools/runs/r04_ab.sh tag "L S" "default potrf00 potrf01"'
 set -u
 TAG=${1:-ab}; CFGS=${2:-"L S"}; LIBS=${3:-"default"}; STEPS=${4:-20}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}

@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd $ROOT
 timeout 120 tools/bench_potrf > $OUT/potrf.txt 2>&1
 cat $OUT/potrf.txt
-timeout 600 bash tools/r04_ab.sh r04a "L S" "default potrf00 potrf01 potrf11 potrf20" 20 2>&1 | tee $OUT/ab.txt
+timeout 600 bash tools/runs/r04_ab.sh r04a "L S" "default potrf00 potrf01 potrf11 potrf20" 20 2>&1 | tee $OUT/ab.txt
 timeout 300 bash tools/quick_prof.sh L r04a_L > /dev/null 2>&1
 cat gpurun_out/prof_r04a_L/kernel_stats_table.md | head -30
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest.txt
