@@ -974,8 +974,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             nc_all += nc; max_nt = std::max(max_nt, g1 - g0);
             if (P.sp_chunk_off[lv + 1] > P.sp_chunk_off[lv]) { ++n_split; nc_split += nc; }
         }
-        fprintf(stderr, "[plan] %d tile columns, %d levels (%d split: %lld of %lld list entries), %d chunks in all, largest level %d targets, partial buffer %d tiles, %lld tile products\n",
-                T, n_levels, n_split, nc_split, nc_all, (int)P.sp_tgt.size() / 2, max_nt, P.sp_max_chunks, P.tile_products);
+        fprintf(stderr, "[plan] %d tile columns, %d levels (%d split: %lld of %lld list entries), %d chunks in all, largest level %d targets, partial buffer %d tiles, %lld tile products; "
+                        "%d block entries of which %d Gram cells\n",
+                T, n_levels, n_split, nc_split, nc_all, (int)P.sp_tgt.size() / 2, max_nt, P.sp_max_chunks, P.tile_products, P.n_writes, k.n_gt_cells);
     }
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);

@@ -705,11 +705,12 @@ int chol_setup(xrsfm_ba_context* c) {
         if (c->wide) c->w.camS = both; else c->d.camS = both;
         h.Sblk = both + (size_t)Nc * cam_vals;
     }
-    {   // collections with long tracks (>= 1 M per-pair blocks): the blocks are formed from stored operands where they are summed
-        // (ba_kernels.h: k_chol_segsum_v) instead of being written per pair and read back; XRSFM_BA_PAIR_V=0 / 1 forces one form
+    {   // collections with long tracks (>= 4 M block entries = per-pair blocks + Gram cells in use): the blocks are formed from stored
+        // operands where they are summed (ba_kernels.h: k_chol_segsum_v) instead of being written per pair and read back;
+        // XRSFM_BA_PAIR_V=0 / 1 forces one form.  (A ragged sequential map — config R: 0.66 M entries, few of them per pair — is
+        // faster with the plain segmented sum: 45 us against 73.)
         const char* pe = std::getenv("XRSFM_BA_PAIR_V");        // (read per set-up: the A/B test switches it)
-        const long long n_obs_pairs = (long long)P.n_pairs - k.n_gt_cells;
-        h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : n_obs_pairs >= 1000000);
+        h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : P.n_writes >= 4000000);
         if (h.pair_from_v) {
             const size_t ne = (size_t)std::max(1, P.n_writes);
             TRYC(dev_alloc(c, &h.ent_src, ne));
@@ -835,34 +836,45 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
             if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<false, true, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, pv);
             else hipLaunchKernelGGL((k_schur_pairs<false, false, 0>), dim3(h.n_pairs_other), dim3(kWave), h.pairs_shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, pv);
         };
-        auto launch_gram = [&](auto ni, int n, size_t shm, const int* items) {
+        auto launch_gram = [&](auto ni, int n, size_t shm, const int* items, hipStream_t st) {
             constexpr int NI = decltype(ni)::value;
-            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
-            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, c->stream, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
+            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
+        };
+        // Gram tiles: one launch per (operand height, LDS class) that occurs.  The launches write disjoint outputs; a ragged map has
+        // four to six of them, most with too few tiles to fill the chip (config R: 149 + 34 + 16 + 16 + 17 us one after the other):
+        // when the second stream is forked anyway, the largest bucket stays on the main stream and the others follow the non-Gram
+        // items on the second one (XRSFM_BA_GRAM_FORK=0: all on the main stream, rounds 3-4)
+        static const bool gram_fork = [] { const char* e = std::getenv("XRSFM_BA_GRAM_FORK"); return !(e && e[0] == '0'); }();
+        int big = -1;
+        for (int b = 0; b < 8; ++b) if (h.gram_n[b] > 0 && (big < 0 || h.gram_n[b] > h.gram_n[big])) big = b;
+        auto launch_buckets = [&](bool main_side) {
+            const int* items = h.pairs_items;
+            for (int b = 0; b < 8; ++b) {
+                const int n = h.gram_n[b];
+                const bool on_main = !(fork && gram_fork) || b == big;
+                if (n > 0 && on_main == main_side) {
+                    hipStream_t st = on_main ? c->stream : h.aux;
+                    switch (b >> 1) {
+                        case 0: launch_gram(std::integral_constant<int, 1>{}, n, h.gram_shm[b], items, st); break;
+                        case 1: launch_gram(std::integral_constant<int, 2>{}, n, h.gram_shm[b], items, st); break;
+                        case 2: launch_gram(std::integral_constant<int, 3>{}, n, h.gram_shm[b], items, st); break;
+                        default: launch_gram(std::integral_constant<int, 4>{}, n, h.gram_shm[b], items, st); break;
+                    }
+                }
+                items += n;
+            }
         };
         if (fork) {
             HIPCHK(hipEventRecord(h.ev_fork, c->stream));
             HIPCHK(hipStreamWaitEvent(h.aux, h.ev_fork, 0));
             launch_other(h.aux);
+            launch_buckets(false);
             HIPCHK(hipEventRecord(h.ev_join, h.aux));
         } else if (h.n_pairs_other > 0) {
             launch_other(c->stream);
         }
-        {   // Gram tiles: one launch per (operand height, LDS class) that occurs
-            const int* items = h.pairs_items;
-            for (int b = 0; b < 8; ++b) {
-                const int n = h.gram_n[b];
-                if (n > 0) {
-                    switch (b >> 1) {
-                        case 0: launch_gram(std::integral_constant<int, 1>{}, n, h.gram_shm[b], items); break;
-                        case 1: launch_gram(std::integral_constant<int, 2>{}, n, h.gram_shm[b], items); break;
-                        case 2: launch_gram(std::integral_constant<int, 3>{}, n, h.gram_shm[b], items); break;
-                        default: launch_gram(std::integral_constant<int, 4>{}, n, h.gram_shm[b], items); break;
-                    }
-                }
-                items += n;
-            }
-        }
+        launch_buckets(true);
         if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
     if (d.n_cams + h.n_blocks > 0) {
