@@ -553,6 +553,18 @@ def main():
                 "accounting": "BASELINE.md section 4 B_iter(0) + nnzb*288 (explicit block-sparse S, exact Cholesky: K = 0); "
                               "t_iter = timed region / LM iterations (includes the iteration-0 linearisations)"}
 
+    per_rank = None
+    if world > 1:
+        # the dominant streaming kernel on EVERY rank (each streams its own shard): rank 0 reports the list next to its own block
+        mine = None if roofline is None else {"rank": rank, "kernel": roofline["kernel"], "avg_launch_us": roofline["avg_launch_us"],
+                                              "algorithmic_bytes_per_launch": roofline["algorithmic_bytes_per_launch"], "frac": roofline["frac"],
+                                              "points": int(prob.n_points), "obs": int(prob.n_obs)}
+        try:
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            per_rank = gathered
+        except Exception:
+            per_rank = None
     if rank == 0:
         n_res = 2 * n_obs
         out = {
@@ -575,6 +587,8 @@ def main():
             "termination_reason": last.termination_reason,
             "roofline": roofline, "cpu_baseline": None, "kernels": kernel_table,
         }
+        if per_rank is not None and roofline is not None:
+            roofline["per_rank"] = per_rank
         if args.config == "Lb9":
             out["config"]["workload"] += "; bal9 mode: every camera's {f, k1, k2} variable, 9-wide camera blocks"
         if world == 1 and not args.no_cpu:
