@@ -348,8 +348,8 @@ def test_packed_tile_storage_equals_dense(lib, monkeypatch, mode, n_cams, n_pts,
 @pytest.mark.gpu
 def test_blocks_from_stored_operands_equal_per_pair_blocks(lib, monkeypatch):
     """Round 4, collections with long tracks: the camera-pair blocks of tracks that do not fit a Gram tile are formed where they
-    are summed, from the stored operands V of their two observations (k_chol_segsum_v, XRSFM_BA_PAIR_V=1; automatic from 4 M
-    block entries), instead of being written per pair by k_schur_pairs and read back.  Same products, another (fixed) order of a block's sum:
+    are summed, from the stored operands V of their two observations (k_chol_segsum_v, XRSFM_BA_PAIR_V=1; automatic when
+    most block entries are per-pair blocks), instead of being written per pair by k_schur_pairs and read back.  Same products, another (fixed) order of a block's sum:
     the reduced camera matrix, the solve and a full run must not differ beyond the order of a block's sum (S to 1e-13
     relative, identical LM decisions, cameras to 1e-9) — on a collection whose tracks reach 80 photos (both per-pair paths: tracks
     inside one tile and tracks longer than a tile) and with the round-2 schedule that reads the point factors from memory."""

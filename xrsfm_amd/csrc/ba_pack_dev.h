@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256) void k_buckets(const int* __restrict__ slot_ca
 
 struct KeysResult {
     int *spp = nullptr, *pair_dst = nullptr, *blk_ptr = nullptr, *blk_rc = nullptr, *pairs_items = nullptr;     // device (kept)
-    int n_pairs = 0, n_writes = 0, n_blocks = 0;
+    int n_pairs = 0, n_writes = 0, n_pair_writes = 0, n_blocks = 0;        // n_pair_writes: entries that are per-pair blocks (the others: Gram cells)
     std::vector<int> blk_rc_host;
     int gram_n[8] = {0}, n_other = 0; size_t gram_shm[8] = {0};
     bool duplicate = false;
@@ -692,7 +692,7 @@ inline int device_keys(const Packed& o, const int* slot_cam, const int* slot_pt,
     if (status[0] & 4u) { K.duplicate = true; return 0; }
     const int n_obs_pairs = totals[0], k1 = totals[1], nw = totals[1] + totals[2];
     if ((long long)n_obs_pairs + o.n_gt_cells > INT32_MAX) return XRSFM_BA_EINVAL;
-    K.n_pairs = n_obs_pairs + o.n_gt_cells; K.n_writes = nw;
+    K.n_pairs = n_obs_pairs + o.n_gt_cells; K.n_writes = nw; K.n_pair_writes = k1;
     XBA_TMP(u64, key_a, nw + 1); XBA_TMP(u64, key_b, nw + 1); XBA_TMP(int, val_a, nw + 1); XBA_TMP(int, val_b, nw + 1);
     XBA_TMP(int, head, nw + 1); XBA_TMP(int, bid, nw + 1);
     if (nt > 0) hipLaunchKernelGGL(k_pair_keys, dim3(nbw), dim3(kThreads), 0, st, slot_cam, slot_cidx, tile_ncam, tile_gt_off, gt_cell, nt, cnt, K.spp, koff, goff, k1,

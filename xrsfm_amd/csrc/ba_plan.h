@@ -19,6 +19,7 @@ constexpr int kCamsPerTileWide = 7;  // bal9 mode (9 unknowns per camera): 7 cam
 
 struct CholPlan {
     int n = 0, n_pad = 0, T = 0, n_blocks = 0, n_pairs = 0, n_writes = 0, n_tiles_nz = 0, n_levels = 0;
+    int n_pair_writes = 0;           // block entries that are per-pair blocks (n_writes - the Gram cells in use)
     int cam_width = 6, cams_per_tile = kCamsPerTile;     // unknowns per camera (9 in bal9 mode) and cameras per 64-row tile
     int ordering = 0;                // 0 natural, 1 multi-way nested dissection of a band / ring, 3 nested dissection of an unordered camera graph, 2 reverse Cuthill-McKee (unordered
                                      // collections with viewpoint clusters: banded fill instead of a dense factor)
@@ -513,7 +514,7 @@ inline void dissect(int lo, int hi, int w, int leaf, int cap, const std::vector<
 // What the device-side key generation (ba_pack_dev.h: device_keys) hands to the plan instead of the key list: the blocks, the
 // sizes, and the launch buckets of the S assembly; slot_pair_ptr / pair_dst / blk_ptr / pairs_items stay on the device.
 struct PlanPrebuilt {
-    int n_pairs = 0, n_writes = 0;
+    int n_pairs = 0, n_writes = 0, n_pair_writes = 0;
     std::vector<int> blk_rc;
     int gram_n[8] = {0}, n_other = 0; size_t gram_shm[8] = {0};
 };
@@ -531,6 +532,13 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.n = CW * Nc;
     P.n_pairs = pre ? pre->n_pairs : spp[ns] + k.n_gt_cells;      // pair_dst: observation pairs | cells of the Gram tiles' tables
     P.n_writes = pre ? pre->n_writes : (int)keyed.size();
+    if (pre) P.n_pair_writes = pre->n_pair_writes;
+    else {
+        const int n_obs_pairs = spp[ns];
+        long long np = 0;
+        for (const auto& kv : keyed) np += (kv.second < n_obs_pairs);
+        P.n_pair_writes = (int)np;
+    }
     std::vector<unsigned long long> blk_keys;
     if (pre) {
         if (pattern) return XRSFM_BA_EINTERNAL;                  // (device keys are local-pattern only)
@@ -975,8 +983,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             if (P.sp_chunk_off[lv + 1] > P.sp_chunk_off[lv]) { ++n_split; nc_split += nc; }
         }
         fprintf(stderr, "[plan] %d tile columns, %d levels (%d split: %lld of %lld list entries), %d chunks in all, largest level %d targets, partial buffer %d tiles, %lld tile products; "
-                        "%d block entries of which %d Gram cells\n",
-                T, n_levels, n_split, nc_split, nc_all, (int)P.sp_tgt.size() / 2, max_nt, P.sp_max_chunks, P.tile_products, P.n_writes, k.n_gt_cells);
+                        "%d block entries of which %d per pair\n",
+                T, n_levels, n_split, nc_split, nc_all, (int)P.sp_tgt.size() / 2, max_nt, P.sp_max_chunks, P.tile_products, P.n_writes, P.n_pair_writes);
     }
     P.n_levels = n_levels;
     P.use_levels = (2 * n_levels <= T);

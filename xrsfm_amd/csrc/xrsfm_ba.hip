@@ -628,7 +628,7 @@ int chol_setup(xrsfm_ba_context* c) {
         for (auto& b : scratch) g_cache.put(c->device, b.first, b.second);
         if (e) return e;
         if (KR.duplicate) return kErrDuplicateObs;
-        pre.n_pairs = KR.n_pairs; pre.n_writes = KR.n_writes; pre.blk_rc = KR.blk_rc_host; pre.n_other = KR.n_other;
+        pre.n_pairs = KR.n_pairs; pre.n_writes = KR.n_writes; pre.n_pair_writes = KR.n_pair_writes; pre.blk_rc = KR.blk_rc_host; pre.n_other = KR.n_other;
         for (int b = 0; b < 8; ++b) { pre.gram_n[b] = KR.gram_n[b]; pre.gram_shm[b] = KR.gram_shm[b]; }
     } else {
         if ((e = ensure_host_pack(c, 1))) return e;
@@ -705,12 +705,14 @@ int chol_setup(xrsfm_ba_context* c) {
         if (c->wide) c->w.camS = both; else c->d.camS = both;
         h.Sblk = both + (size_t)Nc * cam_vals;
     }
-    {   // collections with long tracks (>= 4 M block entries = per-pair blocks + Gram cells in use): the blocks are formed from stored
-        // operands where they are summed (ba_kernels.h: k_chol_segsum_v) instead of being written per pair and read back;
-        // XRSFM_BA_PAIR_V=0 / 1 forces one form.  (A ragged sequential map — config R: 0.66 M entries, few of them per pair — is
-        // faster with the plain segmented sum: 45 us against 73.)
+    {   // problems whose block entries are mostly PER-PAIR blocks (tracks that fit no Gram tile: random visibility, the long tracks of a
+        // photo collection; >= 256 k of them and at least half of all entries): the blocks are formed from stored operands where they
+        // are summed (ba_kernels.h: k_chol_segsum_v) instead of being written per pair and read back; XRSFM_BA_PAIR_V=0 / 1 forces
+        // one form.  Measured per LM iteration, pairs + sum: config T 11.8 + 3.3 -> 1.3 + 4.4 ms, D 0.37 + 0.86 -> 0.18 + 0.43,
+        // U 0.19 + 0.13 -> 0.10 + 0.09; a ragged sequential map (config R: 0.66 M entries, most of them Gram cells) is faster with
+        // the plain segmented sum (45 us against 73).
         const char* pe = std::getenv("XRSFM_BA_PAIR_V");        // (read per set-up: the A/B test switches it)
-        h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : P.n_writes >= 4000000);
+        h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : (P.n_pair_writes >= 262144 && 2LL * P.n_pair_writes >= P.n_writes));
         if (h.pair_from_v) {
             const size_t ne = (size_t)std::max(1, P.n_writes);
             TRYC(dev_alloc(c, &h.ent_src, ne));
