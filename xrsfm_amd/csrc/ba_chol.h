@@ -1140,11 +1140,83 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
         if (part == 0) out[kNB * kNB + o] = sv;
     }
 }
-__global__ __launch_bounds__(256) void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr,
-                                                        const int* __restrict__ cj, double* __restrict__ Wp) {
+// The launch of its own (level schedules): the same products in the same order with ONE LDS image of the two half-tile operands
+// (35 KB) and the operands of one step ahead in registers (< 128 VGPRs): four workgroups per CU instead of the two the
+// double-buffered body above allows (70 KB, 236 VGPRs — built for k_panel_slot, where a chunk workgroup has its CU to itself).  A
+// chunk is short (six products at config T): its cold start and its partial-tile store are a quarter of its life, and with two
+// workgroups per CU nothing else runs meanwhile (matrix cores busy 61 % of a busy CU's cycles).  XBA_CHUNK_SB=0: the other body.
+#ifndef XBA_CHUNK_SB
+#define XBA_CHUNK_SB 1
+#endif
+__device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
+                                                       const int* __restrict__ cj, double* __restrict__ Wp, double* As, double* Bs, double* yv) {
+    const int i = tgt[2 * bx], k = tgt[2 * bx + 1];
+    const bool diag = (i == k);
+    v4d acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int q0 = qr[2 * bx], q1 = qr[2 * bx + 1];
+    const int t = threadIdx.x, o = t >> 2, part = t & 3;
+    double sv = 0.0;
+    v2d ra[4], rb[4];
+    {
+        const int j = cj[q0];
+        load_half_regs(ra, tile_ptr(c, i, j), c.ld);
+        load_half_regs(rb, tile_ptr(c, k, j), c.ld);
+    }
+    const int ns = 2 * (q1 - q0);
+    for (int s = 0; s < ns; ++s) {
+        const int kh = s & 1;
+        __syncthreads();                       // the previous half product no longer reads LDS
+        store_half_lds(As, ra);
+        store_half_lds(Bs, rb);
+        if (diag && kh == 0 && t < kNB) yv[t] = c.y[cj[q0 + (s >> 1)] * kNB + t];
+        __syncthreads();
+        if (s + 1 < ns) {
+            const int j = cj[q0 + ((s + 1) >> 1)], col = ((s + 1) & 1) * 32;
+            load_half_regs(ra, tile_ptr(c, i, j) + col, c.ld);
+            load_half_regs(rb, tile_ptr(c, k, j) + col, c.ld);
+        }
+        if (diag) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) sv += As[o * kLdH + part * 8 + m] * yv[kh * 32 + part * 8 + m];
+        }
+        half_abt_mfma(As, Bs, acc);
+    }
+    double* out = Wp + (size_t)bx * kPartStride;
+    {
+        const int lane = t & 63, wave = t >> 6;
+        const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n2 = 0; n2 < 2; ++n2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
+                    out[r * kNB + col] = acc[m][n2][g];
+                }
+    }
+    if (diag) {
+        sv += __shfl_xor(sv, 1, kWave);
+        sv += __shfl_xor(sv, 2, kWave);
+        if (part == 0) out[kNB * kNB + o] = sv;
+    }
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XBA_CHUNK_SB ? 4 : 1, XBA_CHUNK_SB ? 4 : 2)))
+void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr, const int* __restrict__ cj, double* __restrict__ Wp) {
+#if XBA_CHUNK_SB
+    __shared__ __attribute__((aligned(16))) double As[kNB * kLdH];
+    __shared__ __attribute__((aligned(16))) double Bs[kNB * kLdH];
+    __shared__ double yv[kNB];
+    ll_update_part_body_sb(c, blockIdx.x, tgt, qr, cj, Wp, As, Bs, yv);
+#else
     __shared__ __attribute__((aligned(16))) double lds[4 * kNB * kLdH];
     __shared__ double yv[2 * kNB];
     ll_update_part_body(c, blockIdx.x, tgt, qr, cj, Wp, lds, yv);
+#endif
 }
 
 // Dense part of a panel schedule: 128x128 macro tile = rows (i0,i1) x columns (k0,k1), contributions j in [q0,q1): every
