@@ -252,3 +252,24 @@ def test_dissection_of_a_disconnected_collection(monkeypatch):
     off = plan["cam_offset"]
     tiles_a, tiles_b = set((off[perm[:na]] // 64).tolist()), set((off[perm[na:]] // 64).tolist())
     assert not (tiles_a & tiles_b)                                   # parts start on tile boundaries: no tile mixes the collections
+
+
+@pytest.mark.parametrize("n_cams,cpc,seed", [(1000, 25, 1), (1600, 40, 2), (2200, 110, 3), (2400, 50, 9)])
+def test_dissected_plans_are_valid_permutations_and_cover_the_factorisation(monkeypatch, n_cams, cpc, seed):
+    """Collections of different cluster sizes (25 .. 110 photos per landmark, 100 .. 250 tile columns): whichever order the plan
+    takes (dissection or chain), every camera gets its own six rows, the plan's self-check passes (every product of the symbolic
+    factorisation covered exactly once by chunks / in-kernel lists), and forcing the other order (XRSFM_BA_ND=0) gives a valid plan
+    over the same blocks."""
+    from xrsfm_amd import synth
+    monkeypatch.setenv("XRSFM_BA_PLAN_CHECK", "1")
+    d = synth.make_collection(n_cams=n_cams, n_points=40 * n_cams, seed=seed, cams_per_cluster=cpc)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(plan, n_cams)
+    assert plan["ordering"] in (2, 3) and plan["tiles"] <= 256
+    if plan["ordering"] == 3:
+        assert plan["level_schedule"] == 1 and 2 * plan["levels"] <= plan["tiles"]
+    monkeypatch.setenv("XRSFM_BA_ND", "0")
+    chain = capi.debug_chol_plan(H.to_product(arr))
+    _check_layout(chain, n_cams)
+    assert chain["ordering"] == 2 and chain["blocks"] == plan["blocks"]
