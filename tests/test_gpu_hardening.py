@@ -430,13 +430,12 @@ def test_one_launch_backward_substitution_equals_level_launches(lib, monkeypatch
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["band", "ragged", "closures", "bal9"])
-def test_one_launch_split_level_equals_three_launches(lib, monkeypatch, case):
-    """Round 5: a thin level near the root of the elimination tree runs as ONE launch (k_lv_split: the chunk workgroups of an
-    entry store their partial tiles write-through, the last arrival on the entry's counter adds them in list order and factors)
-    instead of partial products -> fixed-order sums -> fused factor kernel.  Same chunks, same association of the sums: the solves
-    must be BIT-identical to the three launches (XRSFM_BA_SPLIT_FUSED=0), on a plain band, a ragged band (binary tree: six split
-    levels), a band with hub cameras and in bal9 mode; every plan must really have split levels that take the one-launch form.
-    Repeated solves of one context reuse the counters (left at zero by the last arrival): also bit-identical."""
+def test_split_level_sums_inside_the_factor_kernel_equal_the_sum_launch(lib, monkeypatch, case):
+    """Round 5: on a thin level near the root of the elimination tree the fused factor kernel adds the partial tiles of its two
+    targets itself (split_tile_sub: the association of the sum launch, 64 loads in flight) instead of waiting for a
+    k_ll_update_reduce launch between k_ll_update_part and k_lv_factor.  Same partials, same association: the solves must be
+    BIT-identical to the three launches (XRSFM_BA_SPLIT_SUM=0), on a plain band, a ragged band (binary tree: six split levels), a
+    band with hub cameras and in bal9 mode."""
     from xrsfm_amd import capi, synth
     if case == "band":
         arr = H.make(400, 20000, 4, seed=920)
@@ -450,14 +449,14 @@ def test_one_launch_split_level_equals_three_launches(lib, monkeypatch, case):
         arr = {k: arr[k] for k in capi.ProblemArrays.FIELDS}
     if case != "bal9":
         plan = capi.debug_chol_plan(H.to_product(arr))
-        assert plan["level_schedule"] == 1 and plan["levels"] >= 4 and plan["split_one_launch"] >= 1, plan
+        assert plan["level_schedule"] == 1 and plan["levels"] >= 4, plan
     res = {}
     for mode in ("1", "0"):
-        monkeypatch.setenv("XRSFM_BA_SPLIT_FUSED", mode)
+        monkeypatch.setenv("XRSFM_BA_SPLIT_SUM", mode)
         prod = H.to_product(arr)
         ctx = capi.Context(prod)
         runs = []
-        for rep in range(3 if mode == "1" else 1):
+        for rep in range(2 if mode == "1" else 1):
             ctx.reset()
             s = ctx.run(capi.default_options(max_iterations=12, linear_solver=1))
             q, t, P = ctx.download()
@@ -466,7 +465,7 @@ def test_one_launch_split_level_equals_three_launches(lib, monkeypatch, case):
         for r in runs[1:]:
             assert r[:3] == runs[0][:3] and all(np.array_equal(a, b) for a, b in zip(r[3:], runs[0][3:]))
         res[mode] = runs[0]
-    monkeypatch.delenv("XRSFM_BA_SPLIT_FUSED")
+    monkeypatch.delenv("XRSFM_BA_SPLIT_SUM")
     assert res["1"][0] + res["1"][1] >= 3
     assert res["1"][:3] == res["0"][:3]
     assert all(np.array_equal(a, b) for a, b in zip(res["1"][3:], res["0"][3:]))

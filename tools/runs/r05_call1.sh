@@ -24,3 +24,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py
 python $ROOT/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats_table.md > /dev/null
 rm -rf $OUT/stats
 head -30 $OUT/kernel_stats_table.md
+# RESULT (k_lv_split, removed again): bit-identical, but slower — L 6.31 -> 6.50 ms, R 17.1 -> 18.0, LP 14.9 -> 16.1, K 15.8 -> 16.2, S 2.14 -> 2.19;
+# k_lv_split 33.0 us per level against 6.95 + 5.71 + 16.5 for the three launches: the in-launch hand-off (write-through partial tiles,
+# drain, ticket, acquire, sc1 re-reads) costs what the two kernel boundaries and the sum launch cost.

@@ -445,7 +445,6 @@ def debug_chol_plan(problem: ProblemArrays) -> dict:
     keys = ("tiles", "levels", "ordering", "hubs", "band", "blocks", "level_schedule", "tiles_nz")
     out = dict(zip(keys, (int(v) for v in stats)))
     out["lookahead"] = (out["level_schedule"] >> 1) & 1      # panel schedule with partial products on a second stream (ba_plan.h)
-    out["split_one_launch"] = out["level_schedule"] >> 8     # split levels that run as one launch (k_lv_split)
     out["level_schedule"] &= 1
     out["cam_offset"] = off[:problem.n_cams].copy()
     return out

@@ -1148,8 +1148,6 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
 #ifndef XBA_CHUNK_SB
 #define XBA_CHUNK_SB 1
 #endif
-// WT: the partial tile leaves the CU write-through (agent-scope stores), for a consumer in the same launch (k_lv_split)
-template <bool WT>
 __device__ __forceinline__ void ll_chunk_product_sb(const CholDev& c, const int i, const int k, const int q0, const int q1,
                                                     const int* __restrict__ cj, double* out, double* As, double* Bs, double* yv) {
     const bool diag = (i == k);
@@ -1195,22 +1193,18 @@ __device__ __forceinline__ void ll_chunk_product_sb(const CholDev& c, const int 
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int r = r0 + 16 * m + (lane >> 4) + 4 * g, col = c0 + 16 * n2 + (lane & 15);
-                    if (WT) __hip_atomic_store(out + r * kNB + col, acc[m][n2][g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else out[r * kNB + col] = acc[m][n2][g];
+                    out[r * kNB + col] = acc[m][n2][g];
                 }
     }
     if (diag) {
         sv += __shfl_xor(sv, 1, kWave);
         sv += __shfl_xor(sv, 2, kWave);
-        if (part == 0) {
-            if (WT) __hip_atomic_store(out + kNB * kNB + o, sv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            else out[kNB * kNB + o] = sv;
-        }
+        if (part == 0) out[kNB * kNB + o] = sv;
     }
 }
 __device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
                                                        const int* __restrict__ cj, double* __restrict__ Wp, double* As, double* Bs, double* yv) {
-    ll_chunk_product_sb<false>(c, tgt[2 * bx], tgt[2 * bx + 1], qr[2 * bx], qr[2 * bx + 1], cj, Wp + (size_t)bx * kPartStride, As, Bs, yv);
+    ll_chunk_product_sb(c, tgt[2 * bx], tgt[2 * bx + 1], qr[2 * bx], qr[2 * bx + 1], cj, Wp + (size_t)bx * kPartStride, As, Bs, yv);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XBA_CHUNK_SB ? 4 : 1, XBA_CHUNK_SB ? 4 : 2)))
 void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr, const int* __restrict__ cj, double* __restrict__ Wp) {
@@ -1428,13 +1422,14 @@ __global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* 
 // (what k_tile_fill does: one launch and a global round trip of every level-0 tile less per LM iteration; a single-tile
 // system — LBA-sized calls — has no fill launch at all); workgroups >= n_factor compose the tiles of the other columns.
 struct LvFill { Dev d; FillLists f; const int* fz_q; const int* rest; int n_factor; };
-// One-launch split level (k_lv_split): the entry's tiles start from the assembled values MINUS the fixed-order sums of the partial
-// tiles its chunk workgroups wrote in this launch (own: target (i,k), piv: target (k,k); slots of Wp).
-struct LvSplit { double* Wp; int own0, own1, piv0, piv1; };
+// Split level, sums inside the factor launch (round 5): the entry's tiles start from the assembled values MINUS the fixed-order sums
+// of the partial tiles k_ll_update_part wrote (own: target (i,k), piv: target (k,k); level-relative slots of Wp) — no
+// k_ll_update_reduce launch between the two.
+struct LvSplit { const double* Wp; int own0, own1, piv0, piv1; };
 // tile (accumulator layout of tile_abt_mfma) -= sum of the partial tiles [p0,p1), every element with the association of sum_strided()
-// (what k_ll_update_reduce computes: bit-identical).  The partials were stored write-through by other workgroups of this launch
-// and the caller has passed its acquire: agent-scope loads, a batch of 4 partials x 16 elements in flight.
-__device__ __forceinline__ void split_tile_sub(double* Wp, int p0, int p1, v4d (&tile)[2][2], int r0, int c0, int lk, int li) {
+// (what k_ll_update_reduce computes: bit-identical), a batch of 4 partials x 16 elements in flight per round trip.  (Round 3
+// measured this fold with one dependent L2 round trip per partial and element group: 31 us per level.)
+__device__ __forceinline__ void split_tile_sub(const double* __restrict__ Wp, int p0, int p1, v4d (&tile)[2][2], int r0, int c0, int lk, int li) {
     const int n = p1 - p0;
     if (n <= 0) return;
     double sacc[16];
@@ -1446,7 +1441,7 @@ __device__ __forceinline__ void split_tile_sub(double* Wp, int p0, int p1, v4d (
 #pragma unroll
             for (int g = 0; g < 4; ++g) { sacc[(2 * m + n2) * 4 + g] = 0.0; eoff[(2 * m + n2) * 4 + g] = (r0 + 16 * m + lk + 4 * g) * kNB + c0 + 16 * n2 + li; }
     const double* base = Wp + (size_t)p0 * kPartStride;
-    auto ld = [&](int p, int e) { return __hip_atomic_load(base + (size_t)p * kPartStride + eoff[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ld = [&](int p, int e) { return base[(size_t)p * kPartStride + eoff[e]]; };
     int p = 0;
     for (; p + 8 <= n; p += 8) {
         double h0[16];
@@ -1499,19 +1494,8 @@ __device__ __forceinline__ void split_tile_sub(double* Wp, int p0, int p1, v4d (
             for (int g = 0; g < 4; ++g) tile[m][n2][g] -= sacc[(2 * m + n2) * 4 + g];
 }
 // ... and the 64 values sum_j L_kj y_j behind a diagonal target's partial tiles (thread t < 64), same association
-__device__ __forceinline__ double split_rhs_sum(double* Wp, int p0, int p1, int t) {
-    const int n = p1 - p0;
-    const double* base = Wp + (size_t)p0 * kPartStride + kNB * kNB + t;
-    double s = 0.0;
-    int p = 0;
-    for (; p + 8 <= n; p += 8) {
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = __hip_atomic_load(base + (size_t)(p + u) * kPartStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-    }
-    for (; p < n; ++p) s += __hip_atomic_load(base + (size_t)p * kPartStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return s;
+__device__ __forceinline__ double split_rhs_sum(const double* __restrict__ Wp, int p0, int p1, int t) {
+    return sum_strided(Wp + (size_t)p0 * kPartStride + kNB * kNB + t, kPartStride, p1 - p0);
 }
 // late / Ql (look-ahead schedule, else nullptr): per entry the partial slots of (k,k) and (i,k) whose tiles the accumulators start
 // from (the contribution of column k-2, formed by the previous launch), -1 none.
@@ -1577,7 +1561,7 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
                 akk[m][n2][g] = 0.0; aik[m][n2][g] = 0.0;
             }
     }
-    double rhs_sub = 0.0;           // (one-launch split level, diagonal entry) sum_j L_kj y_j of the partial products
+    double rhs_sub = 0.0;           // (split level, diagonal entry) sum_j L_kj y_j of the partial products
     if (!FILL && sp) {
         split_tile_sub(sp->Wp, sp->piv0, sp->piv1, skk, r0, c0, lk, li);
         if (!diag) split_tile_sub(sp->Wp, sp->own0, sp->own1, sik, r0, c0, lk, li);
@@ -1711,50 +1695,23 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
 #pragma unroll
             for (int g = 0; g < 4; ++g) Sik[(size_t)(r0 + 16 * m + lk + 4 * g) * ld + c0 + 16 * n2 + li] = acc[m][n2][g];
 }
+// sr (split level whose sums ride here, else nullptr): per entry the partial ranges own [p0,p1) | pivot [p0,p1) in Wp
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
                                                    const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
-                                                   LvFill lf) {
+                                                   LvFill lf, const int* __restrict__ sr = nullptr, const double* __restrict__ Wp = nullptr) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Xs[kNB][kLdT];
     __shared__ double Tb[3][16][17];
     __shared__ double yv[kNB], fv[kNB];
-    lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf, A, Li, Xs, Tb, yv, fv);
-}
-
-// A split level in ONE launch (round 5).  Thin levels near the root of the elimination tree ran as three dependent launches — partial
-// products, their fixed-order sums, the fused factor kernel (6.9 + 5.7 + 17.7 us + two kernel boundaries at config L, three such levels
-// per LM iteration).  Here every workgroup is a CHUNK of the list of one fused-kernel entry (ba_plan.h: sf_chunk — the entry's own
-// target, or once more its pivot's: no entry shares partials with another); it stores its partial tile write-through, drains, and
-// takes a ticket on the entry's counter (hand-off recipe R1 of the hardware guide in its counter form: nobody waits); the LAST
-// arrival passes one acquire, adds the entry's partial tiles in list order — the same association as k_ll_update_reduce — and goes on
-// as the factor workgroup of the entry.  Bit-identical to the three launches (XRSFM_BA_SPLIT_FUSED=0); the counter is left at zero.
-__global__ __launch_bounds__(256) void k_lv_split(CholDev c, const int* __restrict__ chunks, const int* __restrict__ ents, const int* __restrict__ tiles,
-                                                  const int* __restrict__ dptr, const int* __restrict__ cj, const int* __restrict__ tile_cam,
-                                                  double* __restrict__ px, double* Wp, unsigned* counters) {
-    __shared__ __attribute__((aligned(16))) double T3[3][kNB][kLdT];      // A | Li | Xs of the factor phase; the chunk's two half-tile operands overlay them
-    __shared__ double Tb[3][16][17];
-    __shared__ double yv[kNB], fv[kNB];
-    __shared__ bool last;
-    static_assert(2 * kNB * kLdH <= 3 * kNB * kLdT, "the chunk operands fit the factor tiles");
-    const int* ch = chunks + 5 * (size_t)blockIdx.x;
-    const int ti = ch[0], tk = ch[1], q0 = ch[2], q1 = ch[3], e = ch[4];
-    const int* en = ents + 5 * (size_t)e;
-    const int own0 = en[0], own1 = en[1], piv0 = en[2], piv1 = en[3], arrivals = en[4];
-    if (q1 > q0) {
-        double* As = &T3[0][0][0];
-        ll_chunk_product_sb<true>(c, ti, tk, q0, q1, cj, Wp + (size_t)blockIdx.x * kPartStride, As, As + kNB * kLdH, yv);
+    if (!FILL && sr) {
+        const int* r = sr + 4 * (size_t)blockIdx.x;
+        const LvSplit sp{Wp, r[0], r[1], r[2], r[3]};
+        lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf, A, Li, Xs, Tb, yv, fv, nullptr, nullptr, &sp);
+        return;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave drains its write-through stores
-    __syncthreads();
-    if (threadIdx.x == 0) last = (__hip_atomic_fetch_add(counters + e, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == (unsigned)arrivals);
-    __syncthreads();
-    if (!last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (threadIdx.x == 0) __hip_atomic_store(counters + e, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const LvSplit sp{Wp, own0, own1, piv0, piv1};
-    lv_factor_body<false>(c, e, tiles, dptr, nullptr, tile_cam, px, LvFill{}, T3[0], T3[1], T3[2], Tb, yv, fv, nullptr, nullptr, &sp);
+    lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf, A, Li, Xs, Tb, yv, fv);
 }
 
 // Look-ahead panel schedule (ba_plan.h: lookahead; level = column): ONE launch per column s.  Workgroups [0, n_factor): the

@@ -67,17 +67,11 @@ struct CholPlan {
     //                 (it then also contributes to tile (i,k)), ~j otherwise;
     //   split level:  empty lists (k_ll_update_part + k_ll_update_reduce have updated the tiles and the right-hand side in place).
     std::vector<int> fz_tile, fz_dptr, fz_dj, fz_off;
-    // split level in ONE launch (round 5, k_lv_split): every fused-kernel entry (i,k) of such a level owns the chunk workgroups of
-    // its two targets — (i,k) and, again for every tile of the column, the pivot (k,k): the partial products of a pivot are formed
-    // once per tile of its column, so that no workgroup of the launch waits for another entry's — and the LAST chunk to arrive on the
-    // entry's counter adds the partial tiles in list order and goes on as the entry's factor workgroup.  Same chunks, same order
-    // of the sums as k_ll_update_part -> k_ll_update_reduce -> k_lv_factor (bit-identical; that path stays for wide levels).
-    //   sf_chunk: per workgroup 5 ints (i, k) of the target, [q0,q1) in lv_cj (empty: an entry without contributions), entry (level-relative);
-    //             its partial slot is its index within the level
-    //   sf_ent:   per fused-kernel entry (same order as fz_tile) 5 ints: own partial range [p0,p1), pivot range [p0,p1), arrivals
-    //   sf_off:   per level (size n_levels+1) offsets into sf_chunk; empty range = the level runs the three-launch form
-    std::vector<int> sf_chunk, sf_ent, sf_off;
-    int sf_max_wg = 0;
+    // split level of a plain level schedule (round 5): the fused factor kernel adds the partial tiles itself — per fused-kernel entry
+    // (same order as fz_tile) the level-relative partial ranges of its own target (i,k) and of its pivot (k,k), 4 ints (empty
+    // ranges: nothing to add); sr_level[lv] != 0: the level runs k_ll_update_part -> k_lv_factor, no k_ll_update_reduce between them
+    std::vector<int> sr_ent;
+    std::vector<char> sr_level;
     // look-ahead schedule: the contribution of column k - 2 to column k is formed in the launch of column k - 1 — one single-product
     // chunk per tile (md_tgt: (i,k); md_q: its entry in md_cj), written to partial slot = its index within the level — and the
     // factor kernel of column k starts its accumulators from it: fz_late, per fused-kernel entry the slot of (k,k) and of (i,k), -1 none
@@ -812,7 +806,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     P.sp_chunk_off.assign(n_levels + 1, 0); P.sp_rt_off.assign(n_levels + 1, 0);
     P.mp_off.assign(n_levels + 1, 0);
     P.fz_off.assign(n_levels + 1, 0); P.fz_dptr.assign(1, 0);
-    P.sf_off.assign(1, 0);
     P.md_off.assign(1, 0);
     std::vector<int> level_cols(n_levels, 0), level_first(n_levels, -1);
     for (int kk = 0; kk < T; ++kk) { if (level_cols[level[kk]]++ == 0) level_first[level[kk]] = kk; }
@@ -891,9 +884,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         //  worth cutting is split, as on the panel schedule)
         const bool nd_lv = P.ordering == 3 && !panel_ll;
         const bool split = !macro && !second && (lookahead ? nc > 0 : ((panel_ll || nd_lv) ? (nt > 0 && nc > 2 * nt) : (nt > 0 && nt <= 128 && nc > 2 * nt)));
-        int split_cs = 0;                     // chunk length of a split level (0: not split)
-        bool sf_fits = false;                 // ... and its one-launch form fits one round of workgroups
-        const int sf_cap = std::getenv("XRSFM_BA_SPLIT_CAP") ? std::atoi(std::getenv("XRSFM_BA_SPLIT_CAP")) : 256;
         if (macro) {
             // every macro target's j range is cut into chunks of >= panel_min_chunk steps, ~macro_chunks chunks per level (about two
             // rounds of resident workgroups: measured faster than one round of equal shares, whose partial-tile stores all
@@ -945,23 +935,10 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             //  factorisations — the chunks are bound by their operand traffic, 64 KB per product, not by their number)
             const int la_chunk = std::getenv("XRSFM_BA_LA_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_LA_CHUNK"))) : 6;
             const int nd_chunk = std::getenv("XRSFM_BA_ND_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_ND_CHUNK"))) : 6;
-            int cs = lookahead ? std::max(la_chunk, (nc + panel_chunks - 1) / panel_chunks)
+            const int cs = lookahead ? std::max(la_chunk, (nc + panel_chunks - 1) / panel_chunks)
                          : panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks)
                          : nd_lv ? std::max(nd_chunk, (nc + 4095) / 4096) : std::max(1, (nc + 511) / 512);
-            if (!lookahead && !panel_ll && !nd_lv) {
-                // (round 5) the level as ONE launch (k_lv_split, below): its workgroups — the chunks of every entry's own list and, again
-                // per entry, of its pivot's — must fit one round of the chip (109 KB of LDS each: one per CU); longer chunks where they
-                // do not (up to 4 x; the same chunks serve the three-launch form, so the two stay bit-identical), else three launches
-                auto workgroups = [&](int len) {
-                    auto chunks_of = [&](int i, int k2) { for (int g = g0; g < g1; ++g) if (P.lv_tgt[2 * g] == i && P.lv_tgt[2 * g + 1] == k2) return (P.lv_cptr[g + 1] - P.lv_cptr[g] + len - 1) / len; return 0; };
-                    int nw = 0;
-                    for (const FzEnt& e : fz_ents) { const int a = chunks_of(e.i, e.k) + (e.i == e.k ? 0 : chunks_of(e.k, e.k)); nw += std::max(1, a); }
-                    return nw;
-                };
-                for (int mul = 1; mul <= 4; ++mul) if (workgroups(cs * mul) <= sf_cap) { cs *= mul; sf_fits = true; break; }
-            }
             int np = 0;
-            split_cs = cs;
             for (int g = g0; g < g1; ++g) {
                 const int p0 = np;
                 for (int q = P.lv_cptr[g]; q < P.lv_cptr[g + 1]; q += cs, ++np) {
@@ -1002,43 +979,23 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             P.fz_dptr.push_back((int)P.fz_dj.size());
         }
         P.fz_off[lv + 1] = (int)P.fz_tile.size() / 2;
-        {   // the split level as one launch (k_lv_split): the chunk workgroups of every entry, own target first, then its pivot's
-            P.sf_ent.resize(5 * (P.fz_tile.size() / 2), 0);
-            const bool eligible = split_cs > 0 && sf_fits && !lookahead && !panel_ll && !nd_lv && !macro;
-            if (eligible) {
-                const int c0 = (int)P.sf_chunk.size() / 5;
-                auto target_of = [&](int i, int k2) { for (int g = g0; g < g1; ++g) if (P.lv_tgt[2 * g] == i && P.lv_tgt[2 * g + 1] == k2) return g; return -1; };
-                int nw = 0;
-                const int e0 = P.fz_off[lv], e1 = P.fz_off[lv + 1];
-                for (int e = e0; e < e1; ++e) {
+        {   // sums of a split level inside the factor launch: the partial ranges of every entry's own target and of its pivot
+            P.sr_ent.resize(4 * (P.fz_tile.size() / 2), 0);
+            const bool fold = split && !macro && !lookahead && !panel_ll && !nd_lv;
+            P.sr_level.push_back(fold ? 1 : 0);
+            if (fold) {
+                const int r0 = P.sp_rt_off[lv];                  // the level's targets in sp_rt / sp_rp (appended by the split block above)
+                const int r1 = (int)P.sp_rt.size() / 2;
+                auto range_of = [&](int i, int k2, int* out) {
+                    out[0] = out[1] = 0;
+                    for (int r = r0; r < r1; ++r) if (P.sp_rt[2 * (size_t)r] == i && P.sp_rt[2 * (size_t)r + 1] == k2) { out[0] = P.sp_rp[2 * (size_t)r]; out[1] = P.sp_rp[2 * (size_t)r + 1]; }
+                };
+                for (int e = P.fz_off[lv]; e < P.fz_off[lv + 1]; ++e) {
                     const int i = P.fz_tile[2 * (size_t)e], k2 = P.fz_tile[2 * (size_t)e + 1];
-                    int* ent = &P.sf_ent[5 * (size_t)e];
-                    int range[2][2];
-                    for (int w = 0; w < 2; ++w) {                // 0: own target (i,k), 1: the pivot (k,k) of an off-diagonal entry
-                        range[w][0] = nw;
-                        const int g = (w == 1 && i == k2) ? -1 : target_of(w == 0 ? i : k2, k2);
-                        if (g >= 0)
-                            for (int q = P.lv_cptr[g]; q < P.lv_cptr[g + 1]; q += split_cs, ++nw) {
-                                const int ch[5] = {P.lv_tgt[2 * g], P.lv_tgt[2 * g + 1], q, std::min(q + split_cs, P.lv_cptr[g + 1]), e - e0};
-                                P.sf_chunk.insert(P.sf_chunk.end(), ch, ch + 5);
-                            }
-                        range[w][1] = nw;
-                    }
-                    if (i == k2) { range[1][0] = range[0][0]; range[1][1] = range[0][1]; }
-                    int arrivals = (range[0][1] - range[0][0]) + (i == k2 ? 0 : range[1][1] - range[1][0]);
-                    if (arrivals == 0) {                         // nothing to add: one workgroup that goes straight to the factorisation
-                        const int ch[5] = {i, k2, 0, 0, e - e0};
-                        P.sf_chunk.insert(P.sf_chunk.end(), ch, ch + 5);
-                        ++nw; arrivals = 1;
-                    }
-                    ent[0] = range[0][0]; ent[1] = range[0][1]; ent[2] = range[1][0]; ent[3] = range[1][1]; ent[4] = arrivals;
+                    range_of(i, k2, &P.sr_ent[4 * (size_t)e]);
+                    range_of(k2, k2, &P.sr_ent[4 * (size_t)e + 2]);
                 }
-                if (nw > sf_cap) {              // (not reached: sf_fits counted the same workgroups)
-                    P.sf_chunk.resize(5 * (size_t)c0);
-                    std::fill(P.sf_ent.begin() + 5 * (size_t)e0, P.sf_ent.end(), 0);
-                } else P.sf_max_wg = std::max(P.sf_max_wg, nw);
             }
-            P.sf_off.push_back((int)P.sf_chunk.size() / 5);
         }
         P.sp_chunk_off[lv + 1] = (int)P.sp_tgt.size() / 2;
         P.sp_rt_off[lv + 1] = (int)P.sp_rt.size() / 2;
@@ -1067,10 +1024,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         if (n_levels <= 16)
             for (int lv = 0; lv < n_levels; ++lv) {
                 const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
-                fprintf(stderr, "[plan]   level %d: %d columns, %d factor tiles, %d targets with %d list entries, %d chunks, %d fused list entries\n", lv, level_cols[lv],
+                fprintf(stderr, "[plan]   level %d: %d columns, %d factor tiles, %d targets with %d list entries, %d chunks%s, %d fused list entries\n", lv, level_cols[lv],
                         P.fz_off[lv + 1] - P.fz_off[lv], g1 - g0, g1 > g0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0, P.sp_chunk_off[lv + 1] - P.sp_chunk_off[lv],
-                        P.fz_dptr[P.fz_off[lv + 1]] - P.fz_dptr[P.fz_off[lv]]);
-                if (P.sf_off[lv + 1] > P.sf_off[lv]) fprintf(stderr, "[plan]            one launch: %d workgroups\n", P.sf_off[lv + 1] - P.sf_off[lv]);
+                        P.sr_level[lv] ? " (summed by the factor kernel)" : "", P.fz_dptr[P.fz_off[lv + 1]] - P.fz_dptr[P.fz_off[lv]]);
             }
     }
     P.n_levels = n_levels;
@@ -1163,43 +1119,20 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             for (long long o2 : owner) written += (o2 != -1);
             if (read != written || (long long)owner.size() > (long long)P.sp_max_chunks) return kErrPlanCheck;
         }
-        // ... and the one-launch form of a split level (sf_*): the chunk workgroups of an entry cover the lists of its own target and of
-        // its pivot, in list order, each exactly once; arrivals = its workgroups; an entry without lists has one empty workgroup
+        // ... and where the factor kernel adds a split level's partial tiles itself (sr_ent), every entry names exactly the partial
+        // ranges the sum launch would have added into its own tile and into its pivot
         for (int lv = 0; lv < n_levels; ++lv) {
-            const int w0 = P.sf_off[lv], w1 = P.sf_off[lv + 1];
-            if (w1 == w0) continue;
-            const int e0 = P.fz_off[lv], e1 = P.fz_off[lv + 1];
-            const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
-            auto list_of = [&](int i, int k2, int& q0, int& q1) {
-                q0 = q1 = 0;
-                for (int g = g0; g < g1; ++g) if (P.lv_tgt[2 * g] == i && P.lv_tgt[2 * g + 1] == k2) { q0 = P.lv_cptr[g]; q1 = P.lv_cptr[g + 1]; }
-            };
-            int seen = 0;
-            for (int e = e0; e < e1; ++e) {
+            if (!P.sr_level[lv]) continue;
+            for (int e = P.fz_off[lv]; e < P.fz_off[lv + 1]; ++e) {
                 const int i = P.fz_tile[2 * (size_t)e], k2 = P.fz_tile[2 * (size_t)e + 1];
-                const int* ent = &P.sf_ent[5 * (size_t)e];
-                int mine = 0;
-                for (int w = 0; w < (i == k2 ? 1 : 2); ++w) {
-                    int q0, q1; list_of(w == 0 ? i : k2, k2, q0, q1);
-                    int q = q0;
-                    for (int p2 = ent[2 * w]; p2 < ent[2 * w + 1]; ++p2, ++mine) {
-                        if (p2 < 0 || p2 >= w1 - w0) return kErrPlanCheck;
-                        const int* ch = &P.sf_chunk[5 * (size_t)(w0 + p2)];
-                        if (ch[0] != (w == 0 ? i : k2) || ch[1] != k2 || ch[2] != q || ch[3] <= ch[2] || ch[3] > q1 || ch[4] != e - e0) return kErrPlanCheck;
-                        q = ch[3];
-                    }
-                    if (q != q1) return kErrPlanCheck;
+                for (int w = 0; w < 2; ++w) {
+                    const int ti = w ? k2 : i;
+                    int want0 = 0, want1 = 0;
+                    for (int r = P.sp_rt_off[lv]; r < P.sp_rt_off[lv + 1]; ++r)
+                        if (P.sp_rt[2 * (size_t)r] == ti && P.sp_rt[2 * (size_t)r + 1] == k2) { want0 = P.sp_rp[2 * (size_t)r]; want1 = P.sp_rp[2 * (size_t)r + 1]; }
+                    if (P.sr_ent[4 * (size_t)e + 2 * w] != want0 || P.sr_ent[4 * (size_t)e + 2 * w + 1] != want1) return kErrPlanCheck;
                 }
-                if (i == k2 && (ent[2] != ent[0] || ent[3] != ent[1])) return kErrPlanCheck;
-                if (mine == 0) {          // the empty workgroup
-                    const int* ch = &P.sf_chunk[5 * (size_t)(w0 + seen)];
-                    if (ch[2] != ch[3] || ch[4] != e - e0) return kErrPlanCheck;
-                    mine = 1;
-                }
-                if (ent[4] != mine) return kErrPlanCheck;
-                seen += mine;
             }
-            if (seen != w1 - w0 || seen > P.sf_max_wg) return kErrPlanCheck;
         }
         for (int k2 = 0; k2 < T; ++k2)
             for (int j = 0; j < T; ++j) {

@@ -132,7 +132,7 @@ struct CholHost {
     int *md_tgt = nullptr, *md_q = nullptr, *md_cj = nullptr, *fz_late = nullptr;        // look-ahead schedule: late partials (ba_plan.h)
     std::vector<int> md_off; int md_max = 0; double* md_work = nullptr;
     int *fz_q = nullptr, *fill_rest = nullptr; int n_fill_rest = 0;    // tile fill inside the first level's launch
-    int *sf_chunk = nullptr, *sf_ent = nullptr; unsigned* sf_ctr = nullptr; std::vector<int> sf_off; bool split_fused = false;   // split levels in one launch (k_lv_split)
+    int* sr_ent = nullptr; std::vector<char> sr_level;                 // split levels whose partial tiles the factor kernel adds itself (ba_plan.h)
     bool S_filled = false;                                   // chol_assemble ran k_tile_fill (else the first level composes its tiles)
     std::vector<int> fz_off;
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
@@ -688,22 +688,18 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
     up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
     up.add(&h.fz_q, P.fz_q); up.add(&h.fill_rest, P.fill_rest); h.n_fill_rest = (int)P.fill_rest.size();
-    {   // split levels in one launch (XRSFM_BA_SPLIT_FUSED=0: partial products, sums and factorisation as three launches — the A/B oracle)
-        const char* sfe = std::getenv("XRSFM_BA_SPLIT_FUSED");        // (read per set-up: the A/B test switches it inside one process)
-        h.split_fused = !(sfe && sfe[0] == '0') && !P.sf_chunk.empty();
-        h.sf_off = P.sf_off;
-        if (h.split_fused) { up.add(&h.sf_chunk, P.sf_chunk); up.add(&h.sf_ent, P.sf_ent); }
+    {   // XRSFM_BA_SPLIT_SUM=0: the partial tiles of a split level are added by a launch of their own (k_ll_update_reduce) — the A/B oracle
+        const char* sse = std::getenv("XRSFM_BA_SPLIT_SUM");          // (read per set-up: the A/B test switches it inside one process)
+        h.sr_level = P.sr_level;
+        if (sse && sse[0] == '0') std::fill(h.sr_level.begin(), h.sr_level.end(), 0);
+        up.add(&h.sr_ent, P.sr_ent);
     }
     up.add(&h.md_tgt, P.md_tgt); up.add(&h.md_q, P.md_q); up.add(&h.md_cj, P.md_cj); up.add(&h.fz_late, P.fz_late);
     h.md_off = P.md_off; h.md_max = P.md_max;
     up.add(&h.tile_cam, P.tile_cam);
     if (dev_keys) h.pairs_items = KR.pairs_items; else up.add(&h.pairs_items, P.pairs_items);
     h.sp_max_chunks = P.sp_max_chunks;
-    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, std::max(P.sp_max_chunks, h.split_fused ? P.sf_max_wg : 0)) * kPartStride * (P.lookahead ? 2 : 1)));
-    if (h.split_fused) {
-        TRYC(dev_alloc(c, &h.sf_ctr, P.fz_tile.size() / 2 + 1));
-        HIPCHK(hipMemsetAsync(h.sf_ctr, 0, sizeof(unsigned) * (P.fz_tile.size() / 2 + 1), c->stream));
-    }
+    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
     if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
     up.add(&d_cam_off, P.cam_off); up.add(&d_tile_rows, P.tile_rows); up.add(&d_tmap, P.tile_map);
     TRYC(up.flush());
@@ -978,21 +974,13 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
             const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
             const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
-            const int nsf = h.split_fused ? h.sf_off[lv + 1] - h.sf_off[lv] : 0;
-            if (nsf > 0) {
-                // split level in one launch: chunk workgroups, the last arrival of an entry sums and factors (k_lv_split)
-                const bool bwd_here = ((!h.panel_ll && !h.bwd_push && !h.bwd_chunk) || T == 1) && lv == h.n_levels - 1;
-                LAUNCH(c, K_POTRF, k_lv_split, dim3(nsf), dim3(256), 0, h.dev, (const int*)(h.sf_chunk + 5 * (size_t)h.sf_off[lv]), (const int*)(h.sf_ent + 5 * (size_t)h.fz_off[lv]),
-                       (const int*)(h.fz_tile + 2 * (size_t)h.fz_off[lv]), (const int*)(h.fz_dptr + h.fz_off[lv]), (const int*)h.lv_cj, (const int*)h.tile_cam,
-                       bwd_here ? px_out : (double*)nullptr, h.sp_work, h.sf_ctr + h.fz_off[lv]);
-                continue;
-            }
             if (nmc > 0)
                 LAUNCH(c, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
             else if (nch > 0)
                 LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
                        h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-            if (nrt > 0)
+            const bool sum_in_factor = nch > 0 && nmc <= 0 && lv < (int)h.sr_level.size() && h.sr_level[lv];
+            if (nrt > 0 && !sum_in_factor)
                 LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
@@ -1016,7 +1004,8 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                            (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
             } else if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
-                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
+                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf,
+                       sum_in_factor ? (const int*)(h.sr_ent + 4 * (size_t)h.fz_off[lv]) : (const int*)nullptr, (const double*)h.sp_work);
         }
         if (h.panel_ll || h.bwd_push) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
@@ -2333,11 +2322,6 @@ int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_
     if ((e = chol_plan_build(k, spp, keyed, nullptr, P, kCholMaxN, kCholMaxBytes, wide ? kW : 6))) return e == kErrPlanCheck ? XRSFM_BA_EINTERNAL : e;
     stats[0] = P.T; stats[1] = P.n_levels; stats[2] = P.ordering; stats[3] = P.n_hubs; stats[4] = P.band; stats[5] = P.n_blocks;
     stats[6] = (P.use_levels ? 1 : 0) | (P.lookahead ? 2 : 0); stats[7] = P.n_tiles_nz;
-    {   // bits 8..: split levels that take the one-launch form (k_lv_split)
-        int n_sf = 0;
-        for (size_t lv = 0; lv + 1 < P.sf_off.size(); ++lv) n_sf += (P.sf_off[lv + 1] > P.sf_off[lv]);
-        stats[6] |= n_sf << 8;
-    }
     if (cam_offset) for (int i = 0; i < k.n_cams; ++i) cam_offset[i] = P.cam_off[i];
     return 0;
 }
