@@ -426,46 +426,3 @@ def test_one_launch_backward_substitution_equals_level_launches(lib, monkeypatch
     assert res["1"][:3] == res["0"][:3]
     assert all(np.array_equal(a, b) for a, b in zip(res["1"][3:], res["0"][3:]))
 
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("case", ["band", "ragged", "closures", "bal9"])
-def test_split_level_sums_inside_the_factor_kernel_equal_the_sum_launch(lib, monkeypatch, case):
-    """Round 5: on a thin level near the root of the elimination tree the fused factor kernel adds the partial tiles of its two
-    targets itself (split_tile_sub: the association of the sum launch, 64 loads in flight) instead of waiting for a
-    k_ll_update_reduce launch between k_ll_update_part and k_lv_factor.  Same partials, same association: the solves must be
-    BIT-identical to the three launches (XRSFM_BA_SPLIT_SUM=0), on a plain band, a ragged band (binary tree: six split levels), a
-    band with hub cameras and in bal9 mode."""
-    from xrsfm_amd import capi, synth
-    if case == "band":
-        arr = H.make(400, 20000, 4, seed=920)
-    elif case == "ragged":
-        arr = H.make(300, 20000, 8, seed=921, dropout=0.35)
-    elif case == "closures":
-        d = synth.make_problem(n_cams=500, n_points=30000, k_obs=4, seed=922, n_hubs=24, hub_tracks=10)
-        arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
-    else:
-        arr = synth.to_bal9(synth.make_problem(n_cams=200, n_points=12000, k_obs=4, seed=923))
-        arr = {k: arr[k] for k in capi.ProblemArrays.FIELDS}
-    if case != "bal9":
-        plan = capi.debug_chol_plan(H.to_product(arr))
-        assert plan["level_schedule"] == 1 and plan["levels"] >= 4, plan
-    res = {}
-    for mode in ("1", "0"):
-        monkeypatch.setenv("XRSFM_BA_SPLIT_SUM", mode)
-        prod = H.to_product(arr)
-        ctx = capi.Context(prod)
-        runs = []
-        for rep in range(2 if mode == "1" else 1):
-            ctx.reset()
-            s = ctx.run(capi.default_options(max_iterations=12, linear_solver=1))
-            q, t, P = ctx.download()
-            runs.append((s.n_successful, s.n_unsuccessful, s.final_cost, q.copy(), t.copy(), P.copy()))
-        ctx.close()
-        for r in runs[1:]:
-            assert r[:3] == runs[0][:3] and all(np.array_equal(a, b) for a, b in zip(r[3:], runs[0][3:]))
-        res[mode] = runs[0]
-    monkeypatch.delenv("XRSFM_BA_SPLIT_SUM")
-    assert res["1"][0] + res["1"][1] >= 3
-    assert res["1"][:3] == res["0"][:3]
-    assert all(np.array_equal(a, b) for a, b in zip(res["1"][3:], res["0"][3:]))

@@ -24,3 +24,6 @@ rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- python $ROOT/bench.py
 python $ROOT/tools/rocprof_summary.py $(find $OUT/stats -name "*.db" | head -1) $OUT/kernel_stats_table.md > /dev/null
 rm -rf $OUT/stats
 head -30 $OUT/kernel_stats_table.md
+# RESULT (sums of a split level inside k_lv_factor, removed again): bit-identical, but slower — L 6.42 -> 6.54 ms, R 17.2 -> 18.0, LP 14.9 -> 16.1,
+# K 15.8 -> 16.3, S 2.17 -> 2.23: the factor workgroup of a thin level pays 8-11 us for 2-5 dependent round trips of 64 loads (k_lv_factor 16.5 ->
+# 25.6 us) where the sum launch spreads the same loads over 16 workgroups per target (5.7 us + a kernel boundary).

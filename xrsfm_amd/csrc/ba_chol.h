@@ -1148,14 +1148,16 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
 #ifndef XBA_CHUNK_SB
 #define XBA_CHUNK_SB 1
 #endif
-__device__ __forceinline__ void ll_chunk_product_sb(const CholDev& c, const int i, const int k, const int q0, const int q1,
-                                                    const int* __restrict__ cj, double* out, double* As, double* Bs, double* yv) {
+__device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
+                                                       const int* __restrict__ cj, double* __restrict__ Wp, double* As, double* Bs, double* yv) {
+    const int i = tgt[2 * bx], k = tgt[2 * bx + 1];
     const bool diag = (i == k);
     v4d acc[2][2];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n2 = 0; n2 < 2; ++n2) acc[m][n2] = (v4d){0.0, 0.0, 0.0, 0.0};
+    const int q0 = qr[2 * bx], q1 = qr[2 * bx + 1];
     const int t = threadIdx.x, o = t >> 2, part = t & 3;
     double sv = 0.0;
     v2d ra[4], rb[4];
@@ -1183,6 +1185,7 @@ __device__ __forceinline__ void ll_chunk_product_sb(const CholDev& c, const int 
         }
         half_abt_mfma(As, Bs, acc);
     }
+    double* out = Wp + (size_t)bx * kPartStride;
     {
         const int lane = t & 63, wave = t >> 6;
         const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
@@ -1201,10 +1204,6 @@ __device__ __forceinline__ void ll_chunk_product_sb(const CholDev& c, const int 
         sv += __shfl_xor(sv, 2, kWave);
         if (part == 0) out[kNB * kNB + o] = sv;
     }
-}
-__device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
-                                                       const int* __restrict__ cj, double* __restrict__ Wp, double* As, double* Bs, double* yv) {
-    ll_chunk_product_sb(c, tgt[2 * bx], tgt[2 * bx + 1], qr[2 * bx], qr[2 * bx + 1], cj, Wp + (size_t)bx * kPartStride, As, Bs, yv);
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XBA_CHUNK_SB ? 4 : 1, XBA_CHUNK_SB ? 4 : 2)))
 void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr, const int* __restrict__ cj, double* __restrict__ Wp) {
@@ -1422,89 +1421,13 @@ __global__ __launch_bounds__(256) void k_ll_update_reduce(CholDev c, const int* 
 // (what k_tile_fill does: one launch and a global round trip of every level-0 tile less per LM iteration; a single-tile
 // system — LBA-sized calls — has no fill launch at all); workgroups >= n_factor compose the tiles of the other columns.
 struct LvFill { Dev d; FillLists f; const int* fz_q; const int* rest; int n_factor; };
-// Split level, sums inside the factor launch (round 5): the entry's tiles start from the assembled values MINUS the fixed-order sums
-// of the partial tiles k_ll_update_part wrote (own: target (i,k), piv: target (k,k); level-relative slots of Wp) — no
-// k_ll_update_reduce launch between the two.
-struct LvSplit { const double* Wp; int own0, own1, piv0, piv1; };
-// tile (accumulator layout of tile_abt_mfma) -= sum of the partial tiles [p0,p1), every element with the association of sum_strided()
-// (what k_ll_update_reduce computes: bit-identical), a batch of 4 partials x 16 elements in flight per round trip.  (Round 3
-// measured this fold with one dependent L2 round trip per partial and element group: 31 us per level.)
-__device__ __forceinline__ void split_tile_sub(const double* __restrict__ Wp, int p0, int p1, v4d (&tile)[2][2], int r0, int c0, int lk, int li) {
-    const int n = p1 - p0;
-    if (n <= 0) return;
-    double sacc[16];
-    int eoff[16];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) { sacc[(2 * m + n2) * 4 + g] = 0.0; eoff[(2 * m + n2) * 4 + g] = (r0 + 16 * m + lk + 4 * g) * kNB + c0 + 16 * n2 + li; }
-    const double* base = Wp + (size_t)p0 * kPartStride;
-    auto ld = [&](int p, int e) { return base[(size_t)p * kPartStride + eoff[e]]; };
-    int p = 0;
-    for (; p + 8 <= n; p += 8) {
-        double h0[16];
-        {
-            double v[4][16];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[u][e] = ld(p + u, e);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) h0[e] = (v[0][e] + v[1][e]) + (v[2][e] + v[3][e]);
-        }
-        {
-            double v[4][16];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) v[u][e] = ld(p + 4 + u, e);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) sacc[e] += h0[e] + ((v[0][e] + v[1][e]) + (v[2][e] + v[3][e]));
-        }
-    }
-    for (; p + 4 <= n; p += 4) {
-        double v[4][16];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[u][e] = ld(p + u, e);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { sacc[e] += v[0][e]; sacc[e] += v[1][e]; sacc[e] += v[2][e]; sacc[e] += v[3][e]; }
-    }
-    if (p < n) {
-        double v[3][16];
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) v[u][e] = (p + u < n) ? ld(p + u, e) : 0.0;
-#pragma unroll
-        for (int u = 0; u < 3; ++u)
-            if (p + u < n) {
-#pragma unroll
-                for (int e = 0; e < 16; ++e) sacc[e] += v[u][e];
-            }
-    }
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) tile[m][n2][g] -= sacc[(2 * m + n2) * 4 + g];
-}
-// ... and the 64 values sum_j L_kj y_j behind a diagonal target's partial tiles (thread t < 64), same association
-__device__ __forceinline__ double split_rhs_sum(const double* __restrict__ Wp, int p0, int p1, int t) {
-    return sum_strided(Wp + (size_t)p0 * kPartStride + kNB * kNB + t, kPartStride, p1 - p0);
-}
 // late / Ql (look-ahead schedule, else nullptr): per entry the partial slots of (k,k) and (i,k) whose tiles the accumulators start
 // from (the contribution of column k-2, formed by the previous launch), -1 none.
 template <bool FILL>
 __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, const int* __restrict__ tiles, const int* __restrict__ dptr,
                                                const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
                                                const LvFill& lf, double (*A)[kLdT], double (*Li)[kLdT], double (*Xs)[kLdT], double (*Tb)[16][17],
-                                               double* yv, double* fv, const int* __restrict__ late = nullptr, const double* __restrict__ Ql = nullptr,
-                                               const LvSplit* sp = nullptr) {
+                                               double* yv, double* fv, const int* __restrict__ late = nullptr, const double* __restrict__ Ql = nullptr) {
     // LDS of the calling kernel: A, Li, Xs [kNB][kLdT], Tb [3][16][17], yv, fv [kNB].  Xs: off-diagonal workgroup: A_ik - update, parked
     // there while the pivot tile is factored (it used to stay in 64 registers across potrf_lds: with them the in-register 16x16
     // factorisation ran out of architectural VGPRs and copied every broadcast value through AGPRs — 4 of its 8 instructions per column
@@ -1560,12 +1483,6 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
                 sik[m][n2][g] = diag ? 0.0 : Sik[(size_t)r * ld + col];
                 akk[m][n2][g] = 0.0; aik[m][n2][g] = 0.0;
             }
-    }
-    double rhs_sub = 0.0;           // (split level, diagonal entry) sum_j L_kj y_j of the partial products
-    if (!FILL && sp) {
-        split_tile_sub(sp->Wp, sp->piv0, sp->piv1, skk, r0, c0, lk, li);
-        if (!diag) split_tile_sub(sp->Wp, sp->own0, sp->own1, sik, r0, c0, lk, li);
-        else if (t < kNB) rhs_sub = split_rhs_sum(sp->Wp, sp->own0, sp->own1, t);
     }
     const int late_kk = (!FILL && late) ? late[2 * b] : -1, late_ik = (!FILL && late) ? late[2 * b + 1] : -1;
     if (late_kk >= 0) {            // (requested with the assembled tiles: no round trip of its own)
@@ -1653,7 +1570,7 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
             const int e = t + 256 * it; const int r = e >> 5, col = (e & 31) * 2;
             reinterpret_cast<double2*>(lo)[e] = make_double2((col <= r) ? Li[r][col] : 0.0, (col + 1 <= r) ? Li[r][col + 1] : 0.0);
         }
-        if (t < kNB) yv[t] = (FILL ? rhs_k : ((!FILL && sp) ? c.rhs[k * kNB + t] - rhs_sub : c.rhs[k * kNB + t])) - fv[t];
+        if (t < kNB) yv[t] = (FILL ? rhs_k : c.rhs[k * kNB + t]) - fv[t];
         __syncthreads();
         double sacc = 0.0;
 #pragma unroll
@@ -1695,22 +1612,15 @@ __device__ __forceinline__ void lv_factor_body(const CholDev& c, const int b, co
 #pragma unroll
             for (int g = 0; g < 4; ++g) Sik[(size_t)(r0 + 16 * m + lk + 4 * g) * ld + c0 + 16 * n2 + li] = acc[m][n2][g];
 }
-// sr (split level whose sums ride here, else nullptr): per entry the partial ranges own [p0,p1) | pivot [p0,p1) in Wp
 template <bool FILL>
 __global__ __launch_bounds__(256) void k_lv_factor(CholDev c, const int* __restrict__ tiles, const int* __restrict__ dptr,
                                                    const int* __restrict__ dj, const int* __restrict__ tile_cam, double* __restrict__ px,
-                                                   LvFill lf, const int* __restrict__ sr = nullptr, const double* __restrict__ Wp = nullptr) {
+                                                   LvFill lf) {
     __shared__ double A[kNB][kLdT];
     __shared__ double Li[kNB][kLdT];
     __shared__ double Xs[kNB][kLdT];
     __shared__ double Tb[3][16][17];
     __shared__ double yv[kNB], fv[kNB];
-    if (!FILL && sr) {
-        const int* r = sr + 4 * (size_t)blockIdx.x;
-        const LvSplit sp{Wp, r[0], r[1], r[2], r[3]};
-        lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf, A, Li, Xs, Tb, yv, fv, nullptr, nullptr, &sp);
-        return;
-    }
     lv_factor_body<FILL>(c, blockIdx.x, tiles, dptr, dj, tile_cam, px, lf, A, Li, Xs, Tb, yv, fv);
 }
 

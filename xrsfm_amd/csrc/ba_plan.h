@@ -67,11 +67,6 @@ struct CholPlan {
     //                 (it then also contributes to tile (i,k)), ~j otherwise;
     //   split level:  empty lists (k_ll_update_part + k_ll_update_reduce have updated the tiles and the right-hand side in place).
     std::vector<int> fz_tile, fz_dptr, fz_dj, fz_off;
-    // split level of a plain level schedule (round 5): the fused factor kernel adds the partial tiles itself — per fused-kernel entry
-    // (same order as fz_tile) the level-relative partial ranges of its own target (i,k) and of its pivot (k,k), 4 ints (empty
-    // ranges: nothing to add); sr_level[lv] != 0: the level runs k_ll_update_part -> k_lv_factor, no k_ll_update_reduce between them
-    std::vector<int> sr_ent;
-    std::vector<char> sr_level;
     // look-ahead schedule: the contribution of column k - 2 to column k is formed in the launch of column k - 1 — one single-product
     // chunk per tile (md_tgt: (i,k); md_q: its entry in md_cj), written to partial slot = its index within the level — and the
     // factor kernel of column k starts its accumulators from it: fz_late, per fused-kernel entry the slot of (k,k) and of (i,k), -1 none
@@ -979,24 +974,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             P.fz_dptr.push_back((int)P.fz_dj.size());
         }
         P.fz_off[lv + 1] = (int)P.fz_tile.size() / 2;
-        {   // sums of a split level inside the factor launch: the partial ranges of every entry's own target and of its pivot
-            P.sr_ent.resize(4 * (P.fz_tile.size() / 2), 0);
-            const bool fold = split && !macro && !lookahead && !panel_ll && !nd_lv;
-            P.sr_level.push_back(fold ? 1 : 0);
-            if (fold) {
-                const int r0 = P.sp_rt_off[lv];                  // the level's targets in sp_rt / sp_rp (appended by the split block above)
-                const int r1 = (int)P.sp_rt.size() / 2;
-                auto range_of = [&](int i, int k2, int* out) {
-                    out[0] = out[1] = 0;
-                    for (int r = r0; r < r1; ++r) if (P.sp_rt[2 * (size_t)r] == i && P.sp_rt[2 * (size_t)r + 1] == k2) { out[0] = P.sp_rp[2 * (size_t)r]; out[1] = P.sp_rp[2 * (size_t)r + 1]; }
-                };
-                for (int e = P.fz_off[lv]; e < P.fz_off[lv + 1]; ++e) {
-                    const int i = P.fz_tile[2 * (size_t)e], k2 = P.fz_tile[2 * (size_t)e + 1];
-                    range_of(i, k2, &P.sr_ent[4 * (size_t)e]);
-                    range_of(k2, k2, &P.sr_ent[4 * (size_t)e + 2]);
-                }
-            }
-        }
         P.sp_chunk_off[lv + 1] = (int)P.sp_tgt.size() / 2;
         P.sp_rt_off[lv + 1] = (int)P.sp_rt.size() / 2;
         P.mp_off[lv + 1] = (int)P.mp_wg.size();
@@ -1024,9 +1001,9 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         if (n_levels <= 16)
             for (int lv = 0; lv < n_levels; ++lv) {
                 const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
-                fprintf(stderr, "[plan]   level %d: %d columns, %d factor tiles, %d targets with %d list entries, %d chunks%s, %d fused list entries\n", lv, level_cols[lv],
+                fprintf(stderr, "[plan]   level %d: %d columns, %d factor tiles, %d targets with %d list entries, %d chunks, %d fused list entries\n", lv, level_cols[lv],
                         P.fz_off[lv + 1] - P.fz_off[lv], g1 - g0, g1 > g0 ? P.lv_cptr[g1] - P.lv_cptr[g0] : 0, P.sp_chunk_off[lv + 1] - P.sp_chunk_off[lv],
-                        P.sr_level[lv] ? " (summed by the factor kernel)" : "", P.fz_dptr[P.fz_off[lv + 1]] - P.fz_dptr[P.fz_off[lv]]);
+                        P.fz_dptr[P.fz_off[lv + 1]] - P.fz_dptr[P.fz_off[lv]]);
             }
     }
     P.n_levels = n_levels;
@@ -1118,21 +1095,6 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             size_t written = 0;
             for (long long o2 : owner) written += (o2 != -1);
             if (read != written || (long long)owner.size() > (long long)P.sp_max_chunks) return kErrPlanCheck;
-        }
-        // ... and where the factor kernel adds a split level's partial tiles itself (sr_ent), every entry names exactly the partial
-        // ranges the sum launch would have added into its own tile and into its pivot
-        for (int lv = 0; lv < n_levels; ++lv) {
-            if (!P.sr_level[lv]) continue;
-            for (int e = P.fz_off[lv]; e < P.fz_off[lv + 1]; ++e) {
-                const int i = P.fz_tile[2 * (size_t)e], k2 = P.fz_tile[2 * (size_t)e + 1];
-                for (int w = 0; w < 2; ++w) {
-                    const int ti = w ? k2 : i;
-                    int want0 = 0, want1 = 0;
-                    for (int r = P.sp_rt_off[lv]; r < P.sp_rt_off[lv + 1]; ++r)
-                        if (P.sp_rt[2 * (size_t)r] == ti && P.sp_rt[2 * (size_t)r + 1] == k2) { want0 = P.sp_rp[2 * (size_t)r]; want1 = P.sp_rp[2 * (size_t)r + 1]; }
-                    if (P.sr_ent[4 * (size_t)e + 2 * w] != want0 || P.sr_ent[4 * (size_t)e + 2 * w + 1] != want1) return kErrPlanCheck;
-                }
-            }
         }
         for (int k2 = 0; k2 < T; ++k2)
             for (int j = 0; j < T; ++j) {

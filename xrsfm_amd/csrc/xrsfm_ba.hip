@@ -132,7 +132,6 @@ struct CholHost {
     int *md_tgt = nullptr, *md_q = nullptr, *md_cj = nullptr, *fz_late = nullptr;        // look-ahead schedule: late partials (ba_plan.h)
     std::vector<int> md_off; int md_max = 0; double* md_work = nullptr;
     int *fz_q = nullptr, *fill_rest = nullptr; int n_fill_rest = 0;    // tile fill inside the first level's launch
-    int* sr_ent = nullptr; std::vector<char> sr_level;                 // split levels whose partial tiles the factor kernel adds itself (ba_plan.h)
     bool S_filled = false;                                   // chol_assemble ran k_tile_fill (else the first level composes its tiles)
     std::vector<int> fz_off;
     int *tf_ptr = nullptr, *tf_ent = nullptr;                // per non-zero tile: its 6x6 blocks (k_tile_fill)
@@ -688,12 +687,6 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
     up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
     up.add(&h.fz_q, P.fz_q); up.add(&h.fill_rest, P.fill_rest); h.n_fill_rest = (int)P.fill_rest.size();
-    {   // XRSFM_BA_SPLIT_SUM=0: the partial tiles of a split level are added by a launch of their own (k_ll_update_reduce) — the A/B oracle
-        const char* sse = std::getenv("XRSFM_BA_SPLIT_SUM");          // (read per set-up: the A/B test switches it inside one process)
-        h.sr_level = P.sr_level;
-        if (sse && sse[0] == '0') std::fill(h.sr_level.begin(), h.sr_level.end(), 0);
-        up.add(&h.sr_ent, P.sr_ent);
-    }
     up.add(&h.md_tgt, P.md_tgt); up.add(&h.md_q, P.md_q); up.add(&h.md_cj, P.md_cj); up.add(&h.fz_late, P.fz_late);
     h.md_off = P.md_off; h.md_max = P.md_max;
     up.add(&h.tile_cam, P.tile_cam);
@@ -979,8 +972,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             else if (nch > 0)
                 LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
                        h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
-            const bool sum_in_factor = nch > 0 && nmc <= 0 && lv < (int)h.sr_level.size() && h.sr_level[lv];
-            if (nrt > 0 && !sum_in_factor)
+            if (nrt > 0)
                 LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
                        h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
@@ -1004,8 +996,7 @@ int chol_factor_solve(xrsfm_ba_context* c) {
                            (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
             } else if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
-                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf,
-                       sum_in_factor ? (const int*)(h.sr_ent + 4 * (size_t)h.fz_off[lv]) : (const int*)nullptr, (const double*)h.sp_work);
+                       (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
         }
         if (h.panel_ll || h.bwd_push) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
