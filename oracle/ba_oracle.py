@@ -91,6 +91,8 @@ class Options:
     linear_solver: str = "exact"         # "exact" (Schur + Cholesky) | "pcg"
     pcg_tol: float = 1e-12
     pcg_max_iter: int = 500
+    pcg_coarse: bool = False             # two-level preconditioner of the HIP PCG path (block-Jacobi + the seven gauge vectors); False = block-Jacobi
+                                         # alone, what the committed goldens were generated with (the converged solutions agree either way)
     # Sensitivity switches (tools/oracle_sensitivity.py; every default = the recalled Ceres 2.0/2.1 behaviour of SURVEY.md
     # Appendix A, which is UNPINNED against real Ceres): each flips ONE recalled detail so that its effect on step counts and
     # the final RMSE can be tabulated.  Never set by tests of the product.
@@ -424,8 +426,25 @@ def _back_substitute(problem, lin, Hinv, yc):
     return np.einsum("nij,nj->ni", Hinv, lin.gp - Wty)
 
 
-def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter):
-    """Implicit-Schur PCG with block-Jacobi (6x6) preconditioner.
+def gauge_vectors(q, t, cam_const, sc_c):
+    """The seven gauge directions of a reconstruction restricted to the cameras, in Jacobi-scaled tangent coordinates [Nc,6,7]:
+    world X' = X + w x X + tau + sigma X  =>  camera (R, t): delta_q = -1/2 R w (Plus(q, d) = dq(d) * q), delta_t = sigma t - R tau;
+    columns 0-2 translation, 3-5 rotation, 6 scale; rows of constant blocks zero (ba_kernels.h: k_pcg_gauge)."""
+    R = rotation_from_quat(q)
+    Nc = q.shape[0]
+    W = np.zeros((Nc, 6, 7))
+    for k in range(3):
+        W[:, 3:6, k] = -R[:, :, k]
+        W[:, 0:3, 3 + k] = -0.5 * R[:, :, k]
+    W[:, 3:6, 6] = t
+    W[(cam_const & 1) != 0, 0:3, :] = 0.0
+    W[(cam_const & 2) != 0, 3:6, :] = 0.0
+    return W / sc_c[:, :6, None]
+
+
+def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter, coarse=None):
+    """Implicit-Schur PCG with block-Jacobi (6x6) preconditioner; coarse = (q, t, sc_c): + the gauge coarse space,
+    M^-1 = blockdiag(S_cc)^-1 + W (W^T S W)^-1 W^T (the HIP path's two-level preconditioner).
 
     Same iteration the HIP path runs: x0 = 0, stop when
     |r|_2 <= tol * |b|_2.
@@ -446,8 +465,23 @@ def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter):
         zz = v - np.einsum("nki,ni->nk", lin.Es, u[pi])
         return Dc2 * p + _scatter_add(Nc, ci, np.einsum("nki,nk->ni", lin.Fs, zz))
 
+    if coarse is not None:
+        Wg = gauge_vectors(coarse[0], coarse[1], problem.cam_const, coarse[2])          # [Nc,6,7]
+        SW = np.stack([matvec(Wg[:, :, g]) for g in range(7)], axis=2)
+        E = np.einsum("nig,nih->gh", Wg, SW); E = 0.5 * (E + E.T)
+        keep = np.diag(E) > 0
+        Einv = np.zeros((7, 7))
+        if keep.any():
+            Einv[np.ix_(keep, keep)] = np.linalg.inv(E[np.ix_(keep, keep)])
+        bj = Minv
+
+        def precond(r_):
+            return np.einsum("nij,nj->ni", bj, r_) + np.einsum("nig,g->ni", Wg, Einv @ np.einsum("nig,ni->g", Wg, r_))
+    else:
+        def precond(r_):
+            return np.einsum("nij,nj->ni", Minv, r_)
     x = np.zeros((Nc, lin.Hcc.shape[1])); r = b.copy()
-    z = np.einsum("nij,nj->ni", Minv, r); p = z.copy()
+    z = precond(r); p = z.copy()
     rz = float(np.sum(r * z)); bnorm = float(np.linalg.norm(b)); it = 0
     if bnorm == 0.0:
         return x, _back_substitute(problem, lin, Hinv, x), 0
@@ -457,7 +491,7 @@ def _solve_pcg(problem: Problem, lin: _Linearization, Dc2, Dp2, tol, max_iter):
         qv = matvec(p)
         alpha = rz / float(np.sum(p * qv))
         x += alpha * p; r -= alpha * qv
-        z = np.einsum("nij,nj->ni", Minv, r)
+        z = precond(r)
         rz_new = float(np.sum(r * z))
         p = z + (rz_new / rz) * p; rz = rz_new; it += 1
     return x, _back_substitute(problem, lin, Hinv, x), it
@@ -572,7 +606,8 @@ def solve(problem: Problem, opt: Optional[Options] = None) -> Summary:
         if opt.linear_solver == "exact":
             yc, yp, k = _solve_exact(problem, lin, Dc2, Dp2)
         else:
-            yc, yp, k = _solve_pcg(problem, lin, Dc2, Dp2, opt.pcg_tol, opt.pcg_max_iter)
+            yc, yp, k = _solve_pcg(problem, lin, Dc2, Dp2, opt.pcg_tol, opt.pcg_max_iter,
+                                   coarse=(q, t, sc_c) if (opt.pcg_coarse and not is_wide) else None)
         summ.pcg_iterations += k
         ok = np.isfinite(yc).all() and np.isfinite(yp).all()
         # step = -y; model residual m = Js*step

@@ -1119,3 +1119,47 @@ def test_twenty_thousand_sequential_cameras_take_the_exact_path(lib):
     prod = H.to_product(dict(arr, cam_q=q, cam_t=t, points=P))
     s3 = capi.solve(prod)
     assert s3.n_successful <= 1 and np.abs(prod.cam_q - q).max() < 1e-4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["random", "sequential", "constant_cameras"])
+def test_pcg_gauge_coarse_space_matches_oracle_and_cuts_iterations(lib, monkeypatch, case):
+    """Round 5: the PCG path's preconditioner is block-Jacobi + the seven gauge directions of the reconstruction as a coarse space
+    (ba_kernels.h: k_pcg_gauge / k_pcg_coarse).  Against the oracle's restatement of the same iteration (Options.pcg_coarse): same
+    LM decisions, same results, PCG iteration count within a few per solve; against block-Jacobi alone (XRSFM_BA_PCG_COARSE=0):
+    same results, at most 60 % of its iterations on random visibility (where the gauge modes are what PCG spends its time on).
+    `constant_cameras`: every rotation and two more translations constant — some gauge directions vanish from the coarse space
+    (zero columns of W: their pivots are dropped, the others stay)."""
+    from xrsfm_amd import capi, synth
+    from oracle import ba_oracle as bo
+    if case == "random":
+        d = synth.make_problem(n_cams=120, n_points=9000, k_obs=5, seed=31, mode="unordered")
+        arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    elif case == "sequential":
+        arr = H.make(150, 8000, 4, seed=32)
+    else:
+        arr = H.make(60, 4000, 4, seed=33)
+        cc = arr["cam_const"].copy(); cc[:] |= 1; cc[5] |= 2; cc[17] |= 2; arr["cam_const"] = cc
+    opt = dict(max_iterations=8, linear_solver=capi.SOLVER_PCG, pcg_max_iterations=3000)
+    ref = H.to_oracle(arr)
+    s_ref = bo.solve(ref, bo.Options(max_iterations=8, linear_solver="pcg", pcg_max_iter=3000, pcg_coarse=True))
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("XRSFM_BA_PCG_COARSE", mode)
+        prod = H.to_product(arr)
+        s = capi.solve(prod, capi.default_options(**opt))
+        out[mode] = (s, prod)
+    monkeypatch.delenv("XRSFM_BA_PCG_COARSE")
+    s, prod = out["1"]
+    s0, prod0 = out["0"]
+    assert s.linear_solver_used == capi.SOLVER_PCG
+    assert (s.n_successful, s.n_unsuccessful) == (s_ref.n_successful, s_ref.n_unsuccessful) == (s0.n_successful, s0.n_unsuccessful)
+    assert abs(s.final_cost - s_ref.final_cost) <= 1e-9 * s_ref.final_cost
+    assert max(np.abs(prod.cam_q - ref.cam_q).max(), np.abs(prod.cam_t - ref.cam_t).max()) < 1e-7
+    assert max(np.abs(prod.cam_q - prod0.cam_q).max(), np.abs(prod.cam_t - prod0.cam_t).max()) < 1e-7
+    print(f"{case}: PCG iterations {s.pcg_iterations} with the gauge coarse space (oracle {s_ref.pcg_iterations}), {s0.pcg_iterations} with block-Jacobi alone")
+    if case == "random":
+        assert abs(s.pcg_iterations - s_ref.pcg_iterations) <= max(4, 0.1 * s_ref.pcg_iterations), (s.pcg_iterations, s_ref.pcg_iterations)
+        assert s.pcg_iterations <= 0.6 * s0.pcg_iterations
+    else:       # (a camera chain takes thousands of iterations either way: rounding decides the exact count; the coarse space must not cost any)
+        assert s.pcg_iterations <= 1.05 * s0.pcg_iterations + 8

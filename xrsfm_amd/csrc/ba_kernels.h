@@ -83,7 +83,10 @@ struct Dev {
     double* part;       // per-item partial sums, 4 * n_items
     double* campart;    // per-camera partials, 2 * n_cams
     double* ptpart;     // per-workgroup partials of point kernels, cdiv(n_pts, 256)
-    double* pcgpart;    // [3][n_cams] per-camera partial dot products of the PCG iteration
+    double* pcgpart;    // [3 + kGauge][n_cams] per-camera partial dot products of the PCG iteration (p.q | r.z | r.r | W_k.r)
+    double* pcgW;       // [kGauge][n_cams][6] gauge coarse space of the PCG preconditioner (k_pcg_gauge), nullptr = block-Jacobi alone
+    double* pcgSW;      // [kGauge][n_cams][6] (S + D^2) W (set-up of the coarse matrix)
+    double* pcgE;       // [kGauge * kGauge] inverse of the coarse matrix W^T (S + D^2) W (k_pcg_coarse)
     double* scal;       // S_COUNT scalars
     PcgStatus* st;
 };
@@ -762,10 +765,111 @@ __device__ __forceinline__ void sym6_mul(const double* __restrict__ m, const dou
 
 constexpr int kPcgThreads = 1024;
 
+// ---- two-level preconditioner (round 5): block-Jacobi + the GAUGE coarse space
+// The reduced camera matrix has (up to) seven eigenvalues at the level of the LM damping: a similarity transform of the whole scene
+// — translation (3), rotation (3), scale (1) — changes no residual, and what two constant translations (the reference's gauge,
+// ba_solver.cc:611-614) leave of it is held by the damping alone.  Block-Jacobi does nothing for them: the iteration count grows as
+// the trust region opens (config V: 37 PCG iterations at the first LM step, 85 at the fourth, 365 on average over a solve).  With
+// M^-1 = blockdiag(S_cc)^-1 + W (W^T S W)^-1 W^T and W = those seven vectors restricted to the cameras (closed form below, in the
+// Jacobi-scaled tangent coordinates, rows of constant blocks zeroed) the count stays at ~15 whatever the radius (tools/pcg_coarse.py).
+//   world:  X' = X + w x X + tau + sigma X   =>   camera (R, t):  delta_q = -1/2 R w  (Plus(q, d) = dq(d) * q),  delta_t = sigma t - R tau
+constexpr int kGauge = 7;
+__global__ void k_pcg_gauge(Dev d) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= d.n_cams) return;
+    const CamRec& cur = d.cam[c];
+    const double q[4] = {cur.q[0], cur.q[1], cur.q[2], cur.q[3]};
+    double M[9];
+    quat_to_mat(q, M);
+    const unsigned cc = d.cam_const[c];
+    const bool active = d.cam_act[c] > 0.0;
+    const double* sc = d.scale_c + 6 * (size_t)c;
+    const double mq = (active && !(cc & 1u)) ? 1.0 : 0.0, mt = (active && !(cc & 2u)) ? 1.0 : 0.0;
+    const size_t n6 = 6 * (size_t)d.n_cams;
+    for (int k = 0; k < kGauge; ++k) {
+        double v[6] = {0, 0, 0, 0, 0, 0};
+        if (k < 3) { v[3] = -M[k]; v[4] = -M[3 + k]; v[5] = -M[6 + k]; }                          // tau = e_k
+        else if (k < 6) { v[0] = -0.5 * M[k - 3]; v[1] = -0.5 * M[3 + k - 3]; v[2] = -0.5 * M[6 + k - 3]; }   // w = e_k
+        else { v[3] = cur.t[0]; v[4] = cur.t[1]; v[5] = cur.t[2]; }                               // sigma = 1
+        double* out = d.pcgW + k * n6 + 6 * (size_t)c;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) out[j] = (j < 3 ? mq : mt) * v[j] / sc[j];                  // scaled coordinates: x = scale * y
+    }
+}
+// SW_k += D_c^2 W_k (the product kernels leave S W_k there)
+__global__ void k_pcg_gauge_damp(Dev d) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n6 = 6 * (size_t)d.n_cams;
+    if (i >= n6) return;
+#pragma unroll
+    for (int k = 0; k < kGauge; ++k) d.pcgSW[k * n6 + i] += d.Dc2[i] * d.pcgW[k * n6 + i];
+}
+// E = W^T (S + D^2) W (symmetrised), Cholesky with a guard — a direction whose pivot is not positive relative to its diagonal
+// entry (a gauge freedom every camera of which is constant) is dropped — and its inverse to d.pcgE.  One workgroup.
+__global__ __launch_bounds__(kPcgThreads) void k_pcg_coarse(Dev d) {
+    __shared__ double lds[kPcgThreads / kWave];
+    __shared__ double E[kGauge][kGauge], L[kGauge][kGauge], Li[kGauge][kGauge];
+    __shared__ int keep[kGauge];
+    const size_t n6 = 6 * (size_t)d.n_cams;
+    for (int a = 0; a < kGauge; ++a)
+        for (int b = 0; b <= a; ++b) {
+            double sum = 0.0;
+            for (size_t i = threadIdx.x; i < n6; i += kPcgThreads) sum += 0.5 * (d.pcgW[a * n6 + i] * d.pcgSW[b * n6 + i] + d.pcgW[b * n6 + i] * d.pcgSW[a * n6 + i]);
+            sum = block_sum<kPcgThreads>(sum, lds);
+            if (threadIdx.x == 0) { E[a][b] = sum; E[b][a] = sum; }
+        }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 0; i < kGauge; ++i)
+            for (int j = 0; j < kGauge; ++j) { L[i][j] = 0.0; Li[i][j] = 0.0; }
+        for (int j = 0; j < kGauge; ++j) {
+            double sjj = E[j][j];
+            for (int k = 0; k < j; ++k) sjj -= L[j][k] * L[j][k];
+            keep[j] = (E[j][j] > 0.0 && sjj > 1e-12 * E[j][j]) ? 1 : 0;
+            if (!keep[j]) continue;                              // row / column j stay zero: the direction takes no part
+            const double ljj = sqrt(sjj);
+            L[j][j] = ljj;
+            for (int i = j + 1; i < kGauge; ++i) {
+                double v = E[i][j];
+                for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+                L[i][j] = v / ljj;
+            }
+        }
+        for (int j = 0; j < kGauge; ++j) {                      // Li = L^-1 on the kept directions
+            if (!keep[j]) continue;
+            Li[j][j] = 1.0 / L[j][j];
+            for (int i = j + 1; i < kGauge; ++i) {
+                if (!keep[i]) continue;
+                double v = 0.0;
+                for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
+                Li[i][j] = v / L[i][i];
+            }
+        }
+        for (int a = 0; a < kGauge; ++a)
+            for (int b = 0; b < kGauge; ++b) {
+                double v = 0.0;
+                for (int k = 0; k < kGauge; ++k) v += Li[k][a] * Li[k][b];
+                d.pcgE[a * kGauge + b] = v;
+            }
+    }
+}
+// z += W (E^-1 wr): the coarse term of the preconditioner for one camera; returns nothing, wr: the seven reduced dot products W_k.r
+__device__ __forceinline__ void pcg_coarse_coef(const Dev& d, const double* wr, double* coef) {
+#pragma unroll
+    for (int a = 0; a < kGauge; ++a) {
+        double v = 0.0;
+#pragma unroll
+        for (int b = 0; b < kGauge; ++b) v += d.pcgE[a * kGauge + b] * wr[b];
+        coef[a] = v;
+    }
+}
+
 // x = 0, r = b, z = M^-1 r, p = z
 __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(Dev d) {
     __shared__ double lds[kPcgThreads / kWave];
     double rz = 0.0, bb = 0.0;
+    const size_t n6 = 6 * (size_t)d.n_cams;
+    double wr[kGauge] = {0, 0, 0, 0, 0, 0, 0};
     for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads) {
         double r[6], z[6];
         for (int k = 0; k < 6; ++k) r[k] = d.b[6 * (size_t)c + k];
@@ -775,9 +879,24 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(Dev d) {
             d.pz[6 * (size_t)c + k] = z[k]; d.pp[6 * (size_t)c + k] = z[k];
             rz += r[k] * z[k]; bb += r[k] * r[k];
         }
+        if (d.pcgW)
+            for (int g = 0; g < kGauge; ++g)
+                for (int k = 0; k < 6; ++k) wr[g] += d.pcgW[g * n6 + 6 * (size_t)c + k] * r[k];
     }
     rz = block_sum<kPcgThreads>(rz, lds);
     bb = block_sum<kPcgThreads>(bb, lds);
+    if (d.pcgW) {        // z = Minv r + W E^-1 W^T r,  r.z = r.Minv r + (W^T r).(E^-1 W^T r)
+        for (int g = 0; g < kGauge; ++g) wr[g] = block_sum<kPcgThreads>(wr[g], lds);
+        double coef[kGauge];
+        pcg_coarse_coef(d, wr, coef);
+        for (int g = 0; g < kGauge; ++g) rz += wr[g] * coef[g];
+        for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads)
+            for (int k = 0; k < 6; ++k) {
+                double add = 0.0;
+                for (int g = 0; g < kGauge; ++g) add += d.pcgW[g * n6 + 6 * (size_t)c + k] * coef[g];
+                d.pp[6 * (size_t)c + k] += add;
+            }
+    }
     if (threadIdx.x == 0) {
         d.st->rz = rz; d.st->rr = bb; d.st->bb = bb; d.st->pq = 0.0; d.st->it = 0; d.st->arrived = 0u;
         d.st->done = (bb == 0.0) ? 1 : 0;
@@ -928,23 +1047,46 @@ __global__ __launch_bounds__(kPcgBlock) void k_pcg_xr(Dev d, double* __restrict_
     for (int k = 0; k < 6; ++k) { d.pz[6 * (size_t)c + k] = z[k]; rz += r[k] * z[k]; rr += r[k] * r[k]; }
     part[(size_t)d.n_cams + c] = rz;
     part[2 * (size_t)d.n_cams + c] = rr;
+    if (d.pcgW) {        // the camera's share of W_k.r (the coarse term of z follows in k_pcg_p, once the seven sums are known)
+        const size_t n6 = 6 * (size_t)d.n_cams;
+#pragma unroll
+        for (int g = 0; g < kGauge; ++g) {
+            double w = 0.0;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) w += d.pcgW[g * n6 + 6 * (size_t)c + k] * r[k];
+            part[(3 + g) * (size_t)d.n_cams + c] = w;
+        }
+    }
 }
 
 // (3) beta = rz_new / rz;  p = z + beta p;  status
 __global__ __launch_bounds__(kPcgBlock) void k_pcg_p(Dev d, const double* __restrict__ part, double tol, int max_it) {
     if (d.st->done) return;
     __shared__ double lds[kPcgBlock / kWave];
-    const double rz_new = reduce_partials(part + d.n_cams, d.n_cams, lds);
+    double rz_new = reduce_partials(part + d.n_cams, d.n_cams, lds);
     const double rr = reduce_partials(part + 2 * (size_t)d.n_cams, d.n_cams, lds);
+    double coef[kGauge] = {0, 0, 0, 0, 0, 0, 0};
+    if (d.pcgW) {        // z = Minv r + W E^-1 W^T r: every workgroup adds the seven partial arrays in the same order
+        double wr[kGauge];
+        for (int g = 0; g < kGauge; ++g) wr[g] = reduce_partials(part + (3 + g) * (size_t)d.n_cams, d.n_cams, lds);
+        pcg_coarse_coef(d, wr, coef);
+        for (int g = 0; g < kGauge; ++g) rz_new += wr[g] * coef[g];
+    }
     const double rz = d.st->rz, bb = d.st->bb, pq = d.st->pq;
     const int it0 = d.st->it;
     const double beta = rz_new / rz;
     const int c = blockIdx.x * kPcgBlock + threadIdx.x;
     if (c < d.n_cams) {
+        const size_t n6 = 6 * (size_t)d.n_cams;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const size_t i = 6 * (size_t)c + k;
-            d.pp[i] = d.pz[i] + beta * d.pp[i];
+            double z = d.pz[i];
+            if (d.pcgW) {
+#pragma unroll
+                for (int g = 0; g < kGauge; ++g) z += d.pcgW[g * n6 + i] * coef[g];
+            }
+            d.pp[i] = z + beta * d.pp[i];
         }
     }
     // the status is written by the LAST workgroup to get here, after every workgroup has read the old one

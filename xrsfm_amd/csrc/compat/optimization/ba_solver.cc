@@ -15,10 +15,12 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <exception>
 #include <iomanip>
 #include <iostream>
 #include <memory>
@@ -78,14 +80,19 @@ class FlatProblem {
     }
     size_t NumFrames() const { return frames_.size(); }
 
-    // run fn(begin, end) over [0, n) on up to 16 threads (large calls only)
+    // run fn(begin, end) over [0, n) on up to 16 threads (large calls only); an exception of a worker is rethrown on the caller's thread
     template <typename F> static void ParallelFor(size_t n, size_t min_n, F &&fn) {
         const unsigned hw = std::thread::hardware_concurrency();
         const size_t nt = (n < min_n || hw < 2) ? 1 : std::min<size_t>(16, hw);
         if (nt == 1) { fn(0, n); return; }
         std::vector<std::thread> th;
-        for (size_t t = 0; t < nt; ++t) th.emplace_back([&, t] { fn(n * t / nt, n * (t + 1) / nt); });
+        std::vector<std::exception_ptr> err(nt);
+        for (size_t t = 0; t < nt; ++t)
+            th.emplace_back([&, t] {
+                try { fn(n * t / nt, n * (t + 1) / nt); } catch (...) { err[t] = std::current_exception(); }
+            });
         for (auto &x : th) x.join();
+        for (auto &e : err) if (e) std::rethrow_exception(e);
     }
     // Observations of the recorded frames -> obs_cam / obs_pt / obs_uv, tracks_ (ascending track id), point_const_.
     void BuildObservations() {
@@ -101,26 +108,46 @@ class FlatProblem {
         std::vector<size_t> off(nf + 1, 0);
         size_t total_feats = 0;
         for (size_t c = 0; c < nf; ++c) total_feats += frames_[c]->track_ids_.size();
-        const size_t par_min = total_feats >= 200000 ? 1 : (size_t)-1;       // frames in parallel only for a large call
-        std::vector<unsigned char> used(map_.tracks_.size(), 0);
-        ParallelFor(nf, par_min, [&](size_t c0, size_t c1) {
-            for (size_t c = c0; c < c1; ++c) {
+        // A large call (global BA) marks its tracks in a table over the whole map and the frames run in parallel; a small one (LBA: a
+        // few thousand observations, once per registered frame) must not pay for the size of the MAP — 1-2 M tracks are 10 MB of
+        // memset and a 2 M-iteration scan per call, as long as the solve itself —: it sorts the track ids it meets (round 5).
+        dense_slots_ = total_feats >= 200000;
+        const size_t par_min = dense_slots_ ? 1 : (size_t)-1;       // frames in parallel only for a large call
+        tracks_.clear();
+        if (dense_slots_) {
+            // (relaxed atomic marks: several frames mark the same track from different threads, all with the same value)
+            std::unique_ptr<std::atomic<unsigned char>[]> used(new std::atomic<unsigned char>[map_.tracks_.size() ? map_.tracks_.size() : 1]);
+            ParallelFor(map_.tracks_.size(), 1, [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) used[i].store(0, std::memory_order_relaxed); });
+            ParallelFor(nf, par_min, [&](size_t c0, size_t c1) {
+                for (size_t c = c0; c < c1; ++c) {
+                    size_t n = 0;
+                    for (const int tid : frames_[c]->track_ids_)
+                        if (tid != -1) { ++n; if (!used[tid].load(std::memory_order_relaxed)) used[tid].store(1, std::memory_order_relaxed); }      // (test first: 16 threads storing into shared lines cost 22 ms)
+                    off[c + 1] = n;
+                }
+            });
+            lap("count + mark tracks");
+            track_slot_.assign(map_.tracks_.size(), -1);
+            for (size_t tid = 0; tid < map_.tracks_.size(); ++tid)
+                if (used[tid].load(std::memory_order_relaxed)) { track_slot_[tid] = static_cast<int>(tracks_.size()); tracks_.push_back(static_cast<int>(tid)); }
+        } else {
+            tracks_.reserve(total_feats);
+            for (size_t c = 0; c < nf; ++c) {
                 size_t n = 0;
                 for (const int tid : frames_[c]->track_ids_)
-                    if (tid != -1) { ++n; if (!used[tid]) used[tid] = 1; }      // (test first: 16 threads storing into shared lines cost 22 ms; every writer stores the same value)
+                    if (tid != -1) { ++n; tracks_.push_back(tid); }
                 off[c + 1] = n;
             }
-        });
-        lap("count + mark tracks");
+            std::sort(tracks_.begin(), tracks_.end());
+            tracks_.erase(std::unique(tracks_.begin(), tracks_.end()), tracks_.end());
+            track_slot_.clear();
+            lap("count + sort tracks");
+        }
         for (size_t c = 0; c < nf; ++c) {
             if (off[c + 1] == 0)
                 std::cerr << (lba_frame_id_ >= 0 ? "LBA" : "BA") << ": NO Measurement In Frame " << frames_[c]->id << std::endl;
             off[c + 1] += off[c];
         }
-        track_slot_.assign(map_.tracks_.size(), -1);
-        tracks_.clear();
-        for (size_t tid = 0; tid < used.size(); ++tid)
-            if (used[tid]) { track_slot_[tid] = static_cast<int>(tracks_.size()); tracks_.push_back(static_cast<int>(tid)); }
         point_const_.assign(tracks_.size(), 0);
         if (lba_frame_id_ >= 0)          // reference rule: `angle_ > 5 || observations_.count(frame_id) == 0` (angle_ is in radians, so only
             for (size_t j = 0; j < tracks_.size(); ++j) {        // the second half can fire, ba_solver.cc:380)
@@ -139,7 +166,8 @@ class FlatProblem {
                 for (size_t i = 0; i < frame.track_ids_.size(); ++i) {
                     const int tid = frame.track_ids_[i];
                     if (tid == -1) continue;
-                    obs_cam_[o] = static_cast<int32_t>(c); obs_pt_[o] = track_slot_[tid];
+                    obs_cam_[o] = static_cast<int32_t>(c);
+                    obs_pt_[o] = dense_slots_ ? track_slot_[tid] : static_cast<int32_t>(std::lower_bound(tracks_.begin(), tracks_.end(), tid) - tracks_.begin());
                     obs_uv_[2 * o] = frame.points[i](0); obs_uv_[2 * o + 1] = frame.points[i](1);
                     ++o;
                 }
@@ -214,7 +242,8 @@ class FlatProblem {
     Map &map_;
     std::vector<Frame *> frames_;
     std::unordered_map<int, int> frame_slot_, intr_slot_;      // (a handful of entries: frames of the call, camera ids)
-    std::vector<int> track_slot_;                              // Map::tracks_ index -> point slot of this call, -1 = not in it
+    std::vector<int> track_slot_;                              // (large calls) Map::tracks_ index -> point slot of this call, -1 = not in it
+    bool dense_slots_ = false;                                 // ... small calls look the slot up in the sorted tracks_ instead
     int lba_frame_id_ = -1;
     std::chrono::steady_clock::time_point t_begin_;
     std::vector<int> tracks_;
@@ -226,6 +255,14 @@ class FlatProblem {
     size_t n_obs_ = 0;
 };
 
+}  // namespace
+
+BASolver::BASolver() {
+    static const int warm = xrsfm_ba_warmup(0, 0, 0, 0);       // once per process; a box without a device is reported by the first solve
+    (void)warm;
+}
+
+namespace {
 xrsfm_ba_options ReferenceOptions(int max_iterations, double ftol, double ptol) {
     xrsfm_ba_options o;
     xrsfm_ba_default_options(&o);       // Ceres defaults + SPARSE_SCHUR-equivalent exact solve

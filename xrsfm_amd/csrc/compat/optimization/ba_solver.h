@@ -31,7 +31,9 @@ int &BASolverFailureCount();
 
 class BASolver {
   public:
-    BASolver() {}
+    // (the reference's constructor is empty, ba_solver.h:16; this one pays the one-off start-up cost of the GPU library — HIP runtime,
+    //  code object, first stream — once per process, so that the mapper's first BA call does not: xrsfm_ba_warmup, include/xrsfm_ba.h)
+    BASolver();
 
     void ScalePoseGraphUnorder(const LoopInfo &loop_info, Map &map, bool use_key = false);
     void KGBA(Map &map, const std::vector<int> fix_key_frame_ids, const bool is_sequential_data);

@@ -175,6 +175,7 @@ struct xrsfm_ba_context {
     bool wide = false;              // bal9 mode: 9-wide camera blocks (ba_wide.h); single rank, exact solver only
     DevW w{};
     std::vector<int> cam_intr_host; // wide: intrinsics entry of every camera (xrsfm_ba_download_intrinsics)
+    bool pcg_coarse = true; double* pcg_w = nullptr;      // PCG path: gauge coarse space of the preconditioner (ba_kernels.h: k_pcg_gauge) and its buffers
     bool prep_fused = true;         // Cholesky path: damped point blocks factored inside k_schur_pairs / k_backsub, LM diagonal of the
                                     // cameras inside the tile fill: no k_point_prep launch (XRSFM_BA_PREP_FUSED=0: round-2 schedule)
     double step_radius = 0.0;       // radius of the step being assembled / solved (prepare_step)
@@ -548,6 +549,21 @@ int schur_product(xrsfm_ba_context* c, const double* p_dev, double* out_dev, int
 
 int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary* sum) {
     Dev& d = c->d;
+    // two-level preconditioner: the seven gauge vectors at the current cameras, (S + D^2) W by seven products, the 7 x 7 coarse
+    // matrix and its inverse — per LM step: both S and D^2 depend on the radius (XRSFM_BA_PCG_COARSE=0: block-Jacobi alone)
+    d.pcgW = c->pcg_coarse ? c->pcg_w : nullptr;
+    if (d.pcgW && d.n_cams > 0) {
+        const size_t n6 = 6 * (size_t)d.n_cams;
+        d.pcgSW = c->pcg_w + kGauge * n6; d.pcgE = c->pcg_w + 2 * kGauge * n6;
+        LAUNCH(c, K_PCG_VEC, k_pcg_gauge, dim3(cdiv(d.n_cams, kBlock)), dim3(kBlock), 0, d);
+        HIPCHK(hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream));        // (the product kernels return at once while st->done is set)
+        for (int g = 0; g < kGauge; ++g) {
+            int e = schur_product(c, d.pcgW + g * n6, d.pcgSW + g * n6, -1);
+            if (e) return e;
+        }
+        LAUNCH(c, K_PCG_VEC, k_pcg_gauge_damp, dim3(cdiv((long long)n6, kBlock)), dim3(kBlock), 0, d);
+        LAUNCH(c, K_PCG_VEC, k_pcg_coarse, dim3(1), dim3(kPcgThreads), 0, d);
+    }
     LAUNCH(c, K_PCG_VEC, k_pcg_init, dim3(1), dim3(kPcgThreads), 0, d);
     const int chunk = 8;
     int launched = 0;
@@ -598,6 +614,28 @@ int ensure_host_pack(xrsfm_ba_context* c, int level) {
         c->host_pack_level = 2;
     }
     return 0;
+}
+
+// dynamic-LDS limits of the S-assembly kernels: once per device and process (each call costs a few microseconds, an LBA-sized solve
+// has few to spare; xrsfm_ba_warmup does it ahead of the first call)
+void set_kernel_attributes(int device) {
+    static std::mutex mu;
+    static std::vector<char> done_for(64, 0);
+    std::lock_guard<std::mutex> g(mu);
+    if (device < 0 || device >= 64 || done_for[device]) return;
+    const int pairs_max = kGramMaxLds + kGramTabLd * kGramTabLd * (int)sizeof(int);
+#define XBA_PAIRS_ATTR(NI) \
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max); \
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    XBA_PAIRS_ATTR(1) XBA_PAIRS_ATTR(2) XBA_PAIRS_ATTR(3) XBA_PAIRS_ATTR(4)
+#undef XBA_PAIRS_ATTR
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    (void)hipFuncSetAttribute((const void*)k9_pairs_gram<1>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    (void)hipFuncSetAttribute((const void*)k9_pairs_gram<2>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    (void)hipFuncSetAttribute((const void*)k9_pairs_gram<3>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    (void)hipFuncSetAttribute((const void*)k9_pairs_gram<4>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
+    done_for[device] = 1;
 }
 
 // ---------------------------------------------------------------- Cholesky path: structures
@@ -787,26 +825,7 @@ int chol_setup(xrsfm_ba_context* c) {
 #undef TRYC
     HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * h.S_doubles, c->stream));
     const int shm = 2 * kNB * kLdT * (int)sizeof(double);
-    {   // dynamic-LDS limits: once per device and process (each call costs a few microseconds, an LBA-sized solve has few to spare)
-        static std::mutex mu;
-        static std::vector<char> done_for(64, 0);
-        std::lock_guard<std::mutex> g(mu);
-        if (c->device < 64 && !done_for[c->device]) {
-            const int pairs_max = kGramMaxLds + kGramTabLd * kGramTabLd * (int)sizeof(int);
-#define XBA_PAIRS_ATTR(NI) \
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max); \
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            XBA_PAIRS_ATTR(1) XBA_PAIRS_ATTR(2) XBA_PAIRS_ATTR(3) XBA_PAIRS_ATTR(4)
-#undef XBA_PAIRS_ATTR
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<1>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<2>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<3>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            (void)hipFuncSetAttribute((const void*)k9_pairs_gram<4>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-            done_for[c->device] = 1;
-        }
-    }
+    set_kernel_attributes(c->device);
     if (h.n_pairs_other > 0 && !h.aux) {              // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
         if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
@@ -1193,6 +1212,51 @@ int xrsfm_ba_version(int* n_devices) {
     return XRSFM_BA_VERSION;
 }
 
+// First call of a process (profiles/r04_adapter_timing.txt: `create` 113 ms against 5.8 ms for the second call): HIP start-up, the
+// code object of this library (75 kernels + the rocPRIM sorts, loaded by the first launch), a stream with its pinned scalar block,
+// ~100 hipMalloc calls.  None of it depends on the problem — only the sizes of the buffers do, hence the hints.
+int xrsfm_ba_warmup(int device, int64_t n_obs_hint, int64_t n_points_hint, int64_t n_cams_hint) {
+    return no_throw([&]() -> int {
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XRSFM_BA_ENODEV;
+        if (device < 0 || device >= ndev) return XRSFM_BA_EINVAL;
+        HIPCHK(hipSetDevice(device));
+        HostBundle hb;
+        if (!g_bundles.get(device, &hb)) return XRSFM_BA_ENODEV;
+        set_kernel_attributes(device);
+        // the first launch loads the code object; device packing and the key generation bring rocPRIM's kernels with them (same object)
+        double* probe = nullptr;
+        size_t cls = 0;
+        probe = (double*)g_cache.get(device, 256 * sizeof(double), &cls);
+        int rc = XRSFM_BA_OK;
+        if (!probe) rc = XRSFM_BA_ENOMEM;
+        else {
+            hipLaunchKernelGGL(k_fill, dim3(1), dim3(kBlock), 0, hb.stream, probe, 0.0, (size_t)256);
+            if (hipStreamSynchronize(hb.stream) != hipSuccess) rc = XRSFM_BA_ENODEV;
+            g_cache.put(device, probe, cls);
+        }
+        g_bundles.put(device, hb);
+        if (rc != XRSFM_BA_OK || n_obs_hint <= 0) return rc;
+        // Device buffers of a problem of about this size: the sizes xrsfm_ba_create / the Cholesky set-up ask for, in units of the
+        // slot count (observations + tile padding), the point and the camera count; every block goes straight back to the cache.
+        const size_t ns = (size_t)(n_obs_hint + n_obs_hint / 8 + 64), np = (size_t)std::max<int64_t>(n_points_hint, 1), nc = (size_t)std::max<int64_t>(n_cams_hint, 1);
+        std::vector<size_t> want;
+        auto add = [&](size_t bytes, int count = 1) { for (int i = 0; i < count; ++i) want.push_back(bytes); };
+        add(ns * 8 * 6, 2);                 // Jp (both linearisation sets)
+        add(ns * 8 * 2, 2);                 // rt
+        add(ns * 8 * 28);                   // camera-major scatter buffer
+        add(ns * 8, 2); add(ns * 4, 5); add(ns, 1);        // slot streams: u, v | cam, pt, campos, campos_g, obs | cidx
+        add(np * 8 * 6, 4); add(np * 8 * 3, 7);            // Hpp x2, Hinv, Hc | gp x2, scale_p, yp, P, P_cand, P0
+        add(nc * 128, 6);                   // camera records
+        add(ns * 8 * 36 / 10);              // block scatter buffer (Gram cells: ~one 6x6 entry per ten observations)
+        add(ns * 8, 6); add(ns * 16, 2);    // scratch of the device-side sorts
+        std::vector<std::pair<void*, size_t>> got;
+        for (size_t b : want) { size_t c2 = 0; void* q = g_cache.get(device, b, &c2); if (!q) break; got.push_back({q, c2}); }
+        for (auto& g2 : got) g_cache.put(device, g2.first, g2.second);
+        return XRSFM_BA_OK;
+    });
+}
+
 void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -1372,7 +1436,9 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
     TRY(dev_alloc(c, &d.part, (size_t)d.n_items * 7));      // [0,4n): own view (linearise 0..3n, back-substitution 2n..4n); [4n,7n): candidate view
     TRY(dev_alloc(c, &d.campart, nc * 2));
     TRY(dev_alloc(c, &d.ptpart, np / kBlock + 2));
-    TRY(dev_alloc(c, &d.pcgpart, nc * 3));
+    TRY(dev_alloc(c, &d.pcgpart, nc * (3 + kGauge)));
+    TRY(dev_alloc(c, &c->pcg_w, nc * 6 * 2 * kGauge + kGauge * kGauge));      // W | (S + D^2) W | inverse of the coarse matrix
+    d.pcgW = nullptr; d.pcgSW = nullptr; d.pcgE = nullptr;
     TRY(dev_alloc(c, &d.scal, (size_t)S_COUNT));
     TRY(dev_alloc(c, &d.st, (size_t)1));
     if (c->wide) {      // 9-wide path: stored Jacobian blocks, wide scale / sums / solution (ba_wide.h)
@@ -1390,6 +1456,8 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
         c->fused = !(fz && fz[0] == '0');
         const char* pf = std::getenv("XRSFM_BA_PREP_FUSED");
         c->prep_fused = !(pf && pf[0] == '0');
+        const char* pc = std::getenv("XRSFM_BA_PCG_COARSE");
+        c->pcg_coarse = !(pc && pc[0] == '0');
     }
     // (the scatter buffers need no clearing: every entry is written before it is read)
     if (hipMemsetAsync(d.scal, 0, sizeof(double) * S_COUNT, c->stream) != hipSuccess || hipMemsetAsync(d.st, 0, sizeof(PcgStatus), c->stream) != hipSuccess ||
