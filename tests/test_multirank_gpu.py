@@ -155,3 +155,35 @@ def test_weak_scaling_shards_equal_their_union(lib, tmp_path):
         assert np.abs(z[r]["q"] - ref.cam_q).max() < 1e-5 and np.abs(z[r]["t"] - ref.cam_t).max() < 1e-5
         assert np.abs(z[r]["P"] - ref.points[r * n0:(r + 1) * n0]).max() < 1e-5
     assert np.array_equal(z[0]["q"], z[1]["q"]) and np.array_equal(z[0]["t"], z[1]["t"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 8])
+def test_config4_sized_problem_on_2_and_8_ranks(lib, tmp_path, world):
+    """BASELINE.json config 4's size — 1000 cameras / 500 000 points / 2 000 000 observations, the parity
+    workload LP (config 4 + 24 hub frames x 50 distant landmarks: the plain ring L leaves 1e-3 of gauge drift, on which no two
+    summation orders agree to 1e-5) — split over 2 and 8 ranks that share the GPU through the transport hook:
+    the complete multi-rank HIP path (union block pattern, length-aware shards, camS | Sblk and camlin all-reduces, the replicated
+    level schedule with its one-launch backward substitution) at the size the driver's 8-GPU run uses.  Every rank takes the
+    single-rank solve's LM decisions, all ranks hold bit-identical cameras, cameras within 1e-5 and RMSE within 1e-6 px of the
+    single-rank solve, shards balanced within 1 %."""
+    from xrsfm_amd import capi, sharding, synth
+    d = synth.make_problem(**synth.CONFIGS["LP"])
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    opt_kw = dict(max_iterations=50)
+    ref = H.to_product(arr)
+    s1 = capi.solve(ref, capi.default_options(linear_solver=1, **opt_kw))
+    assert s1.n_successful + s1.n_unsuccessful >= 10
+    prefix = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(world, _free_port(), arr, 1, opt_kw, prefix), nprocs=world, join=True)
+    z = [np.load(f"{prefix}{r}.npz") for r in range(world)]
+    n_res = 2 * arr["obs_cam"].shape[0]
+    owner = sharding.partition_points(arr["obs_pt"], arr["points"].shape[0], world)
+    assert sharding.imbalance(arr["obs_pt"], owner, world) <= 0.01
+    for r in range(world):
+        assert tuple(z[r]["stat"]) == (s1.n_successful, s1.n_unsuccessful, s1.termination_reason)
+        assert abs(np.sqrt(z[r]["cost"][1] / n_res) - np.sqrt(s1.final_cost / n_res)) < 1e-6
+        assert np.abs(z[r]["q"] - ref.cam_q).max() < 1e-5 and np.abs(z[r]["t"] - ref.cam_t).max() < 1e-5
+        assert np.array_equal(z[0]["q"], z[r]["q"]) and np.array_equal(z[0]["t"], z[r]["t"])
+    print(f"config-4-sized LP on {world} ranks: LM {s1.n_successful}+{s1.n_unsuccessful}, max camera difference to one rank "
+          f"{max(np.abs(z[0]['q'] - ref.cam_q).max(), np.abs(z[0]['t'] - ref.cam_t).max()):.2e}")

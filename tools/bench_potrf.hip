@@ -93,10 +93,6 @@ int main() {
         run("PV0 + OVL", k_bench<0, true>, nb);
         run("PV1 (mov_b64_dpp)", k_bench<1, false>, nb);
         run("PV1 + OVL", k_bench<1, true>, nb);
-        run("PV2 (fmac_f64_dpp)", k_bench<2, false>, nb);
-        run("PV2 + OVL", k_bench<2, true>, nb);
-        run("PV3 (bcast ahead)", k_bench<3, false>, nb);
-        run("PV3 + OVL", k_bench<3, true>, nb);
     }
     return 0;
 }

@@ -21,7 +21,7 @@ for (nc, npts) in [(100, 2000), (100, 5000), (100, 20000), (100, 50000)]:
           "finite", bool(np.isfinite(y1).all()), "| tiles", st["tiles"], "regular", st["regular_tiles"], "small/big/other", g["items_small"], g["items_big"], g["items_other"])
     ctx.close()
 """
-for env in ({}, {"XRSFM_BA_PREP_FUSED": "0"}, {"XRSFM_BA_FILL_FUSED": "0"}, {"XRSFM_BA_FUSED": "0"}, {"XRSFM_BA_PACKED": "1"}, {"XRSFM_BA_LOOKAHEAD": "0"}):
+for env in ({}, {"XRSFM_BA_PREP_FUSED": "0"}, {"XRSFM_BA_FUSED": "0"}, {"XRSFM_BA_PACKED": "1"}, {"XRSFM_BA_LOOKAHEAD": "0"}):
     e = dict(os.environ); e.update(env)
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT], env=e, capture_output=True, text=True, cwd=ROOT)
     print("==", env); print(r.stdout[-3000:]); print(r.stderr[-800:] if r.returncode else "")

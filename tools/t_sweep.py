@@ -2,7 +2,7 @@
 """Developer tool: config T (BASELINE config 5's shape) generated ONCE, then solved under several plan settings.
 
 usage: python tools/t_sweep.py [--scale 1.0] SETTING [SETTING ...]      SETTING = comma-separated ENV=VALUE pairs, or "default"
-e.g.   python tools/t_sweep.py default XRSFM_BA_ND=0 XRSFM_BA_ND_CHUNK=4 XRSFM_BA_ND_CHUNK=10
+e.g.   python tools/t_sweep.py default XRSFM_BA_ND=0
 Per setting: create (incl. plan) ms, solve ms (second run of the context: no set-up), LM iterations, final cost, and the
 HIP-event totals per kernel class of a third, profiled run.  The plan's environment switches are read when the context's
 Cholesky structures are built, so one process can compare them."""

@@ -32,11 +32,6 @@ VARIANTS = {
     "poison": ["-DXBA_POISON", "-ffp-contract=off"],
     "strict": ["-ffp-contract=off"],
     "backsub_w5": ["-DXBA_BACKSUB_WAVES=5"],    # k_backsub register-allocated for 5 waves per SIMD (round-2 finding xi)
-    # A/B builds of the pivot-tile factorisation (ba_chol.h: potrf_lds_t<PV, OVL>; tools/runs/r04_ab.sh): rounds 1-3 = PV 0, OVL 0
-    "potrf00": ["-DXBA_POTRF_PV=0", "-DXBA_POTRF_OVL=0"],
-    "potrf01": ["-DXBA_POTRF_PV=0", "-DXBA_POTRF_OVL=1"],
-    "potrf11": ["-DXBA_POTRF_PV=1", "-DXBA_POTRF_OVL=1"],
-    "potrf20": ["-DXBA_POTRF_PV=2", "-DXBA_POTRF_OVL=0"],
 }
 
 

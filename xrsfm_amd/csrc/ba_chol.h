@@ -580,41 +580,6 @@ __device__ __forceinline__ double row_bcast64(double v, int l) {
         case 12: return row_bcast64_c<12>(v); case 13: return row_bcast64_c<13>(v); case 14: return row_bcast64_c<14>(v); default: return row_bcast64_c<15>(v);
     }
 }
-// Column update of the in-register 16x16 factorisation as v_fmac_f64 WITH the row broadcast folded in (VOP2 + DPP
-// row_newbcast: D = S0[lane CC of the row] * S1 + D): a_cc += u_{cc,jj} * (-tl), l_cc += u_{cc,jj} * (-xs) — two instructions
-// instead of two DPP moves + two FMAs.  The compiler does not fold a 64-bit DPP move into its user, hence inline asm; what it
-// does not do for an asm statement (cdna_hip_programming.md section 5.7) is done here: the DPP source (pivot column a_jj) may
-// have been written or copied by the instruction just before the statement -> two wait states (s_nop 1) open it.
-// Same products, same single rounding as fma(-tl, bcast, a): bit-identical factor.
-template <int CC>
-__device__ __forceinline__ void potrf_upd_dpp(double& a_cc, double& l_cc, double a_jj, double ntl, double nxs) {
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %2, %3 row_newbcast:%c5 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, %2, %4 row_newbcast:%c5 row_mask:0xf bank_mask:0xf"
-                 : "+v"(a_cc), "+v"(l_cc) : "v"(a_jj), "v"(ntl), "v"(nxs), "i"(CC));
-}
-// ... the first update of a step (column jj + 1, the next pivot column) together with the broadcast of the next pivot
-// u_{jj+1,jj+1}: the freshly written a_cc is a DPP source two wait states later
-template <int CC>
-__device__ __forceinline__ double potrf_upd_dpp_pivot(double& a_cc, double& l_cc, double a_jj, double ntl, double nxs) {
-    double piv;
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f64_dpp %0, %3, %4 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t"
-                 "v_fmac_f64_dpp %1, %3, %5 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 0\n\t"
-                 "v_mov_b64_dpp %2, %0 row_newbcast:%c6 row_mask:0xf bank_mask:0xf\n\t"
-                 "s_nop 0"
-                 : "+v"(a_cc), "+v"(l_cc), "=&v"(piv) : "v"(a_jj), "v"(ntl), "v"(nxs), "i"(CC));
-    return piv;
-}
-template <int JJ, int CC>
-__device__ __forceinline__ void potrf_upd_group(double (&a)[16], double (&lcol)[16], double ntl, double nxs) {
-    if constexpr (CC < 16) {
-        potrf_upd_dpp<CC>(a[CC], lcol[CC], a[JJ], ntl, nxs);
-        potrf_upd_group<JJ, CC + 4>(a, lcol, ntl, nxs);
-    }
-}
-
 // Diagonal tile: L = chol(A) and Linv = L^-1, blocked 16x16.
 //   per block column kb: (a) wave 0 factors the 16x16 diagonal block in registers (lane = row; column
 //   broadcasts are DPP row_newbcast moves, one reciprocal per column, square roots applied once at the end) and
@@ -626,43 +591,12 @@ __device__ __forceinline__ void potrf_upd_group(double (&a)[16], double (&lcol)[
 // L^-1 (Li must hold the identity on the padding rows >= 16 nb and zeros elsewhere).  Called by all 256 threads of the
 // workgroup after a barrier; ends with a barrier.
 // (a) of potrf_lds: wave-level factorisation + inverse of the 16x16 diagonal block at (b0,b0), in registers
-// One step (pivot column JJ) of the PV = 2 sweep: compile-time column indices (DPP controls are immediates), the same
-// software pipeline as the loop of the other variants — first the update of the next pivot column together with the broadcast
-// of the next pivot, its v_rcp_f64 issued at once, the two Newton steps dealt out between the four groups of column updates.
-template <int JJ>
-__device__ __forceinline__ void potrf_step_dpp(double (&a)[16], double (&lcol)[16], double (&piv)[16], double& rj) {
-    const double ntl = -(a[JJ] * rj);                  // -(u_ij / u_jj)
-    const double nxs = -(lcol[JJ] * rj);
-    double r = 0.0, un = 1.0, e = 0.0;
-    if constexpr (JJ + 1 < 16) {
-        un = potrf_upd_dpp_pivot<JJ + 1>(a[JJ + 1], lcol[JJ + 1], a[JJ], ntl, nxs);
-        piv[JJ + 1] = un;
-        r = __builtin_amdgcn_rcp(un);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    potrf_upd_group<JJ, JJ + 2>(a, lcol, ntl, nxs);
-    if constexpr (JJ + 1 < 16) e = fma(-un, r, 1.0);
-    __builtin_amdgcn_sched_barrier(0);
-    potrf_upd_group<JJ, JJ + 3>(a, lcol, ntl, nxs);
-    if constexpr (JJ + 1 < 16) r = fma(r, e, r);
-    __builtin_amdgcn_sched_barrier(0);
-    potrf_upd_group<JJ, JJ + 4>(a, lcol, ntl, nxs);
-    if constexpr (JJ + 1 < 16) e = fma(-un, r, 1.0);
-    __builtin_amdgcn_sched_barrier(0);
-    potrf_upd_group<JJ, JJ + 5>(a, lcol, ntl, nxs);
-    if constexpr (JJ + 1 < 16) r = fma(r, e, r);
-    __builtin_amdgcn_sched_barrier(0);
-    rj = r;
-    if constexpr (JJ + 1 < 16) potrf_step_dpp<JJ + 1>(a, lcol, piv, rj);
-}
-
-// PV: how a column update gets its broadcast operand — 0: two v_mov_b32_dpp (rounds 1-3), 1: one v_mov_b64_dpp (compiler-
-// scheduled builtin), 2: folded into v_fmac_f64_dpp (inline asm).  All three form the same products with the same roundings.
-// Measured (tools/bench_potrf, MI355X, one 64x64 tile incl. the full inverse): PV 0 12.7 us, PV 1 11.9, PV 2 13.4 (the DPP form
-// of v_fmac_f64 issues slower than a DPP move + a plain FMA), PV 1 with OVL 10.9 — all bit-identical.  Default: PV 1 + OVL.
-// (Also measured, round 4, and removed: the elimination sweep WITHOUT the inverse — one broadcast + one FMA per column update — and
-//  the forward substitution L X = I afterwards with its operands read from LDS: 15.2 us, the same instruction count issued in two
-//  dependent phases.)
+// PV: how a column update gets its broadcast operand — 0: two v_mov_b32_dpp (rounds 1-3), 1: one v_mov_b64_dpp (compiler-scheduled
+// builtin).  Both form the same products with the same roundings.  Measured (tools/bench_potrf, MI355X, one 64x64 tile incl. the full
+// inverse): PV 0 12.7 us, PV 1 11.9, PV 1 with OVL 10.6 (default) — all bit-identical.
+// (Measured in round 4 and removed in round 5: the broadcast folded into v_fmac_f64_dpp through inline asm, 13.4 us — the DPP form of
+//  a 64-bit FMA issues slower than a DPP move + a plain FMA; the broadcasts of a group issued one group ahead of their FMAs, 12.0 us;
+//  the elimination sweep WITHOUT the inverse and the forward substitution L X = I afterwards, operands from LDS: 15.2 us.)
 #ifndef XBA_POTRF_PV
 #define XBA_POTRF_PV 1
 #endif
@@ -704,57 +638,6 @@ __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kL
     double piv[16];
     piv[0] = row_bcast(a[0], 0);
     double rj = fast_rcp(piv[0]);
-    if constexpr (PV == 2) potrf_step_dpp<0>(a, lcol, piv, rj);
-    else if constexpr (PV == 3) {
-        // PV 3: the broadcasts of a group of (up to four) column updates are issued one group AHEAD of the FMAs that use them.
-        // A wave issues in order: with the broadcast right in front of its two FMAs (the other variants: the register allocator
-        // even reuses ONE temporary pair for all of them) every update waits for its own DPP move; here the moves of group
-        // st + 1 travel with the FMAs of group st, whose operands were requested a group earlier.  Same operations, same values.
-#pragma clang loop unroll(full)
-        for (int jj = 0; jj < 16; ++jj) {
-            const double tl = a[jj] * rj;                      // u_ij / u_jj
-            const double xs = lcol[jj] * rj;
-            double r = 0.0, un = 1.0, e = 0.0;
-            double bq[2][4];
-#pragma clang loop unroll(full)
-            for (int u = 0; u < 4; ++u) { bq[0][u] = 0.0; bq[1][u] = 0.0; }
-#pragma clang loop unroll(full)
-            for (int u = 0; u < 4; ++u) if (jj + 2 + 4 * u < 16) bq[0][u] = row_bcast64(a[jj], jj + 2 + 4 * u);
-            if (jj + 1 < 16) {
-                const double b1 = row_bcast64(a[jj], jj + 1);
-                a[jj + 1] = fma(-tl, b1, a[jj + 1]);
-                lcol[jj + 1] = fma(-b1, xs, lcol[jj + 1]);
-                asm volatile("" : "+v"(lcol[jj + 1]));
-                un = row_bcast64(a[jj + 1], jj + 1);
-                piv[jj + 1] = un;
-                r = __builtin_amdgcn_rcp(un);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma clang loop unroll(full)
-            for (int st = 0; st < 4; ++st) {
-                if (st + 1 < 4) {
-#pragma clang loop unroll(full)
-                    for (int u = 0; u < 4; ++u) if (jj + 3 + st + 4 * u < 16) bq[(st + 1) & 1][u] = row_bcast64(a[jj], jj + 3 + st + 4 * u);
-                }
-#pragma clang loop unroll(full)
-                for (int u = 0; u < 4; ++u) {
-                    const int cc = jj + 2 + st + 4 * u;
-                    if (cc < 16) {
-                        a[cc] = fma(-tl, bq[st & 1][u], a[cc]);
-                        lcol[cc] = fma(-bq[st & 1][u], xs, lcol[cc]);
-                        asm volatile("" : "+v"(lcol[cc]));
-                    }
-                }
-                if (jj + 1 < 16) {
-                    if (st % 2 == 0) e = fma(-un, r, 1.0);
-                    else r = fma(r, e, r);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            rj = r;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else
 #pragma clang loop unroll(full)
     for (int jj = 0; jj < 16; ++jj) {
         const double tl = a[jj] * rj;                      // u_ij / u_jj

@@ -854,12 +854,12 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_coarse(Dev d) {
     }
 }
 // z += W (E^-1 wr): the coarse term of the preconditioner for one camera; returns nothing, wr: the seven reduced dot products W_k.r
-__device__ __forceinline__ void pcg_coarse_coef(const Dev& d, const double* wr, double* coef) {
+__device__ __forceinline__ void pcg_coarse_coef(const double* Einv, const double* wr, double* coef) {
 #pragma unroll
     for (int a = 0; a < kGauge; ++a) {
         double v = 0.0;
 #pragma unroll
-        for (int b = 0; b < kGauge; ++b) v += d.pcgE[a * kGauge + b] * wr[b];
+        for (int b = 0; b < kGauge; ++b) v += Einv[a * kGauge + b] * wr[b];
         coef[a] = v;
     }
 }
@@ -888,7 +888,7 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_init(Dev d) {
     if (d.pcgW) {        // z = Minv r + W E^-1 W^T r,  r.z = r.Minv r + (W^T r).(E^-1 W^T r)
         for (int g = 0; g < kGauge; ++g) wr[g] = block_sum<kPcgThreads>(wr[g], lds);
         double coef[kGauge];
-        pcg_coarse_coef(d, wr, coef);
+        pcg_coarse_coef(d.pcgE, wr, coef);
         for (int g = 0; g < kGauge; ++g) rz += wr[g] * coef[g];
         for (int c = threadIdx.x; c < d.n_cams; c += kPcgThreads)
             for (int k = 0; k < 6; ++k) {
@@ -1007,6 +1007,34 @@ __device__ __forceinline__ double reduce_partials(const double* __restrict__ a, 
     for (int i = threadIdx.x; i < n; i += kPcgBlock) s += a[i];
     return block_sum<kPcgBlock>(s, lds);
 }
+// N partial arrays (n values each, `stride` apart) in ONE pass: N loads in flight per step and one workgroup barrier pair for all of
+// them (nine reductions one after the other cost k_pcg_p 12 us of its 20).  lds: N * kPcgBlock / kWave doubles.  Every thread gets all sums.
+template <int N>
+__device__ __forceinline__ void reduce_partials_multi(const double* __restrict__ a, size_t stride, int n, double* lds, double (&out)[N]) {
+    double s[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) s[j] = 0.0;
+    for (int i = threadIdx.x; i < n; i += kPcgBlock) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] += a[j * stride + i];
+    }
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int j = 0; j < N; ++j) s[j] = wave_sum(s[j]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) lds[j * (kPcgBlock / kWave) + w] = s[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double v = 0.0;
+#pragma unroll
+        for (int i = 0; i < kPcgBlock / kWave; ++i) v += lds[j * (kPcgBlock / kWave) + i];
+        out[j] = v;
+    }
+}
 
 // (1) q = S p (all-reduced sum over the observations) + D_c^2 p;  partial p.q per camera
 __global__ __launch_bounds__(kPcgBlock) void k_pcg_q(Dev d, double* __restrict__ part) {
@@ -1023,6 +1051,30 @@ __global__ __launch_bounds__(kPcgBlock) void k_pcg_q(Dev d, double* __restrict__
         pq += pv * qv;
     }
     part[c] = pq;
+}
+
+// (1') one rank: (1) inside the per-camera sum of the product — the workgroup that adds a camera's partials of S p holds its six values of q
+__global__ __launch_bounds__(kBlock) void k_pcg_segsum_q(Dev d, double* __restrict__ part) {
+    if (d.st->done) return;
+    __shared__ double q6[6];
+    const int c = blockIdx.x;
+    segsum_body<6>(d.scat, d.cam_ptr, d.pq, c, q6);
+    __syncthreads();
+    if (threadIdx.x < kWave) {
+        double pq = 0.0;
+        if (threadIdx.x < 6) {
+            const size_t i = 6 * (size_t)c + threadIdx.x;
+            const double pv = d.pp[i];
+            const double qv = q6[threadIdx.x] + d.Dc2[i] * pv;
+            d.pq[i] = qv;
+            pq = pv * qv;
+        }
+        // lanes 0..5 in lane order, as k_pcg_q adds them (k = 0..5): ((((p0 q0 + p1 q1) + p2 q2) + ...)
+        double acc = __shfl(pq, 0, kWave);
+#pragma unroll
+        for (int k = 1; k < 6; ++k) acc += __shfl(pq, k, kWave);
+        if (threadIdx.x == 0) part[c] = acc;
+    }
 }
 
 // (2) alpha = rz / p.q;  x += alpha p, r -= alpha q, z = M^-1 r;  partial r.z and r.r per camera
@@ -1063,14 +1115,23 @@ __global__ __launch_bounds__(kPcgBlock) void k_pcg_xr(Dev d, double* __restrict_
 __global__ __launch_bounds__(kPcgBlock) void k_pcg_p(Dev d, const double* __restrict__ part, double tol, int max_it) {
     if (d.st->done) return;
     __shared__ double lds[kPcgBlock / kWave];
-    double rz_new = reduce_partials(part + d.n_cams, d.n_cams, lds);
-    const double rr = reduce_partials(part + 2 * (size_t)d.n_cams, d.n_cams, lds);
+    double rz_new, rr;
     double coef[kGauge] = {0, 0, 0, 0, 0, 0, 0};
-    if (d.pcgW) {        // z = Minv r + W E^-1 W^T r: every workgroup adds the seven partial arrays in the same order
-        double wr[kGauge];
-        for (int g = 0; g < kGauge; ++g) wr[g] = reduce_partials(part + (3 + g) * (size_t)d.n_cams, d.n_cams, lds);
-        pcg_coarse_coef(d, wr, coef);
+    if (d.pcgW) {        // z = Minv r + W E^-1 W^T r: every workgroup adds the nine partial arrays in the same order
+        __shared__ double lds9[(2 + kGauge) * (kPcgBlock / kWave)];
+        __shared__ double sE[kGauge * kGauge];
+        if (threadIdx.x < kGauge * kGauge) sE[threadIdx.x] = d.pcgE[threadIdx.x];      // (visible after the barriers of the reduction)
+        double sums[2 + kGauge], wr[kGauge];
+        reduce_partials_multi<2 + kGauge>(part + d.n_cams, (size_t)d.n_cams, d.n_cams, lds9, sums);
+        rz_new = sums[0]; rr = sums[1];
+#pragma unroll
+        for (int g = 0; g < kGauge; ++g) wr[g] = sums[2 + g];
+        pcg_coarse_coef(sE, wr, coef);
+#pragma unroll
         for (int g = 0; g < kGauge; ++g) rz_new += wr[g] * coef[g];
+    } else {
+        rz_new = reduce_partials(part + d.n_cams, d.n_cams, lds);
+        rr = reduce_partials(part + 2 * (size_t)d.n_cams, d.n_cams, lds);
     }
     const double rz = d.st->rz, bb = d.st->bb, pq = d.st->pq;
     const int it0 = d.st->it;

@@ -269,6 +269,35 @@ struct Result {
     unsigned char *slot_cidx = nullptr, *gt_cell = nullptr, *pt_const = nullptr;
 };
 
+// rocPRIM sorts / scans on the packing stream with one temporary buffer that grows on demand (device_pack and device_keys)
+template <typename TmpAlloc>
+struct PrimOps {
+    hipStream_t st; TmpAlloc tmp;
+    void* d_tmp = nullptr; size_t tb = 0;
+    bool need_tmp(size_t bytes) { if (bytes <= tb) return true; d_tmp = tmp(bytes); tb = d_tmp ? bytes : 0; return d_tmp != nullptr; }
+    template <typename K> int sort_pairs(K* kin, K* kout, int* vin, int* vout, size_t n, unsigned bits) {
+        size_t q = 0;
+        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    }
+    int scan_incl(int* in, int* out, size_t n) {
+        size_t q = 0;
+        if (rocprim::inclusive_scan(nullptr, q, in, out, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::inclusive_scan(d_tmp, t, in, out, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    }
+    int scan_excl(int* in, int* out, size_t n) {
+        size_t q = 0;
+        if (rocprim::exclusive_scan(nullptr, q, in, out, 0, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
+        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
+        size_t t = tb;
+        return rocprim::exclusive_scan(d_tmp, t, in, out, 0, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
+    }
+};
+
 // keep(bytes) -> device memory that lives as long as the context; scratch(bytes) -> device memory the caller releases after the call
 // (both nullptr when out of memory).  Returns XRSFM_BA_OK, an error, or +1: "take the host path" (a track longer than 64 observations).
 template <typename Keep, typename Scratch>
@@ -278,36 +307,11 @@ inline int device_pack(const xrsfm_ba_problem& p, hipStream_t st, Keep&& keep, S
     PhaseTimer timer("devpack");
     auto tmp = [&](size_t bytes) -> void* { return scratch_alloc(bytes ? bytes : 8); };
     auto alloc = [&](size_t bytes) -> void* { return keep(bytes ? bytes : 8); };
-    void* d_tmp = nullptr; size_t tb = 0;                     // rocPRIM temporary storage, grown on demand
-    auto need_tmp = [&](size_t bytes) -> bool { if (bytes <= tb) return true; d_tmp = tmp(bytes); tb = d_tmp ? bytes : 0; return d_tmp != nullptr; };
-    auto sort64 = [&](u64* kin, u64* kout, int* vin, int* vout, size_t n, unsigned bits) -> int {
-        size_t q = 0;
-        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
-    auto sort32 = [&](unsigned* kin, unsigned* kout, int* vin, int* vout, size_t n, unsigned bits) -> int {
-        size_t q = 0;
-        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
-    auto scan_incl = [&](int* in, int* out, size_t n) -> int {
-        size_t q = 0;
-        if (rocprim::inclusive_scan(nullptr, q, in, out, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::inclusive_scan(d_tmp, t, in, out, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
-    auto scan_excl = [&](int* in, int* out, size_t n) -> int {
-        size_t q = 0;
-        if (rocprim::exclusive_scan(nullptr, q, in, out, 0, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::exclusive_scan(d_tmp, t, in, out, 0, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
+    PrimOps<decltype(tmp)> prim{st, tmp};
+    auto sort64 = [&](u64* kin, u64* kout, int* vin, int* vout, size_t n, unsigned bits) { return prim.sort_pairs(kin, kout, vin, vout, n, bits); };
+    auto sort32 = [&](unsigned* kin, unsigned* kout, int* vin, int* vout, size_t n, unsigned bits) { return prim.sort_pairs(kin, kout, vin, vout, n, bits); };
+    auto scan_incl = [&](int* in, int* out, size_t n) { return prim.scan_incl(in, out, n); };
+    auto scan_excl = [&](int* in, int* out, size_t n) { return prim.scan_excl(in, out, n); };
     int e = 0;
 #define XBA_TMP(T, name, n) T* name = static_cast<T*>(tmp(sizeof(T) * (size_t)(n))); if (!name) return XRSFM_BA_ENOMEM
 #define XBA_KEEP(T, name, n) name = static_cast<T*>(alloc(sizeof(T) * (size_t)((n) > 0 ? (n) : 1))); if (!name) return XRSFM_BA_ENOMEM
@@ -636,36 +640,11 @@ inline int device_keys(const Packed& o, const int* slot_cam, const int* slot_pt,
     PhaseTimer timer("devkeys");
     auto tmp = [&](size_t bytes) -> void* { return scratch_alloc(bytes ? bytes : 8); };
     auto alloc = [&](size_t bytes) -> void* { return keep(bytes ? bytes : 8); };
-    void* d_tmp = nullptr; size_t tb = 0;
-    auto need_tmp = [&](size_t bytes) -> bool { if (bytes <= tb) return true; d_tmp = tmp(bytes); tb = d_tmp ? bytes : 0; return d_tmp != nullptr; };
-    auto sort64 = [&](u64* kin, u64* kout, int* vin, int* vout, size_t n, unsigned bits) -> int {
-        size_t q = 0;
-        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
-    auto sort32 = [&](unsigned* kin, unsigned* kout, int* vin, int* vout, size_t n, unsigned bits) -> int {
-        size_t q = 0;
-        if (rocprim::radix_sort_pairs(nullptr, q, kin, kout, vin, vout, n, 0u, bits, st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::radix_sort_pairs(d_tmp, t, kin, kout, vin, vout, n, 0u, bits, st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
-    auto scan_incl = [&](int* in, int* out, size_t n) -> int {
-        size_t q = 0;
-        if (rocprim::inclusive_scan(nullptr, q, in, out, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::inclusive_scan(d_tmp, t, in, out, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
-    auto scan_excl = [&](int* in, int* out, size_t n) -> int {
-        size_t q = 0;
-        if (rocprim::exclusive_scan(nullptr, q, in, out, 0, n, rocprim::plus<int>(), st) != hipSuccess) return XRSFM_BA_ENODEV;
-        if (!need_tmp(q)) return XRSFM_BA_ENOMEM;
-        size_t t = tb;
-        return rocprim::exclusive_scan(d_tmp, t, in, out, 0, n, rocprim::plus<int>(), st) == hipSuccess ? 0 : XRSFM_BA_ENODEV;
-    };
+    PrimOps<decltype(tmp)> prim{st, tmp};
+    auto sort64 = [&](u64* kin, u64* kout, int* vin, int* vout, size_t n, unsigned bits) { return prim.sort_pairs(kin, kout, vin, vout, n, bits); };
+    auto sort32 = [&](unsigned* kin, unsigned* kout, int* vin, int* vout, size_t n, unsigned bits) { return prim.sort_pairs(kin, kout, vin, vout, n, bits); };
+    auto scan_incl = [&](int* in, int* out, size_t n) { return prim.scan_incl(in, out, n); };
+    auto scan_excl = [&](int* in, int* out, size_t n) { return prim.scan_excl(in, out, n); };
     int e = 0;
 #define XBA_TMP(T, name, n) T* name = static_cast<T*>(tmp(sizeof(T) * (size_t)(n))); if (!name) return XRSFM_BA_ENOMEM
 #define XBA_KEEP(T, name, n) name = static_cast<T*>(alloc(sizeof(T) * (size_t)((n) > 0 ? (n) : 1))); if (!name) return XRSFM_BA_ENOMEM

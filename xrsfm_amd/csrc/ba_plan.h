@@ -677,7 +677,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             // launch (config 5's shape: 169 levels of 759 columns, 1.02 M tile products against 1.21 M).  XRSFM_BA_ND=0: keep the chain.
             const char* nd_env = std::getenv("XRSFM_BA_ND");
             if (P.ordering == 2 && Tn >= 96 && !(nd_env && nd_env[0] == '0')) {
-                const int leaf = std::getenv("XRSFM_BA_ND_LEAF") ? std::max(2 * CPT, std::atoi(std::getenv("XRSFM_BA_ND_LEAF"))) : std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
+                const int leaf = std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
                 timer.mark("    symbolic counts");
                 // (the fill of a part's own order depends on which end of it the search happens to start from — 1.08 / 1.11 M tile
                 //  products at config 5's shape with 1 / 4 pseudo-peripheral searches —: both are formed, the symbolic count decides)
@@ -928,8 +928,7 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             //  quarter of config T: 100-196 us per column instead of 45; a chunk is a serial walk, short ones in several rounds win)
             // (look-ahead schedule, chunks of 4 / 6 / 8 / 12 / 16 products at a quarter of config T: 41 / 39 / 44 / 41 / 50 ms per four
             //  factorisations — the chunks are bound by their operand traffic, 64 KB per product, not by their number)
-            const int la_chunk = std::getenv("XRSFM_BA_LA_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_LA_CHUNK"))) : 6;
-            const int nd_chunk = std::getenv("XRSFM_BA_ND_CHUNK") ? std::max(1, std::atoi(std::getenv("XRSFM_BA_ND_CHUNK"))) : 6;
+            const int la_chunk = 6, nd_chunk = 6;
             const int cs = lookahead ? std::max(la_chunk, (nc + panel_chunks - 1) / panel_chunks)
                          : panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks)
                          : nd_lv ? std::max(nd_chunk, (nc + 4095) / 4096) : std::max(1, (nc + 511) / 512);

@@ -573,12 +573,20 @@ int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary
         if (c->profiling) profile_collect(c, c->h_st->it);
         if (c->h_st->done || launched >= opt.pcg_max_iterations) break;
         for (int i = 0; i < chunk; ++i) {
-            int e = schur_product(c, d.pp, d.pq, launched);
-            if (e) return e;
+            // one rank: q = S p + D^2 p and the per-camera shares of p.q are formed where a camera's partials of the product are
+            // summed (k_pcg_segsum_q); several ranks: the sums are all-reduced first, k_pcg_q follows
+            const bool fused_q = !c->multi() && d.n_cams > 0;
+            if (fused_q) {
+                if (d.n_items > 0) { Timed t_(c, K_SCHUR_MATVEC, launched); hipLaunchKernelGGL(k_schur_matvec, dim3(cdiv(d.n_items, kWavesPerBlock)), dim3(kBlock), 0, c->stream, d, (const double*)d.pp); }
+                { Timed t_(c, K_CAM_SEGSUM, launched); hipLaunchKernelGGL(k_pcg_segsum_q, dim3(d.n_cams), dim3(kBlock), 0, c->stream, d, d.pcgpart); }
+            } else {
+                int e = schur_product(c, d.pp, d.pq, launched);
+                if (e) return e;
+            }
             if (d.n_cams > 0) {
                 Timed t_(c, K_PCG_VEC, launched);
                 const dim3 grid(cdiv(d.n_cams, kPcgBlock));
-                hipLaunchKernelGGL(k_pcg_q, grid, dim3(kPcgBlock), 0, c->stream, d, d.pcgpart);
+                if (!fused_q) hipLaunchKernelGGL(k_pcg_q, grid, dim3(kPcgBlock), 0, c->stream, d, d.pcgpart);
                 hipLaunchKernelGGL(k_pcg_xr, grid, dim3(kPcgBlock), 0, c->stream, d, d.pcgpart);
                 hipLaunchKernelGGL(k_pcg_p, grid, dim3(kPcgBlock), 0, c->stream, d, (const double*)d.pcgpart, opt.pcg_tolerance, opt.pcg_max_iterations);
             }
@@ -865,8 +873,8 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         // Gram tiles: one launch per (operand height, LDS class) that occurs.  The launches write disjoint outputs; a ragged map has
         // four to six of them, most with too few tiles to fill the chip (config R: 149 + 34 + 16 + 16 + 17 us one after the other):
         // when the second stream is forked anyway, the largest bucket stays on the main stream and the others follow the non-Gram
-        // items on the second one (XRSFM_BA_GRAM_FORK=0: all on the main stream, rounds 3-4)
-        static const bool gram_fork = [] { const char* e = std::getenv("XRSFM_BA_GRAM_FORK"); return !(e && e[0] == '0'); }();
+        // items on the second one
+        constexpr bool gram_fork = true;
         int big = -1;
         for (int b = 0; b < 8; ++b) if (h.gram_n[b] > 0 && (big < 0 || h.gram_n[b] > h.gram_n[big])) big = b;
         auto launch_buckets = [&](bool main_side) {
@@ -905,8 +913,7 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
     }
     int e = allreduce(c, d.camS, (size_t)d.n_cams * 28 + (size_t)h.n_blocks * 36, kNcclSum);   // camS | Sblk are contiguous
     if (e) return e;
-    static const bool fill_in_level0 = [] { const char* e = std::getenv("XRSFM_BA_FILL_FUSED"); return !(e && e[0] == '0'); }();
-    h.S_filled = materialize || !fill_in_level0;
+    h.S_filled = materialize;          // (else the first level's factor launch composes the tiles from the block values)
     if (h.S_filled && h.n_tiles_nz > 0)
         LAUNCH(c, K_DENSE_FILL, k_tile_fill, dim3(h.n_tiles_nz), dim3(256), 0, h.dev, d, h.tiles_nz, h.tf_ptr, h.tf_ent, h.Sblk, h.blk_rc,
                c->step_prep ? c->step_radius : 0.0);
@@ -914,14 +921,12 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
 }
 
 // Factor S = L L^T and solve S x = b (S and b from chol_assemble); the solution lands in d.px
-// push-form backward substitution of a panel schedule: two tile columns per launch from the last one down (XRSFM_BA_BWD2=0: one)
+// push-form backward substitution of a panel schedule: two tile columns per launch from the last one down
 static void panel_backward(xrsfm_ba_context* c) {
     CholHost& h = c->chol;
     const int T = h.T;
-    static const bool pairs = [] { const char* e = std::getenv("XRSFM_BA_BWD2"); return !(e && e[0] == '0'); }();
     int k = T - 1;
-    if (pairs)
-        for (int p = 0; k >= 1; k -= 2, ++p) {
+    for (int p = 0; k >= 1; k -= 2, ++p) {
             const int n = h.bw2_off[p + 1] - h.bw2_off[p];
             LAUNCH(c, K_TRISOLVE, k_bwd2, dim3(1 + n), dim3(256), 0, h.dev, k, h.bw2_link[p], (const int*)(h.bw2_ent + 2 * (size_t)h.bw2_off[p]));
         }
@@ -1782,10 +1787,7 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
     // evaluated, and the linearisation follows once a step is accepted again; once a solve has seen a rejection, two accepted
     // steps in a row are needed before the next one is linearised ahead again (near convergence accepted and rejected steps
     // alternate, and a wasted linearisation costs more than a saved cost pass).
-    // XRSFM_BA_SPECULATE = 0 (never) / 1 (whenever the last step was accepted) overrides the rule: measurement aid
-    const char* spec_env = std::getenv("XRSFM_BA_SPECULATE");
-    const int spec_mode = spec_env ? std::atoi(spec_env) : 2;
-    bool speculate = spec_mode != 0;
+    bool speculate = true;
     int accepted_run = 0;
     while (true) {
         if (it >= opt.max_iterations) return finish(XRSFM_BA_NO_CONVERGENCE, 5, cost);
@@ -1833,7 +1835,7 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
                 xnorm2_pts = c->h_scal[S_XNORM2_PTS];
             }
             ++accepted_run;
-            speculate = spec_mode == 2 ? (sum->n_unsuccessful == 0 || accepted_run >= 2) : spec_mode == 1;
+            speculate = sum->n_unsuccessful == 0 || accepted_run >= 2;
             radius = std::fmin(max_radius, radius / std::fmax(1.0 / 3.0, 1.0 - std::pow(2.0 * rel - 1.0, 3)));
             decrease = 2.0;
             sum->n_successful++;
