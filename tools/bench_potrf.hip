@@ -1,6 +1,6 @@
 // Micro-benchmark + bit-comparison of the 64x64 pivot-tile factorisation (potrf_lds_t of ba_chol.h) in its variants
 // (developer tool, not part of the library):  PV 0 = two v_mov_b32_dpp per broadcast (rounds 1-3), 1 = one v_mov_b64_dpp,
-// 2 = v_fmac_f64_dpp;  OVL = inverse blocks formed inside the block-column loop.
+// 4 = panels of four columns, trailing update on the matrix cores (round 5);  OVL = inverse blocks formed inside the block-column loop.
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -o tools/bench_potrf tools/bench_potrf.hip      run: tools/bench_potrf
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -93,6 +93,8 @@ int main() {
         run("PV0 + OVL", k_bench<0, true>, nb);
         run("PV1 (mov_b64_dpp)", k_bench<1, false>, nb);
         run("PV1 + OVL", k_bench<1, true>, nb);
+        run("PV4 (MFMA panels)", k_bench<4, false>, nb);
+        run("PV4 + OVL", k_bench<4, true>, nb);
     }
     return 0;
 }

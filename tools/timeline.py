@@ -14,11 +14,15 @@ sys.path.insert(0, ROOT)
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "L"
-    lib = os.path.join(ROOT, "tools", "_tl", "libxrsfm_ba_tl.so")
-    if not os.path.exists(lib):
+    # XBA_TL_FLAGS: extra compiler flags of the instrumented build (e.g. -DXBA_POTRF_PV=0), XBA_TL_TAG: a name for that build
+    tag = os.environ.get("XBA_TL_TAG", "tl")
+    lib = os.path.join(ROOT, "tools", "_tl", f"libxrsfm_ba_{tag}.so")
+    srcs = [os.path.join(ROOT, "xrsfm_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "xrsfm_amd", "csrc")) if f.endswith((".h", ".hip"))]
+    if not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in srcs):
         os.makedirs(os.path.dirname(lib), exist_ok=True)
         subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DXBA_TIMELINE", "-Wno-unused-value",
-                        "-Wno-deprecated-declarations", "-o", lib, os.path.join(ROOT, "xrsfm_amd", "csrc", "xrsfm_ba.hip"), "-ldl"], check=True)
+                        "-Wno-deprecated-declarations", *os.environ.get("XBA_TL_FLAGS", "").split(), "-o", lib,
+                        os.path.join(ROOT, "xrsfm_amd", "csrc", "xrsfm_ba.hip"), "-ldl"], check=True)
     from xrsfm_amd import capi, synth
     L = capi.load(lib)
     d = synth.make_problem(**synth.CONFIGS[cfg])

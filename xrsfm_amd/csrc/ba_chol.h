@@ -598,13 +598,122 @@ __device__ __forceinline__ double row_bcast64(double v, int l) {
 //  a 64-bit FMA issues slower than a DPP move + a plain FMA; the broadcasts of a group issued one group ahead of their FMAs, 12.0 us;
 //  the elimination sweep WITHOUT the inverse and the forward substitution L X = I afterwards, operands from LDS: 15.2 us.)
 #ifndef XBA_POTRF_PV
-#define XBA_POTRF_PV 1
+#define XBA_POTRF_PV 4
 #endif
 #ifndef XBA_POTRF_OVL
 #define XBA_POTRF_OVL 1
 #endif
+// ---- PV 4 (round 5): the same 16x16 factorisation + inverse with the rank-1 updates of a PANEL of four pivot columns applied to the
+// trailing columns as ONE rank-4 product on the FP64 matrix cores.
+// The sweep above spends 4 900 cycles on ~480 dependent-ish VALU instructions of one wave (120 column updates x [DPP move + 2 FMA]);
+// its dependent chain — pivot, reciprocal, two Newton steps, scale, update: 82 cycles per column — is a quarter of that.  Here the
+// block lives in the accumulator layout of v_mfma_f64_16x16x4_f64: lane (li, lk) holds row li, columns lk, lk+4, lk+8, lk+12
+// (four registers; lk = 16-lane row group of the wave), and so does the running right-hand side of L X = I (lane = column of X).
+// Panel p = columns 4p .. 4p+3 = register p of the four lane groups:
+//   1. all-gather the panel's four columns across the lane groups (v_permlane16_swap + v_permlane32_swap: 12 cheap VALU per 64-bit
+//      value, no LDS) so that every lane holds its row's four entries;
+//   2. the four elimination steps of the panel, every lane group redundantly (as the sweep above mirrors its rows): 3 + 2 + 1
+//      in-panel column updates with DPP row broadcasts — the 82-cycle chain per column stays, the 120 updates shrink to 24;
+//   3. trailing columns: acc -= T A_p^T with A operand = the lane's own final panel entry of column 4p+lk and B operand = its scaled
+//      entry tl (and xs for the inverse): two v_mfma_f64_16x16x4_f64 per panel, results land in the distributed layout directly.
+// The same products as the sweep; the matrix instruction adds a panel's four terms in one go (k ascending), so the factor
+// differs from PV 0/1 in the last bits — every caller uses ONE variant (the A/B tests compare schedules, not variants).
+__device__ __forceinline__ void allgather4(double v, double (&out)[4]) {     // v: row group g holds x_g  ->  out[k] = x_k in every group
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [x0 x0 x2 x2] | [x1 x1 x3 x3]
+    const auto h1 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const auto le = __builtin_amdgcn_permlane32_swap(l1[0], l1[0], false, false); // [x0 x0 x0 x0] | [x2 x2 x2 x2]
+    const auto he = __builtin_amdgcn_permlane32_swap(h1[0], h1[0], false, false);
+    const auto lo2 = __builtin_amdgcn_permlane32_swap(l1[1], l1[1], false, false); // [x1 ...] | [x3 ...]
+    const auto ho2 = __builtin_amdgcn_permlane32_swap(h1[1], h1[1], false, false);
+    out[0] = __hiloint2double((int)he[0], (int)le[0]); out[2] = __hiloint2double((int)he[1], (int)le[1]);
+    out[1] = __hiloint2double((int)ho2[0], (int)lo2[0]); out[3] = __hiloint2double((int)ho2[1], (int)lo2[1]);
+}
+// (every index below folds to a constant: the panel's values live in named registers, not in arrays a loop variable indexes)
+struct Panel4 { double a0, a1, a2, a3, x0, x1, x2, x3; };
+template <int JJ>          // elimination step of pivot column JJ (= 4P + K) inside its panel: scale, then update the panel's later columns
+__device__ __forceinline__ void potrf_panel_step(double& ak, double& xk, double& r, double& piv,
+                                                 double* a_next, double* x_next, const int n_next) {
+    piv = row_bcast64_c<JJ>(ak);
+    r = fast_rcp(piv);
+    const double tl = ak * r;               // u_ij / u_jj
+    const double xs = xk * r;
+    if (n_next >= 1) { const double bv = row_bcast64_c<(JJ + 1) & 15>(ak); a_next[0] = fma(-tl, bv, a_next[0]); x_next[0] = fma(-bv, xs, x_next[0]); }
+    if (n_next >= 2) { const double bv = row_bcast64_c<(JJ + 2) & 15>(ak); a_next[1] = fma(-tl, bv, a_next[1]); x_next[1] = fma(-bv, xs, x_next[1]); }
+    if (n_next >= 3) { const double bv = row_bcast64_c<(JJ + 3) & 15>(ak); a_next[2] = fma(-tl, bv, a_next[2]); x_next[2] = fma(-bv, xs, x_next[2]); }
+}
+template <int P>
+__device__ __forceinline__ void potrf_panel4(v4d& aa, v4d& ax, bool m1, bool m2, double& Lc, double& Xc, double& Pv) {
+    double pa[4], px[4];
+    allgather4(aa[P], pa);
+    allgather4(ax[P], px);
+    double a0 = pa[0], a1 = pa[1], a2 = pa[2], a3 = pa[3], x0 = px[0], x1 = px[1], x2 = px[2], x3 = px[3];
+    double r0, r1, r2, r3, j0, j1, j2, j3;
+    {
+        double an[3] = {a1, a2, a3}, xn[3] = {x1, x2, x3};
+        potrf_panel_step<4 * P + 0>(a0, x0, r0, j0, an, xn, 3);
+        a1 = an[0]; a2 = an[1]; a3 = an[2]; x1 = xn[0]; x2 = xn[1]; x3 = xn[2];
+    }
+    {
+        double an[3] = {a2, a3, 0.0}, xn[3] = {x2, x3, 0.0};
+        potrf_panel_step<4 * P + 1>(a1, x1, r1, j1, an, xn, 2);
+        a2 = an[0]; a3 = an[1]; x2 = xn[0]; x3 = xn[1];
+    }
+    {
+        double an[3] = {a3, 0.0, 0.0}, xn[3] = {x3, 0.0, 0.0};
+        potrf_panel_step<4 * P + 2>(a2, x2, r2, j2, an, xn, 1);
+        a3 = an[0]; x3 = xn[0];
+    }
+    {
+        double an[3] = {0.0, 0.0, 0.0}, xn[3] = {0.0, 0.0, 0.0};
+        potrf_panel_step<4 * P + 3>(a3, x3, r3, j3, an, xn, 0);
+    }
+    auto sel = [&](double v0, double v1, double v2, double v3) { return m2 ? (m1 ? v3 : v2) : (m1 ? v1 : v0); };
+    // operands of the lane's own panel column 4P+lk: the selected entry, its pivot's reciprocal, and the two scaled entries formed
+    // from them (the same products as tl / xs of the step that owns the column; one negation serves both products)
+    const double a_op = sel(a0, a1, a2, a3), x_op = sel(x0, x1, x2, x3), r_op = sel(r0, r1, r2, r3);
+    if (P < 3) {
+        const double na = -a_op;
+        aa = __builtin_amdgcn_mfma_f64_16x16x4f64(na, a_op * r_op, aa, 0, 0, 0);
+        ax = __builtin_amdgcn_mfma_f64_16x16x4f64(na, x_op * r_op, ax, 0, 0, 0);
+    }
+    // unscaled: the square roots (1 / sqrt(u_jj): column jj of L, row jj of the inverse) are applied after the sweep, off the
+    // dependent chain pivot -> reciprocal -> scale -> update -> next pivot (a wave issues in order)
+    Lc = a_op;                              // column 4P+lk of L, this lane's row
+    Xc = x_op;                              // row 4P+lk of the inverse, this lane's column
+    Pv = sel(j0, j1, j2, j3);               // u_jj of that column
+}
+__device__ __forceinline__ void potrf_block16_mfma(double (*A)[kLdT], double (*Li)[kLdT], int b0, int lane) {
+    const int li = lane & 15, lk = lane >> 4;
+    v4d aa, ax;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { aa[g] = A[b0 + li][b0 + lk + 4 * g]; ax[g] = (lk + 4 * g == li) ? 1.0 : 0.0; }
+    const bool m1 = (lk & 1) != 0, m2 = (lk & 2) != 0;
+    double L0, L1, L2, L3, X0, X1, X2, X3, u0, u1, u2, u3;
+    potrf_panel4<0>(aa, ax, m1, m2, L0, X0, u0);
+    potrf_panel4<1>(aa, ax, m1, m2, L1, X1, u1);
+    potrf_panel4<2>(aa, ax, m1, m2, L2, X2, u2);
+    potrf_panel4<3>(aa, ax, m1, m2, L3, X3, u3);
+    {   // fast_rsqrt of the lane's four pivots, the four chains side by side (same operations as fast_rsqrt)
+        double y0 = __builtin_amdgcn_rsq(u0), y1 = __builtin_amdgcn_rsq(u1), y2 = __builtin_amdgcn_rsq(u2), y3 = __builtin_amdgcn_rsq(u3);
+        const double h0 = 0.5 * u0, h1 = 0.5 * u1, h2 = 0.5 * u2, h3 = 0.5 * u3;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double f0 = fma(-h0 * y0, y0, 1.5), f1 = fma(-h1 * y1, y1, 1.5), f2 = fma(-h2 * y2, y2, 1.5), f3 = fma(-h3 * y3, y3, 1.5);
+            y0 = y0 * f0; y1 = y1 * f1; y2 = y2 * f2; y3 = y3 * f3;
+        }
+        L0 *= y0; X0 *= y0; L1 *= y1; X1 *= y1; L2 *= y2; X2 *= y2; L3 *= y3; X3 *= y3;
+    }
+    // column cc = 4p + lk of L (zero above the diagonal) and row cc of the inverse (zero above the diagonal by construction)
+    A[b0 + li][b0 + lk] = (lk <= li) ? L0 : 0.0;             Li[b0 + lk][b0 + li] = X0;
+    A[b0 + li][b0 + 4 + lk] = (4 + lk <= li) ? L1 : 0.0;     Li[b0 + 4 + lk][b0 + li] = X1;
+    A[b0 + li][b0 + 8 + lk] = (8 + lk <= li) ? L2 : 0.0;     Li[b0 + 8 + lk][b0 + li] = X2;
+    A[b0 + li][b0 + 12 + lk] = (12 + lk <= li) ? L3 : 0.0;   Li[b0 + 12 + lk][b0 + li] = X3;
+}
+
 template <int PV>
 __device__ __forceinline__ void potrf_block16(double (*A)[kLdT], double (*Li)[kLdT], int b0, int lane) {
+    if constexpr (PV == 4) { potrf_block16_mfma(A, Li, b0, lane); return; }
     const int li = lane & 15;
     // lanes 0..15 hold row `lane` of the diagonal block; other lanes mirror lane (lane & 15)
     double a[16];
@@ -707,40 +816,45 @@ __device__ __forceinline__ void potrf_lds_t(double (*A)[kLdT], double (*Li)[kLdT
     };
     // Look-ahead: wave 0 factors diagonal block kb+1 as soon as it has updated it, while waves 1..3 finish the rest of the
     // trailing update of step kb (they would otherwise wait at a barrier for the 2 us the in-register factorisation takes).
-    if (wave == 0) potrf_block16<PV>(A, Li, 0, lane);
-    __syncthreads();
+    // (round 5) The loop starts at kb = -1 — nothing but wave 0's factorisation of block 0 — so that the in-register factorisation
+    // has ONE call site: its ~4 KB of straight-line code exist once per kernel (the factor kernels are 50-60 KB of code against a
+    // 64 KB instruction cache that two CUs share).
 #pragma clang loop unroll(disable)          // (one copy of the in-register factorisation in the loop, not nb: the kernel must stay in the instruction cache)
-    for (int kb = 0; kb < nb; ++kb) {
-        XBA_STAMP(1, 3 + 2 * kb);
+    for (int kb = -1; kb < nb; ++kb) {
         const int b0 = 16 * kb;
-        // (b) rows below: X = A21 * Linv11^T, one 16-row block per wave
-        if (kb + 1 + wave < nb) {
-            const int rb = 16 * (kb + 1 + wave);
-            v4d acc = {0.0, 0.0, 0.0, 0.0};
+        if (kb >= 0) {
+            XBA_STAMP(1, 3 + 2 * kb);
+            // (b) rows below: X = A21 * Linv11^T, one 16-row block per wave
+            if (kb + 1 + wave < nb) {
+                const int rb = 16 * (kb + 1 + wave);
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int k0 = 0; k0 < 16; k0 += 4)
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[rb + li][b0 + k0 + lk], Li[b0 + li][b0 + k0 + lk], acc, 0, 0, 0);
+                for (int k0 = 0; k0 < 16; k0 += 4)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[rb + li][b0 + k0 + lk], Li[b0 + li][b0 + k0 + lk], acc, 0, 0, 0);
 #pragma unroll
-            for (int g = 0; g < 4; ++g) A[rb + lk + 4 * g][b0 + li] = acc[g];
+                for (int g = 0; g < 4; ++g) A[rb + lk + 4 * g][b0 + li] = acc[g];
+            }
+            __syncthreads();
+            XBA_STAMP(1, 4 + 2 * kb);
         }
-        __syncthreads();
-        XBA_STAMP(1, 4 + 2 * kb);
         // (c) trailing update A_ij -= X_i X_j^T for kb < j <= i < nb: wave 0 takes the next diagonal block and factors it,
         // the other blocks are dealt round-robin to waves 1..3
         if (wave == 0) {
             if (kb + 1 < nb) {
                 const int i = kb + 1;
-                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                if (kb >= 0) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int k0 = 0; k0 < 16; k0 += 4)
-                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * i + li][b0 + k0 + lk], A[16 * i + li][b0 + k0 + lk], acc, 0, 0, 0);
+                    for (int k0 = 0; k0 < 16; k0 += 4)
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(A[16 * i + li][b0 + k0 + lk], A[16 * i + li][b0 + k0 + lk], acc, 0, 0, 0);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * i + li] -= acc[g];
-                __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own block is written
-                __builtin_amdgcn_wave_barrier();
+                    for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * i + li] -= acc[g];
+                    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the wave's own block is written
+                    __builtin_amdgcn_wave_barrier();
+                }
                 potrf_block16<PV>(A, Li, 16 * i, lane);
             }
-        } else {
+        } else if (kb >= 0) {
             int idx = 0;
             for (int i = kb + 1; i < nb; ++i)
                 for (int j = kb + 1; j <= i; ++j) {
@@ -753,7 +867,9 @@ __device__ __forceinline__ void potrf_lds_t(double (*A)[kLdT], double (*Li)[kLdT
 #pragma unroll
                     for (int g = 0; g < 4; ++g) A[16 * i + lk + 4 * g][16 * j + li] -= acc[g];
                 }
+            if (kb == nb - 1) XBA_STAMP_W1(1, 14);
             if (OVL && wave - 1 < kb) inv_block(kb, wave - 1);     // row kb of the inverse (its operands are complete, see above)
+            if (kb == nb - 1) XBA_STAMP_W1(1, 15);
         }
         __syncthreads();
     }

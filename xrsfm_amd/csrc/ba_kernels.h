@@ -95,8 +95,11 @@ struct Dev {
 #ifdef XBA_TIMELINE
 __device__ unsigned long long g_stamps[3][64][16];
 #define XBA_STAMP(kern, i) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 64 && (threadIdx.x >> 6) == 0) g_stamps[kern][blockIdx.x / 97][i] = __builtin_readcyclecounter(); } while (0)
+// ... the same from wave 1 of the workgroup (what the other waves of a factor workgroup do while wave 0 sweeps)
+#define XBA_STAMP_W1(kern, i) do { if ((threadIdx.x & 63) == 0 && (blockIdx.x % 97) == 0 && blockIdx.x / 97 < 64 && (threadIdx.x >> 6) == 1) g_stamps[kern][blockIdx.x / 97][i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define XBA_STAMP(kern, i) do {} while (0)
+#define XBA_STAMP_W1(kern, i) do {} while (0)
 #endif
 
 // Parity-hardening build (-DXBA_POISON, tests/test_gpu_hardening.py): every per-lane temporary of the streaming kernels that a lane
