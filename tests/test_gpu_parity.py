@@ -1074,15 +1074,20 @@ def test_unordered_collection_nested_dissection_matches_the_chain_order(lib, mon
     s_again = capi.solve(again, opt)
     assert s.linear_solver_used == capi.SOLVER_CHOLESKY
     assert s_again.final_cost == s.final_cost and np.array_equal(prod.cam_q, again.cam_q) and np.array_equal(prod.points, again.points)
-    # backward substitution of the deep level schedule: a column's tiles shared out over workgroups, last arrival sums (default)
-    # against the push form of the panel schedules (XRSFM_BA_BWD_CHUNK=0)
-    monkeypatch.setenv("XRSFM_BA_BWD_CHUNK", "0")
-    push = H.to_product(arr)
-    sp = capi.solve(push, opt)
+    # backward substitution of the deep level schedule: ONE launch for all levels (default since round 5: k_lv_bwd_all with its lists
+    # walked from the root side) against one launch per level with a column's tiles shared out over workgroups (XRSFM_BA_BWD_ALL=0)
+    # and against the push form of the panel schedules (... and XRSFM_BA_BWD_CHUNK=0)
+    monkeypatch.setenv("XRSFM_BA_BWD_ALL", "0")
+    for chunk_env in (None, "0"):
+        if chunk_env is not None:
+            monkeypatch.setenv("XRSFM_BA_BWD_CHUNK", chunk_env)
+        other = H.to_product(arr)
+        so = capi.solve(other, opt)
+        assert (s.n_successful, s.n_unsuccessful) == (so.n_successful, so.n_unsuccessful)
+        assert abs(s.final_cost - so.final_cost) <= 1e-9 * so.final_cost
+        assert np.abs(prod.cam_q - other.cam_q).max() < 1e-7 and np.abs(prod.cam_t - other.cam_t).max() < 1e-6
     monkeypatch.delenv("XRSFM_BA_BWD_CHUNK")
-    assert (s.n_successful, s.n_unsuccessful) == (sp.n_successful, sp.n_unsuccessful)
-    assert abs(s.final_cost - sp.final_cost) <= 1e-9 * sp.final_cost
-    assert np.abs(prod.cam_q - push.cam_q).max() < 1e-7 and np.abs(prod.cam_t - push.cam_t).max() < 1e-6
+    monkeypatch.delenv("XRSFM_BA_BWD_ALL")
     monkeypatch.setenv("XRSFM_BA_ND", "0")
     plan0 = capi.debug_chol_plan(H.to_product(arr))
     assert plan0["ordering"] == 2 and plan0["level_schedule"] == 0

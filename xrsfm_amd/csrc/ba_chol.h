@@ -1680,14 +1680,16 @@ __global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict
 #pragma unroll
     for (int m = 0; m < 16; ++m) lk[m] = Lk[(part * 16 + m) * kNB + o];
     const double yk = c.y[k * kNB + o];
+    // (round 5) the list is walked from its LAST entry — the ancestor nearest the root, solved first — down to the parent: the order in
+    // which the one-launch form (k_lv_bwd_all) finds its operands ready; both forms add the same terms in the same order
     double s = 0.0;
-    for (int qb = q0; qb < q1; qb += 64) {
-        const int n = min(64, q1 - qb);
+    for (int qe = q1; qe > q0; qe -= 64) {
+        const int qb = max(q0, qe - 64), n = qe - qb;
         __syncthreads();
         if (t < n) ids[t] = ci[qb + t];
         __syncthreads();
 #pragma unroll 4
-        for (int e = 0; e < n; ++e) {
+        for (int e = n - 1; e >= 0; --e) {
             const int i = ids[e];
             const double* M = tile_ptr(c, i, k) + (size_t)(part * 16) * c.ld + o;
             const double* xv = c.x + i * kNB + part * 16;
@@ -1825,9 +1827,14 @@ __global__ __launch_bounds__(256) void k_lv_bwd_all(CholDev c, const int* __rest
 #pragma unroll
     for (int m = 0; m < 16; ++m) lk[m] = Lk[(part * 16 + m) * kNB + o];
     const double yk = c.y[k * kNB + o];
+    // The column's list in ascending row order names its parent first and the ancestor nearest the root last; the root side is solved
+    // first.  Walking the list forwards made every workgroup wait for its PARENT in its first round and run the other rounds — a tile-
+    // load round trip each, 18 of them for a 70-tile column of a dissected photo collection — only afterwards: the per-level hop was
+    // rounds x 2 us (20 ms per solve at config T, round 4).  Backwards, the rounds of the far ancestors run while the near ones are
+    // still being solved and only the last round waits (round 5; k_lv_bwd walks the same way: bit-identical).
     double s = 0.0;
-    for (int qb = q0; qb < q1; qb += kBwdPre) {
-        const int n = min(kBwdPre, q1 - qb);
+    for (int qe = q1; qe > q0; qe -= kBwdPre) {
+        const int qb = max(q0, qe - kBwdPre), n = qe - qb;
         double M[kBwdPre][16];
 #pragma unroll
         for (int u = 0; u < kBwdPre; ++u)
@@ -1857,7 +1864,7 @@ __global__ __launch_bounds__(256) void k_lv_bwd_all(CholDev c, const int* __rest
         }
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < kBwdPre; ++u)
+        for (int u = kBwdPre - 1; u >= 0; --u)
             if (u < n) {
 #pragma unroll
                 for (int m = 0; m < 16; ++m) s += M[u][m] * xs[u][part * 16 + m];

@@ -790,12 +790,12 @@ int chol_setup(xrsfm_ba_context* c) {
     {   // one-launch backward substitution (level schedules with at least two levels; XRSFM_BA_BWD_ALL=0: one launch per level)
         const char* be = std::getenv("XRSFM_BA_BWD_ALL");        // (read per context: the A/B test switches it inside one process)
         const bool on = !(be && be[0] == '0');
-        // (shallow trees only: with the 174 levels of a dissected photo collection — 758 workgroups, most of them polling for most of the
-        //  launch — a solve took 20 ms against 1.7 ms of per-level launches; measured at config T)
-        h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2 && (P.n_levels <= 32 || (be && be[0] == '1'));
-        // ... and the pull form per level is no better there (one workgroup walks the up to 70 tiles of its column: 207 us per level):
-        // deep level schedules take the push form of the panel schedules, one workgroup per tile, two columns per launch (6.3 ms)
-        // (XRSFM_BA_BWD_CHUNK=0), or — default — one launch per level with the tiles of a column shared out over workgroups (k_lv_bwd_chunk)
+        // (round 4 kept deep trees off it: with the 174 levels of a dissected photo collection a solve took 20 ms against 4 ms of per-level
+        //  chunk launches — every workgroup walked its list parent first and ran its other rounds only after the parent was solved;
+        //  with the lists walked from the root side (round 5, ba_chol.h) the same launch takes 0.68 ms: config T 1086 -> 970 ms)
+        h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2;
+        // XRSFM_BA_BWD_ALL=0 on a deep level schedule: one launch per level with the tiles of a column shared out over workgroups
+        // (k_lv_bwd_chunk), or — XRSFM_BA_BWD_CHUNK=0 as well — the push form of the panel schedules, two columns per launch
         const char* bce = std::getenv("XRSFM_BA_BWD_CHUNK");
         const bool deep = P.use_levels && !P.panel_ll && !h.bwd_all && P.n_levels > 32;
         h.bwd_chunk = deep && !(bce && bce[0] == '0');
