@@ -1483,6 +1483,7 @@ int xrsfm_ba_comm_unique_id(unsigned char id[128]) {
 }
 
 int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigned char id[128]) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || !id || n_ranks < 1 || n_ranks > kMaxRanks || rank < 0 || rank >= n_ranks) return XRSFM_BA_EINVAL;
     // a single rank needs no communicator; XRSFM_BA_FORCE_COMM=1 creates one anyway (exercises the RCCL plumbing
     // on a 1-GPU box: every all-reduce then really goes through ncclAllReduce)
@@ -1503,6 +1504,7 @@ int xrsfm_ba_comm_init(xrsfm_ba_context* c, int n_ranks, int rank, const unsigne
 }
 
 int xrsfm_ba_debug_comm_hook(xrsfm_ba_context* c, int n_ranks, int rank, xrsfm_ba_allreduce_fn fn, void* user) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || !fn || n_ranks < 1 || n_ranks > kMaxRanks || rank < 0 || rank >= n_ranks || c->comm) return XRSFM_BA_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     c->hook = fn; c->hook_user = user; c->n_ranks = n_ranks; c->rank = rank;
@@ -2179,6 +2181,7 @@ int xrsfm_ba_filter_tracks(const xrsfm_ba_problem* p, double max_reproj_error, d
 // ---------------------------------------------------------------- diagnostics
 int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scaling, double* r, double* Jc, double* Jp,
                              double* Hpp, double* gp, double* Hcc_diag, double* gc, double* cost) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || c->wide) return XRSFM_BA_EINVAL;          // (bal9 contexts: xrsfm_ba_debug_wide)
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
@@ -2241,6 +2244,7 @@ int xrsfm_ba_debug_linearize(xrsfm_ba_context* c, double huber_a, int use_scalin
 // per camera diag(Hcc) and g_c [n_cams][9]; step y [n_cams][9] (skipped if NULL).
 int xrsfm_ba_debug_wide(xrsfm_ba_context* c, double huber_a, double radius, double* cost, double* r, double* Jc, double* Jp,
                         double* Hcc_diag, double* gc, double* y) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || !c->wide) return XRSFM_BA_EINVAL;
     HIPCHK(hipSetDevice(c->device));
     Dev& d = c->d;
@@ -2297,6 +2301,7 @@ int xrsfm_ba_debug_wide(xrsfm_ba_context* c, double huber_a, double radius, doub
 // bal9 mode: the intrinsics {f, k1, k2} of the cameras that keep them variable, written into intr_params [n_intr][8] (rows of
 // the other entries untouched) — what xrsfm_ba_solve does for the caller's problem->intr_params.
 int xrsfm_ba_download_intrinsics(xrsfm_ba_context* c, double* intr_params) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || !intr_params) return XRSFM_BA_EINVAL;
     if (!c->wide) return XRSFM_BA_OK;
     HIPCHK(hipSetDevice(c->device));
@@ -2310,6 +2315,7 @@ int xrsfm_ba_download_intrinsics(xrsfm_ba_context* c, double* intr_params) {
 }
 
 int xrsfm_ba_debug_schur_product(xrsfm_ba_context* c, double radius, const double* x, double* y, double* b) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (c && c->wide) return XRSFM_BA_EINVAL;
     if (!c || !x || !y) return XRSFM_BA_EINVAL;
     if (!c->linearized) return XRSFM_BA_ESTATE;
@@ -2388,6 +2394,7 @@ int xrsfm_ba_debug_chol_plan(const xrsfm_ba_problem* p, int32_t stats[8], int32_
 }
 
 int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context* c, int n_pairs, const int32_t* row_col) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || n_pairs < 0 || (n_pairs > 0 && !row_col)) return XRSFM_BA_EINVAL;
     if (c->chol.ready) return XRSFM_BA_ESTATE;
     c->pattern_keys.clear();
@@ -2403,6 +2410,7 @@ int xrsfm_ba_debug_set_block_pattern(xrsfm_ba_context* c, int n_pairs, const int
 }
 
 int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y, double* S_dense) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || !y || c->wide) return XRSFM_BA_EINVAL;
     if (!c->linearized) return XRSFM_BA_ESTATE;
     HIPCHK(hipSetDevice(c->device));
@@ -2440,6 +2448,7 @@ int xrsfm_ba_debug_cholesky_solve(xrsfm_ba_context* c, double radius, double* y,
 
 int xrsfm_ba_debug_backsub(xrsfm_ba_context* c, double* part_model, double* part_step2, double* cand_points, double* point_step,
                            double* cand_cam_q, double* cand_cam_t) {
+    if (c && c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context's stream: nothing may wait for it again
     if (!c || c->wide) return XRSFM_BA_EINVAL;
     // needs the camera part of a step (d.px) and the radius / point factors it was assembled with: without a preceding
     // xrsfm_ba_debug_cholesky_solve of the SAME linearisation the kernel would read uninitialised Hinv / px (or divide by a zero radius)
