@@ -221,8 +221,6 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int cp = d.slot_campos_g[s.slot];
         const int cidx_raw = GRAM ? (int)d.slot_cidx[s.slot] : 0;
-        double jv[6];                                  // (slot-indexed: requested for every lane, with the slot record — ba_kernels.h: load_Jp)
-        load_Jp(d, s.slot, jv);
         const int L = d.tile_stride[it.first_tile];
         double V[18];                 // (lanes without an observation: never staged, never a pair partner — XBA_POISON checks it)
 #pragma unroll
@@ -245,7 +243,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                     gv[0] = g[0]; gv[1] = g[1]; gv[2] = g[2];
                 }
                 double F[12], E[6];
-                build_FE(d, jv, s.cam, s.pt, F, E);
+                load_FE(d, s.slot, s.cam, s.pt, F, E);
                 if (PREP) { double hf[6]; point_factor(hcv, radius, hf);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) hcv[k] = hf[k]; }

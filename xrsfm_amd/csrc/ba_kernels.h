@@ -201,21 +201,11 @@ __device__ __forceinline__ SlotCtx load_slot(const Dev& d, int tile, int lane) {
 
 // Rebuild the Jacobi-scaled, robustified blocks of one observation:
 //   F (2x6) = [ -2 (j x M P) * sq | j * st ],   E (2x3) = (j M) * sp        (j = rows of Jp)
-// (round 5) the slot-indexed part of an observation's record — its six Jp values — needs no index load: load_Jp() requests it
-// for EVERY lane of the tile (padding slots exist in the arrays, their values are never used) together with the slot record, before the
-// `valid` test that the camera- and point-indexed loads sit behind: one more 48-byte stream in flight during the first round trip
-__device__ __forceinline__ void load_Jp(const Dev& d, int slot, double (&j)[6]) {
+__device__ __forceinline__ void load_FE(const Dev& d, int slot, int cam, int pt, double (&F)[12], double (&E)[6]) {
     const size_t ns = (size_t)d.n_slots;
+    double j[6];
 #pragma unroll
     for (int k = 0; k < 6; ++k) j[k] = d.Jp[k * ns + slot];
-}
-__device__ __forceinline__ void build_FE(const Dev& d, const double (&j)[6], int cam, int pt, double (&F)[12], double (&E)[6]);
-__device__ __forceinline__ void load_FE(const Dev& d, int slot, int cam, int pt, double (&F)[12], double (&E)[6]) {
-    double j[6];
-    load_Jp(d, slot, j);
-    build_FE(d, j, cam, pt, F, E);
-}
-__device__ __forceinline__ void build_FE(const Dev& d, const double (&j)[6], int cam, int pt, double (&F)[12], double (&E)[6]) {
     const CamLin& c = d.camrec[cam];
     double M[9];
 #pragma unroll
@@ -289,7 +279,6 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double cs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         double spk[3] = {XBA_DEAD1, XBA_DEAD1, XBA_DEAD1};   // point scaling, kept for the gradient norm after the reduction (a reload
-        const double obs_u = d.slot_u[s.slot], obs_v = d.slot_v[s.slot];     // (slot-indexed: requested for every lane, with the slot record)
         if (s.valid) {                                 // there would be a third dependent memory round trip)
             const CamRec& c = d.cam[s.cam];
             double q[4] = {c.q[0], c.q[1], c.q[2], c.q[3]};
@@ -299,7 +288,7 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
             double M[9];
             quat_to_mat(q, M);
             Proj pr;
-            project<true>(M, t, c.intr, d.cam_model[s.cam], Pw, obs_u, obs_v, pr);
+            project<true>(M, t, c.intr, d.cam_model[s.cam], Pw, d.slot_u[s.slot], d.slot_v[s.slot], pr);
             double rho1;
             const double rho = huber(pr.r0 * pr.r0 + pr.r1 * pr.r1, huber_a, rho1);
             cost = cost + rho;
@@ -934,10 +923,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
         for (int k = 0; k < 6; ++k) E[k] = XBA_DEAD;
 #endif
         double w[3] = {0, 0, 0};                   // operand of the segmented sum: zeros on lanes without an observation
-        double jv[6];
-        load_Jp(d, s.slot, jv);
         if (s.valid) {
-            build_FE(d, jv, s.cam, s.pt, F, E);
+            load_FE(d, s.slot, s.cam, s.pt, F, E);
             v0 = 0.0; v1 = 0.0;
             const double* p = pvec + 6 * (size_t)s.cam;
 #pragma unroll
@@ -1253,9 +1240,6 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, doubl
         double hh[6] = {XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD}, gg[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
         double spv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD}, Pv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
         bool var = false;
-        double jv[6];                                                           // slot-indexed: requested for every lane, with the slot record
-        load_Jp(d, s.slot, jv);
-        const double r0_all = d.rt[s.slot], r1_all = d.rt[ns + s.slot];
         if (s.valid) {
             const double* h = (PREP ? d.Hpp : d.Hinv) + 6 * (size_t)s.pt;
             const double* g = d.gp + 3 * (size_t)s.pt;
@@ -1271,9 +1255,9 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, doubl
         if (s.valid) {
             const double* yp = d.px + 6 * (size_t)s.cam;
             const double y[6] = {yp[0], yp[1], yp[2], yp[3], yp[4], yp[5]};
-            r0 = r0_all; r1 = r1_all;
+            r0 = d.rt[s.slot]; r1 = d.rt[ns + s.slot];
             double F[12];
-            build_FE(d, jv, s.cam, s.pt, F, E);
+            load_FE(d, s.slot, s.cam, s.pt, F, E);
             v0 = 0.0; v1 = 0.0;
 #pragma unroll
             for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
