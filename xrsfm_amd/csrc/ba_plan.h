@@ -677,7 +677,8 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
             // launch (config 5's shape: 169 levels of 759 columns, 1.02 M tile products against 1.21 M).  XRSFM_BA_ND=0: keep the chain.
             const char* nd_env = std::getenv("XRSFM_BA_ND");
             if (P.ordering == 2 && Tn >= 96 && !(nd_env && nd_env[0] == '0')) {
-                const int leaf = std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
+                // (XRSFM_BA_ND_LEAF: developer aid of tools/t_sweep.py — the leaf size trades fill against the depth of the tree)
+                const int leaf = std::getenv("XRSFM_BA_ND_LEAF") ? std::max(2 * CPT, std::atoi(std::getenv("XRSFM_BA_ND_LEAF"))) : std::max(200, std::min(1200, Nc / 6));   // (config 5: 1200 of 7500)
                 timer.mark("    symbolic counts");
                 // (the fill of a part's own order depends on which end of it the search happens to start from — 1.08 / 1.11 M tile
                 //  products at config 5's shape with 1 / 4 pseudo-peripheral searches —: both are formed, the symbolic count decides)
