@@ -965,8 +965,9 @@ def test_config5_size_properties(lib):
     registered frames for 1DSfM Trafalgar; the data set is not available offline, so synth.make_collection generates an
     unordered collection of that size with viewpoint clusters, power-law track lengths and shuffled camera ids — 45 000 camera
     unknowns, no band in the natural order: until round 2 only the implicit-Schur PCG ran at this size (block-Jacobi: 1800
-    iterations per LM step, 10 s per solve); with the reverse Cuthill-McKee order of the camera graph the exact tile Cholesky
-    does).  No oracle
+    iterations per LM step, 10 s per solve); the exact tile Cholesky does since round 3 — on the reverse Cuthill-McKee chain of
+    the camera graph then, since round 4 on its nested dissection (ba_plan.h: ordering 3, a level schedule of ~174 levels; since
+    round 5 with the one-launch backward substitution: ~1 s per solve).  No oracle
     finishes at this size, so the checks are the size-independent ones (rec_1dsfm.cc:66-98 runs GBA on exactly this shape):
     termination by a Ceres rule, cost of the returned state (oracle evaluation) = reported cost, bit-reproducibility of a
     second run, the gradient max-norm of the objective falls by > 1e2, the RMSE approaches the noise level."""
@@ -990,8 +991,10 @@ def test_config5_size_properties(lib):
     print(f"config T: {n_obs} obs, generate {t1 - t0:.1f} s, create+solve {t2 - t1:.1f} s ({s.n_successful}+{s.n_unsuccessful} LM, "
           f"solver {s.linear_solver_used}, {s.pcg_iterations} PCG iterations, solve {s.total_time_s:.2f} s), second run {t3 - t2:.1f} s ({s2.total_time_s:.2f} s), "
           f"rmse {math.sqrt(s.initial_cost / n_obs):.3f} -> {math.sqrt(s.final_cost / n_obs):.3f} px, termination {s.termination}/{s.termination_reason}")
-    # round 3: the reverse Cuthill-McKee order of the camera graph (ba_plan.h) keeps the exact solve affordable at this size
+    # the nested dissection of the camera graph (ba_plan.h: ordering 3; round 3: its reverse Cuthill-McKee chain) keeps the exact solve affordable at this size
     assert s.linear_solver_used == capi.SOLVER_CHOLESKY
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["ordering"] == 3 and plan["level_schedule"] == 1, plan
     assert s.termination in (0, 1) and s.termination_reason in (2, 3, 5)       # tolerance exit, or the iteration cap of GBA-fast
     assert s.final_cost < 0.05 * s.initial_cost
     assert s2.final_cost == s.final_cost and (s2.n_successful, s2.n_unsuccessful) == (s.n_successful, s.n_unsuccessful)

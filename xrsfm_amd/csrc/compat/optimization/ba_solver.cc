@@ -20,6 +20,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <exception>
 #include <iomanip>
 #include <iostream>
@@ -111,13 +112,16 @@ class FlatProblem {
         // A large call (global BA) marks its tracks in a table over the whole map and the frames run in parallel; a small one (LBA: a
         // few thousand observations, once per registered frame) must not pay for the size of the MAP — 1-2 M tracks are 10 MB of
         // memset and a 2 M-iteration scan per call, as long as the solve itself —: it sorts the track ids it meets (round 5).
-        dense_slots_ = total_feats >= 200000;
-        const size_t par_min = dense_slots_ ? 1 : (size_t)-1;       // frames in parallel only for a large call
+        // (the table over the map costs ~2 ns per track of the MAP, the sort ~50 ns per observation of the CALL: the table wherever the map
+        //  is at most 16 x the call — mapper replay, 45 000 tracks: LBA 0.84 ms with the table, 1.04 ms sorted)
+        dense_slots_ = total_feats >= 200000 || map_.tracks_.size() <= 16 * total_feats;
+        const size_t par_min = total_feats >= 200000 ? 1 : (size_t)-1;       // frames in parallel only for a large call
         tracks_.clear();
         if (dense_slots_) {
             // (relaxed atomic marks: several frames mark the same track from different threads, all with the same value)
             std::unique_ptr<std::atomic<unsigned char>[]> used(new std::atomic<unsigned char>[map_.tracks_.size() ? map_.tracks_.size() : 1]);
-            ParallelFor(map_.tracks_.size(), 1, [&](size_t a, size_t b) { for (size_t i = a; i < b; ++i) used[i].store(0, std::memory_order_relaxed); });
+            static_assert(sizeof(std::atomic<unsigned char>) == 1, "the mark table is cleared as bytes");
+            ParallelFor(map_.tracks_.size(), par_min, [&](size_t a, size_t b) { std::memset(static_cast<void *>(used.get() + a), 0, b - a); });
             ParallelFor(nf, par_min, [&](size_t c0, size_t c1) {
                 for (size_t c = c0; c < c1; ++c) {
                     size_t n = 0;
