@@ -814,7 +814,9 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_coarse(Dev d) {
     __shared__ double E[kGauge][kGauge], L[kGauge][kGauge], Li[kGauge][kGauge];
     __shared__ int keep[kGauge];
     const size_t n6 = 6 * (size_t)d.n_cams;
+#pragma clang loop unroll(disable)
     for (int a = 0; a < kGauge; ++a)
+#pragma clang loop unroll(disable)
         for (int b = 0; b <= a; ++b) {
             double sum = 0.0;
             for (size_t i = threadIdx.x; i < n6; i += kPcgThreads) sum += 0.5 * (d.pcgW[a * n6 + i] * d.pcgSW[b * n6 + i] + d.pcgW[b * n6 + i] * d.pcgSW[a * n6 + i]);
@@ -822,36 +824,48 @@ __global__ __launch_bounds__(kPcgThreads) void k_pcg_coarse(Dev d) {
             if (threadIdx.x == 0) { E[a][b] = sum; E[b][a] = sum; }
         }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0) {        // (one thread, 7 x 7, LDS-resident: a few hundred scalar operations per LM step; loops kept rolled)
+#pragma clang loop unroll(disable)
         for (int i = 0; i < kGauge; ++i)
-            for (int j = 0; j < kGauge; ++j) { L[i][j] = 0.0; Li[i][j] = 0.0; }
+    #pragma clang loop unroll(disable)
+        for (int j = 0; j < kGauge; ++j) { L[i][j] = 0.0; Li[i][j] = 0.0; }
+#pragma clang loop unroll(disable)
         for (int j = 0; j < kGauge; ++j) {
             double sjj = E[j][j];
-            for (int k = 0; k < j; ++k) sjj -= L[j][k] * L[j][k];
+    #pragma clang loop unroll(disable)
+        for (int k = 0; k < j; ++k) sjj -= L[j][k] * L[j][k];
             keep[j] = (E[j][j] > 0.0 && sjj > 1e-12 * E[j][j]) ? 1 : 0;
             if (!keep[j]) continue;                              // row / column j stay zero: the direction takes no part
             const double ljj = sqrt(sjj);
             L[j][j] = ljj;
-            for (int i = j + 1; i < kGauge; ++i) {
+    #pragma clang loop unroll(disable)
+        for (int i = j + 1; i < kGauge; ++i) {
                 double v = E[i][j];
-                for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+        #pragma clang loop unroll(disable)
+        for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
                 L[i][j] = v / ljj;
             }
         }
+#pragma clang loop unroll(disable)
         for (int j = 0; j < kGauge; ++j) {                      // Li = L^-1 on the kept directions
             if (!keep[j]) continue;
             Li[j][j] = 1.0 / L[j][j];
-            for (int i = j + 1; i < kGauge; ++i) {
+    #pragma clang loop unroll(disable)
+        for (int i = j + 1; i < kGauge; ++i) {
                 if (!keep[i]) continue;
                 double v = 0.0;
-                for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
+        #pragma clang loop unroll(disable)
+        for (int k = j; k < i; ++k) v -= L[i][k] * Li[k][j];
                 Li[i][j] = v / L[i][i];
             }
         }
+#pragma clang loop unroll(disable)
         for (int a = 0; a < kGauge; ++a)
-            for (int b = 0; b < kGauge; ++b) {
+    #pragma clang loop unroll(disable)
+        for (int b = 0; b < kGauge; ++b) {
                 double v = 0.0;
-                for (int k = 0; k < kGauge; ++k) v += Li[k][a] * Li[k][b];
+        #pragma clang loop unroll(disable)
+        for (int k = 0; k < kGauge; ++k) v += Li[k][a] * Li[k][b];
                 d.pcgE[a * kGauge + b] = v;
             }
     }
