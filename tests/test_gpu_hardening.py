@@ -385,6 +385,45 @@ def test_blocks_from_stored_operands_equal_per_pair_blocks(lib, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["band", "two", "three", "mixed"])
+def test_gram_blocks_from_4x4_instructions_equal_16x16_tiles(lib, monkeypatch, case):
+    """Round 5: a Gram tile of up to 4 cameras forms its camera-pair blocks with v_mfma_f64_4x4x4_4b_f64 — the wanted 4x4 result
+    blocks only, four per instruction (ba_chol.h: gram_tile4) — instead of 16x16 result tiles of which 28 % is wanted
+    (XRSFM_BA_GRAM4=0: every tile in the 16x16 form).  Same products over the same K columns in the same order: the reduced camera
+    matrix, its solve and a full run must be BIT-identical — on tiles of 4 cameras (band), of 2 and of 3 (12 / 18 operand rows: the
+    last group of four rows is half empty) and on a map whose tiles have 3-7 cameras with missing cells (mixed: both forms in one launch)."""
+    from xrsfm_amd import capi
+    if case == "band":
+        arr = H.make(300, 40000, 4, seed=920)
+    elif case == "two":
+        arr = H.make(300, 30000, 2, seed=921)
+    elif case == "three":
+        arr = H.make(300, 30000, 3, seed=922)
+    else:
+        arr = H.make(300, 30000, 5, seed=924, dropout=0.2)
+    g = capi.debug_pack_gram(H.to_product(arr))
+    nc = np.bincount(g["tile_ncam"], minlength=5)
+    assert nc[2:5].sum() > 50, nc
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("XRSFM_BA_GRAM4", flag)
+        ctx = capi.Context(H.to_product(arr))
+        ctx.debug_linearize(5.99, False)
+        y, S = ctx.debug_cholesky_solve(2e3, want_S=True)
+        ctx.reset()
+        s = ctx.run(capi.default_options(max_iterations=8, linear_solver=capi.SOLVER_CHOLESKY))
+        q, t, P = ctx.download()
+        ctx.close()
+        out[flag] = (y, S, s, q, t, P)
+    monkeypatch.delenv("XRSFM_BA_GRAM4")
+    a, b = out["0"], out["1"]
+    assert np.abs(a[1]).max() > 0 and np.all(np.isfinite(b[0]))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    assert (a[2].n_successful, a[2].n_unsuccessful, a[2].final_cost) == (b[2].n_successful, b[2].n_unsuccessful, b[2].final_cost)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["band", "ragged", "closures", "bal9"])
 def test_one_launch_backward_substitution_equals_level_launches(lib, monkeypatch, case):
     """Round 4: the backward substitution of a level schedule runs as ONE launch (k_lv_bwd_all: one workgroup per tile column,

@@ -184,6 +184,155 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
     }
 }
 
+// ---- (round 5) the same Gram product on v_mfma_f64_4x4x4_4b_f64: four independent 4x4 result blocks per instruction.
+// FP64 matrix instructions run on the SIMD's vector data path on gfx950 — they do not overlap with the vector instructions of the
+// SIMD's other waves (tools/bench_pipes.hip: 2 vector + 2 matrix waves take exactly the sum of the two alone) and deliver the vector
+// rate (16x16x4: 64 cycles, 4x4x4 x 4 blocks: 16.5) — so what a 16x16 result tile computes outside the camera-pair blocks is vector
+// time lost.  A tile of 4 cameras (24 operand rows) needs 6 blocks of 36 elements: the 16-row form computes 3 x 256 elements per
+// K-step (28 % wanted, 192 cycles), 4-row groups 17 blocks of 16 in 5 instructions (64 % wanted, 83 cycles).
+// Schedule: the operand rows are cut into groups of 4; block (rg >= cg) is wanted when some row of group rg belongs to a later
+// camera than some row of group cg.  e[C] lists the wanted blocks of a tile of C cameras, four per instruction (rg | cg << 8; padded
+// with block (0,0): one camera, nothing of it is stored), n[C] = instructions.
+// Measured (tools/runs/r05_call19.sh, _call21.sh; results bit-identical to the 16x16 form): config L (tiles of 4 cameras, 5 instructions)
+// 99.6-101.2 -> 96.2 us per launch; tiles of 7-8 cameras (config R: 15-18 instructions against 6 of the 16-row form per K-step) and
+// 9-wide blocks (config Lb9) gain nothing — the form is used for schedules of at most kGram4MaxInst instructions (6-wide: <= 4 cameras).
+// Operand / result layout of the instruction (found by one-hot probing, tools/probe_mfma4.hip): lane l holds A_b[i][k] and B_b[k][j]
+// with i = j = l & 3, b = (l >> 2) & 3, k = l >> 4, and receives D_b[l >> 4][l & 3].
+constexpr int kGram4MaxInst = 6;
+template <int CW>
+struct GramSched4 {
+    static constexpr int kMaxC = CW == 6 ? kGramMaxCams : kGramMaxCamsWide;
+    static constexpr int kMaxG = (CW * kMaxC + 3) / 4;
+    static constexpr int kMaxE = ((kMaxG * (kMaxG + 1) / 2 + 3) / 4) * 4;
+    unsigned short e[kMaxC + 1][kMaxE];
+    int n[kMaxC + 1];
+};
+template <int CW>
+constexpr GramSched4<CW> make_gram_sched4() {
+    GramSched4<CW> s{};
+    for (int C = 1; C <= GramSched4<CW>::kMaxC; ++C) {
+        const int R = CW * C, G = (R + 3) / 4;
+        int cnt = 0;
+        for (int rg = 0; rg < G; ++rg)
+            for (int cg = 0; cg <= rg; ++cg) {
+                const int last_row = 4 * rg + 3 < R - 1 ? 4 * rg + 3 : R - 1;
+                if (last_row / CW > (4 * cg) / CW) s.e[C][cnt++] = (unsigned short)(rg | (cg << 8));
+            }
+        while (cnt & 3) s.e[C][cnt++] = 0;
+        s.n[C] = cnt / 4;
+    }
+    return s;
+}
+__device__ const GramSched4<6> g_gram_sched6 = make_gram_sched4<6>();
+template <int CW> __device__ __forceinline__ const GramSched4<CW>& gram_sched4();
+template <> __device__ __forceinline__ const GramSched4<6>& gram_sched4<6>() { return g_gram_sched6; }
+
+// The lane's entry of the schedule of a tile of C cameras (n_inst = 0: the tile takes the 16x16 form), requested at kernel start and parked in LDS behind
+// the destination table once that is written: a lookup in global memory where the products start would be a memory round trip in
+// the middle of every tile (measured: +3 000 cycles per wave).
+template <int CW>
+__device__ __forceinline__ int gram4_sched_load(int C, int lane, int& n_inst) {
+    const GramSched4<CW>& S = gram_sched4<CW>();
+    n_inst = S.n[C];
+    if (n_inst > kGram4MaxInst) { n_inst = 0; return 0; }          // (uniform) larger tiles: 16x16 result tiles
+    const int ne = 4 * n_inst;
+    return lane < ne ? (int)S.e[C][lane] : 0;        // (kGram4MaxInst x 4 entries: one per lane is enough)
+}
+static_assert(4 * kGram4MaxInst <= kWave, "one schedule entry per lane");
+__device__ __forceinline__ void gram4_sched_store(unsigned short* sched, int se, int lane, int n_inst) {
+    if (lane < 4 * n_inst) sched[lane] = (unsigned short)se;
+}
+
+// row / CW for row < 64 without an integer division (v_mul_hi is a quarter-rate instruction)
+template <int CW> __device__ __forceinline__ int gram_cam_of_row(int row) {
+    static_assert(CW == 6 || CW == 9, "6-wide or bal9 camera blocks");
+    return CW == 6 ? (row * 43) >> 8 : (row * 57) >> 9;
+}
+
+// NB instructions of the schedule (entries ent[0], ent[4], ...: the lane's block of each, in LDS): K loop, then the wanted elements to their
+// destinations — element (row, col) of the tile, camera rb = row / CW > camera ra = col / CW, goes to block dtab[ra][rb] (-1: nothing).
+template <int CW, int NB>
+__device__ __forceinline__ void gram4_batch(const double* __restrict__ Vst, int R, int Cp, int C4, const unsigned short* __restrict__ ent,
+                                            const int* __restrict__ dtab, double* __restrict__ scat2, int lane) {
+    const int i4 = lane & 3, kk = lane >> 4;
+    int e[NB];
+#pragma unroll
+    for (int u = 0; u < NB; ++u) e[u] = ent[4 * u];
+    typedef const __attribute__((address_space(3))) char* lds_ptr;       // (explicit: as generic pointers the induction variables below become flat loads)
+    typedef const __attribute__((address_space(3))) double* lds_dptr;
+    lds_ptr pa[NB];                                     // the lane's element of the two operands of each instruction, advancing with K
+    lds_ptr pb[NB];
+    double acc[NB];
+    lds_ptr Vb = (lds_ptr)Vst + 8 * kk;
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int rg = e[u] & 255, cg = e[u] >> 8;
+        pa[u] = Vb + 8 * (min(4 * rg + i4, R - 1) * Cp);      // (rows past the operand: clamped, their results are never stored)
+        pb[u] = Vb + 8 * (min(4 * cg + i4, R - 1) * Cp);
+        acc[u] = 0.0;
+    }
+    int k0 = 0;
+    for (; k0 + 16 <= C4; k0 += 16) {                   // four K-steps per round: one address update per operand, the rest immediate offsets
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int u = 0; u < NB; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(*(lds_dptr)(pa[u] + 32 * j), *(lds_dptr)(pb[u] + 32 * j), acc[u], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NB; ++u) { pa[u] += 128; pb[u] += 128; }
+    }
+    for (; k0 < C4; k0 += 4) {
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            acc[u] = __builtin_amdgcn_mfma_f64_4x4x4f64(*(lds_dptr)pa[u], *(lds_dptr)pb[u], acc[u], 0, 0, 0);
+            pa[u] += 32; pb[u] += 32;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+        const int row = 4 * (e[u] & 255) + kk, col = 4 * (e[u] >> 8) + i4;
+        const int rb = gram_cam_of_row<CW>(row), ra = gram_cam_of_row<CW>(col);
+        const int dst = dtab[ra * kGramTabLd + rb];
+        if (dst >= 0) scat2[(CW * CW) * (size_t)dst + CW * (row - CW * rb) + (col - CW * ra)] = acc[u];
+    }
+}
+
+// gram_tile for a tile staged in ONE round (passes == 1: every tile of the small LDS class that fits it, ba_pack.h: gram_lds_need)
+template <int CW = 6>
+__device__ __forceinline__ void gram_tile4(double* __restrict__ Vst, int R, int Cp, int C, const int* __restrict__ dtab,
+                                           double* __restrict__ scat2, int lane, const double (&V)[3 * CW], bool valid, int t, int cidx,
+                                           int T, bool dense, const unsigned short* __restrict__ sched, int n_inst) {
+    const unsigned short* ent = sched + ((lane >> 2) & 3);      // (LDS copy of the tile's schedule: gram4_sched_load / _store)
+    const int C4 = (3 * T + 3) & ~3;
+    if (dense) {
+        const int padc = C4 - 3 * T;
+        for (int e = lane; e < R * padc; e += kWave) {
+            const int row = e / padc, cc = 3 * T + (e - row * padc);
+            Vst[row * Cp + cc] = 0.0;
+        }
+    } else {
+        for (int e = lane; e < (R * Cp) / 2; e += kWave) reinterpret_cast<double2*>(Vst)[e] = make_double2(0.0, 0.0);
+    }
+    if (valid) {
+#pragma unroll
+        for (int i = 0; i < CW; ++i)
+#pragma unroll
+            for (int m = 0; m < 3; ++m) Vst[(CW * cidx + i) * Cp + 3 * t + m] = V[3 * i + m];
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the staged operand (and dtab) are in LDS
+    __builtin_amdgcn_wave_barrier();
+    XBA_STAMP(0, 6);
+    switch (n_inst) {                              // (uniform; the caller takes this path for schedules of at most kGram4MaxInst instructions)
+        case 6: gram4_batch<CW, 6>(Vst, R, Cp, C4, ent, dtab, scat2, lane); break;
+        case 5: gram4_batch<CW, 5>(Vst, R, Cp, C4, ent, dtab, scat2, lane); break;
+        case 4: gram4_batch<CW, 4>(Vst, R, Cp, C4, ent, dtab, scat2, lane); break;
+        case 3: gram4_batch<CW, 3>(Vst, R, Cp, C4, ent, dtab, scat2, lane); break;
+        case 2: gram4_batch<CW, 2>(Vst, R, Cp, C4, ent, dtab, scat2, lane); break;
+        default: gram4_batch<CW, 1>(Vst, R, Cp, C4, ent, dtab, scat2, lane); break;
+    }
+    XBA_STAMP(0, 7);
+}
+
 // GRAM = true: the item list holds Gram tiles only (the common case, compiled without the other paths so that their register
 // needs do not shape its allocation: 118 VGPRs, no spills); GRAM = false: per-pair tiles and long tracks.  The two
 // instantiations write disjoint outputs and run concurrently on two streams.
@@ -196,7 +345,7 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
 template <bool GRAM, bool PREP, int NIK>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu((GRAM && NIK < 4) ? 4 : (GRAM ? 3 : 2), (GRAM && NIK < 4) ? 4 : 3)))      // no instantiation may spill (tests/test_capi_cpu.py)
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
-                   int n_obs_pairs, double* __restrict__ scat2, double radius, double* __restrict__ pair_v = nullptr) {
+                   int n_obs_pairs, double* __restrict__ scat2, double radius, double* __restrict__ pair_v = nullptr, int gram4 = 1) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;
     XBA_STAMP(0, 0);
@@ -210,6 +359,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
         // requested before anything else: two dependent loads whose latency then hides behind the operand loads and the
         // diagonal terms instead of sitting in front of the Gram stage
         int dt0 = -1, dt1 = -1;         // entries lane and lane + 64 of the kGramTabLd x kGramTabLd table
+        int g4_se = 0, g4_n = 0;        // ... and of the tile's schedule of 4x4 result blocks (gram_tile4)
         if (GRAM) {
             const int C0 = d.tile_ncam[it.first_tile];
             const int* src = pair_dst + n_obs_pairs + d.tile_gt_off[it.first_tile];
@@ -217,6 +367,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             const int a1 = (lane + kWave) / kGramTabLd, b1 = lane + kWave - kGramTabLd * a1;
             if (b0 > a0 && b0 < C0) dt0 = src[a0 * C0 + b0];
             if (b1 > a1 && b1 < C0 && a1 < kGramTabLd) dt1 = src[a1 * C0 + b1];
+            if (NIK <= 2 && gram4) g4_se = gram4_sched_load<6>(C0, lane, g4_n);
         }
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int cp = d.slot_campos_g[s.slot];
@@ -384,7 +535,14 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             if (lane + kWave < kGramTabLd * kGramTabLd) dtab[lane + kWave] = dt1;
             const bool dense = nvalid == T * C;
             (void)Rp;
-            gram_tile<(NIK > 0 ? NIK : 1)>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
+            // one staging round: 4x4 result blocks (gram_tile4); two rounds (the accumulators carry over): 16x16 tiles.  gram4 = 0: always
+            // the latter (XRSFM_BA_GRAM4=0, the A/B oracle of tests/test_gpu_parity.py)
+            unsigned short* sched = reinterpret_cast<unsigned short*>(dtab + kGramTabLd * kGramTabLd);
+            if (NIK <= 2 && g4_n > 0 && passes == 1) {
+                gram4_sched_store(sched, g4_se, lane, g4_n);
+                gram_tile4<6>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, dense, sched, g4_n);
+            }
+            else gram_tile<(NIK > 0 ? NIK : 1)>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
             XBA_STAMP(0, 8);
             return;
         }

@@ -29,7 +29,9 @@ constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly
 __host__ __device__
 #endif
 inline int gram_lds_need(int C, int T, int* passes, int cw = 6) {     // cw: operand rows per camera (9 in bal9 mode, ba_wide.h)
-    constexpr int tab = (kGramMaxCams + 1) * (kGramMaxCams + 1) * 4;      // destination table with a fixed row stride (ba_chol.h: kGramTabLd)
+    // destination table with a fixed row stride (ba_chol.h: kGramTabLd) + the schedule of 4x4 result blocks of a small tile (ba_chol.h:
+    // gram_tile4, at most 6 instructions x 4 blocks x 2 bytes)
+    constexpr int tab = (kGramMaxCams + 1) * (kGramMaxCams + 1) * 4 + 48;
     const int one = cw * C * ((((3 * T + 3) & ~3)) + 2) * 8 + tab;
     if (one <= kGramSmallLds) { *passes = 1; return one; }
     const int Th = (T + 1) / 2;

@@ -16,6 +16,12 @@ namespace xba {
 constexpr int kW = 9;                       // unknowns per camera
 constexpr int kWS = 56;                     // per-observation diagonal-block record: 45 (upper triangle) + 9 (rhs) + 2 pad
 constexpr int kWB = 81;                     // off-diagonal block
+#ifndef XBA_K9LIN_W
+#define XBA_K9LIN_W 3
+#endif
+#ifndef XBA_K9G_W
+#define XBA_K9G_W 3
+#endif
 
 struct DevW {
     double* Fw;        // [18][n_slots] sqrt(rho') d r / d cam (2x9), Jacobi-scaled, constant blocks zero
@@ -96,18 +102,20 @@ __device__ __forceinline__ void tile_camera_runs(int cidx, int lane, int C, int&
 // (round 4) Gram tiles (ba_pack.h: tile_ncam > 0) sum the 18 camera-side values of their observations per distinct camera of
 // the tile through LDS and write ONE entry per camera (slot_campos_g / cam_ptr_g, the entries of the S assembly) instead of one
 // per observation: 144 bytes per observation less to write, and the fixed-order sum that follows reads a sixteenth.
-__global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double huber_a) {
-    __shared__ double red_all[kWavesPerBlock][kWave * kRedLd];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
-    if (item >= d.n_items) return;
-    const Item it = d.items[item];
+// LONG = the item is one track of more than 64 observations spread over several tiles: the sums that carry over its tiles live in
+// the wave's LDS slice (a long item is never a Gram tile) and exist only in that instantiation, as in linearize_item (ba_kernels.h).
+template <bool LONG>
+__device__ __forceinline__ void linearize9_item(const Dev& d, const DevW& w, const Item& it, int item, int lane, double huber_a, double* red) {
+    constexpr bool is_long = LONG;
     const size_t ns = (size_t)d.n_slots;
-    double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // long item: sums over its tiles (lane 0)
+    double* acc = red;                                // long item: sums over its tiles (lane 0)
+    if (is_long && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+    }
     double cost = 0.0, xn2 = 0.0, gm = 0.0;
     int long_pt = -1;
-    const bool is_long = it.n_tiles > 1;
-    for (int tl = 0; tl < it.n_tiles; ++tl) {
+    for (int tl = 0; tl < (LONG ? it.n_tiles : 1); ++tl) {
         const SlotCtx s = load_slot(d, it.first_tile + tl, lane);
         const int maxlen = d.tile_maxlen[it.first_tile + tl];
         double v[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -173,7 +181,6 @@ __global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double hub
                 const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
                 int mypos, run_pk[2];
                 tile_camera_runs<9>(cidx, lane, Cg, mypos, run_pk);
-                double* red = red_all[threadIdx.x >> 6];
                 tile_camera_sums<9>(red, cs0, lane, Cg, mypos, run_pk, cpg, w.scat, 18, 0);
                 tile_camera_sums<9>(red, cs1, lane, Cg, mypos, run_pk, cpg, w.scat, 18, 9);
             } else if (s.valid) {
@@ -211,6 +218,18 @@ __global__ __launch_bounds__(kBlock) void k9_linearize(Dev d, DevW w, double hub
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) gm = fmax(gm, __shfl_xor(gm, off, kWave));
     if (lane == 0) { d.part[item] = cost; d.part[d.n_items + item] = xn2; d.part[2 * (size_t)d.n_items + item] = gm; }
+}
+
+// 168 VGPRs: 3 waves per SIMD (the 24 values of F and E are live across the stores and the products)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(XBA_K9LIN_W, XBA_K9LIN_W))) void k9_linearize(Dev d, DevW w, double huber_a) {
+    __shared__ double red_all[kWavesPerBlock][kWave * kRedLd];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6));
+    if (item >= d.n_items) return;
+    const Item it = d.items[item];
+    double* red = red_all[threadIdx.x >> 6];
+    if (it.n_tiles > 1) linearize9_item<true>(d, w, it, item, lane, huber_a, red);
+    else linearize9_item<false>(d, w, it, item, lane, huber_a, red);
 }
 
 __global__ void k9_scale_from_norms(Dev d, DevW w) {
@@ -377,7 +396,7 @@ __device__ __forceinline__ void diag9_store(double* dst, const double (&F)[18], 
 // distinct camera of the tile through LDS before they are written (four rounds of 14 values): one wave = one tile, one
 // instantiation per operand height NI = ceil(9 C / 16).
 template <int NI>
-__global__ __launch_bounds__(kWave) void k9_pairs_gram(Dev d, DevW w, const int* __restrict__ tile_list, const int* __restrict__ pair_dst,
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NI < 4 ? XBA_K9G_W : 2, NI < 4 ? XBA_K9G_W : 2))) void k9_pairs_gram(Dev d, DevW w, const int* __restrict__ tile_list, const int* __restrict__ pair_dst,
                                                        int n_obs_pairs, double* __restrict__ scat2, double radius) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int lane = threadIdx.x;

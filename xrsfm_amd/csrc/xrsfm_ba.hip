@@ -103,6 +103,7 @@ struct CholHost {
     double *scat2 = nullptr, *Sblk = nullptr;
     bool bwd_push = false;                        // level schedule with a deep tree: backward substitution in push form (k_bwd2)
     bool bwd_chunk = false; int4* bc_chunks = nullptr; std::vector<int> bc_off; double* bc_part = nullptr; unsigned* bc_ctr = nullptr;   // ... or per level, columns in chunks (k_lv_bwd_chunk)
+    int gram4 = 1;                  // Gram tiles staged in one round: 4x4 result blocks (ba_chol.h: gram_tile4); XRSFM_BA_GRAM4=0: 16x16 tiles
     bool pair_from_v = false; int2* ent_src = nullptr; double* pair_v = nullptr;      // long tracks: blocks formed from stored operands (k_chol_segsum_v)
     int* tiles_nz = nullptr;                      // device: (ti,tj) of every structurally non-zero tile
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
@@ -757,6 +758,8 @@ int chol_setup(xrsfm_ba_context* c) {
         // one form.  Measured per LM iteration, pairs + sum: config T 11.8 + 3.3 -> 1.3 + 4.4 ms, D 0.37 + 0.86 -> 0.18 + 0.43,
         // U 0.19 + 0.13 -> 0.10 + 0.09; a ragged sequential map (config R: 0.66 M entries, most of them Gram cells) is faster with
         // the plain segmented sum (45 us against 73).
+        const char* g4 = std::getenv("XRSFM_BA_GRAM4");          // (read per set-up: the A/B test switches it)
+        h.gram4 = !(g4 && g4[0] == '0');
         const char* pe = std::getenv("XRSFM_BA_PAIR_V");        // (read per set-up: the A/B test switches it)
         h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : (P.n_pair_writes >= 262144 && 2LL * P.n_pair_writes >= P.n_writes));
         if (h.pair_from_v) {
@@ -867,8 +870,8 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
         };
         auto launch_gram = [&](auto ni, int n, size_t shm, const int* items, hipStream_t st) {
             constexpr int NI = decltype(ni)::value;
-            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
-            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr);
+            if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr, h.gram4);
+            else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr, h.gram4);
         };
         // Gram tiles: one launch per (operand height, LDS class) that occurs.  The launches write disjoint outputs; a ragged map has
         // four to six of them, most with too few tiles to fill the chip (config R: 149 + 34 + 16 + 16 + 17 us one after the other):
