@@ -374,13 +374,9 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
         const int cidx_raw = GRAM ? (int)d.slot_cidx[s.slot] : 0;
         const int L = d.tile_stride[it.first_tile];
         double V[18];                 // (lanes without an observation: never staged, never a pair partner — XBA_POISON checks it)
-#pragma unroll
-        for (int k = 0; k < 18; ++k) V[k] = XBA_DEAD;
         int npair = 0, pbase = 0;
         {
             double o28[28];
-#pragma unroll
-            for (int k = 0; k < 28; ++k) o28[k] = XBA_DEAD;
             XBA_STAMP(0, 1);
             if (s.valid) {
                 // the point's factor of Hinv and gradient are requested with the Jacobian records (left where they are used, the
@@ -402,6 +398,12 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 pairs_V<PREP>(F, E, hcv, V);
                 XBA_STAMP(0, 3);
                 pairs_diag<PREP>(F, V, hcv, gv, o28);
+            } else if (PREP) { dead_values(V); dead_values(o28); }
+            else {                 // (the round-2 schedule, a test oracle: plain initialisers — the definitions without an instruction cost it two spilled registers)
+#pragma unroll
+                for (int k = 0; k < 18; ++k) V[k] = XBA_DEAD;
+#pragma unroll
+                for (int k = 0; k < 28; ++k) o28[k] = XBA_DEAD;
             }
             XBA_STAMP(0, 4);
             const int Cg = GRAM ? d.tile_ncam[it.first_tile] : 0;

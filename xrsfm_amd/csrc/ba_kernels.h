@@ -107,13 +107,21 @@ __device__ unsigned long long g_stamps[3][64][16];
 // instead of 0.  The result of a solve must not change by one bit: a value that leaks from such a lane through a shuffle,
 // a reduction or a store turns into NaN and fails the test.  (Lanes whose values ARE read under a 0/1 mask — the operands of
 // seg_reduce / strided_reduce — must hold zeros and keep them.)
+// In the shipped build such a temporary is "some value": XBA_DEAD_VALUE(x) defines x without an instruction (an initialiser is a
+// v_mov per register pair on every lane — 46 of the ~790 vector instructions k_schur_pairs spends on a tile, 28 of k_backsub's ~285).
 #ifdef XBA_POISON
 #define XBA_DEAD (__builtin_nan(""))
 #define XBA_DEAD1 (__builtin_nan(""))
+#define XBA_DEAD_VALUE(x) ((x) = __builtin_nan(""))
 #else
 #define XBA_DEAD 0.0
 #define XBA_DEAD1 1.0
+#define XBA_DEAD_VALUE(x) asm volatile("" : "=v"(x))
 #endif
+template <int N> __device__ __forceinline__ void dead_values(double (&v)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) XBA_DEAD_VALUE(v[k]);
+}
 // Register-allocation probe (-DXBA_BACKSUB_WAVES=5, tools/backsub_waves_probe.py): k_backsub built for 5 waves per SIMD.
 #ifndef XBA_BACKSUB_WAVES
 #define XBA_BACKSUB_WAVES 0
@@ -931,11 +939,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
     const Item it = d.items[item];
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
-        double F[12], E[6], v0 = XBA_DEAD, v1 = XBA_DEAD;
-#ifdef XBA_POISON
-        for (int k = 0; k < 12; ++k) F[k] = XBA_DEAD;
-        for (int k = 0; k < 6; ++k) E[k] = XBA_DEAD;
-#endif
+        double F[12], E[6], v0, v1;
         double w[3] = {0, 0, 0};                   // operand of the segmented sum: zeros on lanes without an observation
         if (s.valid) {
             load_FE(d, s.slot, s.cam, s.pt, F, E);
@@ -944,15 +948,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_matvec(Dev d, const double* __
 #pragma unroll
             for (int k = 0; k < 6; ++k) { const double pk = p[k]; v0 += F[k] * pk; v1 += F[6 + k] * pk; }
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
-        }
+        } else { dead_values(F); dead_values(E); XBA_DEAD_VALUE(v0); XBA_DEAD_VALUE(v1); }
         seg_reduce<3>(w, s.pt, lane, d.tile_maxlen[it.first_tile]);
-        double u[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
+        double u[3];
         if (s.head) {
             const double* h = d.Hinv + 6 * (size_t)s.pt;
             u[0] = h[0] * w[0] + h[1] * w[1] + h[2] * w[2];
             u[1] = h[1] * w[0] + h[3] * w[1] + h[4] * w[2];
             u[2] = h[2] * w[0] + h[4] * w[1] + h[5] * w[2];
-        }
+        } else dead_values(u);
         const int hl = seg_head_lane(s.head || !s.valid, lane);
         u[0] = __shfl(u[0], hl, kWave); u[1] = __shfl(u[1], hl, kWave); u[2] = __shfl(u[2], hl, kWave);
         double y[6] = {0, 0, 0, 0, 0, 0};
@@ -1246,13 +1250,11 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, doubl
     if (it.n_tiles == 1) {
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int maxlen = d.tile_maxlen[it.first_tile];
-        double E[6] = {XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD};
-        double v0 = XBA_DEAD, v1 = XBA_DEAD, r0 = XBA_DEAD, r1 = XBA_DEAD;      // read by lanes with an observation only
+        double E[6], v0, v1, r0, r1;                                            // read by lanes with an observation only
         double w[3] = {0, 0, 0};                                                // operand of the segmented sum: zeros on the other lanes
         // what the head lane of a track needs after the reduction depends on the point only: every lane of the track requests
         // it now (same addresses: one transaction), so that it does not cost a third memory round trip after the shuffles
-        double hh[6] = {XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD, XBA_DEAD}, gg[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
-        double spv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD}, Pv[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};
+        double hh[6], gg[3], spv[3], Pv[3];
         bool var = false;
         if (s.valid) {
             const double* h = (PREP ? d.Hpp : d.Hinv) + 6 * (size_t)s.pt;
@@ -1265,7 +1267,7 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, doubl
 #pragma unroll
             for (int k = 0; k < 3; ++k) { spv[k] = sp[k]; Pv[k] = P[k]; }
             var = !d.pt_const[s.pt];
-        }
+        } else { dead_values(hh); dead_values(gg); dead_values(spv); dead_values(Pv); }
         if (s.valid) {
             const double* yp = d.px + 6 * (size_t)s.cam;
             const double y[6] = {yp[0], yp[1], yp[2], yp[3], yp[4], yp[5]};
@@ -1276,9 +1278,9 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, doubl
 #pragma unroll
             for (int k = 0; k < 6; ++k) { v0 += F[k] * y[k]; v1 += F[6 + k] * y[k]; }
             w[0] = E[0] * v0 + E[3] * v1; w[1] = E[1] * v0 + E[4] * v1; w[2] = E[2] * v0 + E[5] * v1;
-        }
+        } else { dead_values(E); XBA_DEAD_VALUE(v0); XBA_DEAD_VALUE(v1); XBA_DEAD_VALUE(r0); XBA_DEAD_VALUE(r1); }
         seg_reduce<3>(w, s.pt, lane, maxlen);
-        double u[3] = {XBA_DEAD, XBA_DEAD, XBA_DEAD};      // head lanes compute it, the lanes of the track fetch it from their head
+        double u[3];                                       // head lanes compute it, the lanes of the track fetch it from their head
         if (s.head) {
             const double a0 = gg[0] - w[0], a1 = gg[1] - w[1], a2 = gg[2] - w[2];
             if (PREP) {
@@ -1303,7 +1305,7 @@ void k_backsub(Dev d, int n_item_blocks, CamLin* __restrict__ camrec_cand, doubl
                 const double df = pn - Pv[k];
                 step2 += df * df;
             }
-        }
+        } else dead_values(u);
         const int hl = seg_head_lane(s.head || !s.valid, lane);
         u[0] = __shfl(u[0], hl, kWave); u[1] = __shfl(u[1], hl, kWave); u[2] = __shfl(u[2], hl, kWave);
         if (s.valid) {
