@@ -244,7 +244,7 @@ __device__ __forceinline__ void gram4_sched_store(unsigned short* sched, int se,
 }
 
 // row / CW for row < 64 without an integer division (v_mul_hi is a quarter-rate instruction)
-template <int CW> __device__ __forceinline__ int gram_cam_of_row(int row) {
+template <int CW> __device__ __forceinline__ unsigned gram_cam_of_row(unsigned row) {
     static_assert(CW == 6 || CW == 9, "6-wide or bal9 camera blocks");
     return CW == 6 ? (row * 43) >> 8 : (row * 57) >> 9;
 }
@@ -288,13 +288,20 @@ __device__ __forceinline__ void gram4_batch(const double* __restrict__ Vst, int 
             pa[u] += 32; pb[u] += 32;
         }
     }
+    // (the destinations of all NB values are requested before the first store: one LDS round trip, not NB in a row; unsigned
+    //  arithmetic: one 64-bit multiply-add and one shift-add form an address — with ints the compiler sign-extends every term)
+    int dst[NB];
+    unsigned off[NB];
 #pragma unroll
     for (int u = 0; u < NB; ++u) {
-        const int row = 4 * (e[u] & 255) + kk, col = 4 * (e[u] >> 8) + i4;
-        const int rb = gram_cam_of_row<CW>(row), ra = gram_cam_of_row<CW>(col);
-        const int dst = dtab[ra * kGramTabLd + rb];
-        if (dst >= 0) scat2[(CW * CW) * (size_t)dst + CW * (row - CW * rb) + (col - CW * ra)] = acc[u];
+        const unsigned row = 4u * (unsigned)(e[u] & 255) + (unsigned)kk, col = 4u * (unsigned)(e[u] >> 8) + (unsigned)i4;
+        const unsigned rb = gram_cam_of_row<CW>(row), ra = gram_cam_of_row<CW>(col);
+        dst[u] = dtab[ra * kGramTabLd + rb];
+        off[u] = CW * (row - CW * rb) + (col - CW * ra);
     }
+#pragma unroll
+    for (int u = 0; u < NB; ++u)
+        if (dst[u] >= 0) scat2[(unsigned long long)(unsigned)dst[u] * (unsigned)(CW * CW) + off[u]] = acc[u];
 }
 
 // gram_tile for a tile staged in ONE round (passes == 1: every tile of the small LDS class that fits it, ba_pack.h: gram_lds_need)
@@ -530,7 +537,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             int passes = 1;
             (void)gram_lds_need(C, T, &passes);                             // one staging round, or two with half the tracks each
             const int Th = (T + passes - 1) / passes;
-            const int R = 6 * C, Rp = (R + 15) & ~15, Cp = ((3 * Th + 3) & ~3) + 2;
+            const int R = 6 * C, Rp = (R + 15) & ~15, Cp = ((3 * Th + 3) & ~3) + kGramPad;
             double* Vst = smem;                                             // only the R rows that hold data are staged
             int* dtab = reinterpret_cast<int*>(smem + R * Cp);              // [kGramTabLd][kGramTabLd] destination of block (cb > ca) at [ca][cb], -1 none
             dtab[lane] = dt0;

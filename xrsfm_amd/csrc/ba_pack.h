@@ -20,6 +20,10 @@ namespace xba {
 
 constexpr int kGramMaxCams = 10;         // 60 operand rows: 4 MFMA row tiles
 constexpr int kGramMaxLds = 20 * 1024;   // staged operand of one tile (bytes); larger tiles use the per-pair path
+#ifndef XBA_GRAM_PAD
+#define XBA_GRAM_PAD 1
+#endif
+constexpr int kGramPad = XBA_GRAM_PAD;    // padding columns of a staged operand row (LDS bank spread)
 constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly launches: 160 KB / 16 workgroups
 
 // LDS bytes of a Gram tile with C cameras and T tracks: operand [6C][3T'+pad] + the C x C destination table, where the tracks
@@ -32,11 +36,11 @@ inline int gram_lds_need(int C, int T, int* passes, int cw = 6) {     // cw: ope
     // destination table with a fixed row stride (ba_chol.h: kGramTabLd) + the schedule of 4x4 result blocks of a small tile (ba_chol.h:
     // gram_tile4, at most 6 instructions x 4 blocks x 2 bytes)
     constexpr int tab = (kGramMaxCams + 1) * (kGramMaxCams + 1) * 4 + 48;
-    const int one = cw * C * ((((3 * T + 3) & ~3)) + 2) * 8 + tab;
+    const int one = cw * C * ((((3 * T + 3) & ~3)) + kGramPad) * 8 + tab;
     if (one <= kGramSmallLds) { *passes = 1; return one; }
     const int Th = (T + 1) / 2;
     *passes = 2;
-    return cw * C * ((((3 * Th + 3) & ~3)) + 2) * 8 + tab;
+    return cw * C * ((((3 * Th + 3) & ~3)) + kGramPad) * 8 + tab;
 }
 constexpr int kGramMaxCamsWide = 7;      // bal9 mode: 7 cameras x 9 rows = 63 operand rows
 

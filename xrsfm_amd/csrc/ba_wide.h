@@ -452,7 +452,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NI < 4 ? 
     int passes = 1;
     (void)gram_lds_need(C, T, &passes, kW);
     const int Th = (T + passes - 1) / passes;
-    const int R = kW * C, Cp = ((3 * Th + 3) & ~3) + 2;
+    const int R = kW * C, Cp = ((3 * Th + 3) & ~3) + kGramPad;
     double* Vst = smem;
     int* dtab = reinterpret_cast<int*>(smem + R * Cp);
     dtab[lane] = dt0;
