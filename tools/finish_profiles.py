@@ -79,7 +79,7 @@ def main():
         if os.path.exists(os.path.join(src, f"kernel_stats_table_{cfgk}.md")):
             with open(os.path.join(dst, f"{tag}_{cfgk}_kernel_stats.md"), "w") as f:
                 f.write(f"# Round {tag[1:]} — rocprofv3 kernel-trace summary, bench.py --config {cfgk} --no-cpu --no-extras --steps 2: {title}\n\n" + rd(f"kernel_stats_table_{cfgk}.md"))
-    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt", "mapper_trace.txt", "potrf.txt", "lat.txt", "pack_crossover.txt", "pack_phases.txt", "adapter_timing.txt"):
+    for extra in ("lba_phases.txt", "lba_timing.txt", "probe.txt", "mapper_trace.txt", "potrf.txt", "lat.txt", "pack_crossover.txt", "pack_phases.txt", "adapter_timing.txt", "pipes.txt"):
         if os.path.exists(os.path.join(src, extra)):
             shutil.copy(os.path.join(src, extra), os.path.join(dst, f"{tag}_{extra}"))
     # strong / weak scaling MODEL from the one-GPU kernel table (tools/scaling_projection.py)

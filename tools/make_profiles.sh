@@ -50,6 +50,7 @@ python tools/mapper_trace.py $OUT/mapper_trace.txt > /dev/null 2>&1
   python $ROOT/tools/rocprof_summary.py $(find $OUT/statsT -name "*.db" | head -1) $OUT/kernel_stats_table_T.md > /dev/null; rm -rf $OUT/statsT )
 [ -x tools/bench_potrf ] && tools/bench_potrf > $OUT/potrf.txt 2>&1
 [ -x tools/bench_lat ] && tools/bench_lat > $OUT/lat.txt 2>&1
+[ -x tools/bench_pipes ] && tools/bench_pipes > $OUT/pipes.txt 2>&1
 python tools/pack_crossover.py > $OUT/pack_crossover.txt 2>&1
 XRSFM_BA_PACK_TIMING=1 python tools/pack_phases.py L 2>&1 | tail -22 > $OUT/pack_phases.txt
 python tools/adapter_timing.py L > $OUT/adapter_timing.txt 2>&1

@@ -413,11 +413,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NI < 4 ? 
     const SlotCtx s = load_slot(d, tile, lane);
     const int cp = d.slot_campos_g[s.slot];
     const int cidx_raw = (int)d.slot_cidx[s.slot];
-    double V[27], F[18], u0 = 0.0, u1 = 0.0, u2 = 0.0;
-#pragma unroll
-    for (int k = 0; k < 27; ++k) V[k] = 0.0;
-#pragma unroll
-    for (int k = 0; k < 18; ++k) F[k] = 0.0;
+    double V[27], F[18], u0, u1, u2;         // (lanes without an observation: never staged, their sums parked in a row no camera reads)
     if (s.valid) {
         double E[6], cf[6];
         load_FE9(d, w, s.slot, F, E);
@@ -428,7 +424,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NI < 4 ? 
         point_factor(h, radius, cf);
         pairs9_V(F, E, cf, V);
         u0 = cf[0] * g[0]; u1 = cf[1] * g[0] + cf[3] * g[1]; u2 = cf[2] * g[0] + cf[4] * g[1] + cf[5] * g[2];      // C^T g
-    }
+    } else { dead_values(V); dead_values(F); XBA_DEAD_VALUE(u0); XBA_DEAD_VALUE(u1); XBA_DEAD_VALUE(u2); }
 
     const unsigned long long headmask = __ballot(s.head);
     const int T = __popcll(headmask);
