@@ -16,3 +16,6 @@ for v in "" _k9a _k9b; do
   echo "== lib '$v'"; grep -E "k9_" $OUT/table$v.md
   grep -o '"ms_per_step": [0-9.]*' $OUT/bench$v.log | tail -1
 done
+# RESULT: pipes — 2 vector + 2 matrix waves per SIMD take exactly t(vector alone) + t(matrix alone) (18.8 = 1.56 + 17.3 ms): FP64 matrix
+# instructions run on the vector data path; 16x16x4 = 64 cycles, 4x4x4 (4 blocks) = 16.5, a vector FMA 4.5.  bal9: Lb9 18.6 (2/2 waves) -> 17.2 ms
+# (3/3: k9_pairs_gram 235 -> 199 us, k9_linearize 172 -> 148); k9_linearize at 4 waves (2 spills) 142 us: not taken.

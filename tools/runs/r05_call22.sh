@@ -11,3 +11,4 @@ for cfg in L Lb9 S K; do
   python bench.py --config $cfg --no-cpu --no-extras --steps 10 --warmup 3 > $OUT/bench_$cfg.log 2>&1
   echo "== $cfg"; grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$cfg.log | tail -1; grep -o '"frac": [0-9.]*' $OUT/bench_$cfg.log | head -2
 done
+# RESULT: 75 + 24 tests green; L 6.23 ms (frac 0.459), Lb9 17.2, S 2.07, K 15.5.

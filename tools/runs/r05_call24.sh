@@ -12,3 +12,4 @@ python $ROOT/tools/rocprof_summary.py $(find $OUT/st -name "*.db" | head -1) $OU
 grep -E "k_schur_pairs|k_backsub|k_linearize" $OUT/table_L.md
 grep -o '"ms_per_step": [0-9.]*' $OUT/bench_L.log | tail -1
 bash $ROOT/tools/pmc_mix.sh L r05c24 > $OUT/mix.md 2>&1; grep -E "kernel|k_schur_pairs|k_linearize|k_backsub" $OUT/mix.md | head -20
+# RESULT: 92.1 -> 90.7 us; 774 vector instructions per tile incl. 59 matrix (round 4: 789 + 35.5), bank-conflict cycles 2.18e5 of 2.66e5 LDS-active.

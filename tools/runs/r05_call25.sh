@@ -14,3 +14,4 @@ for v in "" _pad1; do
   python $ROOT/tools/pmc_generic.py $(find $OUT/p -name "*.db" | head -1) $OUT/mix$v.md > /dev/null; rm -rf $OUT/p
   grep -E "kernel|k_schur_pairs" $OUT/mix$v.md | head -3
 done
+# RESULT: bank-conflict cycles 2.18e5 -> 1.49e5, 92.6 -> 90.4 us on this box: adopted (kGramPad = 1).

@@ -13,3 +13,4 @@ for cfg in L R; do
   echo "== $cfg"; grep -E "k_schur_pairs|k_backsub|k_linearize|k_cost" $OUT/table_$cfg.md | head -5
   grep -o '"ms_per_step": [0-9.]*' $OUT/bench_$cfg.log | tail -1
 done
+# RESULT (not adopted): k_linearize 77.3 us either way — it is not bound by its instruction count; the change was reverted.
