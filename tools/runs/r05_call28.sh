@@ -20,3 +20,6 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/st -o st -- python $ROOT/tools/lba_phases.py > $OUT/trace.log 2>&1
 python $ROOT/tools/rocprof_summary.py $(find $OUT/st -name "*.db" | head -1) $OUT/table.md > /dev/null; rm -rf $OUT/st
 head -30 $OUT/table.md
+# RESULT: steady state (7 cameras / 6000 observations, 5 LM iterations): create 0.24 ms = host packing 0.14 + uploads 0.02 + buffers 0.02 + Cholesky set-up 0.05;
+# run 0.39 ms = 57 us of kernels per iteration (k_lv_factor<true> 16.3, k_lin_tail 10.0 x 1.4, k_schur_pairs 7.9, k_linearize 6.4 x 1.4, k_backsub 5.5,
+# k_chol_segsum 4.6: each one tile's latency) x 5 + launches; download 0.06.
