@@ -346,7 +346,8 @@ def test_packed_tile_storage_equals_dense(lib, monkeypatch, mode, n_cams, n_pts,
 
 
 @pytest.mark.gpu
-def test_blocks_from_stored_operands_equal_per_pair_blocks(lib, monkeypatch):
+@pytest.mark.parametrize("case", ["collection", "ragged_map"])
+def test_blocks_from_stored_operands_equal_per_pair_blocks(lib, monkeypatch, case):
     """Round 4, collections with long tracks: the camera-pair blocks of tracks that do not fit a Gram tile are formed where they
     are summed, from the stored operands V of their two observations (k_chol_segsum_v, XRSFM_BA_PAIR_V=1; automatic when
     most block entries are per-pair blocks), instead of being written per pair by k_schur_pairs and read back.  Same products, another (fixed) order of a block's sum:
@@ -354,10 +355,17 @@ def test_blocks_from_stored_operands_equal_per_pair_blocks(lib, monkeypatch):
     relative, identical LM decisions, cameras to 1e-9) — on a collection whose tracks reach 80 photos (both per-pair paths: tracks
     inside one tile and tracks longer than a tile) and with the round-2 schedule that reads the point factors from memory."""
     from xrsfm_amd import capi, synth
-    d = synth.make_collection(n_cams=600, n_points=30000, seed=5, cams_per_cluster=60, max_track=80)
-    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
-    L = np.bincount(arr["obs_pt"])
-    assert (L > 64).sum() > 20 and ((L > 10) & (L <= 64)).sum() > 500
+    if case == "collection":
+        d = synth.make_collection(n_cams=600, n_points=30000, seed=5, cams_per_cluster=60, max_track=80)
+        arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+        L = np.bincount(arr["obs_pt"])
+        assert (L > 64).sum() > 20 and ((L > 10) & (L <= 64)).sum() > 500
+    else:
+        # a ragged sequential map: thousands of Gram tiles next to a few per-pair items — with stored operands (forced) the scatter
+        # buffer holds the Gram cells alone, renumbered compactly (k_gram_compact)
+        arr = H.make(300, 20000, 8, seed=911, dropout=0.35)
+        g = capi.debug_pack_gram(H.to_product(arr))
+        assert g["gram_tiles"] > 1000 and g["items_other"] > 0, g
     for prep in (None, "0"):
         if prep is not None:
             monkeypatch.setenv("XRSFM_BA_PREP_FUSED", prep)

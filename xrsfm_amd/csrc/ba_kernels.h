@@ -537,6 +537,18 @@ __global__ __launch_bounds__(kWave) void k_pair_sources(Dev d, const int* __rest
         for (int dd = 1; dd <= npair; ++dd) ent_src[pair_dst[pbase + dd - 1]] = make_int2(sa, sa + dd);
     }
 }
+// With stored operands the scatter buffer holds the Gram tiles' cells only: every cell with a destination gets a compact record
+// number (in arrival order: it names a place, not a position in a sum), which replaces the entry index in the tile's destination
+// table and is noted in the entry's source record (x < 0: a Gram cell, y = its record).
+__global__ void k_gram_compact(int* __restrict__ cell_dst, int n_cells, int2* __restrict__ ent_src, int* __restrict__ counter) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cells) return;
+    const int e = cell_dst[i];
+    if (e < 0) return;
+    const int rec = atomicAdd(counter, 1);
+    ent_src[e] = make_int2(-1, rec);
+    cell_dst[i] = rec;
+}
 // One WAVE per block (four blocks per workgroup, no workgroup barrier): the sources of the next kPairVAhead entries are fetched with one
 // load (lane u: entry e0 + u) and handed round as scalars; lanes 0..17 / 18..35 fetch Va / Vb with one coalesced load per entry (two
 // runs of 144 bytes), park them in the wave's LDS rows, and lane k < 36 forms element k = (rb, ca) from six LDS reads.  Entries
@@ -568,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void k_chol_segsum_v(const double* __restri
             sx[u] = __builtin_amdgcn_readlane(mine.x, u); sy[u] = __builtin_amdgcn_readlane(mine.y, u);
             v[u] = 0.0;
             if (e0 + u < end && lane < K)                    // (the first condition is wave-uniform)
-                v[u] = sx[u] < 0 ? scat2[36 * (size_t)(e0 + u) + lane] : pair_v[18 * (size_t)(lane < 18 ? sx[u] : sy[u]) + (lane < 18 ? lane : lane - 18)];
+                v[u] = sx[u] < 0 ? scat2[36 * (size_t)sy[u] + lane] : pair_v[18 * (size_t)(lane < 18 ? sx[u] : sy[u]) + (lane < 18 ? lane : lane - 18)];
         }
 #pragma unroll
         for (int u = 0; u < kPairVAhead; ++u) {

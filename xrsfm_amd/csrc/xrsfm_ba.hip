@@ -745,7 +745,6 @@ int chol_setup(xrsfm_ba_context* c) {
     TRYC(up.flush());
     timer.mark("uploads");
     const size_t blk_vals = c->wide ? kWB : 36, cam_vals = c->wide ? kWS : 28;
-    TRYC(dev_alloc(c, &h.scat2, (size_t)(P.n_writes > 0 ? P.n_writes : 1) * blk_vals));
     {   // diagonal-block buffer and off-diagonal block values in one allocation: one all-reduce per LM step
         double* both = nullptr;
         TRYC(dev_alloc(c, &both, (size_t)Nc * cam_vals + (size_t)(P.n_blocks > 0 ? P.n_blocks : 1) * blk_vals));
@@ -762,6 +761,10 @@ int chol_setup(xrsfm_ba_context* c) {
         h.gram4 = !(g4 && g4[0] == '0');
         const char* pe = std::getenv("XRSFM_BA_PAIR_V");        // (read per set-up: the A/B test switches it)
         h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : (P.n_pair_writes >= 262144 && 2LL * P.n_pair_writes >= P.n_writes));
+        // the scatter buffer of the block entries: one 36-value record per entry — with stored operands only the Gram tiles' cells are
+        // ever written, so it holds those alone, numbered compactly (config T: 0.6 GB instead of 17.8)
+        const size_t n_scat2 = h.pair_from_v ? (size_t)std::max(0, P.n_writes - P.n_pair_writes) : (size_t)std::max(0, P.n_writes);
+        TRYC(dev_alloc(c, &h.scat2, std::max<size_t>(1, n_scat2) * blk_vals));
         if (h.pair_from_v) {
             const size_t ne = (size_t)std::max(1, P.n_writes);
             TRYC(dev_alloc(c, &h.ent_src, ne));
@@ -770,6 +773,14 @@ int chol_setup(xrsfm_ba_context* c) {
             hipLaunchKernelGGL(k_pair_sources, dim3(h.n_pairs_other), dim3(kWave), 0, c->stream, c->d, (const int*)(h.pairs_items + h.n_pairs_small + h.n_pairs_big),
                                (const int*)h.slot_pair_ptr, (const int*)h.pair_dst, h.ent_src);
             HIPCHK(hipGetLastError());
+            const int n_cells = c->pk.n_gt_cells;
+            if (n_cells > 0) {
+                int* counter = nullptr;
+                TRYC(dev_alloc(c, &counter, (size_t)1));
+                HIPCHK(hipMemsetAsync(counter, 0, sizeof(int), c->stream));
+                hipLaunchKernelGGL(k_gram_compact, dim3(cdiv(n_cells, 256)), dim3(256), 0, c->stream, h.pair_dst + (h.n_pairs - n_cells), n_cells, h.ent_src, counter);
+                HIPCHK(hipGetLastError());
+            }
         }
     }
     h.dev.n = P.n; h.dev.n_pad = P.n_pad; h.dev.T = P.T; h.dev.cam_off = d_cam_off; h.dev.tile_rows = d_tile_rows;
