@@ -762,7 +762,7 @@ int chol_setup(xrsfm_ba_context* c) {
         const char* pe = std::getenv("XRSFM_BA_PAIR_V");        // (read per set-up: the A/B test switches it)
         h.pair_from_v = !c->wide && h.n_pairs_other > 0 && (pe ? pe[0] != '0' : (P.n_pair_writes >= 262144 && 2LL * P.n_pair_writes >= P.n_writes));
         // the scatter buffer of the block entries: one 36-value record per entry — with stored operands only the Gram tiles' cells are
-        // ever written, so it holds those alone, numbered compactly (config T: 0.6 GB instead of 17.8)
+        // ever written, so it holds those alone, numbered compactly (config T: 0.6 MB instead of 17.8 GB)
         const size_t n_scat2 = h.pair_from_v ? (size_t)std::max(0, P.n_writes - P.n_pair_writes) : (size_t)std::max(0, P.n_writes);
         TRYC(dev_alloc(c, &h.scat2, std::max<size_t>(1, n_scat2) * blk_vals));
         if (h.pair_from_v) {
