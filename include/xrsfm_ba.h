@@ -349,6 +349,12 @@ int xrsfm_ba_debug_pack(const xrsfm_ba_problem *problem, int32_t stats[8], int32
 int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem *problem, int32_t stats[8], int32_t *tile_ncam, uint8_t *slot_cidx,
                              int32_t *slot_campos_g);
 
+/* TEST ENTRY (no GPU needed): the schedule of 4x4 result blocks by which k_schur_pairs forms the camera-pair blocks of a Gram tile
+ * of n_cams cameras (6 operand rows per camera, groups of 4 rows; csrc/ba_chol.h: gram_tile4).  entries [4 * *n_inst]: four blocks
+ * per matrix instruction, row group | column group << 8, padded with block (0, 0).  *n_inst = 0 when the tile takes the 16x16 form
+ * (more than 6 instructions).  Returns XRSFM_BA_EINVAL for n_cams outside 1..10; entries must hold 128 values. */
+int xrsfm_ba_debug_gram_schedule(int n_cams, int32_t *n_inst, int32_t *n_inst_all, uint16_t *entries);
+
 /* Host-side plan of the Cholesky path (no GPU needed): stats[0] tiles T, [1] elimination-tree levels, [2] ordering
  * (0 natural, 1 nested dissection of a band/ring, 2 reverse Cuthill-McKee of an unordered collection, 3 nested dissection of an unordered collection's camera graph), [3] hub cameras, [4] band width in cameras, [5] off-diagonal blocks,
  * [6] schedule BITS: bit 0 (value 1) = level schedule (one launch per elimination-tree level; clear = the panel schedule of

@@ -152,3 +152,31 @@ def test_bal9_problems_pack_per_observation_and_plan_with_nine_rows_per_camera(l
     bad = dict(arr); bad["intr_model"] = np.full(40, 2, np.int32)
     with pytest.raises(RuntimeError):
         capi.debug_pack(H.to_product(bad))
+
+
+@pytest.mark.parametrize("C", list(range(1, 11)))
+def test_gram_schedule_of_4x4_blocks_covers_every_camera_pair_element_once(lib, C):
+    """Round 5 (ba_chol.h: gram_tile4): the camera-pair blocks of a Gram tile of C cameras are formed from 4x4 result blocks of the
+    [6C x 6C] Gram matrix, four per v_mfma_f64_4x4x4 instruction.  The schedule (a constexpr table of the library, read back through
+    xrsfm_ba_debug_gram_schedule) must list every block (row group >= column group) that holds an element of a camera pair
+    (camera of the row > camera of the column) exactly once and no block without one, padded to whole instructions with block
+    (0, 0) — which lies inside camera 0 and stores nothing; tiles with more than 6 instructions keep the 16x16 form."""
+    from xrsfm_amd import capi
+    s = capi.debug_gram_schedule(C)
+    R = 6 * C
+    wanted = {(r, c) for r in range(R) for c in range(R) if r // 6 > c // 6}
+    blocks = s["blocks"]
+    assert len(blocks) == 4 * s["n_inst_all"]
+    real = [b for b in blocks if b != (0, 0)]
+    assert blocks[:len(real)] == real and all(b == (0, 0) for b in blocks[len(real):]) and len(blocks) - len(real) < 4
+    assert len(set(real)) == len(real) and all(rg >= cg for rg, cg in real)
+    covered = []
+    for rg, cg in real:
+        el = [(4 * rg + i, 4 * cg + j) for i in range(4) for j in range(4) if 4 * rg + i < R and 4 * cg + j < R and (4 * rg + i) // 6 > (4 * cg + j) // 6]
+        assert el, (rg, cg)                 # no block without a wanted element
+        covered += el
+    assert len(covered) == len(set(covered)) and set(covered) == wanted
+    assert s["n_inst_all"] == (len(real) + 3) // 4
+    assert s["n_inst"] == (s["n_inst_all"] if s["n_inst_all"] <= 6 else 0)
+    if C == 4:
+        assert (len(real), s["n_inst"]) == (17, 5)          # the tiles of a sequential map: 17 blocks of 16 for 6 blocks of 36

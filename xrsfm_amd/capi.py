@@ -87,7 +87,7 @@ EXPORTS = [
     "xrsfm_ba_default_options", "xrsfm_ba_version", "xrsfm_ba_create", "xrsfm_ba_comm_unique_id",
     "xrsfm_ba_comm_init", "xrsfm_ba_run", "xrsfm_ba_reset", "xrsfm_ba_download", "xrsfm_ba_destroy",
     "xrsfm_ba_solve", "xrsfm_ba_filter_tracks", "xrsfm_ba_profile_entry", "xrsfm_ba_debug_linearize", "xrsfm_ba_debug_schur_product",
-    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram",
+    "xrsfm_ba_debug_cholesky_solve", "xrsfm_ba_debug_set_block_pattern", "xrsfm_ba_debug_pack", "xrsfm_ba_debug_chol_plan", "xrsfm_ba_refine_pose", "xrsfm_ba_refine_pose_options", "xrsfm_ba_debug_comm_hook", "xrsfm_pg_default_options", "xrsfm_pg_solve", "xrsfm_ba_debug_pack_gram", "xrsfm_ba_debug_gram_schedule",
     "xrsfm_tag_default_options", "xrsfm_tag_refine", "xrsfm_ba_refine_poses", "xrsfm_ba_quiesce", "xrsfm_ba_debug_backsub", "xrsfm_ba_device_memory", "xrsfm_ba_download_intrinsics", "xrsfm_ba_debug_wide",
     "xrsfm_ba_debug_device_pack_check", "xrsfm_ba_warmup",
 ]
@@ -576,6 +576,19 @@ def tag_refine(frame_q, frame_t, tag_corners, tag_obs_tag, tag_obs_frame, tag_ob
     sums = (CPgSummary * 2)()
     check(load().xrsfm_tag_refine(C.byref(o), C.byref(p), int(stages), sums), "xrsfm_tag_refine")
     return dict(scale=p.scale, tag_q=tq, tag_t=tt, tag_corners=corners, points=pts, summaries=[sums[i] for i in range(stages)])
+
+
+def debug_gram_schedule(n_cams: int) -> dict:
+    """Schedule of 4x4 result blocks of a Gram tile of n_cams cameras (works without a GPU): instructions used by the 4x4 form (0 = the tile
+    takes 16x16 result tiles), instructions of the full schedule, and its (row group, column group) blocks, four per instruction."""
+    n = C.c_int32(0); na = C.c_int32(0)
+    ent = np.zeros(128, np.uint16)
+    f = load().xrsfm_ba_debug_gram_schedule
+    f.argtypes = [C.c_int, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_uint16)]
+    f.restype = C.c_int
+    check(f(int(n_cams), C.byref(n), C.byref(na), ent.ctypes.data_as(C.POINTER(C.c_uint16))), "xrsfm_ba_debug_gram_schedule")
+    e = ent[:4 * na.value]
+    return dict(n_inst=n.value, n_inst_all=na.value, blocks=[(int(v & 255), int(v >> 8)) for v in e])
 
 
 def debug_pack_gram(problem: ProblemArrays) -> dict:

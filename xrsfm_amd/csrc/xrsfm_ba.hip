@@ -2370,6 +2370,15 @@ int xrsfm_ba_debug_pack(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* sl
     return 0;
 }
 
+int xrsfm_ba_debug_gram_schedule(int n_cams, int32_t* n_inst, int32_t* n_inst_all, uint16_t* entries) {
+    if (n_cams < 1 || n_cams > kGramMaxCams || !n_inst || !n_inst_all || !entries) return XRSFM_BA_EINVAL;
+    static const GramSched4<6> S = make_gram_sched4<6>();        // (the table the device copy g_gram_sched6 is initialised from)
+    *n_inst_all = S.n[n_cams];
+    *n_inst = S.n[n_cams] <= kGram4MaxInst ? S.n[n_cams] : 0;
+    for (int i = 0; i < 4 * S.n[n_cams] && i < 128; ++i) entries[i] = S.e[n_cams][i];
+    return 0;
+}
+
 int xrsfm_ba_debug_pack_gram(const xrsfm_ba_problem* p, int32_t stats[8], int32_t* tile_ncam, uint8_t* slot_cidx, int32_t* slot_campos_g) {
     if (!p || !stats) return XRSFM_BA_EINVAL;
     Packed k;
