@@ -1888,6 +1888,11 @@ __global__ __launch_bounds__(256) void k_lv_bwd(CholDev c, const int* __restrict
 // ticket on the column's counter, and the LAST chunk to arrive (hand-off recipe R1 of the hardware guide: payload stored
 // write-through and drained, one relaxed agent-scope arrival per workgroup, acquire fence on the reading side — nobody waits)
 // adds the partials in chunk order and forms x_k = Linv_k^T (y_k - sum): deterministic.  The counter is left at zero.
+// (Ordering, for the reader who looks for a release: the payload is written by agent-scope atomic stores — `global_store ... sc1`,
+//  performed at the device's coherence point, not parked in the XCD's L2 —, `s_waitcnt vmcnt(0)` + the workgroup barrier put every
+//  one of them before the ticket, which is an agent-scope read-modify-write at the same point; the reader's acquire fence + agent-scope
+//  loads complete the pair.  A __ATOMIC_RELEASE on the ticket would state the same in the HIP memory model and costs a
+//  `buffer_wbl2` — a write-back of the whole L2 — per arriving workgroup; this is the guide's recipe R1, which names the instructions.)
 constexpr int kBwdChunk = 4;          // (8: two dependent rounds of tile loads per workgroup, 32 us per level at config T)
 __global__ __launch_bounds__(256) void k_lv_bwd_chunk(CholDev c, const int* __restrict__ klist, const int* __restrict__ ci, const int* __restrict__ tile_cam,
                                                       double* __restrict__ px, const int4* __restrict__ chunks, double* part_buf, unsigned* counter) {
