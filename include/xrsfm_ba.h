@@ -140,7 +140,8 @@ int xrsfm_ba_version(int *n_devices);
 /* Optional: pay the one-off costs of the first call of a process NOW — HIP runtime start-up, loading the library's code
  * object, a stream with its pinned scalar block, the kernels' dynamic-LDS attributes and, with n_obs_hint > 0, the device
  * buffers of a problem of about that many observations / n_points_hint points / n_cams_hint cameras (they go to the
- * allocation cache the next xrsfm_ba_create draws from).  The adapter calls it from BASolver's constructor (the reference
+ * allocation cache the next xrsfm_ba_create draws from; capped at a quarter of the device memory that is free at the time of
+ * the call).  The adapter calls it from BASolver's constructor (the reference
  * pays the equivalent when ceres::Problem is first used).  Returns XRSFM_BA_ENODEV without a device; never required. */
 int xrsfm_ba_warmup(int device, int64_t n_obs_hint, int64_t n_points_hint, int64_t n_cams_hint);
 

@@ -48,7 +48,25 @@ int main(int argc, char **argv) {
     int filter_ret = 0;
     const std::string mode = argv[3];
     if (mode == "gba") solver.GBA(map);
-    else if (mode == "gba_timed") { xrsfm::Map warm = map; solver.GBA(warm); solver.GBA(map); }      // tools/adapter_timing.py: the second call is the warm one
+    else if (mode == "gba_timed" || mode == "gba_cached") {
+        // tools/adapter_timing.py: the second call is the warm one (a COPY of the map first: other storage, the adapter's observation
+        // cache misses), the third repeats the second on the SAME map from the same state — the cache hit (ba_solver.cc:
+        // BASolverObsCache).  gba_cached (tests/test_adapter.py): exit code 3 unless the cached call reproduces the uncached one bit for bit.
+        { xrsfm::Map warm = map; solver.GBA(warm); }
+        const xrsfm::Map start = map;
+        solver.GBA(map);
+        const xrsfm::Map first = map;
+        for (size_t i = 0; i < map.frames_.size(); ++i) map.frames_[i].Tcw = start.frames_[i].Tcw;
+        for (size_t j = 0; j < map.tracks_.size(); ++j) map.tracks_[j].point3d_ = start.tracks_[j].point3d_;
+        solver.GBA(map);
+        bool same = true;
+        for (size_t i = 0; i < map.frames_.size() && same; ++i)
+            same = memcmp(map.frames_[i].Tcw.q.coeffs().data(), first.frames_[i].Tcw.q.coeffs().data(), 4 * sizeof(double)) == 0 &&
+                   memcmp(map.frames_[i].Tcw.t.data(), first.frames_[i].Tcw.t.data(), 3 * sizeof(double)) == 0;
+        for (size_t j = 0; j < map.tracks_.size() && same; ++j)
+            same = memcmp(map.tracks_[j].point3d_.data(), first.tracks_[j].point3d_.data(), 3 * sizeof(double)) == 0;
+        if (!same) { fprintf(stderr, "gba_cached: the call served from the observation cache differs from the uncached one\n"); return 3; }
+    }
     else if (mode == "gba_fast") solver.GBA(map, false);
     else if (mode == "structure") solver.GBA(map, true, true);
     else if (mode == "kgba") solver.KGBA(map, {3}, true);

@@ -28,7 +28,8 @@ struct Input {
     std::vector<int32_t> cam_intr, model, oc, op;
 };
 
-struct Stats { std::vector<double> ms[4]; double wall_ms = 0; unsigned long long free_bytes = 0, cached = 0; };
+struct Stats { std::vector<double> ms[6];      // GBA | LBA | KGBA | pose refinement | per-frame filter | whole-map filter
+                double wall_ms = 0; unsigned long long free_bytes = 0, cached = 0; };
 
 static double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -162,14 +163,14 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
             if (p3.size() >= 10) timed(3, [&] { xrsfm::RefineFramePose(fr, map.Camera(fr.camera_id), p3, ids, inl); });
         }
         triangulate_frame(f);
-        timed(3, [&] { xrsfm::FilterPointsFrameGPU(map, f, th_rpe_lba, th_angle_lba); });
+        timed(4, [&] { xrsfm::FilterPointsFrameGPU(map, f, th_rpe_lba, th_angle_lba); });
         timed(1, [&] { solver.LBA(f, map); });
         if (solver.last_status() != 0) return solver.last_status();
-        timed(3, [&] { xrsfm::FilterPointsFrameGPU(map, f, th_rpe_lba, th_angle_lba); });
+        timed(4, [&] { xrsfm::FilterPointsFrameGPU(map, f, th_rpe_lba, th_angle_lba); });
         if (num_image_reg++ > 1.2 * num_image_reg_pre) {
             timed(2, [&] { solver.KGBA(map, std::vector<int>(0), true); });
             if (solver.last_status() != 0) return solver.last_status();
-            timed(3, [&] { xrsfm::FilterPoints3dGPU(map, th_rpe_gba, th_angle_gba); });
+            timed(5, [&] { xrsfm::FilterPoints3dGPU(map, th_rpe_gba, th_angle_gba); });
             num_image_reg_pre = num_image_reg;
         }
         update_covisibility(f);
@@ -219,7 +220,7 @@ int main(int argc, char **argv) {
     fwrite(&n_out, 4, 1, o);
     fwrite(&n_never, 4, 1, o);
     for (int r = 0; r < repeats; ++r) {
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 6; ++c) {
             std::vector<double> v = all[r].ms[c];
             std::sort(v.begin(), v.end());
             double tot = 0; for (double x : v) tot += x;

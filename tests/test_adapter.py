@@ -465,3 +465,27 @@ def test_update_by_ref_frame_keeps_relative_poses(lib, tmp_path):
         assert np.abs(q0 - q1).max() < 1e-12 and np.abs(t0 - t1).max() < 1e-10
     # the key frames themselves carry the motion that was applied (they moved), the others followed (they moved too)
     assert np.abs(t - arr["cam_t"]).min(axis=1).max() > 0 and np.abs(t[~key] - arr["cam_t"][~key]).max() > 1e-3
+
+
+@pytest.mark.gpu
+def test_second_gba_on_an_unchanged_map_is_served_from_the_observation_cache(exe, tmp_path):
+    """Round 6: BASolver keeps the observation arrays of the last large call; a GBA over the same frames
+    with the same track_ids_ finds them by key (FNV hash over every frame's id, camera id, track_ids_ and the identity of its
+    key-point storage) and refreshes only poses and points.  The harness (mode gba_cached) calls GBA on a COPY of the map (a miss:
+    other storage), then twice on the map itself from the same state: the second of those must be a hit and reproduce the first bit
+    for bit (exit code 3 otherwise); the result must be the one a single GBA gives."""
+    arr = H.make(120, 60000, 4, seed=171)                     # 240 000 observations: above the adapter's large-call threshold
+    env_trace = dict(os.environ, XRSFM_BA_TRACE_CALLS="1")
+    inp, out = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    _dump(arr, inp)
+    p = subprocess.run([exe, inp, out, "gba_cached"], capture_output=True, text=True, timeout=600, env=env_trace)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stderr.splitlines() if ln.startswith("[BASolver adapter] frames")]
+    assert len(lines) == 3, p.stderr[-2000:]
+    assert "cached" not in lines[0] and "cached" not in lines[1] and "(observations cached)" in lines[2], lines
+    raw = open(out, "rb").read()                              # (gba_cached's final state = one GBA from the input state)
+    nc = arr["cam_q"].shape[0]
+    cams = np.frombuffer(raw, dtype="f8", count=7 * nc, offset=4).reshape(nc, 7).copy()
+    status, q, t, P, _, _ = _run(exe, arr, tmp_path, "gba")
+    assert status == 0
+    assert np.array_equal(cams[:, :4], q) and np.array_equal(cams[:, 4:], t)

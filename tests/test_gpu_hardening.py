@@ -38,29 +38,31 @@ def _tiles_of(arr):
         C, T = len(set(cams.tolist())), len(set(pts.tolist()))
         ragged = not all(int((pts == p).sum()) == C for p in set(pts.tolist()))
         passes = 1
-        if ncam[t] > 0:
-            one = 6 * C * (((3 * T + 3) & ~3) + 2) * 8 + C * C * 4
-            passes = 1 if one <= 10240 else 2
+        if ncam[t] > 0:            # ba_pack.h: gram_lds_need — the smallest number of staging passes that fits the 10 KB LDS class
+            while 6 * C * (((3 * -(-T // passes) + 3) & ~3) + 1) * 8 + 11 * 11 * 4 + 48 > 10240 and -(-T // passes) > 1:
+                passes += 1
         out.append((C, T, ragged, passes, "gram" if ncam[t] > 0 else "pair"))
     return out, g
 
 
 def test_shape_catalogue_covers_every_cell(lib):
-    """CPU: the catalogue realises every cell, in the class (Gram / per-pair) the cell is meant to exercise, and Gram tiles
-    with two staging passes stay in the Gram launch (not demoted to the per-pair path by the 5 % rule of ba_pack.h)."""
+    """CPU: the catalogue realises every cell, in the class (Gram / per-pair) the cell is meant to exercise; since round 6 every
+    Gram tile fits the ONE LDS class of the S-assembly launch in enough staging passes (no big-LDS class, nothing demoted to the
+    per-pair path for its size): the catalogue must hold tiles of two passes and tiles of three or more."""
     cells = H.shape_cells()
     assert len(cells) >= 120
-    got, n_big, n_two_pass = set(), 0, 0
+    got, n_big, n_two_pass, n_more_pass = set(), 0, 0, 0
     for arr, mine in H.shape_problems():
         tiles, g = _tiles_of(arr)
         n_big += g["items_big"]
         for C, T, ragged, passes, klass in tiles:
             got.add((C, T, ragged, klass))
             n_two_pass += (klass == "gram" and passes == 2)
+            n_more_pass += (klass == "gram" and passes >= 3)
     for C, T, ragged in cells:
         want = "gram" if C <= 10 else "pair"
         assert (C, T, ragged, want) in got, (C, T, ragged, want)
-    assert n_big >= 4 and n_two_pass >= 4
+    assert n_big == 0 and n_two_pass >= 4 and n_more_pass >= 4
     # Gram cells: C = 2..10 x tracks-per-tile {1, 2, 3, 5, 16, 21} wherever 64 slots allow it
     for C in range(2, 11):
         for T in (1, 2, 3, 5, 16, 21):
@@ -424,6 +426,44 @@ def test_gram_blocks_from_4x4_instructions_equal_16x16_tiles(lib, monkeypatch, c
         ctx.close()
         out[flag] = (y, S, s, q, t, P)
     monkeypatch.delenv("XRSFM_BA_GRAM4")
+    a, b = out["0"], out["1"]
+    assert np.abs(a[1]).max() > 0 and np.all(np.isfinite(b[0]))
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])
+    assert (a[2].n_successful, a[2].n_unsuccessful, a[2].final_cost) == (b[2].n_successful, b[2].n_unsuccessful, b[2].final_cost)
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["ragged8", "short_tracks", "mixed"])
+def test_one_gram_launch_equals_one_launch_per_height(lib, monkeypatch, case):
+    """Round 6: the Gram tiles of operand heights 1..3 (2-8 cameras) go through ONE launch of k_schur_pairs<true, ., 0> — every tile in
+    the small LDS class, staged in as many passes as that takes (gram_lds_need; until round 5 at most two, with a second LDS class
+    behind it), the height read from the tile — instead of one launch per (height, class) bucket (XRSFM_BA_GRAM_MERGE=0).  A pass
+    boundary only inserts zero columns into the K loop and the per-tile arithmetic is the same code: the reduced camera matrix,
+    its solve and a full run must be BIT-identical.  Cases: 8-frame windows with missed detections (heights 2-3, two passes),
+    8-frame windows with 60 % missed detections (17+ short tracks over 6-8 cameras per tile: three passes), a mix of track lengths."""
+    from xrsfm_amd import capi
+    if case == "ragged8":
+        arr = H.make(300, 20000, 8, seed=931, dropout=0.35)
+    elif case == "short_tracks":
+        arr = H.make(300, 20000, 8, seed=932, dropout=0.6)       # 17+ tracks of 6-8 cameras per tile: 3 staging passes
+    else:
+        a = H.make(200, 12000, 6, seed=933, dropout=0.25)
+        arr = a
+    g = capi.debug_pack_gram(H.to_product(arr))
+    assert g["gram_tiles"] > 100 and g["items_big"] == 0, g      # one LDS class
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("XRSFM_BA_GRAM_MERGE", flag)
+        ctx = capi.Context(H.to_product(arr))
+        ctx.debug_linearize(5.99, False)
+        y, S = ctx.debug_cholesky_solve(2e3, want_S=True)
+        ctx.reset()
+        s = ctx.run(capi.default_options(max_iterations=8, linear_solver=capi.SOLVER_CHOLESKY))
+        q, t, P = ctx.download()
+        ctx.close()
+        out[flag] = (y, S, s, q, t, P)
+    monkeypatch.delenv("XRSFM_BA_GRAM_MERGE")
     a, b = out["0"], out["1"]
     assert np.abs(a[1]).max() > 0 and np.all(np.isfinite(b[0]))
     assert np.array_equal(a[1], b[1]) and np.array_equal(a[0], b[0])

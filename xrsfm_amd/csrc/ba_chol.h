@@ -135,8 +135,12 @@ __device__ __forceinline__ void gram_tile(double* __restrict__ Vst, int R, int C
                 Vst[row * Cp + cc] = 0.0;
             }
         } else {
-            // LDS operations of one wave complete in order; 16-byte stores (Cp is even and the operand 16-byte aligned)
+            // LDS operations of one wave complete in order; 16-byte stores (the operand is 16-byte aligned).  With kGramPad = 1 the row
+            // stride Cp is ODD: an odd R * Cp leaves one last element, which is zeroed on its own (it is the pad column of the last row,
+            // never read by the K loop today — zeroed anyway so that the layout can change without a silent gap; a 16-byte store there
+            // would run into the destination table that follows the operand)
             for (int e = lane; e < (R * Cp) / 2; e += kWave) reinterpret_cast<double2*>(Vst)[e] = make_double2(0.0, 0.0);
+            if (((R * Cp) & 1) && lane == kWave - 1) Vst[R * Cp - 1] = 0.0;
         }
         if (valid && t >= t0 && t < t0 + tn) {
 #pragma unroll
@@ -319,6 +323,7 @@ __device__ __forceinline__ void gram_tile4(double* __restrict__ Vst, int R, int 
         }
     } else {
         for (int e = lane; e < (R * Cp) / 2; e += kWave) reinterpret_cast<double2*>(Vst)[e] = make_double2(0.0, 0.0);
+        if (((R * Cp) & 1) && lane == kWave - 1) Vst[R * Cp - 1] = 0.0;        // (odd row stride: see gram_tile)
     }
     if (valid) {
 #pragma unroll
@@ -347,8 +352,13 @@ __device__ __forceinline__ void gram_tile4(double* __restrict__ Vst, int R, int 
 // no Hinv / Hc arrays); false: read from d.Hc (round-2 schedule, XRSFM_BA_PREP_FUSED=0).
 // NIK: GRAM = true — the operand height of the tiles of this launch in 16-row MFMA tiles (1..4; ba_plan.h sorts the Gram tiles
 // into one launch per height, so the 80 accumulator registers of a 10-camera tile exist only in the instantiation that
-// needs them; a single instantiation with a switch spilled 21-26 VGPRs in its common path, and one such build produced
+// needs them; a single instantiation with a switch over 1..4 spilled 21-26 VGPRs in its common path, and one such build produced
 // wrong blocks at scale — DESIGN.md section 5); GRAM = false — 0.
+// (round 6) NIK = 0 with GRAM = true: the heights 1..3 in ONE launch, the height taken from the tile's camera count — the 24
+// accumulator registers of a 3-tile operand fit the 128-register budget of 4 waves per SIMD, which the common path has anyway, so
+// only the 10-camera tiles (NIK = 4: 40 accumulators, 3 waves per SIMD) keep a launch of their own.  A ragged map had four to six
+// launches per pass, most of them too small to fill the chip and run side by side on two streams; now one (tiles in descending
+// height: the long ones start first).
 template <bool GRAM, bool PREP, int NIK>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu((GRAM && NIK < 4) ? 4 : (GRAM ? 3 : 2), (GRAM && NIK < 4) ? 4 : 3)))      // no instantiation may spill (tests/test_capi_cpu.py)
 void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restrict__ slot_pair_ptr, const int* __restrict__ pair_dst,
@@ -357,7 +367,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
     const int lane = threadIdx.x;
     XBA_STAMP(0, 0);
     // one launch per LDS class (ba_plan.h); the Gram classes list tiles, the other class items
-    const int entry = item_list[blockIdx.x];
+    const int entry = item_list[(GRAM && NIK == 0) ? gridDim.x - 1 - blockIdx.x : blockIdx.x];      // (merged launch: the list ascends in height)
     Item it;
     if (GRAM) { it.first_tile = entry; it.n_tiles = 1; }
     else it = d.items[entry];
@@ -374,7 +384,7 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             const int a1 = (lane + kWave) / kGramTabLd, b1 = lane + kWave - kGramTabLd * a1;
             if (b0 > a0 && b0 < C0) dt0 = src[a0 * C0 + b0];
             if (b1 > a1 && b1 < C0 && a1 < kGramTabLd) dt1 = src[a1 * C0 + b1];
-            if (NIK <= 2 && gram4) g4_se = gram4_sched_load<6>(C0, lane, g4_n);
+            if (NIK <= 2 && gram4) g4_se = gram4_sched_load<6>(C0, lane, g4_n);       // (NIK = 0: g4_n = 0 for the tiles that take the 16x16 form)
         }
         const SlotCtx s = load_slot(d, it.first_tile, lane);
         const int cp = d.slot_campos_g[s.slot];
@@ -550,6 +560,11 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
             if (NIK <= 2 && g4_n > 0 && passes == 1) {
                 gram4_sched_store(sched, g4_se, lane, g4_n);
                 gram_tile4<6>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, dense, sched, g4_n);
+            }
+            else if (NIK == 0) {
+                if (R > 32) gram_tile<3>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
+                else if (R > 16) gram_tile<2>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
+                else gram_tile<1>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
             }
             else gram_tile<(NIK > 0 ? NIK : 1)>(Vst, R, Cp, C, dtab, scat2, lane, V, s.valid, t, cidx, T, Th, passes, dense);
             XBA_STAMP(0, 8);
@@ -760,7 +775,7 @@ __device__ __forceinline__ double row_bcast64(double v, int l) {
 // (a) of potrf_lds: wave-level factorisation + inverse of the 16x16 diagonal block at (b0,b0), in registers
 // PV: how a column update gets its broadcast operand — 0: two v_mov_b32_dpp (rounds 1-3), 1: one v_mov_b64_dpp (compiler-scheduled
 // builtin).  Both form the same products with the same roundings.  Measured (tools/bench_potrf, MI355X, one 64x64 tile incl. the full
-// inverse): PV 0 12.7 us, PV 1 11.9, PV 1 with OVL 10.6 (default) — all bit-identical.
+// inverse): PV 0 12.7 us, PV 1 11.9, PV 1 with OVL 10.6 — all bit-identical; the DEFAULT since round 5 is PV 4 + OVL (below), 9.7 us.
 // (Measured in round 4 and removed in round 5: the broadcast folded into v_fmac_f64_dpp through inline asm, 13.4 us — the DPP form of
 //  a 64-bit FMA issues slower than a DPP move + a plain FMA; the broadcasts of a group issued one group ahead of their FMAs, 12.0 us;
 //  the elimination sweep WITHOUT the inverse and the forward substitution L X = I afterwards, operands from LDS: 15.2 us.)
@@ -783,8 +798,9 @@ __device__ __forceinline__ double row_bcast64(double v, int l) {
 //      in-panel column updates with DPP row broadcasts — the 82-cycle chain per column stays, the 120 updates shrink to 24;
 //   3. trailing columns: acc -= T A_p^T with A operand = the lane's own final panel entry of column 4p+lk and B operand = its scaled
 //      entry tl (and xs for the inverse): two v_mfma_f64_16x16x4_f64 per panel, results land in the distributed layout directly.
-// The same products as the sweep; the matrix instruction adds a panel's four terms in one go (k ascending), so the factor
-// differs from PV 0/1 in the last bits — every caller uses ONE variant (the A/B tests compare schedules, not variants).
+// The same products as the sweep, and the matrix instruction adds a panel's four terms in k order like the sweep does: measured
+// bit-identical to PV 0 / PV 1 on tools/bench_potrf's tiles (profiles/r05_potrf.txt); that is an observation, not a contract —
+// every caller uses ONE variant (the A/B tests compare schedules, not variants).
 __device__ __forceinline__ void allgather4(double v, double (&out)[4]) {     // v: row group g holds x_g  ->  out[k] = x_k in every group
     const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
     const auto l1 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);      // [x0 x0 x2 x2] | [x1 x1 x3 x3]
@@ -1974,8 +1990,10 @@ __global__ __launch_bounds__(256) void k_lv_bwd_chunk(CholDev c, const int* __re
 //    every workgroup only ever waits for workgroups that already run: no assumption about dispatch order or residency;
 //  * tags: epoch counts the launches of the context (never 0; the granule buffer is zeroed when it is allocated), the ticket
 //    counter is never reset (base = tickets handed out by earlier launches, modulo 2^32) — no memset per launch;
-//  * every spin is bounded: after kBwdSpinMax polls the workgroup raises *err (the host turns it into XRSFM_BA_EINTERNAL at the
-//    end of the solve) and goes on with what it has, so the launch always terminates;
+//  * every spin is bounded: after spin_max (kBwdSpinMax) polls the workgroup raises *err and the scalar slot S_BWD_ERR — which reaches
+//    the host with the NEXT hand-over of the scalar block, i.e. before the LM controller takes another decision on a garbage x
+//    (fetch_scalars() turns it into XRSFM_BA_EINTERNAL; round 6) — and goes on with what it has, so the launch
+//    always terminates; wait_epoch != epoch is the test hook that makes every wait time out (XRSFM_BA_DEBUG_BWD_TIMEOUT);
 //  * columns of the LAST level (col_final) were solved inside their k_lv_factor launch: their x is read from c.x;
 //  * the sums run in the order of k_lv_bwd (list order, then row order): bit-identical solution (XRSFM_BA_BWD_ALL=0 is the A/B).
 typedef __attribute__((address_space(1))) unsigned long long xba_gu64;
@@ -1984,7 +2002,8 @@ constexpr unsigned kBwdSpinMax = 1u << 21;
 __global__ __launch_bounds__(256) void k_lv_bwd_all(CholDev c, const int* __restrict__ klist, const int* __restrict__ cptr, const int* __restrict__ ci,
                                                     const int* __restrict__ tile_cam, double* __restrict__ px, const int* __restrict__ order,
                                                     const unsigned char* __restrict__ col_final, unsigned long long* gx, unsigned* counter,
-                                                    unsigned base, unsigned epoch, unsigned* err) {
+                                                    unsigned base, unsigned epoch, unsigned* err, double* err_scal, unsigned spin_max,
+                                                    unsigned wait_epoch) {
     __shared__ double xs[kBwdPre][kNB];
     __shared__ double acc[kNB];
     __shared__ int s_b;
@@ -2025,9 +2044,9 @@ __global__ __launch_bounds__(256) void k_lv_bwd_all(CholDev c, const int* __rest
                 for (unsigned spins = 0;; ++spins) {
                     a0 = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     a1 = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    const bool ok = (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch;
+                    const bool ok = (unsigned)(a0 >> 32) == wait_epoch && (unsigned)(a1 >> 32) == wait_epoch;
                     if (__all(ok)) break;                // (wave-uniform exit)
-                    if (spins >= kBwdSpinMax) { if (lane == 0) atomicOr(err, 1u); break; }
+                    if (spins >= spin_max) { if (lane == 0) { atomicOr(err, 1u); __hip_atomic_store(err_scal, 1.0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 xv = __hiloint2double((int)(unsigned)a1, (int)(unsigned)a0);

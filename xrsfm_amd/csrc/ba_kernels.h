@@ -33,7 +33,9 @@ struct PcgStatus {
 // scalar slots (device buffer `scal`)
 enum Scal {
     S_COST = 0, S_XNORM2_PTS, S_MODEL, S_STEP2_PTS, S_COST_CAND, S_STEP2_CAMS, S_XNORM2_CAMS,     // [0,4) and [2,5) each travel in one all-reduce
-    S_GRADMAX_PTS, S_GRADMAX_CAMS, S_COUNT = 16
+    S_GRADMAX_PTS, S_GRADMAX_CAMS,
+    S_BWD_ERR,          // != 0: a hand-off of the one-launch backward substitution timed out (k_lv_bwd_all) — travels to the host with every scalar hand-over
+    S_COUNT = 16
 };
 
 // Per-camera data the consumers need to rebuild the Jacobian blocks of an observation (128 bytes, one line).

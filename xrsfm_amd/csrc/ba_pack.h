@@ -19,7 +19,7 @@
 namespace xba {
 
 constexpr int kGramMaxCams = 10;         // 60 operand rows: 4 MFMA row tiles
-constexpr int kGramMaxLds = 20 * 1024;   // staged operand of one tile (bytes); larger tiles use the per-pair path
+constexpr int kGramMaxLds = 20 * 1024;   // upper bound of a tile's staged operand (bytes; since round 6 every Gram tile fits kGramSmallLds in enough passes)
 #ifndef XBA_GRAM_PAD
 #define XBA_GRAM_PAD 1
 #endif
@@ -27,8 +27,11 @@ constexpr int kGramPad = XBA_GRAM_PAD;    // padding columns of a staged operand
 constexpr int kGramSmallLds = 10240;     // LDS class boundary of the S-assembly launches: 160 KB / 16 workgroups
 
 // LDS bytes of a Gram tile with C cameras and T tracks: operand [6C][3T'+pad] + the C x C destination table, where the tracks
-// are staged in ONE pass (T' = T) if that fits the small class and otherwise in TWO passes of T' = ceil(T/2) tracks with the
-// accumulators kept across the passes.  The kernel (k_schur_pairs) evaluates the same rule.
+// are staged in ONE pass (T' = T) if that fits the small class and otherwise in the smallest number of passes of T' = ceil(T/p)
+// tracks that does (round 6; until round 5: at most two, and what still did not fit formed a second LDS class with a launch of its
+// own).  The accumulators are kept across the passes — a pass boundary only inserts zero columns, so the blocks do not depend on
+// the pass count by a bit.  The kernel (k_schur_pairs) evaluates the same rule.  Every tile fits: the largest operand of one
+// track per pass is 63 rows x 5 columns (bal9 mode) = 2.5 KB.
 #if defined(__HIPCC__)
 __host__ __device__
 #endif
@@ -36,11 +39,14 @@ inline int gram_lds_need(int C, int T, int* passes, int cw = 6) {     // cw: ope
     // destination table with a fixed row stride (ba_chol.h: kGramTabLd) + the schedule of 4x4 result blocks of a small tile (ba_chol.h:
     // gram_tile4, at most 6 instructions x 4 blocks x 2 bytes)
     constexpr int tab = (kGramMaxCams + 1) * (kGramMaxCams + 1) * 4 + 48;
-    const int one = cw * C * ((((3 * T + 3) & ~3)) + kGramPad) * 8 + tab;
-    if (one <= kGramSmallLds) { *passes = 1; return one; }
-    const int Th = (T + 1) / 2;
-    *passes = 2;
-    return cw * C * ((((3 * Th + 3) & ~3)) + kGramPad) * 8 + tab;
+    int p = 1, need = 0;
+    for (;; ++p) {
+        const int Th = (T + p - 1) / p;
+        need = cw * C * ((((3 * Th + 3) & ~3)) + kGramPad) * 8 + tab;
+        if (need <= kGramSmallLds || Th <= 1) break;        // (the smallest p of a given T' = ceil(T / p): the last pass is never empty)
+    }
+    *passes = p;
+    return need;
 }
 constexpr int kGramMaxCamsWide = 7;      // bal9 mode: 7 cameras x 9 rows = 63 operand rows
 

@@ -38,6 +38,26 @@ int &BASolverFailureCount() { static int n = 0; return n; }
 
 namespace {
 
+}  // namespace
+
+// (round 6) The observation side of the LAST large call (global BA), kept by the BASolver between calls: which tracks take part,
+// their slots, obs_cam / obs_pt / obs_uv.  A second GBA over the same frames with the same track_ids_ — the mapper's accurate GBA
+// after a KGBA, a final GBA pass, a re-run after the filters removed nothing — finds it by KEY and only refreshes poses and
+// points: Map -> SoA 10-12 ms -> ~3 ms at BASELINE config 4's size.  The key is cheap and
+// conservative: per frame of the call, in order, an FNV-1a hash over its id, camera id, every entry of track_ids_ and the
+// address + size of frame.points (the key points of a frame are written once when it is loaded, map.h:29-64: their VALUES are
+// not hashed); plus the size of Map::tracks_ and the LBA flag.  Any difference rebuilds.  Memory: 24 bytes per observation + 8
+// per track of the map while the BASolver lives (48 MB at 2 M observations).
+struct BASolverObsCache {
+    uint64_t key = 0; bool valid = false;
+    size_t n_frames = 0, total_feats = 0, n_map_tracks = 0, n_obs = 0;
+    std::vector<int> tracks, track_slot;
+    std::unique_ptr<int32_t[]> obs_cam, obs_pt;
+    std::unique_ptr<double[]> obs_uv;
+};
+
+namespace {
+
 // Flat copy of the parameter blocks of one BA call + the way back into the Map.
 class FlatProblem {
   public:
@@ -46,7 +66,8 @@ class FlatProblem {
     // features, a mark per track that occurs, slots = rank of the track id among the marked ones, then every frame fills its own
     // range of the observation arrays — each of these passes runs over the frames in parallel for a large call.  (Rounds 1-3: a
     // hash lookup and a cache-missing Track access per observation, 52 ms of a global BA of 2 M observations on one thread.)
-    explicit FlatProblem(Map &map) : map_(map), t_begin_(std::chrono::steady_clock::now()) {}
+    explicit FlatProblem(Map &map, BASolverObsCache *cache = nullptr) : map_(map), cache_(cache), t_begin_(std::chrono::steady_clock::now()) {}
+    ~FlatProblem() { StoreCache(); }
 
     // One frame = SetUp(problem, map, frame).  `lba_frame_id >= 0` selects SetUpLBA's rule for constant points.
     void AddFrame(Frame &frame, int lba_frame_id = -1) {
@@ -116,6 +137,42 @@ class FlatProblem {
         //  is at most 16 x the call — mapper replay, 45 000 tracks: LBA 0.84 ms with the table, 1.04 ms sorted)
         dense_slots_ = total_feats >= 200000 || map_.tracks_.size() <= 16 * total_feats;
         const size_t par_min = total_feats >= 200000 ? 1 : (size_t)-1;       // frames in parallel only for a large call
+        cache_key_ = 0; cache_total_feats_ = total_feats;
+        if (cache_ && total_feats >= 200000 && lba_frame_id_ < 0) {
+            // the key of this call (see BASolverObsCache): one hash per frame, in parallel, folded in frame order
+            std::vector<uint64_t> fh(nf);
+            ParallelFor(nf, 1, [&](size_t c0, size_t c1) {
+                for (size_t c = c0; c < c1; ++c) {
+                    const Frame &f = *frames_[c];
+                    uint64_t h = 1469598103934665603ull;
+                    auto mix = [&h](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+                    mix(static_cast<uint64_t>(f.id)); mix(static_cast<uint64_t>(f.camera_id)); mix(f.track_ids_.size());
+                    mix(reinterpret_cast<uintptr_t>(f.points.data())); mix(f.points.size());
+                    const int *ids = f.track_ids_.data();
+                    const size_t n = f.track_ids_.size();
+                    size_t i = 0;
+                    for (; i + 2 <= n; i += 2) mix((static_cast<uint64_t>(static_cast<uint32_t>(ids[i])) << 32) | static_cast<uint32_t>(ids[i + 1]));
+                    for (; i < n; ++i) mix(static_cast<uint32_t>(ids[i]));
+                    fh[c] = h;
+                }
+            });
+            uint64_t key = 1469598103934665603ull;
+            for (size_t c = 0; c < nf; ++c) key = (key ^ fh[c]) * 1099511628211ull;
+            key = (key ^ map_.tracks_.size()) * 1099511628211ull;
+            cache_key_ = key ? key : 1;
+            lap("cache key");
+            if (cache_->valid && cache_->key == cache_key_ && cache_->n_frames == nf && cache_->total_feats == total_feats &&
+                cache_->n_map_tracks == map_.tracks_.size()) {
+                tracks_.swap(cache_->tracks); track_slot_.swap(cache_->track_slot);
+                obs_cam_ = std::move(cache_->obs_cam); obs_pt_ = std::move(cache_->obs_pt); obs_uv_ = std::move(cache_->obs_uv);
+                n_obs_ = cache_->n_obs;
+                cache_->valid = false;               // (the arrays are ours until StoreCache hands them back)
+                point_const_.assign(tracks_.size(), 0);
+                cache_hit_ = true;
+                lap("observations from the cache");
+                return;
+            }
+        }
         tracks_.clear();
         if (dense_slots_) {
             // (relaxed atomic marks: several frames mark the same track from different threads, all with the same value)
@@ -236,14 +293,28 @@ class FlatProblem {
         static const bool trace = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;      // the adapter's own share of a call (Map -> SoA and back)
         if (trace) {
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            std::fprintf(stderr, "[BASolver adapter] frames %zu tracks %zu obs %zu | Map -> SoA %.3f ms, xrsfm_ba_solve %.3f ms, SoA -> Map %.3f ms\n", frames_.size(),
-                         tracks_.size(), n_obs_, ms(t_begin_, t_packed), ms(t_packed, t_solved), ms(t_solved, std::chrono::steady_clock::now()));
+            std::fprintf(stderr, "[BASolver adapter] frames %zu tracks %zu obs %zu | Map -> SoA %.3f ms%s, xrsfm_ba_solve %.3f ms, SoA -> Map %.3f ms\n", frames_.size(),
+                         tracks_.size(), n_obs_, ms(t_begin_, t_packed), cache_hit_ ? " (observations cached)" : "", ms(t_packed, t_solved), ms(t_solved, std::chrono::steady_clock::now()));
         }
         return rc;
     }
 
+    // hand the observation arrays of a large call to the BASolver's cache (called by the destructor: after the solve, whatever its outcome)
+    void StoreCache() {
+        if (!cache_ || cache_key_ == 0 || !obs_cam_) return;
+        cache_->key = cache_key_; cache_->n_frames = frames_.size(); cache_->total_feats = cache_total_feats_;
+        cache_->n_map_tracks = map_.tracks_.size(); cache_->n_obs = n_obs_;
+        cache_->tracks.swap(tracks_); cache_->track_slot.swap(track_slot_);
+        cache_->obs_cam = std::move(obs_cam_); cache_->obs_pt = std::move(obs_pt_); cache_->obs_uv = std::move(obs_uv_);
+        cache_->valid = true;
+        cache_key_ = 0;
+    }
+    bool cache_hit() const { return cache_hit_; }
+
   private:
     Map &map_;
+    BASolverObsCache *cache_ = nullptr;
+    uint64_t cache_key_ = 0; size_t cache_total_feats_ = 0; bool cache_hit_ = false;
     std::vector<Frame *> frames_;
     std::unordered_map<int, int> frame_slot_, intr_slot_;      // (a handful of entries: frames of the call, camera ids)
     std::vector<int> track_slot_;                              // (large calls) Map::tracks_ index -> point slot of this call, -1 = not in it
@@ -261,8 +332,11 @@ class FlatProblem {
 
 }  // namespace
 
-BASolver::BASolver() {
-    static const int warm = xrsfm_ba_warmup(0, 0, 0, 0);       // once per process; a box without a device is reported by the first solve
+BASolver::BASolver() : obs_cache_(std::make_shared<BASolverObsCache>()) {
+    // once per process, on device 0 — the device xrsfm_ba_solve runs on (the one-shot entry point has no device argument) —, without
+    // size hints: the library pre-allocates nothing for this call (hinted pre-allocations are capped by the library, xrsfm_ba.hip).
+    // A box without a device is reported by the first solve.
+    static const int warm = xrsfm_ba_warmup(0, 0, 0, 0);
     (void)warm;
 }
 
@@ -371,7 +445,7 @@ std::vector<int> LocalBundle(int frame_id, Map &map, size_t num_images = 4) {
 } // namespace
 
 void BASolver::GBA(Map &map, bool accurate, bool fix_all_frames) {
-    FlatProblem problem(map);
+    FlatProblem problem(map, obs_cache_.get());
     for (auto &frame : map.frames_)
         if (frame.registered) problem.AddFrame(frame);
     if (!fix_all_frames) {
@@ -391,7 +465,7 @@ void BASolver::GBA(Map &map, bool accurate, bool fix_all_frames) {
 void BASolver::KGBA(Map &map, const std::vector<int> fix_key_frame_ids, const bool is_sequential_data) {
     KeyFrameSelection(map, fix_key_frame_ids, is_sequential_data);
     int num_rf = 0, num_kf = 0;
-    FlatProblem problem(map);
+    FlatProblem problem(map, obs_cache_.get());
     for (auto &frame : map.frames_) {
         if (!frame.registered) continue;
         ++num_rf;

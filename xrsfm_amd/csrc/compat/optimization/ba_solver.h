@@ -10,6 +10,7 @@
 #ifndef XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
 #define XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H
 
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -29,6 +30,8 @@ int RefineFramePose(Frame &frame, const Camera &camera, const std::vector<vector
 // the end of the reconstruction.
 int &BASolverFailureCount();
 
+struct BASolverObsCache;       // observation arrays of the last global BA, reused when the same frames and tracks come again (ba_solver.cc)
+
 class BASolver {
   public:
     // (the reference's constructor is empty, ba_solver.h:16; this one pays the one-off start-up cost of the GPU library — HIP runtime,
@@ -46,6 +49,7 @@ class BASolver {
 
   private:
     int last_status_ = 0;
+    std::shared_ptr<BASolverObsCache> obs_cache_;      // (shared: a copied BASolver keeps working, like the reference's empty class)
 };
 } // namespace xrsfm
 #endif // XRSFM_SRC_OPTIMIZATION_BA_SOLVER_H

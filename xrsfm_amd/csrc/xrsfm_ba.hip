@@ -109,6 +109,7 @@ struct CholHost {
     size_t pairs_shm = 0, pairs_shm_big = 0;      // dynamic LDS of k_schur_pairs per class (ba_plan.h)
     int* pairs_items = nullptr; int n_pairs_small = 0, n_pairs_big = 0, n_pairs_other = 0;
     int gram_n[8] = {0}; size_t gram_shm[8] = {0};   // Gram tiles / dynamic LDS per launch bucket (ba_plan.h)
+    bool gram_merge = true;         // the buckets of operand heights 1..3 as ONE launch (XRSFM_BA_GRAM_MERGE=0: one launch per bucket)
     hipStream_t aux = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;     // the non-Gram items run concurrently
     // right-looking schedule (dense patterns): one panel after the other
     int* cols_flat = nullptr;                     // device list: per tile column its row tiles j < k (push-form backward substitution)
@@ -124,6 +125,7 @@ struct CholHost {
     // one-launch backward substitution of a level schedule (k_lv_bwd_all): columns by level (root side first), which columns the
     // last factor launch has solved already, the granule buffer, the ticket counter / error word, launches so far
     int* bw_order = nullptr; unsigned char* bw_final = nullptr; unsigned long long* bw_gx = nullptr; unsigned* bw_ctr = nullptr;
+    bool bw_debug_timeout = false;  // XRSFM_BA_DEBUG_BWD_TIMEOUT=1 (tests): every hand-off of k_lv_bwd_all waits for a tag that never comes
     int bw_n = 0; unsigned bw_launches = 0; bool bwd_all = false;
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
     std::vector<int> sp_chunk_off, sp_rt_off, mp_off;
@@ -168,6 +170,7 @@ struct xrsfm_ba_context {
     bool dev_packed = false; int host_pack_level = 2;       // 0 nothing downloaded, 1 what the plan reads, 2 everything (host packing: always 2)
     int* dpk_slot_obs = nullptr; unsigned char* dpk_gt_cell = nullptr;
     bool linearized = false;
+    unsigned long long debug_stall_ticks = 0;      // XRSFM_BA_DEBUG_STALL_S (test hook): 100 MHz ticks the next scalar hand-over is held back by
     bool poisoned = false;          // the watchdog tripped: the stream may never drain — destroy must not wait for it (fetch_scalars)
     bool fused = true;              // one-launch linearisation tail (k_lin_tail) and candidate cameras in trailing workgroups of k_backsub;
                                     // XRSFM_BA_FUSED=0 (A/B aid, and always with several ranks for the tail): k_cam_segsum -> k_reduce_multi ->
@@ -404,15 +407,40 @@ __global__ void k_publish(const double* __restrict__ scal, double* __restrict__ 
         __hip_atomic_store(reinterpret_cast<unsigned long long*>(host + S_COUNT), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// TEST HOOK (XRSFM_BA_DEBUG_STALL_S=<seconds>, tests/test_lifetime_gpu.py): holds the context's stream for a BOUNDED time (<= 10 s) in
+// front of the first scalar hand-over of a run — a stand-in for a collective no peer joins — so that the watchdog of fetch_scalars() can be seen to trip,
+// poison the context and let xrsfm_ba_destroy return; the kernel always ends by itself (constant 100 MHz counter).
+__global__ void k_debug_stall(unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(127);
+}
+
+// A hand-off of the one-launch backward substitution that timed out (k_lv_bwd_all) leaves a garbage camera step behind: the kernel
+// raises scalar slot S_BWD_ERR, which arrives with the very next hand-over of the scalar block — the run stops here, before the LM
+// controller evaluates a step built on it (until round 5 the device word was read once per solve, after the stream had drained).
+static int bwd_err_check(xrsfm_ba_context* c) {
+    if (c->h_scal[S_BWD_ERR] == 0.0) return 0;
+    fprintf(stderr, "[xrsfm_ba] backward substitution: a hand-off between workgroups timed out (k_lv_bwd_all); rerun with XRSFM_BA_BWD_ALL=0\n");
+    c->h_scal[S_BWD_ERR] = 0.0;
+    (void)hipMemsetAsync(c->d.scal + S_BWD_ERR, 0, sizeof(double), c->stream);
+    if (c->chol.bw_ctr) (void)hipMemsetAsync(c->chol.bw_ctr + 1, 0, sizeof(unsigned), c->stream);
+    return XRSFM_BA_EINTERNAL;
+}
+
 int fetch_scalars(xrsfm_ba_context* c) {
-    const bool tail_published = c->published;
+    bool tail_published = c->published;
     c->published = false;               // (cleared on every exit path, errors included)
     HIPCHK(hipGetLastError());          // a failed launch since the last sync point
+    if (c->debug_stall_ticks) {         // test hook: the stream stalls HERE, where the host polls (not in front of a blocking copy of the set-up)
+        hipLaunchKernelGGL(k_debug_stall, dim3(1), dim3(1), 0, c->stream, c->debug_stall_ticks);
+        c->debug_stall_ticks = 0;
+        tail_published = false;         // (a fresh hand-over behind the stall)
+    }
     if (c->profiling || !c->h_scal_dev) {
         HIPCHK(hipMemcpyAsync(c->h_scal, c->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(hipStreamSynchronize(c->stream));
         if (c->profiling) profile_collect(c);
-        return 0;
+        return bwd_err_check(c);
     }
     unsigned long long want;
     if (tail_published) want = c->seq;                                  // k_lin_tail hands the block over itself
@@ -446,7 +474,7 @@ int fetch_scalars(xrsfm_ba_context* c) {
         }
         __builtin_ia32_pause();
     }
-    return 0;
+    return bwd_err_check(c);
 }
 
 // Linearise at the state `d` views (the context's own Dev, or the candidate view of finish_step).  Leaves S_COST, S_XNORM2_PTS in
@@ -552,7 +580,7 @@ int pcg_solve(xrsfm_ba_context* c, const xrsfm_ba_options& opt, xrsfm_ba_summary
     Dev& d = c->d;
     // two-level preconditioner: the seven gauge vectors at the current cameras, (S + D^2) W by seven products, the 7 x 7 coarse
     // matrix and its inverse — per LM step: both S and D^2 depend on the radius (XRSFM_BA_PCG_COARSE=0: block-Jacobi alone)
-    d.pcgW = c->pcg_coarse ? c->pcg_w : nullptr;
+    d.pcgW = (c->pcg_coarse && d.n_cams > 0) ? c->pcg_w : nullptr;        // (no cameras: the coarse matrix would never be written)
     if (d.pcgW && d.n_cams > 0) {
         const size_t n6 = 6 * (size_t)d.n_cams;
         d.pcgSW = c->pcg_w + kGauge * n6; d.pcgE = c->pcg_w + 2 * kGauge * n6;
@@ -636,7 +664,7 @@ void set_kernel_attributes(int device) {
 #define XBA_PAIRS_ATTR(NI) \
     (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, true, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max); \
     (void)hipFuncSetAttribute((const void*)k_schur_pairs<true, false, NI>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
-    XBA_PAIRS_ATTR(1) XBA_PAIRS_ATTR(2) XBA_PAIRS_ATTR(3) XBA_PAIRS_ATTR(4)
+    XBA_PAIRS_ATTR(0) XBA_PAIRS_ATTR(1) XBA_PAIRS_ATTR(2) XBA_PAIRS_ATTR(3) XBA_PAIRS_ATTR(4)
 #undef XBA_PAIRS_ATTR
     (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
     (void)hipFuncSetAttribute((const void*)k_schur_pairs<false, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, pairs_max);
@@ -717,6 +745,7 @@ int chol_setup(xrsfm_ba_context* c) {
     h.n_blocks = P.n_blocks; h.n_pairs = P.n_pairs; h.T = P.T; h.n_tiles_nz = P.n_tiles_nz; h.n_levels = P.n_levels;
     h.use_levels = P.use_levels; h.panel_ll = P.panel_ll; h.lookahead = P.lookahead; h.ordering = P.ordering; h.pairs_shm = P.pairs_shm; h.pairs_shm_big = P.pairs_shm_big; h.n_pairs_small = P.n_pairs_small; h.n_pairs_big = P.n_pairs_big; h.n_pairs_other = P.n_pairs_other; h.cam_off_host = P.cam_off;
     for (int b = 0; b < 8; ++b) { h.gram_n[b] = P.gram_n[b]; h.gram_shm[b] = P.gram_shm[b]; }
+    { const char* me = std::getenv("XRSFM_BA_GRAM_MERGE"); h.gram_merge = !(me && me[0] == '0'); }      // (read per set-up: the A/B test switches it)
     h.cols_off = P.cols_off; h.bw2_off = P.bw2_off; h.bw2_link = P.bw2_link;
     h.lv_k_off = P.lv_k_off; h.lv_tgt_off = P.lv_tgt_off;
     h.sp_chunk_off = P.sp_chunk_off; h.sp_rt_off = P.sp_rt_off; h.mp_off = P.mp_off; h.fz_off = P.fz_off;
@@ -808,6 +837,7 @@ int chol_setup(xrsfm_ba_context* c) {
         //  chunk launches — every workgroup walked its list parent first and ran its other rounds only after the parent was solved;
         //  with the lists walked from the root side (round 5, ba_chol.h) the same launch takes 0.68 ms: config T 1086 -> 970 ms)
         h.bwd_all = on && P.use_levels && !P.panel_ll && P.n_levels >= 2;
+        { const char* te = std::getenv("XRSFM_BA_DEBUG_BWD_TIMEOUT"); h.bw_debug_timeout = te && te[0] == '1'; }      // (read per set-up: the test switches it)
         // XRSFM_BA_BWD_ALL=0 on a deep level schedule: one launch per level with the tiles of a column shared out over workgroups
         // (k_lv_bwd_chunk), or — XRSFM_BA_BWD_CHUNK=0 as well — the push form of the panel schedules, two columns per launch
         const char* bce = std::getenv("XRSFM_BA_BWD_CHUNK");
@@ -884,19 +914,26 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
             if (c->step_prep) hipLaunchKernelGGL((k_schur_pairs<true, true, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr, h.gram4);
             else hipLaunchKernelGGL((k_schur_pairs<true, false, NI>), dim3(n), dim3(kWave), shm, st, d, items, h.slot_pair_ptr, h.pair_dst, n_obs_pairs, h.scat2, radius, (double*)nullptr, h.gram4);
         };
-        // Gram tiles: one launch per (operand height, LDS class) that occurs.  The launches write disjoint outputs; a ragged map has
-        // four to six of them, most with too few tiles to fill the chip (config R: 149 + 34 + 16 + 16 + 17 us one after the other):
-        // when the second stream is forked anyway, the largest bucket stays on the main stream and the others follow the non-Gram
-        // items on the second one
+        // Gram tiles (round 6): ONE launch for the operand heights 1..3 — every tile fits the small LDS class in enough staging
+        // passes (ba_pack.h: gram_lds_need), the height is read from the tile's camera count — on the main stream; only tiles of
+        // 9-10 cameras (40 accumulator registers: 3 waves per SIMD) keep a launch of their own, next to the non-Gram items on the
+        // second stream when there is one.  Until round 5: one launch per (height, LDS class), four to six on a ragged map (config R:
+        // 158 + 23 + 16 + 25 + 77 us side by side on two streams).  XRSFM_BA_GRAM_MERGE=0 keeps those launches (bit-identical blocks:
+        // tests/test_gpu_parity.py).
+        int n_merged = 0; size_t shm_merged = 0;
+        for (int b = 0; b < 6; ++b) { n_merged += h.gram_n[b]; if (h.gram_n[b] > 0) shm_merged = std::max(shm_merged, h.gram_shm[b]); }
+        const bool merge = h.gram_merge && n_merged > 0;
         constexpr bool gram_fork = true;
         int big = -1;
         for (int b = 0; b < 8; ++b) if (h.gram_n[b] > 0 && (big < 0 || h.gram_n[b] > h.gram_n[big])) big = b;
+        if (merge) big = -2;                 // (the merged launch is the main-stream launch)
         auto launch_buckets = [&](bool main_side) {
             const int* items = h.pairs_items;
+            if (merge && main_side) launch_gram(std::integral_constant<int, 0>{}, n_merged, shm_merged, items, c->stream);
             for (int b = 0; b < 8; ++b) {
                 const int n = h.gram_n[b];
                 const bool on_main = !(fork && gram_fork) || b == big;
-                if (n > 0 && on_main == main_side) {
+                if (n > 0 && on_main == main_side && !(merge && b < 6)) {
                     hipStream_t st = on_main ? c->stream : h.aux;
                     switch (b >> 1) {
                         case 0: launch_gram(std::integral_constant<int, 1>{}, n, h.gram_shm[b], items, st); break;
@@ -1055,7 +1092,8 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const unsigned base = h.bw_launches * (unsigned)h.bw_n;       // tickets handed out so far (unsigned wrap-around is fine)
             const unsigned epoch = ++h.bw_launches;
             LAUNCH(c, K_TRISOLVE, k_lv_bwd_all, dim3(h.bw_n), dim3(256), 0, h.dev, (const int*)h.lv_k, (const int*)h.lv_bptr, (const int*)h.lv_bi,
-                   (const int*)h.tile_cam, px_out, (const int*)h.bw_order, (const unsigned char*)h.bw_final, h.bw_gx, h.bw_ctr, base, epoch, h.bw_ctr + 1);
+                   (const int*)h.tile_cam, px_out, (const int*)h.bw_order, (const unsigned char*)h.bw_final, h.bw_gx, h.bw_ctr, base, epoch, h.bw_ctr + 1,
+                   d.scal + S_BWD_ERR, h.bw_debug_timeout ? 64u : kBwdSpinMax, h.bw_debug_timeout ? epoch + 1u : epoch);
             return 0;
         }
         for (int lv = h.n_levels - 2; lv >= 0; --lv) {      // (the last level: inside its k_lv_factor launch)
@@ -1269,8 +1307,17 @@ int xrsfm_ba_warmup(int device, int64_t n_obs_hint, int64_t n_points_hint, int64
         add(nc * 128, 6);                   // camera records
         add(ns * 8 * 36 / 10);              // block scatter buffer (Gram cells: ~one 6x6 entry per ten observations)
         add(ns * 8, 6); add(ns * 16, 2);    // scratch of the device-side sorts
+        //  the hints are the caller's guess: what they pin in the allocation cache is capped at a quarter of the
+        // device memory that is free right now — a wrong hint must not take the memory the real problem needs
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return XRSFM_BA_OK;
+        const size_t budget = free_b / 4;
+        size_t taken = 0;
         std::vector<std::pair<void*, size_t>> got;
-        for (size_t b : want) { size_t c2 = 0; void* q = g_cache.get(device, b, &c2); if (!q) break; got.push_back({q, c2}); }
+        for (size_t b : want) {
+            if (taken + b > budget) break;
+            size_t c2 = 0; void* q = g_cache.get(device, b, &c2); if (!q) break; got.push_back({q, c2}); taken += b;
+        }
         for (auto& g2 : got) g_cache.put(device, g2.first, g2.second);
         return XRSFM_BA_OK;
     });
@@ -1735,6 +1782,8 @@ static int ba_run_impl(xrsfm_ba_context* c, const xrsfm_ba_options* optp, xrsfm_
     if (c->poisoned) return XRSFM_BA_ESTATE;       // the watchdog gave up on this context: only xrsfm_ba_destroy is left
     const xrsfm_ba_options opt = *optp;
     HIPCHK(hipSetDevice(c->device));
+    if (const char* se = std::getenv("XRSFM_BA_DEBUG_STALL_S"))          // test hook: see k_debug_stall
+        c->debug_stall_ticks = (unsigned long long)(std::fmin(std::fmax(std::atof(se), 0.0), 10.0) * 1e8);
     memset(sum, 0, sizeof(*sum));
     Dev& d = c->d;
     hipStream_t st = c->stream;

@@ -13,7 +13,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHIM = os.path.join(ROOT, "tests", "shim")
 EXE = os.path.join(SHIM, "_build", "mapper_main")
-CLASSES = ("GBA", "LBA", "KGBA", "filters+refine")
+CLASSES = ("GBA", "LBA", "KGBA", "refine", "frame_filter", "map_filter")
+FILTER_CLASSES = ("refine", "frame_filter", "map_filter")      # "filters+refine" of rounds 3-5 = their sum
 
 
 def build() -> str:
@@ -59,11 +60,15 @@ def run(arr: dict, repeats: int = 1, timeout: float = 1800.0) -> dict:
     n_out, n_never = struct.unpack("2i", raw[off:off + 8]); off += 8
     replays = []
     for _ in range(repeats):
-        rec = np.frombuffer(raw, dtype="f8", count=27, offset=off); off += 27 * 8
+        nrec = 6 * len(CLASSES) + 3
+        rec = np.frombuffer(raw, dtype="f8", count=nrec, offset=off); off += nrec * 8
         classes = {}
         for c, name in enumerate(CLASSES):
             v = rec[6 * c:6 * c + 6]
             classes[name] = dict(count=int(v[0]), total_ms=float(v[1]), p50=float(v[2]), p90=float(v[3]), p99=float(v[4]), max=float(v[5]))
-        replays.append(dict(classes=classes, wall_ms=float(rec[24]), free_bytes=int(rec[25])))
+        fr = [classes[n] for n in FILTER_CLASSES]
+        classes["filters+refine"] = dict(count=sum(c["count"] for c in fr), total_ms=sum(c["total_ms"] for c in fr), p50=float("nan"), p90=float("nan"),
+                                         p99=float("nan"), max=max(c["max"] for c in fr))
+        replays.append(dict(classes=classes, wall_ms=float(rec[6 * len(CLASSES)]), free_bytes=int(rec[6 * len(CLASSES) + 1])))
     return dict(status=status, same_end_state=bool(same), cam_q=cams[:, :4].copy(), cam_t=cams[:, 4:].copy(), points=pts.copy(),
                 n_outlier_tracks=n_out - n_never, n_never_triangulated=n_never, replays=replays, returncode=p.returncode, stderr=p.stderr[-2000:])
