@@ -138,7 +138,13 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
         std::sort(mine.begin(), mine.end());
     };
     xrsfm::BASolver solver;
-    auto timed = [&](int cls, auto &&fn) { const double t0 = now_ms(); fn(); st.ms[cls].push_back(now_ms() - t0); };
+    int cur_frame = 0;
+    static const bool slow_trace = std::getenv("MAPPER_TRACE_SLOW") != nullptr;       // developer aid: calls of 5 ms and more, with the frame they belong to
+    auto timed = [&](int cls, auto &&fn) {
+        const double t0 = now_ms(); fn(); const double dt = now_ms() - t0;
+        st.ms[cls].push_back(dt);
+        if (slow_trace && dt >= 5.0) fprintf(stderr, "[mapper_main] class %d frame %d: %.2f ms (registered %d)\n", cls, cur_frame, dt, (int)st.ms[1].size() + 2);
+    };
     const double t_begin = now_ms();
     // 1. initial pair + GBA
     map.init_id1 = 0; map.init_id2 = 1;
@@ -150,6 +156,7 @@ static int replay(const Input &in, xrsfm::Map &map, Stats &st) {
     // 2. iterative extension
     int num_image_reg = 2, num_image_reg_pre = 2;
     for (int f = 2; f < in.nc; ++f) {
+        cur_frame = f;
         auto &fr = map.frames_[f];
         fr.registered = true; fr.is_keyframe = true;
         place_frame(f);

@@ -1103,6 +1103,40 @@ def test_unordered_collection_nested_dissection_matches_the_chain_order(lib, mon
 
 
 @pytest.mark.gpu
+def test_level_look_ahead_of_a_dissected_collection(lib, monkeypatch):
+    """Round 6: on the level schedule of a dissected photo collection (BASELINE config 5's shape: ~170 levels of update -> sum ->
+    factor) the partial products of a level whose operand columns were factored la_depth + 1 levels earlier ("early": all but a few
+    per cent) run on a second stream while the main stream is still at the levels in between; the late ones follow the previous
+    level's factor kernel and the fixed-order sum adds both (ba_plan.h: la_depth, sp_slot; xrsfm_ba.hip: chol_factor_solve).
+    XRSFM_BA_LA_DEPTH=0 is the round-5 schedule (every chunk in one launch, list order).  The early / late split reorders a
+    target's sum, nothing else: same LM decisions, costs to 1e-9, cameras to 1e-7 / 1e-6 — for depth 1, 2 (default) and 3 —
+    and a depth run twice is bit-identical (two streams, fixed-order sums: no race)."""
+    from xrsfm_amd import capi, synth
+    d = synth.make_collection(n_cams=2400, n_points=100000, seed=4, cams_per_cluster=60)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["ordering"] == 3 and plan["level_schedule"] == 1 and plan["levels"] >= 16
+    opt = capi.default_options(max_iterations=6)
+    res = {}
+    for depth in ("0", "1", "2", "2", "3"):
+        monkeypatch.setenv("XRSFM_BA_LA_DEPTH", depth)
+        prod = H.to_product(arr)
+        s = capi.solve(prod, opt)
+        assert s.linear_solver_used == capi.SOLVER_CHOLESKY
+        key = depth if depth not in res else depth + "'"
+        res[key] = (s, prod.cam_q.copy(), prod.cam_t.copy(), prod.points.copy())
+    monkeypatch.delenv("XRSFM_BA_LA_DEPTH")
+    s0, q0, t0, P0 = res["0"]
+    for key in ("1", "2", "3"):
+        s, q, t, P = res[key]
+        assert (s.n_successful, s.n_unsuccessful) == (s0.n_successful, s0.n_unsuccessful), key
+        assert abs(s.final_cost - s0.final_cost) <= 1e-9 * s0.final_cost, key
+        assert np.abs(q - q0).max() < 1e-7 and np.abs(t - t0).max() < 1e-6, key
+    a, b = res["2"], res["2'"]
+    assert a[0].final_cost == b[0].final_cost and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+
+@pytest.mark.gpu
 def test_twenty_thousand_sequential_cameras_take_the_exact_path(lib):
     """120 000 camera unknowns: the dense tile array of the reduced camera matrix would be 161 GB; the packed form (non-zero tiles of
     the nested-dissection factor only, ba_chol.h: tile_ptr) is 0.24 GB, so AUTO stays on the exact Cholesky path (round 2: PCG).

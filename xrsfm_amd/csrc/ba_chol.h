@@ -64,6 +64,7 @@ constexpr int kRedLd = 15;      // row stride (doubles) of the LDS reduction buf
 // (A host-built "store plan" — one int per accumulator element — was measured in round 3 and removed again: 107.6-111.4 us per
 //  launch at config L against 103.6 for index arithmetic; its loads are one more dependent round trip at the end of every tile.)
 constexpr int kGramTabLd = kGramMaxCams + 1;      // rows 60..63 of the last operand tile map to "camera 10": always -1
+static_assert(kTileRunLd == kGramMaxCams, "one run record per distinct camera of a Gram tile (ba_kernels.h: k_gram_runs)");
 
 // UPPER = false: hc = lower factor {c00 c10 c20 c11 c21 c22} stored by k_point_prep;  UPPER = true: hc = upper factor
 // {c00 c01 c02 c11 c12 c22} of point_factor() (formed in the kernel).  Either way hc hc^T = Hinv and V = W hc.
@@ -390,6 +391,16 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
         const int cp = d.slot_campos_g[s.slot];
         const int cidx_raw = GRAM ? (int)d.slot_cidx[s.slot] : 0;
         const int L = d.tile_stride[it.first_tile];
+        int g_pos = kWave - 1, g_pk0 = 0, g_pk1 = 0, g_pk2 = 0;      // ragged Gram tile: the per-camera sums' tables (used far below: the loads ride with the slot record)
+        if (GRAM && L == 0) {
+            const int C0 = d.tile_ncam[it.first_tile];
+            const int* trun = d.tile_run + (size_t)it.first_tile * kTileRunLd;
+            const int c0 = lane / 14, c1 = (lane + 64) / 14, c2 = (lane + 128) / 14;
+            g_pos = (int)d.slot_gpos[s.slot];
+            if (c0 < C0) g_pk0 = trun[c0];
+            if (c1 < C0) g_pk1 = trun[c1];
+            if (c2 < C0) g_pk2 = trun[c2];
+        }
         double V[18];                 // (lanes without an observation: never staged, never a pair partner — XBA_POISON checks it)
         int npair = 0, pbase = 0;
         {
@@ -481,23 +492,12 @@ void k_schur_pairs(Dev d, const int* __restrict__ item_list, const int* __restri
                 // of the same camera), from the ballot masks — so that the lane of (camera c, value k) walks a contiguous run of
                 // count_c entries with a counted loop (independent LDS reads) instead of peeling a lane mask bit by bit (a dependent
                 // ffs / read / clear chain per term: 26 % of the wave's life on config R).  Same terms in the same (lane) order.
-                const int cidx = s.valid ? cidx_raw : -1;
                 double* red = smem;
                 const int nq = 14 * Cg;
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                int mypos = kWave - 1;                                      // (lanes without an observation park their zeros in the last row)
-                int pk0 = 0, pk1 = 0, pk2 = 0;          // run start | length << 8 | first lane << 16 of the camera of q = lane, + 64, + 128
-                int run = 0;
-                for (int cc = 0; cc < Cg; ++cc) {
-                    const unsigned long long m = __ballot(cidx == cc);
-                    const int cnt = __popcll(m);
-                    const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);      // (wave-uniform)
-                    if (cidx == cc) mypos = run + __popcll(m & lt);
-                    if (lane / 14 == cc) pk0 = pk;
-                    if ((lane + 64) / 14 == cc) pk1 = pk;
-                    if ((lane + 128) / 14 == cc) pk2 = pk;
-                    run += cnt;
-                }
+                // (round 6) deposit position and runs from the per-context tables (k_gram_runs, ba_kernels.h), requested at the head of the
+                // kernel — until round 5 a ballot loop over the tile's cameras: ~110 vector and ~80 scalar instructions of a ragged tile's 1 240 / 440
+                const int mypos = g_pos;                                    // (lanes without an observation park their zeros in the last row, 63)
+                const int pk0 = g_pk0, pk1 = g_pk1, pk2 = g_pk2;           // run start | length << 8 | first lane << 16 of the camera of q = lane, + 64, + 128
                 // (run < 64 whenever a lane has no observation, so row 63 — where those lanes park their dead values — is in no camera's run)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -1238,7 +1238,7 @@ __device__ __forceinline__ void half_abt_mfma(const double* __restrict__ As, con
 // of config T with a single buffer and the loads one step ahead: 5.5 us per product against 1.7 us of matrix instructions).
 // Same products in the same order.
 __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
-                                                    const int* __restrict__ cj, double* __restrict__ Wp, double* lds, double* yv) {
+                                                    const int* __restrict__ cj, double* __restrict__ Wp, double* lds, double* yv, int out_slot = -1) {
     const int i = tgt[2 * bx], k = tgt[2 * bx + 1];
     const bool diag = (i == k);
     v4d acc[2][2];
@@ -1302,7 +1302,7 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
             }
         }
     }
-    double* out = Wp + (size_t)bx * kPartStride;
+    double* out = Wp + (size_t)(out_slot >= 0 ? out_slot : bx) * kPartStride;
     {
         const int lane = t & 63, wave = t >> 6;
         const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
@@ -1331,7 +1331,7 @@ __device__ __forceinline__ void ll_update_part_body(const CholDev& c, const int 
 #define XBA_CHUNK_SB 1
 #endif
 __device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const int bx, const int* __restrict__ tgt, const int* __restrict__ qr,
-                                                       const int* __restrict__ cj, double* __restrict__ Wp, double* As, double* Bs, double* yv) {
+                                                       const int* __restrict__ cj, double* __restrict__ Wp, double* As, double* Bs, double* yv, int out_slot) {
     const int i = tgt[2 * bx], k = tgt[2 * bx + 1];
     const bool diag = (i == k);
     v4d acc[2][2];
@@ -1367,7 +1367,7 @@ __device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const i
         }
         half_abt_mfma(As, Bs, acc);
     }
-    double* out = Wp + (size_t)bx * kPartStride;
+    double* out = Wp + (size_t)out_slot * kPartStride;
     {
         const int lane = t & 63, wave = t >> 6;
         const int r0 = (wave >> 1) * 32, c0 = (wave & 1) * 32;
@@ -1388,16 +1388,20 @@ __device__ __forceinline__ void ll_update_part_body_sb(const CholDev& c, const i
     }
 }
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XBA_CHUNK_SB ? 4 : 1, XBA_CHUNK_SB ? 4 : 2)))
-void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr, const int* __restrict__ cj, double* __restrict__ Wp) {
+void k_ll_update_part(CholDev c, const int* __restrict__ tgt, const int* __restrict__ qr, const int* __restrict__ cj, double* __restrict__ Wp,
+                      const int* __restrict__ slot) {
+    // slot (ba_plan.h: sp_slot): the partial slot of the chunk — its index in the level's list, or, with the level look-ahead, its
+    // place inside its target's contiguous range (the early and the late chunks of a level are two launches)
+    const int out_slot = slot[blockIdx.x];
 #if XBA_CHUNK_SB
     __shared__ __attribute__((aligned(16))) double As[kNB * kLdH];
     __shared__ __attribute__((aligned(16))) double Bs[kNB * kLdH];
     __shared__ double yv[kNB];
-    ll_update_part_body_sb(c, blockIdx.x, tgt, qr, cj, Wp, As, Bs, yv);
+    ll_update_part_body_sb(c, blockIdx.x, tgt, qr, cj, Wp, As, Bs, yv, out_slot);
 #else
     __shared__ __attribute__((aligned(16))) double lds[4 * kNB * kLdH];
     __shared__ double yv[2 * kNB];
-    ll_update_part_body(c, blockIdx.x, tgt, qr, cj, Wp, lds, yv);
+    ll_update_part_body(c, blockIdx.x, tgt, qr, cj, Wp, lds, yv, out_slot);
 #endif
 }
 

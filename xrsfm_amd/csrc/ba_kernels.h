@@ -59,6 +59,11 @@ struct Dev {
     const int* tile_gt_off;   // [n_tiles] offset of its C x C destination table behind the observation pairs in pair_dst
     const unsigned char* slot_cidx;   // [n_slots] index of the slot's camera among the tile's distinct cameras
     const int* slot_campos_g; // [n_slots] like slot_campos, for the S assembly (one writer per distinct camera of a Gram tile)
+    // (round 6) per-camera sums of a RAGGED Gram tile go through LDS with the lanes' values deposited sorted by camera; where a lane
+    // deposits and which run a (camera, value) lane adds are properties of the tiling — computed once per context (k_gram_runs)
+    // instead of by a ballot loop over the tile's cameras in every launch of k_linearize and k_schur_pairs:
+    const unsigned char* slot_gpos;   // [n_slots] position of the slot's lane in the camera-sorted order of its tile (63 = no observation)
+    const int* tile_run;      // [n_tiles][kTileRunLd] per distinct camera: run start | length << 8 | first lane << 16
     const int* cam_ptr_g;     // [n_cams+1]
     // cameras
     CamRec* cam; CamRec* cam_cand; const int* cam_model; const unsigned char* cam_const; const int* cam_ptr;
@@ -189,6 +194,33 @@ __device__ __forceinline__ int seg_head_lane(bool head, int lane) {
     const unsigned long long m = __ballot(head);
     const unsigned long long below = m & ((2ull << lane) - 1ull);
     return 63 - __clzll((long long)below);
+}
+
+constexpr int kTileRunLd = 10;            // = kGramMaxCams (ba_pack.h)
+// one wave per tile, once per context
+__global__ __launch_bounds__(256) void k_gram_runs(const int* __restrict__ slot_cam, const unsigned char* __restrict__ slot_cidx, const int* __restrict__ tile_ncam,
+                                                   int n_tiles, unsigned char* __restrict__ slot_gpos, int* __restrict__ tile_run) {
+    const int lane = threadIdx.x & 63;
+    const int t = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (t >= n_tiles) return;
+    const int s = 64 * t + lane;
+    const int C = tile_ncam[t];
+    int mypos = 63, mypk = 0;
+    if (C > 0) {                                        // (wave-uniform)
+        const int cidx = slot_cam[s] >= 0 ? (int)slot_cidx[s] : -1;
+        const unsigned long long lt = (1ull << lane) - 1ull;
+        int run = 0;
+        for (int cc = 0; cc < C; ++cc) {
+            const unsigned long long m = __ballot(cidx == cc);
+            const int cnt = __popcll(m);
+            const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);
+            if (cidx == cc) mypos = run + __popcll(m & lt);
+            if (lane == cc) mypk = pk;
+            run += cnt;
+        }
+    }
+    slot_gpos[s] = (unsigned char)mypos;
+    if (lane < kTileRunLd) tile_run[(size_t)t * kTileRunLd + lane] = mypk;
 }
 
 struct SlotCtx {
@@ -356,18 +388,12 @@ __device__ __forceinline__ void linearize_item(const Dev& d, const Item& it, int
                 double* red = lin_smem + (threadIdx.x >> 6) * (kWave * 13);          // this wave's [64][13]
                 // (round 4: values deposited sorted by camera — position = lanes of earlier cameras + earlier lanes of the own one — so
                 //  that a reducer lane walks a contiguous run with a counted loop instead of peeling a lane mask: k_schur_pairs, ba_chol.h)
-                const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
-                const unsigned long long lt = (1ull << lane) - 1ull;
-                int mypos = kWave - 1, pk0 = 0, pk1 = 0, run = 0;                    // pk: run start | length << 8 | first lane << 16
-                for (int cc = 0; cc < Cg; ++cc) {
-                    const unsigned long long m = __ballot(cidx == cc);
-                    const int cnt = __popcll(m);
-                    const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);
-                    if (cidx == cc) mypos = run + __popcll(m & lt);
-                    if (lane / 12 == cc) pk0 = pk;
-                    if ((lane + 64) / 12 == cc) pk1 = pk;
-                    run += cnt;
-                }
+                // (round 6: the lane's deposit position and the runs of the (camera, value) lanes come from the per-context tables of
+                //  k_gram_runs — until round 5 a ballot loop over the tile's cameras here and in k_schur_pairs)
+                const int mypos = (int)d.slot_gpos[s.slot];                          // pk: run start | length << 8 | first lane << 16
+                const int* trun = d.tile_run + (size_t)tile * kTileRunLd;
+                const int c0 = lane / 12, c1 = (lane + 64) / 12;
+                const int pk0 = c0 < Cg ? trun[c0] : 0, pk1 = c1 < Cg ? trun[c1] : 0;
 #pragma unroll
                 for (int k = 0; k < 12; ++k) red[mypos * 13 + k] = cs[k];            // (lanes without an observation: row 63, in no run)
                 __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -1587,7 +1613,17 @@ __global__ __launch_bounds__(kBlock) void k_lin_tail(Dev d, TailArgs a) {
         const int op = isgm ? 1 : (on ? a.jobs.op[j] : 0);
         const double* in = a.part2 + (size_t)j * G;
         double v = 0.0;
-        if (on) for (int i = l32; i < G; i += 32) v = (op == 0) ? v + in[i] : fmax(v, in[i]);
+        // (round 6) eight loads in flight per lane, added in index order as before: the loop used to wait for every load in turn — up to 32
+        // dependent L2 round trips on the one workgroup the host is waiting for
+        if (on)
+            for (int i0 = l32; i0 < G; i0 += 32 * 8) {
+                double x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int i = i0 + 32 * u; x[u] = (i < G) ? in[i] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (i0 + 32 * u < G) v = (op == 0) ? v + x[u] : fmax(v, x[u]);
+            }
 #pragma unroll
         for (int off = 16; off > 0; off >>= 1) {
             const double ov = __shfl_down(v, off, 32);

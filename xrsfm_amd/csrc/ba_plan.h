@@ -50,6 +50,15 @@ struct CholPlan {
     std::vector<int> sp_rt, sp_rp;      // per split target: (i,k) and its [p0,p1) range of partials (level-relative)
     std::vector<int> sp_chunk_off, sp_rt_off;   // per level (size n_levels+1)
     int sp_max_chunks = 0;
+    // (round 6) look-ahead on the LEVEL schedule of a dissected collection (config 5's shape: 174 levels, each update -> sum -> factor
+    // with the chip idle through the last two): the contributions of a level-l target are cut into EARLY ones — columns of levels
+    // <= l - 1 - la_depth, final long before level l is reached — and LATE ones; the early chunks of level l run on a second stream
+    // while the main stream is still at the levels l - la_depth .. l - 1, the late chunks (a few per cent of the products) follow the
+    // previous level's factor kernel, and the fixed-order sum adds both.  Per level the chunk list holds the early chunks first
+    // (sp_e_cnt of them); a chunk's partial slot is sp_slot (a target's slots stay one contiguous range: early, then late).
+    int la_depth = 0;                   // 0: off (every chunk in one launch, list order)
+    std::vector<int> sp_slot;           // per chunk: partial slot (level-relative)
+    std::vector<int> sp_e_cnt;          // per level: early chunks
     // panel schedule, dense part of the pattern: an even number of consecutive single-column levels (columns K0, K0+1, ...) share
     // one update launch of 128x128 macro tiles (k_panel2_part: rows (i0,i1) x columns (k0,k1), contributions j in [q0,q1) of
     // [0,K0)); the later levels of the panel then only add the panel's own earlier columns inside the fused factor kernel.
@@ -846,6 +855,15 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
     };
     struct FzEnt { int i, k; };
     std::vector<FzEnt> fz_ents;
+    // look-ahead on the level schedule: dissected collections with a deep tree (XRSFM_BA_LA_DEPTH: 0 = off, default 2)
+    {
+        const char* le = std::getenv("XRSFM_BA_LA_DEPTH");
+        const int want = le ? std::max(0, std::min(8, std::atoi(le))) : 2;
+        P.la_depth = (P.ordering == 3 && !panel_ll && n_levels >= 16) ? want : 0;
+    }
+    const bool la_lv = P.la_depth > 0;
+    P.sp_e_cnt.assign(n_levels, 0);
+    std::vector<int> lv_ne;               // per target (lv_tgt order): early contributions at the head of its list
     for (int lv = 0; lv < n_levels; ++lv) {
         fz_ents.clear();
         const int panel_cols = dense_panel(lv);
@@ -864,6 +882,12 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                 for (int j = first_j[kk]; j < kk; ++j) if (nz[(size_t)i * T + j] && nz[(size_t)kk * T + j]) contrib.push_back(j);
                 fz_ents.push_back({i, kk});
                 if (contrib.empty()) continue;
+                int n_early = 0;
+                if (la_lv) {          // early contributions first (stable: ascending j inside both parts)
+                    const auto mid = std::stable_partition(contrib.begin(), contrib.end(), [&](int j) { return level[j] <= lv - 1 - P.la_depth; });
+                    n_early = (int)(mid - contrib.begin());
+                }
+                lv_ne.push_back(n_early);
                 P.lv_tgt.push_back(i); P.lv_tgt.push_back(kk);
                 for (int j : contrib) P.lv_cj.push_back(j);
                 P.lv_cptr.push_back((int)P.lv_cj.size());
@@ -934,11 +958,41 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                          : panel_ll ? std::max(panel_min_chunk, (nc + panel_chunks - 1) / panel_chunks)
                          : nd_lv ? std::max(nd_chunk, (nc + 4095) / 4096) : std::max(1, (nc + 511) / 512);
             int np = 0;
+            if (la_lv && nd_lv) {
+                // early chunks of every target, then the late ones; a target's slots: [early chunks | late chunks], contiguous
+                std::vector<int> base(g1 - g0 + 1, 0);
+                auto n_chunks = [&](int len) { return (len + cs - 1) / cs; };
+                for (int g = g0; g < g1; ++g) {
+                    const int len = P.lv_cptr[g + 1] - P.lv_cptr[g], ne = lv_ne[g];
+                    base[g - g0 + 1] = base[g - g0] + n_chunks(ne) + n_chunks(len - ne);
+                }
+                // (measured and not adopted, tools/runs/r06_call9.sh: the late contributions inside the fused factor kernel instead of
+                //  chunks of their own — one launch less per level, but 12-17 us more on every factor kernel: config T 954 ms against 922)
+                for (int pass = 0; pass < 2; ++pass)
+                    for (int g = g0; g < g1; ++g) {
+                        const int q_lo = P.lv_cptr[g], q_mid = q_lo + lv_ne[g], q_hi = P.lv_cptr[g + 1];
+                        const int a = pass == 0 ? q_lo : q_mid, b = pass == 0 ? q_mid : q_hi;
+                        int slot = base[g - g0] + (pass == 0 ? 0 : n_chunks(lv_ne[g]));
+                        for (int q = a; q < b; q += cs, ++slot) {
+                            P.sp_tgt.push_back(P.lv_tgt[2 * g]); P.sp_tgt.push_back(P.lv_tgt[2 * g + 1]);
+                            P.sp_q.push_back(q); P.sp_q.push_back(std::min(q + cs, b));
+                            P.sp_slot.push_back(slot);
+                            if (pass == 0) P.sp_e_cnt[lv]++;
+                        }
+                    }
+                for (int g = g0; g < g1; ++g) {
+                    if (base[g - g0 + 1] == base[g - g0]) continue;       // (late contributions only: nothing to sum)
+                    P.sp_rt.push_back(P.lv_tgt[2 * g]); P.sp_rt.push_back(P.lv_tgt[2 * g + 1]);
+                    P.sp_rp.push_back(base[g - g0]); P.sp_rp.push_back(base[g - g0 + 1]);
+                }
+                np = base[g1 - g0];
+            } else
             for (int g = g0; g < g1; ++g) {
                 const int p0 = np;
                 for (int q = P.lv_cptr[g]; q < P.lv_cptr[g + 1]; q += cs, ++np) {
                     P.sp_tgt.push_back(P.lv_tgt[2 * g]); P.sp_tgt.push_back(P.lv_tgt[2 * g + 1]);
                     P.sp_q.push_back(q); P.sp_q.push_back(std::min(q + cs, P.lv_cptr[g + 1]));
+                    P.sp_slot.push_back(np);
                 }
                 P.sp_rt.push_back(P.lv_tgt[2 * g]); P.sp_rt.push_back(P.lv_tgt[2 * g + 1]);
                 P.sp_rp.push_back(p0); P.sp_rp.push_back(np);
@@ -998,6 +1052,15 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
         fprintf(stderr, "[plan] %d tile columns, %d levels (%d split: %lld of %lld list entries), %d chunks in all, largest level %d targets, partial buffer %d tiles, %lld tile products; "
                         "%d block entries of which %d per pair\n",
                 T, n_levels, n_split, nc_split, nc_all, (int)P.sp_tgt.size() / 2, max_nt, P.sp_max_chunks, P.tile_products, P.n_writes, P.n_pair_writes);
+        {   // levels whose factor launch exceeds one workgroup per CU (k_lv_factor holds 109 KB of LDS)
+            int n_over = 0; long long tiles_over = 0, tiles_all = 0;
+            for (int lv = 0; lv < n_levels; ++lv) {
+                const int nf = P.fz_off[lv + 1] - P.fz_off[lv];
+                tiles_all += nf;
+                if (nf > 256) { ++n_over; tiles_over += nf; }
+            }
+            fprintf(stderr, "[plan] factor launches: %lld tiles in %d levels, of which %lld in the %d levels of more than 256 tiles\n", tiles_all, n_levels, tiles_over, n_over);
+        }
         if (n_levels <= 16)
             for (int lv = 0; lv < n_levels; ++lv) {
                 const int g0 = P.lv_tgt_off[lv], g1 = P.lv_tgt_off[lv + 1];
@@ -1083,8 +1146,14 @@ inline int chol_plan_build(const Packed& k, const std::vector<int>& spp, const P
                             }
                     }
             } else {
-                for (int c2 = P.sp_chunk_off[lv]; c2 < P.sp_chunk_off[lv + 1]; ++c2)
-                    if (!put(c2 - P.sp_chunk_off[lv], P.sp_tgt[2 * (size_t)c2], P.sp_tgt[2 * (size_t)c2 + 1])) return kErrPlanCheck;
+                for (int c2 = P.sp_chunk_off[lv]; c2 < P.sp_chunk_off[lv + 1]; ++c2) {
+                    if (!put(P.sp_slot[c2], P.sp_tgt[2 * (size_t)c2], P.sp_tgt[2 * (size_t)c2 + 1])) return kErrPlanCheck;
+                    // look-ahead: an early chunk only names columns that are final when it may run, and the early chunks come first
+                    const bool early = c2 - P.sp_chunk_off[lv] < P.sp_e_cnt[lv];
+                    for (int q = P.sp_q[2 * (size_t)c2]; q < P.sp_q[2 * (size_t)c2 + 1]; ++q)
+                        if (P.la_depth > 0 && (level[P.lv_cj[q]] <= lv - 1 - P.la_depth) != early) return kErrPlanCheck;
+                    if (P.la_depth == 0 && early) return kErrPlanCheck;
+                }
             }
             size_t read = 0;
             for (int r = P.sp_rt_off[lv]; r < P.sp_rt_off[lv + 1]; ++r) {

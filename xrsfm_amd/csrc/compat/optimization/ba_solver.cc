@@ -242,7 +242,7 @@ class FlatProblem {
     // over the host's threads (the solve itself takes 15 ms at that size).
     template <typename F> void ForTracks(F &&fn) { ParallelFor(tracks_.size(), 50000, fn); }
     void GatherPoints() {
-        points_.resize(3 * tracks_.size());
+        points_.reset(new double[3 * tracks_.size() + 1]);      // (uninitialised: resize() of a vector zero-fills 12 MB on one thread first, ~1 ms at config 4's size)
         ForTracks([&](size_t j0, size_t j1) {
             for (size_t j = j0; j < j1; ++j) {
                 const double *p = map_.tracks_[tracks_[j]].point3d_.data();
@@ -262,7 +262,7 @@ class FlatProblem {
         p.n_intr = static_cast<int32_t>(intr_model_.size());
         p.cam_q = cam_q_.data(); p.cam_t = cam_t_.data(); p.cam_const = cam_const_.data(); p.cam_intr = cam_intr_.data();
         p.intr_model = intr_model_.data(); p.intr_params = intr_params_.data();
-        p.points = points_.data(); p.point_const = point_const_.data();
+        p.points = points_.get(); p.point_const = point_const_.data();
         p.obs_cam = obs_cam_.get(); p.obs_pt = obs_pt_.get(); p.obs_uv = obs_uv_.get();
         const auto t_packed = std::chrono::steady_clock::now();
         const int rc = xrsfm_ba_solve(&opt, &p, summary);
@@ -322,7 +322,8 @@ class FlatProblem {
     int lba_frame_id_ = -1;
     std::chrono::steady_clock::time_point t_begin_;
     std::vector<int> tracks_;
-    std::vector<double> cam_q_, cam_t_, intr_params_, points_;
+    std::vector<double> cam_q_, cam_t_, intr_params_;
+    std::unique_ptr<double[]> points_;
     std::vector<uint8_t> cam_const_, point_const_;
     std::vector<int32_t> cam_intr_, intr_model_;
     std::unique_ptr<int32_t[]> obs_cam_, obs_pt_;
@@ -543,6 +544,11 @@ int RefineFramePose(Frame &frame, const Camera &camera, const std::vector<vector
     }
     for (int k = 0; k < 4; ++k) frame.Tcw.q.coeffs().data()[k] = q[k];
     for (int k = 0; k < 3; ++k) frame.Tcw.t.data()[k] = t[k];
+    static const bool trace = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;
+    if (trace)
+        std::fprintf(stderr, "[BASolver adapter] RefineFramePose frame %d: %d correspondences, LM %d+%d, %.3f -> %.3f px, %.3f ms\n", static_cast<int>(frame.id),
+                     static_cast<int>(n), s.n_successful, s.n_unsuccessful, std::sqrt(s.initial_cost / s.num_residuals), std::sqrt(s.final_cost / s.num_residuals),
+                     1e3 * s.total_time_s);
     std::cout << "Initial cost : " << std::setprecision(6) << std::sqrt(s.initial_cost / s.num_residuals) << " [px]" << std::endl;
     std::cout << "Final cost : " << std::setprecision(6) << std::sqrt(s.final_cost / s.num_residuals) << " [px]" << std::endl;
     return e;

@@ -128,6 +128,9 @@ struct CholHost {
     bool bw_debug_timeout = false;  // XRSFM_BA_DEBUG_BWD_TIMEOUT=1 (tests): every hand-off of k_lv_bwd_all waits for a tag that never comes
     int bw_n = 0; unsigned bw_launches = 0; bool bwd_all = false;
     int *sp_tgt = nullptr, *sp_q = nullptr, *sp_rt = nullptr, *sp_rp = nullptr;   // split levels (ba_plan.h)
+    int* sp_slot = nullptr;                         // per chunk: its partial slot
+    // level look-ahead (ba_plan.h: la_depth): early chunks of level l on the second stream while the main stream is at the levels before it
+    int la_depth = 0; std::vector<int> sp_e_cnt; std::vector<hipEvent_t> la_ev_factor, la_ev_early;
     std::vector<int> sp_chunk_off, sp_rt_off, mp_off;
     int *mp_chunk = nullptr, *mp_wg = nullptr;    // macro-tile entries of the panel schedule and their split over workgroups (ba_plan.h)
     double* sp_work = nullptr; int sp_max_chunks = 0;
@@ -272,6 +275,38 @@ struct BundleCache {
     }
 };
 BundleCache g_bundles;
+
+// Pinned staging memory of the one-shot helpers (track filter): grow-only, one block per use, recycled.  A multi-megabyte
+// hipMemcpyAsync from PAGEABLE memory makes the runtime pin the caller's pages for the copy and release them afterwards — measured
+// in the mapper replay as a 10-25 ms stall of the NEXT GPU call of the process (the pose refinement after a whole-map filter).
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, size_t>> free_blocks;
+    void* get(size_t bytes, size_t* cap) {
+        {
+            std::lock_guard<std::mutex> g(mu);
+            for (size_t i = 0; i < free_blocks.size(); ++i)
+                if (free_blocks[i].second >= bytes) { void* p = free_blocks[i].first; *cap = free_blocks[i].second; free_blocks.erase(free_blocks.begin() + i); return p; }
+        }
+        size_t c = 1 << 16;
+        while (c < bytes) c *= 2;
+        void* p = nullptr;
+        if (hipHostMalloc(&p, c, hipHostMallocDefault) != hipSuccess) return nullptr;
+        *cap = c;
+        return p;
+    }
+    void put(void* p, size_t cap) {
+        std::lock_guard<std::mutex> g(mu);
+        if (free_blocks.size() >= 4 || cap > ((size_t)256 << 20)) { (void)hipHostFree(p); return; }
+        free_blocks.push_back({p, cap});
+    }
+    void release_all() {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto& b : free_blocks) (void)hipHostFree(b.first);
+        free_blocks.clear();
+    }
+};
+PinnedPool g_pinned;
 
 // Deferred release of the host side of large contexts (xrsfm_ba_destroy).  One joinable thread, started on first use.
 struct Reaper {
@@ -759,7 +794,8 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.lv_cj, P.lv_cj);
     up.add(&h.lv_bptr, P.lv_bptr); up.add(&h.lv_bi, P.lv_bi);
     up.add(&h.sp_tgt, P.sp_tgt); up.add(&h.sp_q, P.sp_q); up.add(&h.mp_chunk, P.mp_chunk); up.add(&h.mp_wg, P.mp_wg);
-    up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp);
+    up.add(&h.sp_rt, P.sp_rt); up.add(&h.sp_rp, P.sp_rp); up.add(&h.sp_slot, P.sp_slot);
+    h.la_depth = P.la_depth; h.sp_e_cnt = P.sp_e_cnt;
     up.add(&h.tf_ptr, P.tf_ptr); up.add(&h.tf_ent, P.tf_ent);
     up.add(&h.fz_tile, P.fz_tile); up.add(&h.fz_dptr, P.fz_dptr); up.add(&h.fz_dj, P.fz_dj);
     up.add(&h.fz_q, P.fz_q); up.add(&h.fill_rest, P.fill_rest); h.n_fill_rest = (int)P.fill_rest.size();
@@ -768,7 +804,9 @@ int chol_setup(xrsfm_ba_context* c) {
     up.add(&h.tile_cam, P.tile_cam);
     if (dev_keys) h.pairs_items = KR.pairs_items; else up.add(&h.pairs_items, P.pairs_items);
     h.sp_max_chunks = P.sp_max_chunks;
-    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : 1)));
+    // (partial tiles: one buffer; two with the look-ahead panel schedule; la_depth + 1 with the level look-ahead — level l's buffer is
+    //  l mod (la_depth + 1): written from the moment level l - 1 - la_depth is factored until level l has been summed)
+    TRYC(dev_alloc(c, &h.sp_work, (size_t)std::max(1, P.sp_max_chunks) * kPartStride * (P.lookahead ? 2 : (P.la_depth > 0 ? P.la_depth + 1 : 1))));
     if (P.lookahead) TRYC(dev_alloc(c, &h.md_work, (size_t)std::max(1, P.md_max) * kPartStride * 2));
     up.add(&d_cam_off, P.cam_off); up.add(&d_tile_rows, P.tile_rows); up.add(&d_tmap, P.tile_map);
     TRYC(up.flush());
@@ -878,12 +916,26 @@ int chol_setup(xrsfm_ba_context* c) {
     HIPCHK(hipMemsetAsync(h.dev.S, 0, sizeof(double) * h.S_doubles, c->stream));
     const int shm = 2 * kNB * kLdT * (int)sizeof(double);
     set_kernel_attributes(c->device);
-    if (h.n_pairs_other > 0 && !h.aux) {              // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
+    if ((h.n_pairs_other > 0 || h.la_depth > 0) && !h.aux) {              // lives in the context's recycled bundle (xrsfm_ba_destroy hands it back)
         if (hipStreamCreateWithFlags(&h.aux, hipStreamNonBlocking) != hipSuccess) h.aux = nullptr;
         if (h.aux && (hipEventCreateWithFlags(&h.ev_fork, hipEventDisableTiming) != hipSuccess ||
                       hipEventCreateWithFlags(&h.ev_join, hipEventDisableTiming) != hipSuccess)) {
             if (h.ev_fork) (void)hipEventDestroy(h.ev_fork);
             (void)hipStreamDestroy(h.aux); h.aux = nullptr; h.ev_fork = h.ev_join = nullptr;
+        }
+    }
+    if (h.la_depth > 0) {
+        // one event per level and direction (created once per context, destroyed with it): "level l is factored" for the second
+        // stream, "the early chunks of level l are done" for the main one
+        bool ok = h.aux != nullptr;
+        h.la_ev_factor.assign(h.n_levels, nullptr); h.la_ev_early.assign(h.n_levels, nullptr);
+        for (int lv = 0; lv < h.n_levels && ok; ++lv)
+            ok = hipEventCreateWithFlags(&h.la_ev_factor[lv], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&h.la_ev_early[lv], hipEventDisableTiming) == hipSuccess;
+        if (!ok) {          // no second stream / no events: every chunk in the main stream's launch, early ones first (still a valid order)
+            for (hipEvent_t e2 : h.la_ev_factor) if (e2) (void)hipEventDestroy(e2);
+            for (hipEvent_t e2 : h.la_ev_early) if (e2) (void)hipEventDestroy(e2);
+            h.la_ev_factor.clear(); h.la_ev_early.clear();
         }
     }
     timer.mark("allocations + attributes");
@@ -945,17 +997,20 @@ int chol_assemble(xrsfm_ba_context* c, bool materialize = false) {
                 items += n;
             }
         };
+        // (round 6) the main-stream launch — the one that takes the time — is issued FIRST: until round 5 the side-stream launches were,
+        // and the big kernel started 20 us after the first small one (config R trace: other @ 22 us, 10-camera tiles @ 32, main @ 43)
         if (fork) {
             HIPCHK(hipEventRecord(h.ev_fork, c->stream));
+            launch_buckets(true);
             HIPCHK(hipStreamWaitEvent(h.aux, h.ev_fork, 0));
             launch_other(h.aux);
             launch_buckets(false);
             HIPCHK(hipEventRecord(h.ev_join, h.aux));
-        } else if (h.n_pairs_other > 0) {
-            launch_other(c->stream);
+            HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
+        } else {
+            if (h.n_pairs_other > 0) launch_other(c->stream);
+            launch_buckets(true);
         }
-        launch_buckets(true);
-        if (fork) HIPCHK(hipStreamWaitEvent(c->stream, h.ev_join, 0));
     }
     if (d.n_cams + h.n_blocks > 0) {
         if (h.pair_from_v) LAUNCH(c, K_BLOCK_SEGSUM, k_chol_segsum_v, dim3(d.n_cams + (h.n_blocks + 3) / 4), dim3(kBlock), 0, d.scat, d.cam_ptr_g, d.camS, d.n_cams, h.scat2, h.blk_ptr, h.Sblk,
@@ -1042,14 +1097,21 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             const int nt = h.lv_tgt_off[lv + 1] - h.lv_tgt_off[lv];
             const int nch = h.sp_chunk_off[lv + 1] - h.sp_chunk_off[lv], nmc = h.mp_off[lv + 1] - h.mp_off[lv] - 1;
             const int nrt = h.sp_rt_off[lv + 1] - h.sp_rt_off[lv];
+            // level look-ahead (ba_plan.h): the early chunks of this level were put on the second stream when level lv - 1 - la_depth
+            // had been factored; here only the late ones follow the previous level's factor kernel.  Without the second stream
+            // (la_on false) all chunks run here, early ones first — the same sums.
+            const bool la_on = h.la_depth > 0 && !h.la_ev_factor.empty();
+            const int n_early = la_on ? h.sp_e_cnt[lv] : 0;
+            double* const Wlv = h.sp_work + (h.la_depth > 0 ? (size_t)(lv % (h.la_depth + 1)) * (size_t)std::max(1, h.sp_max_chunks) * kPartStride : 0);
             if (nmc > 0)
                 LAUNCH(c, K_UPDATE, k_panel2_part, dim3(nmc), dim3(256), 0, h.dev, h.mp_chunk, h.mp_wg + h.mp_off[lv], h.sp_work);
-            else if (nch > 0)
-                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[lv],
-                       h.sp_q + 2 * (size_t)h.sp_chunk_off[lv], h.lv_cj, h.sp_work);
+            else if (nch - n_early > 0)
+                LAUNCH(c, K_UPDATE, k_ll_update_part, dim3(nch - n_early), dim3(256), 0, h.dev, h.sp_tgt + 2 * (size_t)(h.sp_chunk_off[lv] + n_early),
+                       h.sp_q + 2 * (size_t)(h.sp_chunk_off[lv] + n_early), h.lv_cj, Wlv, (const int*)(h.sp_slot + h.sp_chunk_off[lv] + n_early));
+            if (n_early > 0) HIPCHK(hipStreamWaitEvent(c->stream, h.la_ev_early[lv], 0));
             if (nrt > 0)
                 LAUNCH(c, K_UPDATE, k_ll_update_reduce, dim3(nrt, 16), dim3(256), 0, h.dev, h.sp_rt + 2 * (size_t)h.sp_rt_off[lv],
-                       h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], h.sp_work);
+                       h.sp_rp + 2 * (size_t)h.sp_rt_off[lv], Wlv);
             const int nf = h.fz_off[lv + 1] - h.fz_off[lv];
             // the columns of the last level have nothing below them: their backward substitution rides in the same launch
             // (a single-tile system — LBA-sized calls — is its own last level on either schedule)
@@ -1072,6 +1134,23 @@ int chol_factor_solve(xrsfm_ba_context* c) {
             } else if (nf > 0)
                 LAUNCH(c, K_POTRF, k_lv_factor<false>, dim3(nf), dim3(256), 0, h.dev, h.fz_tile + 2 * (size_t)h.fz_off[lv], h.fz_dptr + h.fz_off[lv], h.fz_dj,
                        (const int*)h.tile_cam, with_bwd ? px_out : (double*)nullptr, lf);
+            if (la_on) {
+                // level lv is factored: the early chunks of level lv + 1 + la_depth (every column they name has level <= lv) go to the
+                // second stream, where they run next to the main stream's late chunks / sums / factor kernels of the levels in between
+                const int le = lv + 1 + h.la_depth;
+                const int ne = le < h.n_levels ? h.sp_e_cnt[le] : 0;
+                if (ne > 0) {
+                    HIPCHK(hipEventRecord(h.la_ev_factor[lv], c->stream));
+                    HIPCHK(hipStreamWaitEvent(h.aux, h.la_ev_factor[lv], 0));
+                    double* const Wle = h.sp_work + (size_t)(le % (h.la_depth + 1)) * (size_t)std::max(1, h.sp_max_chunks) * kPartStride;
+                    {
+                        Timed t_(c, K_UPDATE, -1, h.aux);
+                        hipLaunchKernelGGL(k_ll_update_part, dim3(ne), dim3(256), 0, h.aux, h.dev, h.sp_tgt + 2 * (size_t)h.sp_chunk_off[le],
+                                           h.sp_q + 2 * (size_t)h.sp_chunk_off[le], h.lv_cj, Wle, (const int*)(h.sp_slot + h.sp_chunk_off[le]));
+                    }
+                    HIPCHK(hipEventRecord(h.la_ev_early[le], h.aux));
+                }
+            }
         }
         if (h.panel_ll || h.bwd_push) {       // long columns: push form, one workgroup per tile of the column
             if (T == 1) return 0;               // solved inside the factor launch
@@ -1337,6 +1416,8 @@ void xrsfm_ba_destroy(xrsfm_ba_context* c) {
     }
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     if (c->chol.aux) (void)hipStreamSynchronize(c->chol.aux);
+    for (hipEvent_t e : c->chol.la_ev_factor) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->chol.la_ev_early) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i < c->allocs.size(); ++i) g_cache.put(c->device, c->allocs[i], c->alloc_class[i]);
@@ -1358,6 +1439,7 @@ int xrsfm_ba_quiesce(uint64_t* cached_bytes) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return XRSFM_BA_OK;      // nothing can be cached without a device
     g_cache.release_all();
+    g_pinned.release_all();
     return XRSFM_BA_OK;
 }
 
@@ -1516,6 +1598,12 @@ static int create_body(const xrsfm_ba_problem* p, int device, xrsfm_ba_context* 
     }
     TRY(dev_alloc(c, &c->part2, (size_t)kTailJobs * kTailGrid));
     TRY(dev_alloc(c, &c->ticket, (size_t)32 * 9));
+    {   // camera-sorted deposit positions and per-camera runs of the Gram tiles (k_gram_runs, ba_kernels.h): once per context
+        unsigned char* gpos = nullptr; int* trun = nullptr;
+        TRY(dev_alloc(c, &gpos, ns ? ns : 1)); TRY(dev_alloc(c, &trun, (size_t)std::max(1, k.n_tiles) * kTileRunLd));
+        if (k.n_tiles > 0) hipLaunchKernelGGL(k_gram_runs, dim3(cdiv(k.n_tiles, 4)), dim3(256), 0, c->stream, d.slot_cam, d.slot_cidx, d.tile_ncam, k.n_tiles, gpos, trun);
+        d.slot_gpos = gpos; d.tile_run = trun;
+    }
 #undef TRY
     {
         const char* fz = std::getenv("XRSFM_BA_FUSED");
@@ -2042,10 +2130,13 @@ static int refine_poses_kernel(const xrsfm_ba_options& o, int32_t n_frames, cons
     const size_t off_res = (off_uv + sizeof(double) * 2 * M + 255) & ~(size_t)255;
     const size_t total = off_res + sizeof(RefineResult) * (size_t)n_frames;
     size_t cls = 0;
+    static const bool trace_phases = std::getenv("XRSFM_BA_TRACE_CALLS") != nullptr;
+    const auto t_a = std::chrono::steady_clock::now();
     unsigned char* dev = static_cast<unsigned char*>(g_cache.get(device, total, &cls));
     if (!dev) return XRSFM_BA_ENOMEM;
     HostBundle hb;
     if (!g_bundles.get(device, &hb)) { g_cache.put(device, dev, cls); return XRSFM_BA_ENODEV; }
+    const auto t_b = std::chrono::steady_clock::now();
     std::vector<unsigned char> stage(off_res);
     double* hP = reinterpret_cast<double*>(stage.data() + off_P);
     double* hU = reinterpret_cast<double*>(stage.data() + off_uv);
@@ -2069,7 +2160,9 @@ static int refine_poses_kernel(const xrsfm_ba_options& o, int32_t n_frames, cons
     RefineOpt ro{o.max_iterations, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance, o.initial_radius, o.huber_a};
     std::vector<RefineResult> res(n_frames);
     int e = XRSFM_BA_OK;
+    const auto t_c = std::chrono::steady_clock::now();
     if (hipMemcpyAsync(dev, stage.data(), off_res, hipMemcpyHostToDevice, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    const auto t_d = std::chrono::steady_clock::now();
     if (!e) {
         hipLaunchKernelGGL(k_refine_pose, dim3(n_frames), dim3(kBlock), 0, hb.stream, reinterpret_cast<const RefineJob*>(dev), ro,
                            reinterpret_cast<RefineResult*>(dev + off_res));
@@ -2081,6 +2174,11 @@ static int refine_poses_kernel(const xrsfm_ba_options& o, int32_t n_frames, cons
     g_cache.put(device, dev, cls);
     if (e) return e;
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
+    if (trace_phases && secs > 2e-3) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "[xrsfm_ba_refine_pose] slow call: prologue %.3f | block + stream %.3f | staging %.3f | upload call %.3f | kernel + download + sync %.3f ms (%zu bytes)\n",
+                ms(t_begin, t_a), ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, std::chrono::steady_clock::now()), total);
+    }
     for (int f = 0; f < n_frames; ++f) {
         xrsfm_ba_summary* sm = summaries + f;
         memset(sm, 0, sizeof(*sm));
@@ -2191,48 +2289,61 @@ static int filter_tracks_impl(const xrsfm_ba_problem* p, double max_reproj_error
         model[i] = p->intr_model[p->cam_intr[i]];
     }
     HIPCHK(hipSetDevice(0));
-    std::vector<void*> bufs;
-    auto up = [&](const void* h, size_t bytes, void** dptr) -> int {
-        if (hipMalloc(dptr, bytes ? bytes : 8) != hipSuccess) return XRSFM_BA_ENOMEM;
-        bufs.push_back(*dptr);
-        if (h && bytes && hipMemcpy(*dptr, h, bytes, hipMemcpyHostToDevice) != hipSuccess) return XRSFM_BA_ENODEV;
-        return 0;
-    };
+    // (round 6) ONE device block from the allocation cache, ONE upload, the two kernels on a recycled stream, ONE download: until
+    // round 5 a call cost 12 hipMalloc + 7 blocking uploads + 5 downloads + 12 hipFree — 0.31 ms for the 2 000 tracks of a frame,
+    // 600 times per 300-frame reconstruction (the mapper replay's "filters" total was larger than its BA total).
+    // Layout: inputs | outputs, every array 256-byte aligned; the outputs travel back as one contiguous range.
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off += al(bytes ? bytes : 8); return o; };
+    const size_t o_cam = take(sizeof(CamRec) * (size_t)Nc), o_model = take(sizeof(int) * (size_t)Nc), o_P = take(sizeof(double) * 3 * (size_t)Np),
+                 o_ptr = take(sizeof(int) * ((size_t)Np + 1)), o_ocam = take(sizeof(int) * (size_t)No), o_ouv = take(sizeof(double) * 2 * (size_t)No);
+    const size_t in_bytes = off;
+    const size_t o_centre = take(sizeof(double) * 3 * (size_t)Nc);
+    const size_t out0 = off;
+    const size_t o_cnt = take(sizeof(int) * 2), o_del = take((size_t)No), o_out = take((size_t)Np), o_err = take(sizeof(double) * (size_t)Np),
+                 o_ang = take(sizeof(double) * (size_t)Np);
+    const size_t out_bytes = off - out0;
+    HostBundle hb;
+    if (!g_bundles.get(0, &hb)) return XRSFM_BA_ENODEV;
+    size_t cls = 0;
+    unsigned char* base = (unsigned char*)g_cache.get(0, off, &cls);
+    if (!base) { g_bundles.put(0, hb); return XRSFM_BA_ENOMEM; }
     int e = 0;
-    void *d_cam, *d_model, *d_centre, *d_P, *d_ptr, *d_ocam, *d_ouv, *d_del, *d_out, *d_err, *d_ang, *d_cnt;
-    if (!e) e = up(cams.data(), sizeof(CamRec) * (size_t)Nc, &d_cam);
-    if (!e) e = up(model.data(), sizeof(int) * (size_t)Nc, &d_model);
-    if (!e) e = up(nullptr, sizeof(double) * 3 * (size_t)Nc, &d_centre);
-    if (!e) e = up(p->points, sizeof(double) * 3 * (size_t)Np, &d_P);
-    if (!e) e = up(ptr.data(), sizeof(int) * ((size_t)Np + 1), &d_ptr);
-    if (!e) e = up(ocam.data(), sizeof(int) * (size_t)No, &d_ocam);
-    if (!e) e = up(ouv.data(), sizeof(double) * 2 * (size_t)No, &d_ouv);
-    if (!e) e = up(nullptr, (size_t)No, &d_del);
-    if (!e) e = up(nullptr, (size_t)Np, &d_out);
-    if (!e) e = up(nullptr, sizeof(double) * (size_t)Np, &d_err);
-    if (!e) e = up(nullptr, sizeof(double) * (size_t)Np, &d_ang);
-    if (!e) e = up(nullptr, sizeof(int) * 2, &d_cnt);
-    if (!e && hipMemset(d_cnt, 0, sizeof(int) * 2) != hipSuccess) e = XRSFM_BA_ENODEV;
-    if (!e) {
-        if (Nc > 0) hipLaunchKernelGGL(k_cam_centres, dim3(cdiv(Nc, 256)), dim3(256), 0, 0, (const CamRec*)d_cam, Nc, (double*)d_centre);
-        if (Np > 0) hipLaunchKernelGGL(k_filter_tracks, dim3(cdiv(Np, 128)), dim3(128), 0, 0, (const CamRec*)d_cam, (const int*)d_model, (const double*)d_centre,
-                                       (const double*)d_P, (const int*)d_ptr, (const int*)d_ocam, (const double*)d_ouv, Np, max_reproj_error, min_tri_angle_rad,
-                                       (unsigned char*)d_del, (unsigned char*)d_out, (double*)d_err, (double*)d_ang, (int*)d_cnt);
-        std::vector<unsigned char> del(No);
-        std::vector<double> err(Np), ang(Np);
-        int cnt[2] = {0, 0};
-        if (hipDeviceSynchronize() != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (!e && No && hipMemcpy(del.data(), d_del, (size_t)No, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (!e && Np && hipMemcpy(track_outlier, d_out, (size_t)Np, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (!e && Np && track_error && hipMemcpy(track_error, d_err, sizeof(double) * (size_t)Np, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (!e && Np && track_angle && hipMemcpy(track_angle, d_ang, sizeof(double) * (size_t)Np, hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
-        if (!e && hipMemcpy(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost) != hipSuccess) e = XRSFM_BA_ENODEV;
+    {
+        // (pinned staging from a recycled pool: see PinnedPool)
+        struct Pin { unsigned char* p = nullptr; size_t cap = 0; unsigned char* data() const { return p; } ~Pin() { if (p) g_pinned.put(p, cap); } } stage, back;
+        stage.p = (unsigned char*)g_pinned.get(in_bytes, &stage.cap); back.p = (unsigned char*)g_pinned.get(out_bytes, &back.cap);
+        if (!stage.p || !back.p) { g_cache.put(0, base, cls); g_bundles.put(0, hb); return XRSFM_BA_ENOMEM; }
+        auto put = [&](size_t o, const void* h, size_t bytes) { if (bytes) memcpy(stage.data() + o, h, bytes); };
+        put(o_cam, cams.data(), sizeof(CamRec) * (size_t)Nc); put(o_model, model.data(), sizeof(int) * (size_t)Nc);
+        put(o_P, p->points, sizeof(double) * 3 * (size_t)Np); put(o_ptr, ptr.data(), sizeof(int) * ((size_t)Np + 1));
+        put(o_ocam, ocam.data(), sizeof(int) * (size_t)No); put(o_ouv, ouv.data(), sizeof(double) * 2 * (size_t)No);
+        hipStream_t st = hb.stream;
+        if (hipMemcpyAsync(base, stage.data(), in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e && hipMemsetAsync(base + o_cnt, 0, sizeof(int) * 2, st) != hipSuccess) e = XRSFM_BA_ENODEV;
         if (!e) {
+            if (Nc > 0) hipLaunchKernelGGL(k_cam_centres, dim3(cdiv(Nc, 256)), dim3(256), 0, st, (const CamRec*)(base + o_cam), Nc, (double*)(base + o_centre));
+            if (Np > 0) hipLaunchKernelGGL(k_filter_tracks, dim3(cdiv(Np, 128)), dim3(128), 0, st, (const CamRec*)(base + o_cam), (const int*)(base + o_model),
+                                           (const double*)(base + o_centre), (const double*)(base + o_P), (const int*)(base + o_ptr), (const int*)(base + o_ocam),
+                                           (const double*)(base + o_ouv), Np, max_reproj_error, min_tri_angle_rad, (unsigned char*)(base + o_del),
+                                           (unsigned char*)(base + o_out), (double*)(base + o_err), (double*)(base + o_ang), (int*)(base + o_cnt));
+            if (hipGetLastError() != hipSuccess) e = XRSFM_BA_ENODEV;
+        }
+        if (!e && hipMemcpyAsync(back.data(), base + out0, out_bytes, hipMemcpyDeviceToHost, st) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (hipStreamSynchronize(st) != hipSuccess) e = XRSFM_BA_ENODEV;
+        if (!e) {
+            const unsigned char* o = back.data() - out0;            // (offsets above are relative to the block)
+            const unsigned char* del = o + o_del;
             for (int k2 = 0; k2 < No; ++k2) obs_delete[order[k2]] = del[k2];
-            if (num_filtered) { num_filtered[0] = cnt[0]; num_filtered[1] = cnt[1]; }
+            if (Np) memcpy(track_outlier, o + o_out, (size_t)Np);
+            if (Np && track_error) memcpy(track_error, o + o_err, sizeof(double) * (size_t)Np);
+            if (Np && track_angle) memcpy(track_angle, o + o_ang, sizeof(double) * (size_t)Np);
+            if (num_filtered) { int cnt[2]; memcpy(cnt, o + o_cnt, sizeof(cnt)); num_filtered[0] = cnt[0]; num_filtered[1] = cnt[1]; }
         }
     }
-    for (void* b : bufs) (void)hipFree(b);
+    g_cache.put(0, base, cls);
+    g_bundles.put(0, hb);
     return e;
 }
 
