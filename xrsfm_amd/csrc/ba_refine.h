@@ -102,9 +102,14 @@ __global__ __launch_bounds__(kBlock) void k_refine_pose(const RefineJob* __restr
     __shared__ double sq[4], st[3];          // pose to evaluate next
     __shared__ int sh_go;                    // 1: evaluate (sq, st) and continue; 0: finished
     const RefineJob& job = jobs[blockIdx.x];
-    // lane 0 state
-    double q[4], t[3], H[21], g[6], S[6], cost = 0.0, gmax = 0.0, radius = opt.radius0, decrease = 2.0;
-    double qc[4], tc[3], delta[6], model = 0.0;
+    // lane 0 state.  The arrays the LM step indexes with loop variables live in LDS, not in private memory (round 6): as private
+    // arrays they made this the library's only kernel with a scratch segment (304 bytes per lane), and the runtime re-allocates a
+    // queue's scratch when a dispatch needs it after a large launch of another kernel with scratch has released it (the device-side
+    // packing's radix sorts): 20-28 ms on the first pose refinement after every KGBA of a map of 140+ frames (mapper replay,
+    // tools/runs/r06_call12.sh: device idle, kernel 0.1 ms, 24 ms between the launch and the end of hipStreamSynchronize).
+    __shared__ double H[21], g[6], S[6], delta[6], A[36], b[6];
+    double q[4], t[3], cost = 0.0, gmax = 0.0, radius = opt.radius0, decrease = 2.0;
+    double qc[4], tc[3], model = 0.0;
     int it = 0, invalid = 0, n_succ = 0, n_unsucc = 0, attempted = 0, term = 0, reason = 0;
     if (threadIdx.x == 0) {
         for (int k = 0; k < 4; ++k) { q[k] = job.q[k]; sq[k] = q[k]; }
@@ -136,7 +141,6 @@ __global__ __launch_bounds__(kBlock) void k_refine_pose(const RefineJob* __restr
                 if (it >= opt.max_it) { term = XRSFM_BA_NO_CONVERGENCE; reason = 5; break; }
                 ++it; ++attempted;
                 // (S H S + D^2) y = -S g,  D^2 = clamp(diag(S H S), 1e-6, 1e32) / radius
-                double A[36], b[6];
                 for (int a = 0; a < 6; ++a) {
                     for (int c2 = a; c2 < 6; ++c2) { const double v = H[ref_idx(a, c2)] * S[a] * S[c2]; A[a * 6 + c2] = v; A[c2 * 6 + a] = v; }
                     b[a] = -S[a] * g[a];
@@ -229,7 +233,8 @@ __global__ __launch_bounds__(kBlock) void k_refine_pose(const RefineJob* __restr
         for (int k = 0; k < 3; ++k) r.t[k] = t[k];
         r.initial_cost = initial_cost; r.final_cost = cost;
         r.n_successful = n_succ; r.n_unsuccessful = n_unsucc; r.termination = term; r.reason = reason; r.attempted = attempted; r.pad = 0;
-        results[blockIdx.x] = r;
+        results[blockIdx.x] = r;          // (device memory or — the library's own call — pinned host memory: no copy-engine round trip)
+        __threadfence_system();
     }
 }
 

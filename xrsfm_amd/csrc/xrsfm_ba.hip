@@ -434,6 +434,15 @@ void profile_collect(xrsfm_ba_context* c, int tag_limit = 1 << 30) {
 // The LM controller needs ~10 scalars on the host twice per iteration.  A D2H copy + hipStreamSynchronize costs 20-30 us of
 // idle GPU each time; instead one tiny kernel stores the scalars and then a sequence number (system-scope release) into
 // coherent host memory and the host spins on the sequence number.
+// developer aid (XRSFM_BA_TRACE_CALLS): the device's 100 MHz clock into (pinned) memory
+__global__ void k_stamp(unsigned long long* out) { *out = wall_clock64(); __threadfence_system(); }
+
+// n 8-byte words from (pinned, device-visible) host memory to device memory
+__global__ void k_copy_words(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+
 __global__ void k_publish(const double* __restrict__ scal, double* __restrict__ host, unsigned long long seq) {
     if (threadIdx.x < S_COUNT) host[threadIdx.x] = scal[threadIdx.x];
     __threadfence_system();
@@ -2137,7 +2146,12 @@ static int refine_poses_kernel(const xrsfm_ba_options& o, int32_t n_frames, cons
     HostBundle hb;
     if (!g_bundles.get(device, &hb)) { g_cache.put(device, dev, cls); return XRSFM_BA_ENODEV; }
     const auto t_b = std::chrono::steady_clock::now();
-    std::vector<unsigned char> stage(off_res);
+    // (round 6) staging in PINNED memory from the recycled pool, results included: the hipMemcpyAsync of the 112-byte result into a
+    // pageable vector was where the mapper replay's slow pose refinements sat — 20-28 ms inside that one call, each time right after a
+    // KGBA + whole-map filter had released tens of MB of host memory (the runtime pins pageable pages on the fly; tools/runs/r06_call12.sh)
+    struct Pin { unsigned char* p = nullptr; size_t cap = 0; unsigned char* data() const { return p; } ~Pin() { if (p) g_pinned.put(p, cap); } } stage;
+    stage.p = (unsigned char*)g_pinned.get(total, &stage.cap);
+    if (!stage.p) { g_bundles.put(device, hb); g_cache.put(device, dev, cls); return XRSFM_BA_ENOMEM; }
     double* hP = reinterpret_cast<double*>(stage.data() + off_P);
     double* hU = reinterpret_cast<double*>(stage.data() + off_uv);
     for (int f = 0; f < n_frames; ++f) {
@@ -2158,26 +2172,47 @@ static int refine_poses_kernel(const xrsfm_ba_options& o, int32_t n_frames, cons
         }
     }
     RefineOpt ro{o.max_iterations, o.function_tolerance, o.parameter_tolerance, o.gradient_tolerance, o.initial_radius, o.huber_a};
-    std::vector<RefineResult> res(n_frames);
+    RefineResult* const res = reinterpret_cast<RefineResult*>(stage.data() + off_res);
     int e = XRSFM_BA_OK;
+    double pending_ms = 0.0;
+    if (trace_phases) {         // (developer aid: is the device still busy with something an earlier call left behind?)
+        const auto t0 = std::chrono::steady_clock::now();
+        (void)hipDeviceSynchronize();
+        pending_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     const auto t_c = std::chrono::steady_clock::now();
-    if (hipMemcpyAsync(dev, stage.data(), off_res, hipMemcpyHostToDevice, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    // Both directions WITHOUT the copy engines: a kernel pulls the staged block from the pinned buffer (device-visible) and
+    // k_refine_pose writes its result records straight into it.  With hipMemcpyAsync the same call took 20-37 ms whenever the
+    // process had not used a copy engine for ~10 ms (the host-only phase after a whole-map filter): the copy, not the kernel
+    // (0.1 ms in the kernel trace), was what hipStreamSynchronize waited for (tools/runs/r06_call13.sh).
+    unsigned long long* stamps = reinterpret_cast<unsigned long long*>(hb.h_st);          // (pinned; the PCG status block is idle here)
+    if (trace_phases) { stamps[0] = 0; stamps[1] = 0; hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, hb.stream, stamps); }
+    hipLaunchKernelGGL(k_copy_words, dim3(cdiv((long long)(off_res / 8), 256)), dim3(256), 0, hb.stream, reinterpret_cast<const double*>(stage.data()),
+                       reinterpret_cast<double*>(dev), off_res / 8);
     const auto t_d = std::chrono::steady_clock::now();
     if (!e) {
-        hipLaunchKernelGGL(k_refine_pose, dim3(n_frames), dim3(kBlock), 0, hb.stream, reinterpret_cast<const RefineJob*>(dev), ro,
-                           reinterpret_cast<RefineResult*>(dev + off_res));
+        hipLaunchKernelGGL(k_refine_pose, dim3(n_frames), dim3(kBlock), 0, hb.stream, reinterpret_cast<const RefineJob*>(dev), ro, res);
         if (hipGetLastError() != hipSuccess) e = XRSFM_BA_ENODEV;
     }
-    if (!e && hipMemcpyAsync(res.data(), dev + off_res, sizeof(RefineResult) * (size_t)n_frames, hipMemcpyDeviceToHost, hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    if (trace_phases) hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, hb.stream, stamps + 1);
+    const auto t_e = std::chrono::steady_clock::now();
+    const auto t_f = std::chrono::steady_clock::now();
+    double seen_ms = -1.0;
+    if (trace_phases) {           // when does the last kernel's stamp become visible in pinned memory? (before hipStreamSynchronize is asked)
+        volatile unsigned long long* v = stamps + 1;
+        while (*v == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t_f).count() < 0.2) __builtin_ia32_pause();
+        seen_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_f).count();
+    }
     if (hipStreamSynchronize(hb.stream) != hipSuccess) e = XRSFM_BA_ENODEV;
+    const auto t_g = std::chrono::steady_clock::now();
     g_bundles.put(device, hb);
     g_cache.put(device, dev, cls);
     if (e) return e;
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count();
-    if (trace_phases && secs > 2e-3) {
+    if (trace_phases && secs > 2e-3) {          // (the poll above is part of `sync` in trace mode)
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        fprintf(stderr, "[xrsfm_ba_refine_pose] slow call: prologue %.3f | block + stream %.3f | staging %.3f | upload call %.3f | kernel + download + sync %.3f ms (%zu bytes)\n",
-                ms(t_begin, t_a), ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d), ms(t_d, std::chrono::steady_clock::now()), total);
+        fprintf(stderr, "[xrsfm_ba_refine_pose] slow call: prologue %.3f | block + stream %.3f | staging %.3f (of which device sync %.3f) | upload call %.3f | launch call %.3f | download call %.3f | sync %.3f ms (%zu bytes) | on the DEVICE first kernel start -> last kernel end %.3f ms; the last kernel's stamp reached pinned memory %.3f ms after the launches\n",
+                ms(t_begin, t_a), ms(t_a, t_b), ms(t_b, t_c), pending_ms, ms(t_c, t_d), ms(t_d, t_e), ms(t_e, t_f), ms(t_f, t_g), total, (double)(stamps[1] - stamps[0]) * 1e-5, seen_ms);
     }
     for (int f = 0; f < n_frames; ++f) {
         xrsfm_ba_summary* sm = summaries + f;
