@@ -26,6 +26,7 @@ _init = dist.init_process_group
 dist.init_process_group = lambda backend=None, device_id=None, **k: _init(backend="gloo", **k)
 from xrsfm_amd import capi, synth
 synth.CONFIGS["S"] = dict(n_cams=12, n_points=300, k_obs=4, seed=2)          # keep the generated problems tiny
+synth.CONFIGS["T"] = dict(n_cams=60, n_points=400, seed=12, cams_per_cluster=20)      # (BASELINE config 5's generator, at toy size)
 LOG = []
 class FakeSummary:
     n_successful, n_unsuccessful, pcg_iterations, linear_solver_used, termination_reason = 5, 1, 0, 1, 3
@@ -105,3 +106,29 @@ def test_two_rank_launch_contract(tmp_path, scaling):
     for rank, log in enumerate(logs):
         assert log[0][:3] == ("ctx", rank, per_rank_points)
         assert log[1] == ("comm", 2, rank, 128, sum(range(128)))
+
+
+def test_two_ranks_on_the_collection_config(tmp_path):
+    """`bench.py --gpus 2 --config T` (BASELINE config 5: the unordered photo collection, the configuration BASELINE.json places on
+    8 GPUs): strong scaling — the collection is generated once and its tracks are sharded over the ranks by the length-aware
+    partition, cameras replicated; one JSON line, the workload named as the clustered collection."""
+    port = _free_port()
+    argv = ["--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "T", "--no-cpu", "--no-extras"]
+    script = tmp_path / "driver.py"
+    script.write_text(DRIVER.format(root=ROOT, argv=argv))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, WORLD_SIZE="2", RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (o, e) in zip(procs, outs):
+        assert p.returncode == 0, e[-2000:]
+    lines0 = [l for l in outs[0][0].splitlines() if l.startswith("{")]
+    assert len(lines0) == 1 and not [l for l in outs[1][0].splitlines() if l.startswith("{")]
+    j = json.loads(lines0[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong" and "clustered photo collection" in j["config"]["workload"] and "sharded x2" in j["config"]["parallelism"]
+    logs = [eval([l for l in o.splitlines() if l.startswith("LOG")][0][4:]) for o, _ in outs]
+    pts = [log[0][2] for log in logs]
+    obs = [log[0][3] for log in logs]
+    assert abs(obs[0] - obs[1]) <= 0.02 * sum(obs) and min(pts) > 0            # observations balanced within 1 % of the total per rank
+    assert all(log[1] == ("comm", 2, rank, 128, sum(range(128))) for rank, log in enumerate(logs))

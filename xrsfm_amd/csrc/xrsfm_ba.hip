@@ -285,8 +285,10 @@ struct PinnedPool {
     void* get(size_t bytes, size_t* cap) {
         {
             std::lock_guard<std::mutex> g(mu);
+            size_t best = free_blocks.size();          // best fit: a small request must not take the block a large one will need next
             for (size_t i = 0; i < free_blocks.size(); ++i)
-                if (free_blocks[i].second >= bytes) { void* p = free_blocks[i].first; *cap = free_blocks[i].second; free_blocks.erase(free_blocks.begin() + i); return p; }
+                if (free_blocks[i].second >= bytes && (best == free_blocks.size() || free_blocks[i].second < free_blocks[best].second)) best = i;
+            if (best < free_blocks.size()) { void* p = free_blocks[best].first; *cap = free_blocks[best].second; free_blocks.erase(free_blocks.begin() + best); return p; }
         }
         size_t c = 1 << 16;
         while (c < bytes) c *= 2;
@@ -297,7 +299,7 @@ struct PinnedPool {
     }
     void put(void* p, size_t cap) {
         std::lock_guard<std::mutex> g(mu);
-        if (free_blocks.size() >= 4 || cap > ((size_t)256 << 20)) { (void)hipHostFree(p); return; }
+        if (free_blocks.size() >= 8 || cap > ((size_t)256 << 20)) { (void)hipHostFree(p); return; }
         free_blocks.push_back({p, cap});
     }
     void release_all() {
@@ -374,9 +376,15 @@ struct BatchUpload {
         if (reqs.empty()) return 0;
         unsigned char* base = nullptr;
         if ((err = dev_alloc(c, &base, total))) return err;
-        std::vector<unsigned char> stage(total);
-        for (const Req& r : reqs) if (r.bytes) memcpy(stage.data() + r.off, r.src, r.bytes);
-        if (hipMemcpy(base, stage.data(), total, hipMemcpyHostToDevice) != hipSuccess) return err = XRSFM_BA_ENODEV;
+        // (round 6) staged in pinned memory from the recycled pool: a copy from a pageable vector goes through the runtime's own
+        // staging (or has its pages pinned on the fly)
+        size_t cap = 0;
+        unsigned char* stage = static_cast<unsigned char*>(g_pinned.get(total, &cap));
+        if (!stage) return err = XRSFM_BA_ENOMEM;
+        for (const Req& r : reqs) if (r.bytes) memcpy(stage + r.off, r.src, r.bytes);
+        const bool ok = hipMemcpy(base, stage, total, hipMemcpyHostToDevice) == hipSuccess;
+        g_pinned.put(stage, cap);
+        if (!ok) return err = XRSFM_BA_ENODEV;
         for (const Req& r : reqs) *r.dst = base + r.off;
         reqs.clear(); total = 0;
         return 0;
@@ -1688,23 +1696,33 @@ int xrsfm_ba_download(xrsfm_ba_context* c, double* cam_q, double* cam_t, double*
     if (c->poisoned) return XRSFM_BA_ESTATE;       // (a blocking copy would wait for the stream the watchdog gave up on)
     HIPCHK(hipSetDevice(c->device));
     const Packed& k = c->pk;
-    if (cam_q || cam_t) {
-        std::vector<CamRec> cams(k.n_cams);
-        if (k.n_cams) HIPCHK(hipMemcpy(cams.data(), c->d.cam, sizeof(CamRec) * (size_t)k.n_cams, hipMemcpyDeviceToHost));
+    // (round 6) both copies land in ONE pinned block from the recycled pool (cameras | points) and are permuted from there
+    const size_t cam_bytes = (cam_q || cam_t) ? sizeof(CamRec) * (size_t)k.n_cams : 0;
+    const size_t off_P = (cam_bytes + 255) & ~(size_t)255, pt_bytes = points ? sizeof(double) * 3 * (size_t)k.n_pts : 0;
+    if (cam_bytes + pt_bytes == 0) return 0;
+    size_t cap = 0;
+    unsigned char* host = static_cast<unsigned char*>(g_pinned.get(off_P + pt_bytes, &cap));
+    if (!host) return XRSFM_BA_ENOMEM;
+    bool ok = true;
+    if (cam_bytes) ok = hipMemcpyAsync(host, c->d.cam, cam_bytes, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    if (ok && pt_bytes) ok = hipMemcpyAsync(host + off_P, c->d.P, pt_bytes, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = (hipStreamSynchronize(c->stream) == hipSuccess) && ok;
+    if (ok && cam_bytes) {
+        const CamRec* cams = reinterpret_cast<const CamRec*>(host);
         for (int i = 0; i < k.n_cams; ++i) {
             if (cam_q) for (int j = 0; j < 4; ++j) cam_q[4 * (size_t)i + j] = cams[i].q[j];
             if (cam_t) for (int j = 0; j < 3; ++j) cam_t[3 * (size_t)i + j] = cams[i].t[j];
         }
     }
-    if (points) {
-        RawVec<double> P(3 * (size_t)k.n_pts);       // (uninitialised: overwritten by the copy)
-        if (k.n_pts) HIPCHK(hipMemcpy(P.data(), c->d.P, sizeof(double) * P.size(), hipMemcpyDeviceToHost));
+    if (ok && pt_bytes) {
+        const double* P = reinterpret_cast<const double*>(host + off_P);
         pack_parallel_for(k.n_pts, [&](long long j0, long long j1) {      // back to the caller's point order
             for (long long j = j0; j < j1; ++j)
                 for (int a = 0; a < 3; ++a) points[3 * (size_t)k.pt_orig[j] + a] = P[3 * (size_t)j + a];
         });
     }
-    return 0;
+    g_pinned.put(host, cap);
+    return ok ? 0 : XRSFM_BA_ENODEV;
 }
 
 // bal9 mode: the same trust-region loop over the 9-wide kernels of ba_wide.h.  Plain schedule — linearise, assemble,
