@@ -566,14 +566,32 @@ __global__ __launch_bounds__(kWave) void k_pair_sources(Dev d, const int* __rest
     }
 }
 // With stored operands the scatter buffer holds the Gram tiles' cells only: every cell with a destination gets a compact record
-// number (in arrival order: it names a place, not a position in a sum), which replaces the entry index in the tile's destination
-// table and is noted in the entry's source record (x < 0: a Gram cell, y = its record).
-__global__ void k_gram_compact(int* __restrict__ cell_dst, int n_cells, int2* __restrict__ ent_src, int* __restrict__ counter) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_cells) return;
-    const int e = cell_dst[i];
+// number — its rank among the cells with a destination, in cell order (round 6: deterministic; until round 5 an atomic counter
+// numbered them in arrival order, so the record layout differed from run to run and from rank to rank: ADVICE round 5) —, which
+// replaces the entry index in the tile's destination table and is noted in the entry's source record (x < 0: a Gram cell, y = its
+// record).  Three tiny launches: cells with a destination per block of 256, a serial exclusive scan of the block counts (one
+// workgroup; the table of a collection has a few thousand cells), rank inside the block + block offset.
+__global__ __launch_bounds__(256) void k_gram_compact_count(const int* __restrict__ cell_dst, int n_cells, int* __restrict__ block_cnt) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool on = i < n_cells && cell_dst[i] >= 0;
+    const int c = __syncthreads_count(on);
+    if (threadIdx.x == 0) block_cnt[blockIdx.x] = c;
+}
+__global__ void k_gram_compact_scan(int* __restrict__ block_cnt, int n_blocks) {       // in place: counts -> exclusive offsets (one thread: a few thousand blocks at most)
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    int run = 0;
+    for (int b = 0; b < n_blocks; ++b) { const int v = block_cnt[b]; block_cnt[b] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void k_gram_compact(int* __restrict__ cell_dst, int n_cells, int2* __restrict__ ent_src, const int* __restrict__ block_off) {
+    __shared__ int wave_cnt[4];
+    const int i = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = i < n_cells ? cell_dst[i] : -1;
+    const unsigned long long m = __ballot(e >= 0);
+    if (lane == 0) wave_cnt[wave] = __popcll(m);
+    __syncthreads();
     if (e < 0) return;
-    const int rec = atomicAdd(counter, 1);
+    int rec = block_off[blockIdx.x] + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) rec += wave_cnt[w];
     ent_src[e] = make_int2(-1, rec);
     cell_dst[i] = rec;
 }

@@ -859,10 +859,13 @@ int chol_setup(xrsfm_ba_context* c) {
             HIPCHK(hipGetLastError());
             const int n_cells = c->pk.n_gt_cells;
             if (n_cells > 0) {
-                int* counter = nullptr;
-                TRYC(dev_alloc(c, &counter, (size_t)1));
-                HIPCHK(hipMemsetAsync(counter, 0, sizeof(int), c->stream));
-                hipLaunchKernelGGL(k_gram_compact, dim3(cdiv(n_cells, 256)), dim3(256), 0, c->stream, h.pair_dst + (h.n_pairs - n_cells), n_cells, h.ent_src, counter);
+                const int nb = cdiv(n_cells, 256);
+                int* block_off = nullptr;
+                TRYC(dev_alloc(c, &block_off, (size_t)nb));
+                int* cells = h.pair_dst + (h.n_pairs - n_cells);
+                hipLaunchKernelGGL(k_gram_compact_count, dim3(nb), dim3(256), 0, c->stream, (const int*)cells, n_cells, block_off);
+                hipLaunchKernelGGL(k_gram_compact_scan, dim3(1), dim3(64), 0, c->stream, block_off, nb);
+                hipLaunchKernelGGL(k_gram_compact, dim3(nb), dim3(256), 0, c->stream, cells, n_cells, h.ent_src, (const int*)block_off);
                 HIPCHK(hipGetLastError());
             }
         }
