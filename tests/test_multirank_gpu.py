@@ -187,3 +187,33 @@ def test_config4_sized_problem_on_2_and_8_ranks(lib, tmp_path, world):
         assert np.array_equal(z[0]["q"], z[r]["q"]) and np.array_equal(z[0]["t"], z[r]["t"])
     print(f"config-4-sized LP on {world} ranks: LM {s1.n_successful}+{s1.n_unsuccessful}, max camera difference to one rank "
           f"{max(np.abs(z[0]['q'] - ref.cam_q).max(), np.abs(z[0]['t'] - ref.cam_t).max()):.2e}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_dissected_collection_on_2_4_8_ranks(lib, tmp_path, world):
+    """VERDICT round 5, item 3 (its test half): a photo collection in the shape of BASELINE config 5 — 2400 photos in 40 viewpoint
+    clusters, 100 000 tracks with a power-law length distribution — split over 2, 4 and 8 ranks that share the GPU through the
+    transport hook.  Every rank derives the SAME nested dissection of the camera graph from the all-reduced block pattern
+    (ordering 3), the same level schedule with its level look-ahead on a second stream (round 6) and the same stored-operand
+    block sums; the factorisation is replicated.  Every rank takes the single-rank solve's LM decisions, all ranks hold
+    bit-identical cameras, cameras within 1e-5 and RMSE within 1e-6 px of the single-rank solve, shards balanced within 1 %."""
+    from xrsfm_amd import capi, sharding, synth
+    d = synth.make_collection(n_cams=2400, n_points=100000, seed=4, cams_per_cluster=60)
+    arr = {k: d[k] for k in capi.ProblemArrays.FIELDS}
+    plan = capi.debug_chol_plan(H.to_product(arr))
+    assert plan["ordering"] == 3 and plan["level_schedule"] == 1 and plan["levels"] >= 16
+    opt_kw = dict(max_iterations=6)
+    ref = H.to_product(arr)
+    s1 = capi.solve(ref, capi.default_options(linear_solver=1, **opt_kw))
+    prefix = str(tmp_path / "rank")
+    mp.spawn(_worker, args=(world, _free_port(), arr, 1, opt_kw, prefix), nprocs=world, join=True)
+    z = [np.load(f"{prefix}{r}.npz") for r in range(world)]
+    n_res = 2 * arr["obs_cam"].shape[0]
+    owner = sharding.partition_points(arr["obs_pt"], arr["points"].shape[0], world)
+    assert sharding.imbalance(arr["obs_pt"], owner, world) <= 0.01
+    for r in range(world):
+        assert tuple(z[r]["stat"]) == (s1.n_successful, s1.n_unsuccessful, s1.termination_reason)
+        assert abs(np.sqrt(z[r]["cost"][1] / n_res) - np.sqrt(s1.final_cost / n_res)) < 1e-6
+        assert np.abs(z[r]["q"] - ref.cam_q).max() < 1e-5 and np.abs(z[r]["t"] - ref.cam_t).max() < 1e-5
+        assert np.array_equal(z[0]["q"], z[r]["q"]) and np.array_equal(z[0]["t"], z[r]["t"])

@@ -81,21 +81,15 @@ __device__ __forceinline__ void tile_camera_sums(double* red, const double (&v)[
 }
 // What tile_camera_sums needs: the lane's position in the camera-sorted order (lanes of earlier cameras + earlier lanes of the
 // own camera; a lane without an observation parks in row 63, which is in no run) and, for the (camera, value) slots lane and
-// lane + 64, the camera's run: start | length << 8 | first lane << 16.
+// lane + 64, the camera's run: start | length << 8 | first lane << 16 — from the per-context tables of k_gram_runs (ba_kernels.h;
+// round 6: until then a ballot loop over the tile's cameras in every launch).
 template <int NV>
-__device__ __forceinline__ void tile_camera_runs(int cidx, int lane, int C, int& mypos, int (&run_pk)[2]) {
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    mypos = kWave - 1; run_pk[0] = 0; run_pk[1] = 0;
-    int run = 0;
-    for (int cc = 0; cc < C; ++cc) {
-        const unsigned long long m = __ballot(cidx == cc);
-        const int cnt = __popcll(m);
-        const int pk = run | (cnt << 8) | ((__ffsll((long long)m) - 1) << 16);
-        if (cidx == cc) mypos = run + __popcll(m & lt);
-        if (lane / NV == cc) run_pk[0] = pk;
-        if ((lane + kWave) / NV == cc) run_pk[1] = pk;
-        run += cnt;
-    }
+__device__ __forceinline__ void tile_camera_runs(const Dev& d, int tile, int slot, int lane, int C, int& mypos, int (&run_pk)[2]) {
+    const int* trun = d.tile_run + (size_t)tile * kTileRunLd;
+    const int c0 = lane / NV, c1 = (lane + kWave) / NV;
+    mypos = (int)d.slot_gpos[slot];
+    run_pk[0] = c0 < C ? trun[c0] : 0;
+    run_pk[1] = c1 < C ? trun[c1] : 0;
 }
 
 // ---------------------------------------------------------------- linearise
@@ -178,9 +172,8 @@ __device__ __forceinline__ void linearize9_item(const Dev& d, const DevW& w, con
             const int Cg = is_long ? 0 : d.tile_ncam[it.first_tile + tl];
             const int cpg = d.slot_campos_g[s.slot];
             if (Cg > 0) {
-                const int cidx = s.valid ? (int)d.slot_cidx[s.slot] : -1;
                 int mypos, run_pk[2];
-                tile_camera_runs<9>(cidx, lane, Cg, mypos, run_pk);
+                tile_camera_runs<9>(d, it.first_tile + tl, s.slot, lane, Cg, mypos, run_pk);
                 tile_camera_sums<9>(red, cs0, lane, Cg, mypos, run_pk, cpg, w.scat, 18, 0);
                 tile_camera_sums<9>(red, cs1, lane, Cg, mypos, run_pk, cpg, w.scat, 18, 9);
             } else if (s.valid) {
@@ -432,7 +425,7 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_waves_per_eu(NI < 4 ? 
     const bool dense = nvalid == T * C;
     {   // the 56 diagonal-block / rhs values, summed per distinct camera of the tile (tile_camera_sums), four rounds of 14
         int mypos, run_pk[2];
-        tile_camera_runs<14>(s.valid ? cidx_raw : -1, lane, C, mypos, run_pk);
+        tile_camera_runs<14>(d, tile, s.slot, lane, C, mypos, run_pk);
         double* red = smem;                                         // [64][kRedLd]
         auto round = [&](auto hc) {
             constexpr int h = decltype(hc)::value;
