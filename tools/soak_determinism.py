@@ -1,6 +1,6 @@
 """Developer tool: repeat the same solve many times on one context (reset + run) and require bit-identical results: the two-stream
 S assembly, the level-scheduled Cholesky, the polled host hand-off and the deterministic reductions must not depend on timing.
-Needs a GPU:  python tools/soak_determinism.py [config] [repeats]"""
+Needs a GPU:  python tools/soak_determinism.py [config | C | T] [repeats] [max LM iterations]"""
 import os
 import sys
 
@@ -14,10 +14,12 @@ from xrsfm_amd import capi, synth
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "L"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-    full = synth.make_problem(**synth.CONFIGS[cfg])
+    # "C": a dissected photo collection (2400 photos in clusters): level schedule with the level look-ahead on two streams (round 6)
+    full = synth.make_collection(n_cams=2400, n_points=100000, seed=4, cams_per_cluster=60) if cfg == "C" else \
+        (synth.make_collection(**synth.CONFIGS[cfg]) if cfg == "T" else synth.make_problem(**synth.CONFIGS[cfg]))
     prob = capi.ProblemArrays(**{k: np.array(full[k], copy=True) for k in capi.ProblemArrays.FIELDS})
     ctx = capi.Context(prob)
-    opt = capi.default_options()
+    opt = capi.default_options(max_iterations=int(sys.argv[3])) if len(sys.argv) > 3 else capi.default_options()
     ref = None
     for i in range(n):
         ctx.reset()
